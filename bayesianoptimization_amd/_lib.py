@@ -1,0 +1,124 @@
+"""ctypes binding of libgpbo.so (the C ABI declared in include/gpbo.h).
+
+There is NO CPU fallback: if the HIP library is missing or no AMD GPU is visible, loading or context
+creation raises.  Nothing in this package imports the test oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpbo.so")
+
+GPBO_OK = 0
+ERR_INVALID, ERR_HIP, ERR_NOT_PD, ERR_STATE, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5, -6
+MAX_MODELS = 8
+MAX_DIM = 64
+MAX_SEEDS = 64
+ABI_VERSION = 1
+
+_c_double_p = C.POINTER(C.c_double)
+_c_int64_p = C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes); must list every symbol include/gpbo.h declares (tests check this)
+SIGNATURES = {
+    "gpbo_abi_version": (C.c_int, []),
+    "gpbo_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "gpbo_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "gpbo_destroy": (C.c_int, [C.c_void_p]),
+    "gpbo_last_error": (C.c_char_p, [C.c_void_p]),
+    "gpbo_synchronize": (C.c_int, [C.c_void_p]),
+    "gpbo_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "gpbo_fit": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, C.c_int64, C.c_int, C.c_int,
+                           _c_double_p, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)]),
+    "gpbo_get_K": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
+    "gpbo_get_L": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
+    "gpbo_get_Linv": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
+    "gpbo_get_alpha": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
+    "gpbo_set_candidates": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, C.c_int]),
+    "gpbo_posterior": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, _c_double_p, _c_double_p]),
+    "gpbo_predict": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int64, C.c_int, C.c_double, C.c_double,
+                               _c_double_p, _c_double_p]),
+    "gpbo_acq_argbest": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, _c_double_p,
+                                   _c_double_p, C.c_int, C.c_int64, _c_int64_p, _c_double_p, _c_int64_p,
+                                   _c_double_p, _c_double_p]),
+    "gpbo_last_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
+    "gpbo_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "gpbo_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    "gpbo_comm_allgather_best": (C.c_int, [C.c_void_p, _c_double_p, _c_int64_p, C.c_int, _c_double_p,
+                                           _c_int64_p]),
+    "gpbo_comm_destroy": (C.c_int, [C.c_void_p]),
+    "gpbo_debug_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, _c_double_p, _c_double_p,
+                                  C.c_int, C.c_double, _c_double_p]),
+    "gpbo_mfma_f64_peak": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
+    "gpbo_hbm_copy_peak": (C.c_int, [C.c_void_p, C.c_int64, _c_double_p]),
+}
+
+_lib = None
+
+
+class GpboError(RuntimeError):
+    """HIP / state / communicator failure reported by libgpbo."""
+
+
+def load_library(path: str | None = None):
+    """Load libgpbo.so and attach prototypes. Raises ImportError (loudly) when it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: the HIP extension has not been built. Run "
+            "`python -m bayesianoptimization_amd.build` (needs hipcc). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gpbo_abi_version() != ABI_VERSION:
+        raise ImportError(f"libgpbo ABI {lib.gpbo_abi_version()} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def dptr(a: np.ndarray | None):
+    if a is None:
+        return None
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_c_double_p)
+
+
+def iptr(a: np.ndarray | None):
+    if a is None:
+        return None
+    assert a.dtype == np.int64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_c_int64_p)
+
+
+def device_count() -> int:
+    lib = load_library()
+    n = C.c_int(0)
+    rc = lib.gpbo_device_count(C.byref(n))
+    return n.value if rc == GPBO_OK else 0
+
+
+def raise_for_status(lib, handle, rc: int, info: int = 0):
+    if rc == GPBO_OK:
+        return
+    msg = lib.gpbo_last_error(handle)
+    msg = msg.decode(errors="replace") if msg else f"libgpbo error {rc}"
+    if rc == ERR_NOT_PD:
+        # same hint as sklearn (gaussian_process/_gpr.py:350-358)
+        raise np.linalg.LinAlgError(
+            f"The kernel is not returning a positive definite matrix ({info}-th leading minor of the array "
+            "is not positive definite). Try gradually increasing the 'alpha' parameter of your "
+            f"GaussianProcessRegressor estimator. [{msg}]")
+    if rc == ERR_INVALID:
+        raise ValueError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise GpboError(msg)

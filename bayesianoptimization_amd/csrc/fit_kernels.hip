@@ -1,0 +1,369 @@
+// Fit-side kernels (gfx950): scaling, kernel-matrix assembly, blocked Cholesky, triangular inverse,
+// alpha solve and MFMA-fragment packing of W = L^-1.
+//
+// What they replace (SK = sklearn, reference paths relative to /root/reference):
+//   prescale      X / length_scale                         SK/gaussian_process/kernels.py:1711,1556
+//   kmat          Matern(nu=2.5)/RBF __call__(X) + alpha*I  kernels.py:1711-1738, :1556-1565; _gpr.py:346-347
+//   potrf/gemm    cholesky(K, lower=True) -> LAPACK dpotrf  _gpr.py:349
+//   trtri         W = L^-1: turns the per-candidate solve_triangular (_gpr.py:454-456) into a GEMM
+//   trmv          alpha = cho_solve((L, True), y)           _gpr.py:360-364, as W^T (W y)
+#include "gpbo_internal.h"
+
+namespace gpbo {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// X / length_scale into a zero-padded [n_pad][DP] image (true division, as numpy does).
+__global__ void prescale_kernel(const double* __restrict__ X, int64_t n, int d, int DP,
+                                const double* __restrict__ ls, double* __restrict__ out,
+                                int64_t total) {
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int64_t row = idx / DP;
+  int t = (int)(idx - row * DP);
+  double v = 0.0;
+  if (row < n && t < d) v = X[row * d + t] / ls[t];
+  out[idx] = v;
+}
+
+int launch_prescale(gpbo_ctx* ctx, const double* X, int64_t n, int d, int DP, const double* ls,
+                    double* out, int64_t n_pad) {
+  int64_t total = n_pad * DP;
+  if (total == 0) return GPBO_OK;
+  int64_t blocks = (total + 255) / 256;
+  prescale_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(X, n, d, DP, ls, out, total);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Kernel value from a squared scaled distance.
+template <int KERNEL>
+__device__ __forceinline__ double kernel_value(double d2) {
+  if (KERNEL == GPBO_KERNEL_MATERN25) {
+    double k = sqrt(d2) * 2.23606797749978969641;  // dists * sqrt(5)
+    return (1.0 + k + k * k / 3.0) * exp(-k);
+  } else {
+    return exp(-0.5 * d2);
+  }
+}
+
+// K (lower block triangle, 64x64 tiles): one workgroup per tile, 4x4 outputs per thread, the two
+// point tiles staged k-major in LDS.  HBM-write bound: N^2/2 * 8 B.
+template <int KERNEL>
+__global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ Xs, int DP, int64_t N,
+                                                   int64_t NP, double noise, double* __restrict__ K) {
+  const int bj = blockIdx.x, bi = blockIdx.y;
+  if (bj > bi) return;
+  extern __shared__ __attribute__((aligned(16))) double kmat_smem[];
+  double* XiT = kmat_smem;            // [DP][64]
+  double* XjT = kmat_smem + DP * 64;  // [DP][64]
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 64 * DP; e += 256) {
+    int r = e / DP, t = e - r * DP;
+    XiT[t * 64 + r] = Xs[((int64_t)bi * 64 + r) * DP + t];
+    XjT[t * 64 + r] = Xs[((int64_t)bj * 64 + r) * DP + t];
+  }
+  __syncthreads();
+  const int ty = tid >> 4, tx = tid & 15;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int t = 0; t < DP; ++t) {
+    double xi[4], xj[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) xi[a] = XiT[t * 64 + ty * 4 + a];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) xj[b] = XjT[t * 64 + tx * 4 + b];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        double df = xi[a] - xj[b];
+        acc[a][b] = fma(df, df, acc[a][b]);
+      }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int64_t i = (int64_t)bi * 64 + ty * 4 + a;
+    double out[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int64_t j = (int64_t)bj * 64 + tx * 4 + b;
+      double v;
+      if (i >= N || j >= N) v = (i == j) ? 1.0 : 0.0;       // identity padding
+      else if (i == j) v = 1.0 + noise;                       // unit diagonal (+ alpha, _gpr.py:347)
+      else v = kernel_value<KERNEL>(acc[a][b]);
+      out[b] = v;
+    }
+    double2* dst = reinterpret_cast<double2*>(K + i * NP + (int64_t)bj * 64 + tx * 4);
+    dst[0] = make_double2(out[0], out[1]);
+    dst[1] = make_double2(out[2], out[3]);
+  }
+}
+
+int launch_kmat(gpbo_ctx* ctx, Model& m, double noise) {
+  dim3 grid((unsigned)(m.NP / 64), (unsigned)(m.NP / 64));
+  const size_t lds = (size_t)2 * m.DP * 64 * sizeof(double);
+  if (m.kernel == GPBO_KERNEL_MATERN25)
+    kmat_kernel<GPBO_KERNEL_MATERN25><<<grid, dim3(256), lds, ctx->stream>>>(m.Xs, m.DP, m.N, m.NP, noise, m.K);
+  else
+    kmat_kernel<GPBO_KERNEL_RBF><<<grid, dim3(256), lds, ctx->stream>>>(m.Xs, m.DP, m.N, m.NP, noise, m.K);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cholesky of one 64x64 diagonal block in LDS by one 256-thread workgroup (right-looking, one
+// column per step), followed by the inverse of the factor (thread c owns column c of L_kk^-1).
+// Writes L_kk in place (upper part zeroed) and L_kk^-1 to dinv[kb].
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, int kb,
+                                                         double* __restrict__ dinv, int* info) {
+  __shared__ double Ls[64 * 65];
+  __shared__ int bad_sh;
+  const int tid = threadIdx.x;
+  double* A = L + (int64_t)kb * 64 * ld + (int64_t)kb * 64;
+  for (int e = tid; e < 4096; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    Ls[r * 65 + c] = (c <= r) ? A[(int64_t)r * ld + c] : 0.0;
+  }
+  if (tid == 0) bad_sh = 0;
+  __syncthreads();
+  for (int j = 0; j < 64; ++j) {
+    if (tid == 0) {
+      double piv = Ls[j * 65 + j];
+      if (!(piv > 0.0)) {
+        if (!bad_sh) bad_sh = j + 1;
+        piv = 1.0;
+      }
+      Ls[j * 65 + j] = sqrt(piv);
+    }
+    __syncthreads();
+    if (tid > j && tid < 64) Ls[tid * 65 + j] = Ls[tid * 65 + j] / Ls[j * 65 + j];
+    __syncthreads();
+    // trailing update of the lower triangle: (i, c) with j < c <= i
+    for (int e = tid; e < 4096; e += 256) {
+      const int i = e >> 6, c = e & 63;
+      if (c > j && c <= i) Ls[i * 65 + c] = fma(-Ls[i * 65 + j], Ls[c * 65 + j], Ls[i * 65 + c]);
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < 4096; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    A[(int64_t)r * ld + c] = Ls[r * 65 + c];
+  }
+  if (tid == 0 && bad_sh && *info == 0) *info = kb * 64 + bad_sh;
+  __syncthreads();
+  // inverse by forward substitution on the identity; column c is private to thread c and is kept
+  // in the (free) strict upper triangle of the LDS image: W[i][c] (i >= c) lives at Ls[c][i + 1].
+  if (tid < 64) {
+    const int c = tid;
+    double* wc = Ls + c * 65 + 1;
+    for (int i = c; i < 64; ++i) wc[i] = (i == c) ? 1.0 : 0.0;
+    for (int k = c; k < 64; ++k) {
+      const double wk = wc[k] / Ls[k * 65 + k];
+      wc[k] = wk;
+      for (int i = k + 1; i < 64; ++i) wc[i] = fma(-Ls[i * 65 + k], wk, wc[i]);
+    }
+  }
+  __syncthreads();
+  double* D = dinv + (int64_t)kb * 64 * 64;
+  for (int e = tid; e < 4096; e += 256) {
+    const int i = e >> 6, c = e & 63;
+    D[e] = (i >= c) ? Ls[c * 65 + i + 1] : 0.0;
+  }
+}
+
+int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb) {
+  potrf_diag_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(m.L, m.NP, kb, m.dinv, ctx->info_dev);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp64 MFMA GEMM, 64x64 output tile per 256-thread workgroup (4 waves, 32x32 each as 2x2
+// v_mfma_f64_16x16x4_f64 tiles), BK = 16, operands staged k-major in LDS.
+//   C = alpha * A(m,k) * op(B) + beta * C ;  A row-major; B row-major (k,n), or (n,k) if b_trans.
+// Fragment layout (cdna_hip_programming.md §3): A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15],
+// D lane l, reg r = D[(l>>4) + 4r][l&15].
+template <bool BT>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
+  const int bn = blockIdx.x, bm = blockIdx.y, bz = blockIdx.z;
+  if (g.lower_only && bn > bm) return;
+  __shared__ double As[16][68];
+  __shared__ double Bs[16][68];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const double* A = g.A + (int64_t)bz * g.strideA + (int64_t)bm * 64 * g.lda;
+  const double* B = g.B + (int64_t)bz * g.strideB + (BT ? (int64_t)bn * 64 * g.ldb : (int64_t)bn * 64);
+  double* C = g.C + (int64_t)bz * g.strideC;
+  int kbeg = 0, kend = g.k;
+  if (g.a_lower) kend = min(kend, (bm + 1) * 64);
+  if (g.b_lower) kbeg = bn * 64;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  d4 acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc[t][u] = d4{0.0, 0.0, 0.0, 0.0};
+  const int arow = tid >> 2, akq = (tid & 3) * 4;
+  const int brow = tid >> 4, bnq = (tid & 15) * 4;
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
+    const double* ap = A + (int64_t)arow * g.lda + k0 + akq;
+    const double2 a01 = *reinterpret_cast<const double2*>(ap);
+    const double2 a23 = *reinterpret_cast<const double2*>(ap + 2);
+    double2 b01, b23;
+    if (BT) {
+      const double* bp = B + (int64_t)arow * g.ldb + k0 + akq;
+      b01 = *reinterpret_cast<const double2*>(bp);
+      b23 = *reinterpret_cast<const double2*>(bp + 2);
+    } else {
+      const double* bp = B + (int64_t)(k0 + brow) * g.ldb + bnq;
+      b01 = *reinterpret_cast<const double2*>(bp);
+      b23 = *reinterpret_cast<const double2*>(bp + 2);
+    }
+    __syncthreads();
+    As[akq + 0][arow] = a01.x;
+    As[akq + 1][arow] = a01.y;
+    As[akq + 2][arow] = a23.x;
+    As[akq + 3][arow] = a23.y;
+    if (BT) {
+      Bs[akq + 0][arow] = b01.x;
+      Bs[akq + 1][arow] = b01.y;
+      Bs[akq + 2][arow] = b23.x;
+      Bs[akq + 3][arow] = b23.y;
+    } else {
+      Bs[brow][bnq + 0] = b01.x;
+      Bs[brow][bnq + 1] = b01.y;
+      Bs[brow][bnq + 2] = b23.x;
+      Bs[brow][bnq + 3] = b23.y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int kr = kk * 4 + (lane >> 4);
+      const double a0 = As[kr][wm + (lane & 15)];
+      const double a1 = As[kr][wm + 16 + (lane & 15)];
+      const double b0 = Bs[kr][wn + (lane & 15)];
+      const double b1 = Bs[kr][wn + 16 + (lane & 15)];
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = (int64_t)bm * 64 + wm + 16 * t + (lane >> 4) + 4 * r;
+        const int64_t colx = (int64_t)bn * 64 + wn + 16 * u + (lane & 15);
+        double* cp = C + row * g.ldc + colx;
+        double v = g.alpha * acc[t][u][r];
+        if (g.beta != 0.0) v += g.beta * (*cp);
+        *cp = v;
+      }
+}
+
+int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g) {
+  if (g.m <= 0 || g.n <= 0 || g.batch <= 0) return GPBO_OK;
+  if (g.m % 64 || g.n % 64 || g.k % 16) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gemm: m,n must be multiples of 64 and k of 16");
+  dim3 grid((unsigned)(g.n / 64), (unsigned)(g.m / 64), (unsigned)g.batch);
+  if (g.b_trans)
+    gemm_f64_kernel<true><<<grid, dim3(256), 0, ctx->stream>>>(g);
+  else
+    gemm_f64_kernel<false><<<grid, dim3(256), 0, ctx->stream>>>(g);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// W := blockdiag(dinv) (W has been zero-filled).
+__global__ __launch_bounds__(256) void fill_w_diag_kernel(const double* __restrict__ dinv,
+                                                          double* __restrict__ W, int64_t NP) {
+  const int kb = blockIdx.x;
+  const double* D = dinv + (int64_t)kb * 4096;
+  for (int e = threadIdx.x; e < 4096; e += 256) {
+    int r = e >> 6, c = e & 63;
+    W[((int64_t)kb * 64 + r) * NP + (int64_t)kb * 64 + c] = D[e];
+  }
+}
+
+int launch_fill_w_diag(gpbo_ctx* ctx, Model& m) {
+  GPBO_HIP(ctx, hipMemsetAsync(m.W, 0, (size_t)m.NP * m.NP * sizeof(double), ctx->stream));
+  fill_w_diag_kernel<<<dim3((unsigned)(m.NP / 64)), dim3(256), 0, ctx->stream>>>(m.dinv, m.W, m.NP);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// t = W y (one wave per row, fixed shuffle tree) and alpha = W^T t (64 columns per workgroup).
+__global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restrict__ W,
+                                                         const double* __restrict__ y,
+                                                         double* __restrict__ t, int64_t NP) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= NP) return;
+  const double* row = W + i * NP;
+  double s = 0.0;
+  for (int64_t j = lane; j <= i; j += 64) s = fma(row[j], y[j], s);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  if (lane == 0) t[i] = s;
+}
+
+__global__ __launch_bounds__(256) void trmv_lower_t_kernel(const double* __restrict__ W,
+                                                           const double* __restrict__ t,
+                                                           double* __restrict__ alpha, int64_t NP) {
+  __shared__ double red[4][64];
+  const int ig = threadIdx.x >> 6, jl = threadIdx.x & 63;
+  const int64_t j0 = (int64_t)blockIdx.x * 64;
+  double s = 0.0;
+  for (int64_t i = j0 + ig; i < NP; i += 4) s = fma(W[i * NP + j0 + jl], t[i], s);
+  red[ig][jl] = s;
+  __syncthreads();
+  if (ig == 0) alpha[j0 + jl] = ((red[0][jl] + red[1][jl]) + red[2][jl]) + red[3][jl];
+}
+
+int launch_trmv(gpbo_ctx* ctx, Model& m) {
+  trmv_lower_kernel<<<dim3((unsigned)((m.NP + 3) / 4)), dim3(256), 0, ctx->stream>>>(m.W, m.yn, m.tvec, m.NP);
+  GPBO_HIP(ctx, hipGetLastError());
+  trmv_lower_t_kernel<<<dim3((unsigned)(m.NP / 64)), dim3(256), 0, ctx->stream>>>(m.W, m.tvec, m.alpha, m.NP);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pack W into the order the posterior kernel's waves consume it: for row slab s (32 rows), k-pair p
+// (8 columns) and 16-row tile t, 64 lanes x 2 doubles contiguous (1 KiB): lane l, element e holds
+// W[32 s + 16 t + (l & 15)][8 p + 4 e + (l >> 4)] — the A fragment of v_mfma_f64_16x16x4_f64 for
+// k-steps 2p and 2p+1.  Entries outside the N x N lower triangle are zero.
+__global__ __launch_bounds__(256) void pack_w_kernel(const double* __restrict__ W,
+                                                     double* __restrict__ Wp, int64_t N, int64_t NP) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= NP * NP) return;
+  const int e = (int)(idx & 1);
+  const int lane = (int)((idx >> 1) & 63);
+  const int t = (int)((idx >> 7) & 1);
+  const int64_t sp = idx >> 8;
+  const int64_t pairs = NP / 8;
+  const int64_t s = sp / pairs, p = sp - s * pairs;
+  const int64_t row = 32 * s + 16 * t + (lane & 15);
+  const int64_t colx = 8 * p + 4 * e + (lane >> 4);
+  double v = 0.0;
+  if (row < N && colx < N && colx <= row) v = W[row * NP + colx];
+  Wp[idx] = v;
+}
+
+int launch_pack_w(gpbo_ctx* ctx, Model& m) {
+  int64_t total = m.NP * m.NP;
+  pack_w_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream>>>(m.W, m.Wp, m.N, m.NP);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+}  // namespace gpbo

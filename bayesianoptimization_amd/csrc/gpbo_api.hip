@@ -1,0 +1,435 @@
+// C-ABI entry points of libgpbo (see include/gpbo.h for the contract and the reference call each
+// function replaces).  Host-side orchestration only: every numeric step is a HIP kernel launched
+// on the context's stream.
+#include <cmath>
+#include <mutex>
+#include <vector>
+
+#include "gpbo_internal.h"
+
+namespace gpbo {
+
+static std::mutex g_err_mu;
+static std::string g_err;
+
+void set_global_error(const std::string& s) {
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  g_err = s;
+}
+
+static int check_slot(gpbo_ctx* ctx, int slot) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  if (slot < 0 || slot >= GPBO_MAX_MODELS) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "slot out of range");
+  return GPBO_OK;
+}
+
+static void free_model(Model& m) {
+  double** ptrs[] = {&m.ls, &m.Xs, &m.K, &m.L, &m.W, &m.Wp, &m.dinv, &m.tmp, &m.yn, &m.tvec, &m.alpha, &m.mu, &m.sd};
+  for (double** p : ptrs) {
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+  }
+  m = Model();
+}
+
+static int alloc_model(gpbo_ctx* ctx, Model& m, int64_t NP, int DP) {
+  if (NP <= m.cap_NP && DP <= m.cap_DP && m.K) return GPBO_OK;
+  double* mu = m.mu; double* sd = m.sd; int64_t cap_M = m.cap_M;   // keep posterior buffers
+  m.mu = m.sd = nullptr;
+  free_model(m);
+  m.mu = mu; m.sd = sd; m.cap_M = cap_M;
+  const size_t sq = (size_t)NP * NP * sizeof(double);
+  const int64_t tmp_elems = std::max<int64_t>(NP * NP / 2, NP * (int64_t)GPBO_MAX_DIM);
+  GPBO_HIP(ctx, hipMalloc((void**)&m.ls, GPBO_MAX_DIM * sizeof(double)));
+  GPBO_HIP(ctx, hipMalloc((void**)&m.Xs, (size_t)NP * DP * sizeof(double)));
+  GPBO_HIP(ctx, hipMalloc((void**)&m.K, sq));
+  GPBO_HIP(ctx, hipMalloc((void**)&m.L, sq));
+  GPBO_HIP(ctx, hipMalloc((void**)&m.W, sq));
+  GPBO_HIP(ctx, hipMalloc((void**)&m.Wp, sq));
+  GPBO_HIP(ctx, hipMalloc((void**)&m.dinv, (size_t)(NP / NB) * NB * NB * sizeof(double)));
+  GPBO_HIP(ctx, hipMalloc((void**)&m.tmp, (size_t)tmp_elems * sizeof(double)));
+  GPBO_HIP(ctx, hipMalloc((void**)&m.yn, (size_t)NP * sizeof(double)));
+  GPBO_HIP(ctx, hipMalloc((void**)&m.tvec, (size_t)NP * sizeof(double)));
+  GPBO_HIP(ctx, hipMalloc((void**)&m.alpha, (size_t)NP * sizeof(double)));
+  m.cap_NP = NP;
+  m.cap_DP = DP;
+  return GPBO_OK;
+}
+
+// Blocked right-looking Cholesky of m.L (lower), NB = 64: diagonal block on one wave, panel and
+// trailing update on the MFMA GEMM.
+static int cholesky(gpbo_ctx* ctx, Model& m) {
+  const int nblk = (int)(m.NP / NB);
+  int rc;
+  for (int kb = 0; kb < nblk; ++kb) {
+    if ((rc = launch_potrf_diag(ctx, m, kb))) return rc;
+    const int rem = (int)(m.NP - (int64_t)(kb + 1) * NB);
+    if (rem == 0) break;
+    double* panel = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)kb * NB;
+    GemmArgs g{};
+    // panel: L21 = A21 * L11^-T  (in place)
+    g.m = rem; g.n = NB; g.k = NB; g.alpha = 1.0; g.beta = 0.0;
+    g.A = panel; g.lda = m.NP; g.strideA = 0;
+    g.B = m.dinv + (int64_t)kb * NB * NB; g.ldb = NB; g.strideB = 0; g.b_trans = 1;
+    g.C = panel; g.ldc = m.NP; g.strideC = 0; g.batch = 1;
+    if ((rc = launch_gemm(ctx, g))) return rc;
+    // trailing: A22 -= L21 L21^T (lower tiles only)
+    GemmArgs s{};
+    s.m = rem; s.n = rem; s.k = NB; s.alpha = -1.0; s.beta = 1.0;
+    s.A = panel; s.lda = m.NP; s.B = panel; s.ldb = m.NP; s.b_trans = 1;
+    s.C = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)(kb + 1) * NB; s.ldc = m.NP;
+    s.batch = 1; s.lower_only = 1;
+    if ((rc = launch_gemm(ctx, s))) return rc;
+  }
+  return GPBO_OK;
+}
+
+// W = L^-1 by recursive doubling from the inverted 64x64 diagonal blocks:
+//   [[A,0],[C,B]]^-1 = [[A^-1,0],[-B^-1 C A^-1, B^-1]]  — two batched GEMMs per level.
+static int trtri(gpbo_ctx* ctx, Model& m) {
+  int rc;
+  if ((rc = launch_fill_w_diag(ctx, m))) return rc;
+  const int64_t NP = m.NP;
+  for (int64_t b = NB; b < NP; b *= 2) {
+    const int64_t full = NP / (2 * b);               // pairs with a full-size second block
+    const int64_t rag = NP - full * 2 * b;           // leftover rows; a ragged pair exists if rag > b
+    for (int part = 0; part < 2; ++part) {
+      int64_t npairs, b2, r0;
+      if (part == 0) { npairs = full; b2 = b; r0 = 0; }
+      else { npairs = (rag > b) ? 1 : 0; b2 = rag - b; r0 = full * 2 * b; }
+      if (npairs == 0) continue;
+      GemmArgs t{};   // T = L21 * W11
+      t.m = (int)b2; t.n = (int)b; t.k = (int)b; t.alpha = 1.0; t.beta = 0.0;
+      t.A = m.L + (r0 + b) * NP + r0; t.lda = NP; t.strideA = 2 * b * NP + 2 * b;
+      t.B = m.W + r0 * NP + r0; t.ldb = NP; t.strideB = 2 * b * NP + 2 * b; t.b_lower = 1;
+      t.C = m.tmp; t.ldc = b; t.strideC = b * b; t.batch = (int)npairs;
+      if ((rc = launch_gemm(ctx, t))) return rc;
+      GemmArgs w{};   // W21 = -W22 * T
+      w.m = (int)b2; w.n = (int)b; w.k = (int)b2; w.alpha = -1.0; w.beta = 0.0;
+      w.A = m.W + (r0 + b) * NP + (r0 + b); w.lda = NP; w.strideA = 2 * b * NP + 2 * b; w.a_lower = 1;
+      w.B = m.tmp; w.ldb = b; w.strideB = b * b;
+      w.C = m.W + (r0 + b) * NP + r0; w.ldc = NP; w.strideC = 2 * b * NP + 2 * b; w.batch = (int)npairs;
+      if ((rc = launch_gemm(ctx, w))) return rc;
+    }
+  }
+  return GPBO_OK;
+}
+
+static int copy_square(gpbo_ctx* ctx, const Model& m, const double* dev, double* out, int mode) {
+  // mode 0: symmetric from lower; 1: lower with zero upper
+  std::vector<double> h((size_t)m.NP * m.NP);
+  GPBO_HIP(ctx, hipMemcpyAsync(h.data(), dev, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int64_t i = 0; i < m.N; ++i)
+    for (int64_t j = 0; j < m.N; ++j) {
+      double v;
+      if (j <= i) v = h[i * m.NP + j];
+      else v = mode == 0 ? h[j * m.NP + i] : 0.0;
+      out[i * m.N + j] = v;
+    }
+  return GPBO_OK;
+}
+
+}  // namespace gpbo
+
+using namespace gpbo;
+
+extern "C" {
+
+int gpbo_abi_version(void) { return GPBO_ABI_VERSION; }
+
+const char* gpbo_last_error(const gpbo_ctx* ctx) {
+  if (ctx) return ctx->err.c_str();
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  static thread_local std::string copy;
+  copy = g_err;
+  return copy.c_str();
+}
+
+int gpbo_device_count(int* count) {
+  if (!count) return GPBO_ERR_INVALID;
+  *count = 0;
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    set_global_error(std::string("hipGetDeviceCount failed: ") + hipGetErrorString(e));
+    return GPBO_ERR_HIP;
+  }
+  return GPBO_OK;
+}
+
+int gpbo_create(int device, gpbo_ctx** out) {
+  if (!out) return GPBO_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  int rc = gpbo_device_count(&n);
+  if (rc) return rc;
+  if (device < 0 || device >= n) GPBO_FAIL((gpbo_ctx*)nullptr, GPBO_ERR_INVALID, "gpbo_create: no such device");
+  gpbo_ctx* ctx = new gpbo_ctx();
+  ctx->device = device;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc((void**)&ctx->info_dev, sizeof(int));
+  if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, 64 * 1024, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    set_global_error(std::string("gpbo_create: ") + hipGetErrorString(e));
+    delete ctx;
+    return GPBO_ERR_HIP;
+  }
+  *out = ctx;
+  return GPBO_OK;
+}
+
+int gpbo_destroy(gpbo_ctx* ctx) {
+  if (!ctx) return GPBO_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  gpbo_comm_destroy(ctx);
+  for (auto& m : ctx->models) free_model(m);
+  void* ptrs[] = {ctx->Xc, ctx->Xcs, ctx->part, ctx->mu_part, ctx->ys, ctx->red, ctx->info_dev, ctx->comm_buf};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  for (auto& e : ctx->ev) {
+    if (e.a) (void)hipEventDestroy(e.a);
+    if (e.b) (void)hipEventDestroy(e.b);
+  }
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return GPBO_OK;
+}
+
+int gpbo_synchronize(gpbo_ctx* ctx) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GPBO_OK;
+}
+
+int gpbo_device_info(gpbo_ctx* ctx, char* buf, int buflen) {
+  if (!ctx || !buf || buflen < 64) return GPBO_ERR_INVALID;
+  hipDeviceProp_t p;
+  GPBO_HIP(ctx, hipGetDeviceProperties(&p, ctx->device));
+  snprintf(buf, buflen,
+           "{\"name\": \"%s\", \"arch\": \"%s\", \"compute_units\": %d, \"clock_mhz\": %d, "
+           "\"memory_clock_mhz\": %d, \"hbm_gib\": %.1f, \"l2_mib\": %.1f, \"lds_per_block_kib\": %.0f}",
+           p.name, p.gcnArchName, p.multiProcessorCount, p.clockRate / 1000, p.memoryClockRate / 1000,
+           (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), (double)p.l2CacheSize / (1024.0 * 1024.0),
+           (double)p.sharedMemPerBlock / 1024.0);
+  return GPBO_OK;
+}
+
+int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d,
+             int kernel, const double* length_scale, int n_ls, double noise, int precision,
+             int* info) {
+  int rc = check_slot(ctx, slot);
+  if (rc) return rc;
+  if (info) *info = 0;
+  if (!X || !y_norm || !length_scale) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit: NULL input");
+  if (N < 1 || N > (1 << 16)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit: N out of range [1, 65536]");
+  if (d < 1 || d > GPBO_MAX_DIM) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "gpbo_fit: d out of range [1, 64]");
+  if (kernel != GPBO_KERNEL_RBF && kernel != GPBO_KERNEL_MATERN25)
+    GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "gpbo_fit: kernel must be RBF or Matern(nu=2.5)");
+  if (n_ls != 1 && n_ls != d) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit: length_scale must have 1 or d entries");
+  if (precision != GPBO_F64) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "gpbo_fit: only float64 arithmetic is implemented");
+  for (int t = 0; t < n_ls; ++t)
+    if (!(length_scale[t] > 0.0) || !std::isfinite(length_scale[t]))
+      GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit: length_scale must be positive and finite");
+  if (!(noise >= 0.0)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit: noise must be >= 0");
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+
+  Model& m = ctx->models[slot];
+  m.fitted = false;
+  m.M_post = -1;
+  const int64_t NP = round_up(N, NB);
+  const int DP = pad_dim(d);
+  if ((rc = alloc_model(ctx, m, NP, DP))) return rc;
+  m.N = N; m.NP = NP; m.d = d; m.DP = DP; m.kernel = kernel; m.precision = precision;
+
+  ev_begin(ctx, T_FIT);
+  // inputs -> device
+  double* ls_h = (double*)ctx->pinned;
+  for (int t = 0; t < GPBO_MAX_DIM; ++t) ls_h[t] = (t < d) ? (n_ls == 1 ? length_scale[0] : length_scale[t]) : 1.0;
+  GPBO_HIP(ctx, hipMemcpyAsync(m.ls, ls_h, GPBO_MAX_DIM * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  GPBO_HIP(ctx, hipMemcpyAsync(m.tmp, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  GPBO_HIP(ctx, hipMemsetAsync(m.yn, 0, (size_t)NP * sizeof(double), ctx->stream));
+  GPBO_HIP(ctx, hipMemcpyAsync(m.yn, y_norm, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  GPBO_HIP(ctx, hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream));
+  if ((rc = launch_prescale(ctx, m.tmp, N, d, DP, m.ls, m.Xs, NP))) return rc;
+  // K
+  ev_begin(ctx, T_KMAT);
+  if ((rc = launch_kmat(ctx, m, noise))) return rc;
+  ev_end(ctx, T_KMAT);
+  GPBO_HIP(ctx, hipMemcpyAsync(m.L, m.K, (size_t)NP * NP * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  // L
+  ev_begin(ctx, T_CHOL);
+  if ((rc = cholesky(ctx, m))) return rc;
+  ev_end(ctx, T_CHOL);
+  int* info_h = (int*)((char*)ctx->pinned + 1024);
+  GPBO_HIP(ctx, hipMemcpyAsync(info_h, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  // W, alpha, packed W (issued before the info check resolves; harmless on failure)
+  ev_begin(ctx, T_TRTRI);
+  if ((rc = trtri(ctx, m))) return rc;
+  ev_end(ctx, T_TRTRI);
+  if ((rc = launch_trmv(ctx, m))) return rc;
+  if ((rc = launch_pack_w(ctx, m))) return rc;
+  ev_end(ctx, T_FIT);
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (*info_h != 0) {
+    if (info) *info = *info_h;
+    char b[160];
+    snprintf(b, sizeof(b), "the kernel matrix is not positive definite: leading minor of order %d", *info_h);
+    GPBO_FAIL(ctx, GPBO_ERR_NOT_PD, b);
+  }
+  m.fitted = true;
+  return GPBO_OK;
+}
+
+static int need_fitted(gpbo_ctx* ctx, int slot) {
+  int rc = check_slot(ctx, slot);
+  if (rc) return rc;
+  if (!ctx->models[slot].fitted) GPBO_FAIL(ctx, GPBO_ERR_STATE, "model slot has not been fitted");
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  return GPBO_OK;
+}
+
+int gpbo_get_K(gpbo_ctx* ctx, int slot, double* out) {
+  int rc = need_fitted(ctx, slot);
+  if (rc) return rc;
+  return copy_square(ctx, ctx->models[slot], ctx->models[slot].K, out, 0);
+}
+int gpbo_get_L(gpbo_ctx* ctx, int slot, double* out) {
+  int rc = need_fitted(ctx, slot);
+  if (rc) return rc;
+  return copy_square(ctx, ctx->models[slot], ctx->models[slot].L, out, 1);
+}
+int gpbo_get_Linv(gpbo_ctx* ctx, int slot, double* out) {
+  int rc = need_fitted(ctx, slot);
+  if (rc) return rc;
+  return copy_square(ctx, ctx->models[slot], ctx->models[slot].W, out, 1);
+}
+int gpbo_get_alpha(gpbo_ctx* ctx, int slot, double* out) {
+  int rc = need_fitted(ctx, slot);
+  if (rc) return rc;
+  Model& m = ctx->models[slot];
+  GPBO_HIP(ctx, hipMemcpyAsync(out, m.alpha, (size_t)m.N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GPBO_OK;
+}
+
+int gpbo_set_candidates(gpbo_ctx* ctx, const double* Xc, int64_t M, int d) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  if (!Xc || M < 1 || d < 1 || d > GPBO_MAX_DIM) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "set_candidates: bad arguments");
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, &ctx->Xc, &ctx->cap_Xc, M * d))) return rc;
+  GPBO_HIP(ctx, hipMemcpyAsync(ctx->Xc, Xc, (size_t)M * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->M = M;
+  ctx->d_c = d;
+  for (auto& m : ctx->models) m.M_post = -1;
+  return GPBO_OK;
+}
+
+int gpbo_posterior(gpbo_ctx* ctx, int slot, double y_mean, double y_std, double* mu, double* sd) {
+  int rc = need_fitted(ctx, slot);
+  if (rc) return rc;
+  Model& m = ctx->models[slot];
+  if (ctx->M < 1) GPBO_FAIL(ctx, GPBO_ERR_STATE, "posterior: no candidates resident (call gpbo_set_candidates)");
+  if (ctx->d_c != m.d) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "posterior: candidate dimension differs from the fitted model");
+  if ((rc = launch_posterior(ctx, m, ctx->M, y_mean, y_std))) return rc;
+  if (mu) GPBO_HIP(ctx, hipMemcpyAsync(mu, m.mu, (size_t)ctx->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (sd) GPBO_HIP(ctx, hipMemcpyAsync(sd, m.sd, (size_t)ctx->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (mu || sd) GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GPBO_OK;
+}
+
+int gpbo_predict(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d, double y_mean,
+                 double y_std, double* mu, double* sd) {
+  int rc = gpbo_set_candidates(ctx, Xc, M, d);
+  if (rc) return rc;
+  return gpbo_posterior(ctx, slot, y_mean, y_std, mu, sd);
+}
+
+int gpbo_acq_argbest(gpbo_ctx* ctx, int acq, double acq_param, double y_max, int n_constraints,
+                     const double* lb, const double* ub, int k_seeds, int64_t index_offset,
+                     int64_t* best_idx, double* best_val, int64_t* seed_idx, double* seed_val,
+                     double* ys_out) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  if (acq < GPBO_ACQ_UCB || acq > GPBO_ACQ_POI) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "acq_argbest: unknown acquisition");
+  if (n_constraints < 0 || n_constraints >= GPBO_MAX_MODELS) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "acq_argbest: bad n_constraints");
+  if (n_constraints > 0 && (!lb || !ub)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "acq_argbest: lb/ub required");
+  if (k_seeds < 0 || k_seeds > GPBO_MAX_SEEDS) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "acq_argbest: k_seeds out of range [0, 64]");
+  if (!best_idx || !best_val || (k_seeds > 0 && (!seed_idx || !seed_val)))
+    GPBO_FAIL(ctx, GPBO_ERR_INVALID, "acq_argbest: NULL output");
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  AcqArgs a{};
+  a.acq = acq; a.param = acq_param; a.y_max = y_max; a.n_constraints = n_constraints;
+  for (int j = 0; j <= n_constraints; ++j) {
+    Model& m = ctx->models[j];
+    if (!m.fitted || m.M_post != ctx->M || ctx->M < 1)
+      GPBO_FAIL(ctx, GPBO_ERR_STATE, "acq_argbest: run gpbo_posterior for slots 0..n_constraints first");
+    a.mu[j] = m.mu;
+    a.sd[j] = m.sd;
+  }
+  for (int j = 0; j < n_constraints; ++j) { a.lb[j] = lb[j]; a.ub[j] = ub[j]; }
+  ev_begin(ctx, T_ACQ);
+  int rc = launch_acq_argbest(ctx, a, ctx->M, k_seeds, index_offset, best_idx, best_val, seed_idx, seed_val);
+  ev_end(ctx, T_ACQ);
+  if (rc) return rc;
+  if (ys_out) {
+    GPBO_HIP(ctx, hipMemcpyAsync(ys_out, ctx->ys, (size_t)ctx->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return GPBO_OK;
+}
+
+int gpbo_last_timings(gpbo_ctx* ctx, float* ms, int n) {
+  if (!ctx || !ms) return GPBO_ERR_INVALID;
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < n; ++i) {
+    ms[i] = -1.f;
+    if (i < T_COUNT && ctx->ev[i].used) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, ctx->ev[i].a, ctx->ev[i].b) == hipSuccess) ms[i] = t;
+    }
+  }
+  return GPBO_OK;
+}
+
+int gpbo_debug_gemm(gpbo_ctx* ctx, int m, int n, int k, double alpha, const double* A,
+                    const double* B, int b_trans, double beta, double* C) {
+  if (!ctx || !A || !B || !C) return GPBO_ERR_INVALID;
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  GPBO_HIP(ctx, hipMalloc((void**)&dA, (size_t)m * k * 8));
+  GPBO_HIP(ctx, hipMalloc((void**)&dB, (size_t)n * k * 8));
+  GPBO_HIP(ctx, hipMalloc((void**)&dC, (size_t)m * n * 8));
+  GPBO_HIP(ctx, hipMemcpy(dA, A, (size_t)m * k * 8, hipMemcpyHostToDevice));
+  GPBO_HIP(ctx, hipMemcpy(dB, B, (size_t)n * k * 8, hipMemcpyHostToDevice));
+  GPBO_HIP(ctx, hipMemcpy(dC, C, (size_t)m * n * 8, hipMemcpyHostToDevice));
+  GemmArgs g{};
+  g.m = m; g.n = n; g.k = k; g.alpha = alpha; g.beta = beta;
+  g.A = dA; g.lda = k; g.B = dB; g.ldb = b_trans ? k : n; g.b_trans = b_trans;
+  g.C = dC; g.ldc = n; g.batch = 1;
+  int rc = launch_gemm(ctx, g);
+  if (!rc) {
+    GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GPBO_HIP(ctx, hipMemcpy(C, dC, (size_t)m * n * 8, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+  return rc;
+}
+
+int gpbo_mfma_f64_peak(gpbo_ctx* ctx, int iters, double* tflops) {
+  if (!ctx || !tflops || iters < 1) return GPBO_ERR_INVALID;
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  return run_mfma_peak(ctx, iters, tflops);
+}
+
+int gpbo_hbm_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps) {
+  if (!ctx || !gbps || bytes < (1 << 20)) return GPBO_ERR_INVALID;
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  return run_copy_peak(ctx, bytes, gbps);
+}
+
+}  // extern "C"

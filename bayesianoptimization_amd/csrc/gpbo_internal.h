@@ -1,0 +1,178 @@
+// Internal declarations shared by the HIP translation units of libgpbo (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "gpbo.h"
+
+namespace gpbo {
+
+constexpr int NB = 64;          // Cholesky / inverse block size (one MFMA GEMM tile edge)
+constexpr int POST_ROWS = 256;  // W rows owned by one posterior workgroup (8 waves x 32 rows)
+constexpr int POST_CANDS = 128; // candidates owned by one posterior workgroup
+constexpr int POST_BK = 16;     // train points (k) generated per LDS stage
+constexpr int KS_STRIDE = 144;  // doubles per k-row of the k* stage tile (128 + 16: 32-bank skew)
+
+enum TimingSlot {
+  T_FIT = 0, T_POST_MAIN = 1, T_POST_FINAL = 2, T_ACQ = 3, T_KMAT = 4, T_CHOL = 5, T_TRTRI = 6, T_COUNT = 8
+};
+
+struct Model {
+  bool fitted = false;
+  int64_t N = 0, NP = 0;   // observations, padded to a multiple of NB
+  int d = 0, DP = 0;       // input dimension, padded to {4,8,16,32,64}
+  int kernel = 0;
+  int precision = 0;
+  int64_t cap_NP = 0;      // allocated capacity (NP) of the square buffers
+  int cap_DP = 0;
+  double* ls = nullptr;    // [GPBO_MAX_DIM] length scale per dimension (device)
+  double* Xs = nullptr;    // [NP][DP] train points / length_scale, zero padded
+  double* K = nullptr;     // [NP][NP] kernel matrix + noise (lower triangle valid)
+  double* L = nullptr;     // [NP][NP] Cholesky factor (lower triangle valid)
+  double* W = nullptr;     // [NP][NP] L^-1 (upper triangle zero)
+  double* Wp = nullptr;    // NP*NP doubles, MFMA-fragment packed W for the posterior kernel
+  double* dinv = nullptr;  // [NP/NB][NB][NB] inverses of the diagonal blocks of L
+  double* tmp = nullptr;   // NP*NP/2 doubles workspace (trtri)
+  double* yn = nullptr;    // [NP] normalised targets, zero padded
+  double* tvec = nullptr;  // [NP] W*y
+  double* alpha = nullptr; // [NP]
+  // posterior outputs for the resident candidates
+  double* mu = nullptr;
+  double* sd = nullptr;
+  int64_t cap_M = 0;
+  int64_t M_post = -1;     // number of candidates mu/sd are valid for (-1: none)
+};
+
+struct EventPair {
+  hipEvent_t a = nullptr, b = nullptr;
+  bool used = false;
+};
+
+}  // namespace gpbo
+
+struct gpbo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  gpbo::Model models[GPBO_MAX_MODELS];
+  // candidates
+  double* Xc = nullptr;    // [M][d] raw
+  int64_t cap_Xc = 0;      // capacity in doubles
+  int64_t M = 0;
+  int d_c = 0;
+  double* Xcs = nullptr;   // [Mp][DP] scaled/padded workspace
+  int64_t cap_Xcs = 0;
+  double* part = nullptr;  // [nchunks][Mp] partial |W k*|^2
+  int64_t cap_part = 0;
+  double* mu_part = nullptr;  // [Mp]
+  int64_t cap_mu_part = 0;
+  double* ys = nullptr;    // [M] negated acquisition values
+  int64_t cap_ys = 0;
+  void* red = nullptr;     // reduction scratch
+  int64_t cap_red = 0;
+  int* info_dev = nullptr; // potrf info word
+  void* pinned = nullptr;  // small pinned host staging buffer
+  gpbo::EventPair ev[gpbo::T_COUNT];
+  // RCCL
+  void* comm = nullptr;
+  int world = 1, rank = 0;
+  void* comm_buf = nullptr;
+  int64_t cap_comm_buf = 0;
+};
+
+namespace gpbo {
+
+void set_global_error(const std::string& s);
+
+#define GPBO_HIP(ctx, expr)                                                                  \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      char _b[512];                                                                          \
+      snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),        \
+               __FILE__, __LINE__);                                                          \
+      if (ctx) (ctx)->err = _b;                                                              \
+      gpbo::set_global_error(_b);                                                            \
+      return GPBO_ERR_HIP;                                                                   \
+    }                                                                                        \
+  } while (0)
+
+#define GPBO_FAIL(ctx, code, msg)                                                            \
+  do {                                                                                       \
+    if (ctx) (ctx)->err = (msg);                                                             \
+    gpbo::set_global_error(msg);                                                             \
+    return (code);                                                                           \
+  } while (0)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+inline int pad_dim(int d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : 64; }
+
+template <typename T>
+int ensure(gpbo_ctx* ctx, T** p, int64_t* cap, int64_t need) {
+  if (need <= *cap && *p) return GPBO_OK;
+  if (*p) {
+    GPBO_HIP(ctx, hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+  }
+  void* q = nullptr;
+  GPBO_HIP(ctx, hipMalloc(&q, (size_t)need * sizeof(T)));
+  *p = (T*)q;
+  *cap = need;
+  return GPBO_OK;
+}
+
+// ---- launchers implemented in the kernel translation units ---------------------------------
+// fit_kernels.hip
+int launch_prescale(gpbo_ctx* ctx, const double* X, int64_t n, int d, int DP, const double* ls,
+                    double* out, int64_t n_pad);
+int launch_kmat(gpbo_ctx* ctx, Model& m, double noise);
+int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb);
+int launch_fill_w_diag(gpbo_ctx* ctx, Model& m);
+int launch_trmv(gpbo_ctx* ctx, Model& m);
+int launch_pack_w(gpbo_ctx* ctx, Model& m);
+struct GemmArgs {
+  int m, n, k;            // multiples of 64 / 64 / 16
+  double alpha, beta;
+  const double* A; int64_t lda; int64_t strideA;
+  const double* B; int64_t ldb; int64_t strideB;
+  double* C; int64_t ldc; int64_t strideC;
+  int batch;
+  int b_trans;            // B given as (n,k) row-major
+  int lower_only;         // skip output tiles strictly above the diagonal (m == n)
+  int a_lower;            // A is lower triangular (k == m): k-loop stops at the row tile's diagonal
+  int b_lower;            // B is lower triangular (k == n, not transposed): k-loop starts at the column tile
+};
+int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g);
+// posterior_kernel.hip
+int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std);
+// acq_kernels.hip
+struct AcqArgs {
+  int acq; double param; double y_max; int n_constraints;
+  double lb[GPBO_MAX_MODELS]; double ub[GPBO_MAX_MODELS];
+  const double* mu[GPBO_MAX_MODELS]; const double* sd[GPBO_MAX_MODELS];
+};
+int launch_acq_argbest(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, int64_t offset,
+                       int64_t* best_idx, double* best_val, int64_t* seed_idx, double* seed_val);
+// probe.hip
+int run_mfma_peak(gpbo_ctx* ctx, int iters, double* tflops);
+int run_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);
+
+inline void ev_begin(gpbo_ctx* ctx, int slot) {
+  EventPair& e = ctx->ev[slot];
+  if (!e.a) { (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); }
+  (void)hipEventRecord(e.a, ctx->stream);
+  e.used = false;
+}
+inline void ev_end(gpbo_ctx* ctx, int slot) {
+  EventPair& e = ctx->ev[slot];
+  (void)hipEventRecord(e.b, ctx->stream);
+  e.used = true;
+}
+
+}  // namespace gpbo

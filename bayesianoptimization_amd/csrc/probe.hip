@@ -1,0 +1,79 @@
+// Device micro-benchmarks: calibrate the two ceilings the roofline numbers are quoted against.
+//   mfma_f64_peak : sustained v_mfma_f64_16x16x4_f64 rate (TFLOP/s) — the fp64 matrix peak is not in
+//                   MI355X_MICROARCH.md, so it is measured next to AMD's 78.6 TFLOP/s datasheet figure.
+//   hbm_copy_peak : streaming copy bandwidth (GB/s, read + write), cf. 6.29 TB/s measured in the guide.
+#include "gpbo_internal.h"
+
+namespace gpbo {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) {
+  d4 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+  const double a = 1.0 + threadIdx.x * 1e-6, b = 0.5 - threadIdx.x * 1e-6;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+  out[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+int run_mfma_peak(gpbo_ctx* ctx, int iters, double* tflops) {
+  const int grid = 256 * 2;  // 2 workgroups of 4 waves per CU -> 2 waves per SIMD
+  double* out = nullptr;
+  GPBO_HIP(ctx, hipMalloc((void**)&out, (size_t)grid * 256 * sizeof(double)));
+  hipEvent_t e0, e1;
+  GPBO_HIP(ctx, hipEventCreate(&e0));
+  GPBO_HIP(ctx, hipEventCreate(&e1));
+  mfma_peak_kernel<<<dim3(grid), dim3(256), 0, ctx->stream>>>(out, 16);  // warm-up
+  GPBO_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  mfma_peak_kernel<<<dim3(grid), dim3(256), 0, ctx->stream>>>(out, iters);
+  GPBO_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  GPBO_HIP(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  GPBO_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)grid * 4.0 * (double)iters * 8.0 * 2048.0;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  GPBO_HIP(ctx, hipFree(out));
+  return GPBO_OK;
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(const double2* __restrict__ in, double2* __restrict__ out, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < n; i += stride) out[i] = in[i];
+}
+
+int run_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps) {
+  const int64_t n = bytes / 16;
+  double2 *a = nullptr, *b = nullptr;
+  GPBO_HIP(ctx, hipMalloc((void**)&a, (size_t)n * 16));
+  GPBO_HIP(ctx, hipMalloc((void**)&b, (size_t)n * 16));
+  GPBO_HIP(ctx, hipMemsetAsync(a, 1, (size_t)n * 16, ctx->stream));
+  hipEvent_t e0, e1;
+  GPBO_HIP(ctx, hipEventCreate(&e0));
+  GPBO_HIP(ctx, hipEventCreate(&e1));
+  copy_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>(a, b, n);
+  GPBO_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  const int reps = 5;
+  for (int r = 0; r < reps; ++r) copy_kernel<<<dim3(2048), dim3(256), 0, ctx->stream>>>(a, b, n);
+  GPBO_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  GPBO_HIP(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  GPBO_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  *gbps = 2.0 * (double)n * 16.0 * reps / (ms * 1e-3) / 1e9;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  GPBO_HIP(ctx, hipFree(a));
+  GPBO_HIP(ctx, hipFree(b));
+  return GPBO_OK;
+}
+
+}  // namespace gpbo

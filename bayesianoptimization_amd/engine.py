@@ -1,0 +1,189 @@
+"""GpEngine — thin Python owner of one libgpbo context (one GPU, one HIP stream).
+
+Slot 0 holds the target GP, slots 1.. the constraint GPs; the candidate matrix is uploaded once and
+stays resident in HBM across posterior / acquisition calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+
+import numpy as np
+
+from . import _lib
+from ._lib import dptr, iptr
+
+RBF, MATERN25 = 0, 1
+UCB, EI, POI = 0, 1, 2
+F64, F32 = 0, 1
+
+TIMING_NAMES = ("fit", "posterior_main", "posterior_finalize", "acq_argbest", "kmat", "cholesky", "trtri")
+
+
+class GpEngine:
+    def __init__(self, device: int = 0):
+        self._lib = _lib.load_library()
+        h = C.c_void_p()
+        rc = self._lib.gpbo_create(int(device), C.byref(h))
+        if rc != _lib.GPBO_OK:
+            _lib.raise_for_status(self._lib, None, rc)
+        self._h = h
+        self.device = int(device)
+        self.n_candidates = 0
+        self.world_size = 1
+        self.rank = 0
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpbo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, info=0):
+        if rc != _lib.GPBO_OK:
+            _lib.raise_for_status(self._lib, self._h, rc, info)
+
+    def synchronize(self):
+        self._check(self._lib.gpbo_synchronize(self._h))
+
+    def device_info(self) -> dict:
+        buf = C.create_string_buffer(1024)
+        self._check(self._lib.gpbo_device_info(self._h, buf, 1024))
+        return json.loads(buf.value.decode())
+
+    # -- fit ---------------------------------------------------------------------------------
+    def fit(self, X, y_norm, kernel: int, length_scale, noise: float, slot: int = 0, precision: int = F64):
+        """K + noise*I -> L, W = L^-1, alpha, at fixed theta (sklearn _gpr.py:346-364)."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        if X.ndim != 2:
+            raise ValueError("X must be 2-D (n_samples, n_features)")
+        y_norm = np.ascontiguousarray(y_norm, dtype=np.float64).ravel()
+        if y_norm.shape[0] != X.shape[0]:
+            raise ValueError("X and y have inconsistent numbers of samples")
+        ls = np.ascontiguousarray(np.atleast_1d(np.asarray(length_scale, dtype=np.float64)))
+        info = C.c_int(0)
+        rc = self._lib.gpbo_fit(self._h, int(slot), dptr(X), dptr(y_norm), X.shape[0], X.shape[1], int(kernel),
+                                dptr(ls), int(ls.shape[0]), float(noise), int(precision), C.byref(info))
+        self._check(rc, info.value)
+
+    def _square(self, fn, slot, n):
+        out = np.empty((n, n), dtype=np.float64)
+        self._check(fn(self._h, int(slot), dptr(out)))
+        return out
+
+    def get_K(self, n, slot=0):
+        return self._square(self._lib.gpbo_get_K, slot, n)
+
+    def get_L(self, n, slot=0):
+        return self._square(self._lib.gpbo_get_L, slot, n)
+
+    def get_Linv(self, n, slot=0):
+        return self._square(self._lib.gpbo_get_Linv, slot, n)
+
+    def get_alpha(self, n, slot=0):
+        out = np.empty(n, dtype=np.float64)
+        self._check(self._lib.gpbo_get_alpha(self._h, int(slot), dptr(out)))
+        return out
+
+    # -- candidates / posterior ------------------------------------------------------------------
+    def set_candidates(self, Xc):
+        Xc = np.ascontiguousarray(Xc, dtype=np.float64)
+        if Xc.ndim != 2:
+            raise ValueError("candidates must be 2-D (M, d)")
+        self._check(self._lib.gpbo_set_candidates(self._h, dptr(Xc), Xc.shape[0], Xc.shape[1]))
+        self.n_candidates = Xc.shape[0]
+
+    def posterior(self, slot=0, y_mean=0.0, y_std=1.0, fetch=True):
+        """mu, sd for the resident candidates (sklearn _gpr.py:443-494). fetch=False keeps them on device."""
+        M = self.n_candidates
+        mu = np.empty(M) if fetch else None
+        sd = np.empty(M) if fetch else None
+        self._check(self._lib.gpbo_posterior(self._h, int(slot), float(y_mean), float(y_std), dptr(mu), dptr(sd)))
+        return mu, sd
+
+    def predict(self, Xc, slot=0, y_mean=0.0, y_std=1.0):
+        self.set_candidates(Xc)
+        return self.posterior(slot, y_mean, y_std, fetch=True)
+
+    # -- acquisition -----------------------------------------------------------------------------
+    def acq_argbest(self, acq: int, param: float, y_max: float = 0.0, lb=None, ub=None, k_seeds: int = 0,
+                    index_offset: int = 0, return_values: bool = False):
+        """ys = -acq [* p_c]; returns (best_idx, best_val, seed_idx, seed_val, ys|None)."""
+        lb = np.ascontiguousarray(np.atleast_1d(np.asarray(lb, dtype=np.float64))) if lb is not None else None
+        ub = np.ascontiguousarray(np.atleast_1d(np.asarray(ub, dtype=np.float64))) if ub is not None else None
+        n_c = 0 if lb is None else lb.shape[0]
+        if n_c and (ub is None or ub.shape[0] != n_c):
+            raise ValueError("lb and ub must have the same length")
+        best_idx, best_val = C.c_int64(0), C.c_double(0.0)
+        seed_idx = np.full(max(k_seeds, 1), -1, dtype=np.int64)
+        seed_val = np.full(max(k_seeds, 1), np.nan)
+        ys = np.empty(self.n_candidates) if return_values else None
+        rc = self._lib.gpbo_acq_argbest(self._h, int(acq), float(param), float(y_max if y_max is not None else 0.0),
+                                        n_c, dptr(lb), dptr(ub), int(k_seeds), int(index_offset),
+                                        C.byref(best_idx), C.byref(best_val), iptr(seed_idx), dptr(seed_val),
+                                        dptr(ys))
+        self._check(rc)
+        return best_idx.value, best_val.value, seed_idx[:k_seeds], seed_val[:k_seeds], ys
+
+    # -- timing / probes ---------------------------------------------------------------------------
+    def last_timings(self) -> dict:
+        ms = (C.c_float * 8)()
+        self._check(self._lib.gpbo_last_timings(self._h, ms, 8))
+        return {n: float(ms[i]) for i, n in enumerate(TIMING_NAMES)}
+
+    def debug_gemm(self, A, B, C_in=None, alpha=1.0, beta=0.0, b_trans=False):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        B = np.ascontiguousarray(B, dtype=np.float64)
+        m, k = A.shape
+        n = B.shape[0] if b_trans else B.shape[1]
+        Cm = np.zeros((m, n)) if C_in is None else np.ascontiguousarray(C_in, dtype=np.float64).copy()
+        self._check(self._lib.gpbo_debug_gemm(self._h, m, n, k, float(alpha), dptr(A), dptr(B), int(b_trans),
+                                              float(beta), dptr(Cm)))
+        return Cm
+
+    def mfma_f64_peak(self, iters=20000) -> float:
+        out = C.c_double(0.0)
+        self._check(self._lib.gpbo_mfma_f64_peak(self._h, int(iters), C.byref(out)))
+        return out.value
+
+    def hbm_copy_peak(self, nbytes=1 << 30) -> float:
+        out = C.c_double(0.0)
+        self._check(self._lib.gpbo_hbm_copy_peak(self._h, int(nbytes), C.byref(out)))
+        return out.value
+
+    # -- RCCL ----------------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        lib = _lib.load_library()
+        buf = C.create_string_buffer(128)
+        rc = lib.gpbo_comm_unique_id(buf)
+        if rc != _lib.GPBO_OK:
+            _lib.raise_for_status(lib, None, rc)
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, world_size: int, rank: int):
+        assert len(unique_id) == 128
+        self._check(self._lib.gpbo_comm_init(self._h, unique_id, int(world_size), int(rank)))
+        self.world_size, self.rank = int(world_size), int(rank)
+
+    def comm_allgather_best(self, vals, idxs):
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        idxs = np.ascontiguousarray(idxs, dtype=np.int64)
+        n = vals.shape[0]
+        all_vals = np.empty(n * self.world_size)
+        all_idxs = np.empty(n * self.world_size, dtype=np.int64)
+        self._check(self._lib.gpbo_comm_allgather_best(self._h, dptr(vals), iptr(idxs), n, dptr(all_vals),
+                                                       iptr(all_idxs)))
+        return all_vals, all_idxs

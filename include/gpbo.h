@@ -1,0 +1,141 @@
+/* gpbo.h — C ABI of the MI355X (gfx950) GP-posterior + acquisition engine.
+ *
+ * This is the drop-in boundary (seam B3).  The reference (bayes_opt 3.3.0) is pure
+ * Python and has no FFI of its own: the arithmetic on its suggest() hot path is delegated to
+ * scikit-learn / SciPy.  Each entry point below replaces the call named beside it, so that a
+ * maintainer binds it with ctypes behind the reference's two Python seams —
+ * the sklearn estimator duck type of `optimizer._gp` and `AcquisitionFunction` subclassing.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every function returns an int status: 0 = GPBO_OK, negative = error (see enum); the message is
+ *     available from gpbo_last_error(ctx) (ctx may be NULL for creation errors).
+ *   - host buffers are caller-owned, C-contiguous, borrowed for the duration of the call only.
+ *   - device memory is owned by the context; one HIP stream per context; a context is not
+ *     thread-safe (distinct contexts may be used from distinct threads).
+ *   - all matrices crossing the ABI are row-major float64 (the reference is float64 throughout,
+ *     bayes_opt/target_space.py:95-96); `precision` selects the on-device arithmetic.
+ *   - determinism: fixed reduction trees; arg-best ties -> lowest index; NaN -> first NaN wins
+ *     (numpy argmin semantics, bayes_opt/acquisition.py:313).
+ */
+#ifndef GPBO_H
+#define GPBO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPBO_ABI_VERSION 1
+
+enum gpbo_status {
+  GPBO_OK = 0,
+  GPBO_ERR_INVALID = -1,      /* bad argument (shape, enum, NULL)                    -> ValueError   */
+  GPBO_ERR_HIP = -2,          /* HIP runtime failure (no device, OOM, launch error)  -> RuntimeError */
+  GPBO_ERR_NOT_PD = -3,       /* K + noise*I not positive definite (see `info`)      -> LinAlgError  */
+  GPBO_ERR_STATE = -4,        /* call order (predict before fit, no candidates ...)  -> RuntimeError */
+  GPBO_ERR_UNSUPPORTED = -5,  /* kernel/precision/size outside the HIP path          -> NotImplementedError */
+  GPBO_ERR_COMM = -6          /* RCCL failure                                        -> RuntimeError */
+};
+
+enum gpbo_kernel { GPBO_KERNEL_RBF = 0, GPBO_KERNEL_MATERN25 = 1 };
+enum gpbo_acq { GPBO_ACQ_UCB = 0, GPBO_ACQ_EI = 1, GPBO_ACQ_POI = 2 };
+enum gpbo_precision { GPBO_F64 = 0, GPBO_F32 = 1 };
+
+#define GPBO_MAX_MODELS 8   /* slot 0 = target GP, slots 1.. = constraint GPs */
+#define GPBO_MAX_DIM 64
+#define GPBO_MAX_SEEDS 64
+
+typedef struct gpbo_ctx gpbo_ctx;
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+int gpbo_abi_version(void);
+int gpbo_device_count(int* count);
+int gpbo_create(int device, gpbo_ctx** out);
+int gpbo_destroy(gpbo_ctx* ctx);
+const char* gpbo_last_error(const gpbo_ctx* ctx);
+int gpbo_synchronize(gpbo_ctx* ctx);
+/* Device properties as a JSON string (name, CUs, clocks, memory) for bench/profile headers. */
+int gpbo_device_info(gpbo_ctx* ctx, char* buf, int buflen);
+
+/* ---- fit at fixed theta ----------------------------------------------------------------- */
+/* Replaces the tail of GaussianProcessRegressor.fit (sklearn/gaussian_process/_gpr.py:346-364,
+ * called from bayes_opt/acquisition.py:84 and bayes_opt/constraint.py:148,151):
+ *   K = k(X/ls, X/ls) + noise*I   (Matern-2.5: kernels.py:1711-1738; RBF: kernels.py:1556-1565)
+ *   L = cholesky(K, lower)        (_gpr.py:349)
+ *   alpha = cho_solve(L, y_norm)  (_gpr.py:360-364)
+ * and additionally forms W = L^-1, the operator the posterior kernel applies to k*.
+ * X: (N,d) row-major; y_norm: (N,) already normalised by the caller (_gpr.py:272-277);
+ * length_scale: n_ls == 1 (isotropic) or n_ls == d (anisotropic).
+ * On GPBO_ERR_NOT_PD, *info = 1-based index of the first non-positive pivot (LAPACK potrf info). */
+int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d,
+             int kernel, const double* length_scale, int n_ls, double noise, int precision,
+             int* info);
+
+/* Parity accessors (tests): copy device state back as (N,N) row-major / (N,) float64. */
+int gpbo_get_K(gpbo_ctx* ctx, int slot, double* out);      /* kernel matrix incl. noise, full symmetric */
+int gpbo_get_L(gpbo_ctx* ctx, int slot, double* out);      /* lower Cholesky factor, upper zeroed (gp.L_) */
+int gpbo_get_Linv(gpbo_ctx* ctx, int slot, double* out);   /* W = L^-1, lower */
+int gpbo_get_alpha(gpbo_ctx* ctx, int slot, double* out);  /* gp.alpha_ */
+
+/* ---- candidates ------------------------------------------------------------------------- */
+/* Upload the candidate matrix x_tries (M,d) row-major (bayes_opt/acquisition.py:311,
+ * TargetSpace.random_sample target_space.py:565-603) and keep it resident in HBM. */
+int gpbo_set_candidates(gpbo_ctx* ctx, const double* Xc, int64_t M, int d);
+
+/* ---- posterior -------------------------------------------------------------------------- */
+/* Replaces GaussianProcessRegressor.predict(X, return_std=True) (_gpr.py:443-494; called from
+ * bayes_opt/acquisition.py:205,216 and bayes_opt/constraint.py:200,213) for the resident
+ * candidates: mu = y_std * (k* . alpha) + y_mean ; sd = sqrt(max(1 - |W k*|^2, 0) * y_std^2).
+ * mu / sd may be NULL (results stay on the device for gpbo_acq_argbest). */
+int gpbo_posterior(gpbo_ctx* ctx, int slot, double y_mean, double y_std, double* mu, double* sd);
+
+/* Convenience: set_candidates + posterior for a host batch (the HipGPR.predict path). */
+int gpbo_predict(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d, double y_mean,
+                 double y_std, double* mu, double* sd);
+
+/* ---- acquisition + arg-best ------------------------------------------------------------- */
+/* Replaces the _get_acq closure + base_acq + argmin/min/argsort[:k]
+ * (bayes_opt/acquisition.py:198-217, 485, 660-661, 847-849, 312-317) and, when n_constraints > 0,
+ * ConstraintModel.predict (bayes_opt/constraint.py:199-221) over the resident candidates, using
+ * the posteriors left on the device by gpbo_posterior for slots 0..n_constraints:
+ *   ys = -1 * base_acq(mu0, sd0) [* prod_j (Phi((ub_j-mu_j)/sd_j) - Phi((lb_j-mu_j)/sd_j))]
+ * acq_param = kappa (UCB) or xi (EI/POI); y_max is ignored for UCB.
+ * lb/ub: (n_constraints,), +-inf allowed (short-circuit to 0/1 as the reference does).
+ * Outputs: best_idx/best_val = ys.argmin()/ys.min() (first NaN wins); seed_idx/seed_val (k_seeds,)
+ * = argsort(ys)[:k] with ties -> lowest index and NaNs last; ys_out (M,) optional (NULL to skip).
+ * index_offset is added to every returned index (candidate shards). */
+int gpbo_acq_argbest(gpbo_ctx* ctx, int acq, double acq_param, double y_max, int n_constraints,
+                     const double* lb, const double* ub, int k_seeds, int64_t index_offset,
+                     int64_t* best_idx, double* best_val, int64_t* seed_idx, double* seed_val,
+                     double* ys_out);
+
+/* ---- timing (HIP events on the context stream) ------------------------------------------ */
+/* Milliseconds spent in the last call's kernels: [0] fit total, [1] posterior main kernel,
+ * [2] posterior finalize, [3] acquisition + arg-best, [4] kmat assembly, [5] cholesky, [6] trtri. */
+int gpbo_last_timings(gpbo_ctx* ctx, float* ms, int n);
+
+/* ---- multi-GPU arg-best exchange (RCCL over xGMI; one process per GPU) ------------------- */
+/* rank 0 calls gpbo_comm_unique_id and ships the 128 bytes to its peers through any host channel;
+ * then every rank calls gpbo_comm_init.  gpbo_comm_allgather_best gathers (val,idx) records of
+ * every rank (n_records each) with ncclAllGather on the context stream. */
+int gpbo_comm_unique_id(char id[128]);
+int gpbo_comm_init(gpbo_ctx* ctx, const char id[128], int world_size, int rank);
+int gpbo_comm_allgather_best(gpbo_ctx* ctx, const double* vals, const int64_t* idxs, int n_records,
+                             double* all_vals, int64_t* all_idxs);
+int gpbo_comm_destroy(gpbo_ctx* ctx);
+
+/* ---- device self-tests / micro-benchmarks (used by tests and bench headers) -------------- */
+/* C = alpha * A(m,k) * op(B) + beta * C on the fit GEMM kernel; b_trans: B given as (n,k). */
+int gpbo_debug_gemm(gpbo_ctx* ctx, int m, int n, int k, double alpha, const double* A,
+                    const double* B, int b_trans, double beta, double* C);
+/* Sustained v_mfma_f64_16x16x4_f64 rate in TFLOP/s over `iters` dependent-chain-free MFMAs. */
+int gpbo_mfma_f64_peak(gpbo_ctx* ctx, int iters, double* tflops);
+/* Streaming copy bandwidth in GB/s (read+write bytes) over a `bytes`-sized buffer. */
+int gpbo_hbm_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPBO_H */
