@@ -1,0 +1,65 @@
+"""accelerate(optimizer) — install the HIP engine behind a bayes_opt.BayesianOptimization instance.
+
+Seams B1 + B2: replaces `optimizer._gp` (bayes_opt/bayesian_optimization.py:124-130)
+and each constraint GP `optimizer._space._constraint._model[j]` (bayes_opt/constraint.py:72-81) by a
+`HipGPR` with the same hyper-parameters and the SAME RandomState object (so the stream is consumed
+exactly as before), and replaces a stock UCB/EI/POI acquisition function by its fused counterpart.
+Everything else in the optimizer (space, queue, logging, state I/O) is untouched reference code.
+"""
+from __future__ import annotations
+
+from . import acquisition as A
+from .gpr import HipGPR, describe_kernel, shared_engine
+
+
+def _identity_transform(space) -> bool:
+    cfg = getattr(space, "_params_config", None)
+    if cfg is None:
+        return True
+    return all(type(p).__name__ == "FloatParameter" for p in cfg.values())
+
+
+def _convert_acquisition(fn):
+    name = type(fn).__name__
+    if isinstance(fn, A.AcquisitionFunction):
+        return fn
+    if name == "UpperConfidenceBound":
+        new = A.UpperConfidenceBound(kappa=fn.kappa, exploration_decay=fn.exploration_decay,
+                                     exploration_decay_delay=fn.exploration_decay_delay)
+    elif name == "ExpectedImprovement":
+        new = A.ExpectedImprovement(xi=fn.xi, exploration_decay=fn.exploration_decay,
+                                    exploration_decay_delay=fn.exploration_decay_delay)
+        new.y_max = fn.y_max
+    elif name == "ProbabilityOfImprovement":
+        new = A.ProbabilityOfImprovement(xi=fn.xi, exploration_decay=fn.exploration_decay,
+                                         exploration_decay_delay=fn.exploration_decay_delay)
+        new.y_max = fn.y_max
+    else:
+        return fn  # meta / custom acquisitions keep running reference code over HipGPR.predict
+    new.i = fn.i
+    return new
+
+
+def accelerate(optimizer, device: int = 0, n_random: int | None = None):
+    """Swap the GP(s) and the acquisition function of `optimizer` in place; returns `optimizer`.
+
+    Raises NotImplementedError for kernels outside the HIP path (see gpr.describe_kernel) and
+    RuntimeError/ImportError when no GPU or no built library is available: there is no CPU fallback.
+    `n_random` overrides the number of random candidates per suggest() (reference default 10_000).
+    """
+    engine = shared_engine(device)
+    space = optimizer._space
+    transform = None if _identity_transform(space) else space.kernel_transform
+    describe_kernel(optimizer._gp.kernel)
+    optimizer._gp = HipGPR.from_sklearn(optimizer._gp, transform=transform, engine=engine, slot=0)
+    constraint = getattr(space, "_constraint", None)
+    if constraint is not None:
+        if len(constraint._model) > 7:
+            raise NotImplementedError("at most 7 constraint GPs fit the engine's model slots")
+        for j, m in enumerate(constraint._model):
+            describe_kernel(m.kernel)
+            constraint._model[j] = HipGPR.from_sklearn(m, transform=transform, engine=engine, slot=j + 1)
+    optimizer._acquisition_function = _convert_acquisition(optimizer._acquisition_function)
+    if n_random is not None and isinstance(optimizer._acquisition_function, A.AcquisitionFunction):
+        optimizer._acquisition_function.default_n_random = int(n_random)
+    return optimizer

@@ -1,0 +1,222 @@
+"""HipGPR — the sklearn-estimator duck type of `optimizer._gp`, backed by the HIP engine.
+
+Seam B2 of SURVEY.md §8b.  bayes_opt touches only a handful of members of its
+`GaussianProcessRegressor` (bayes_opt/acquisition.py:84,195,205,216; bayes_opt/constraint.py:148-151,
+192,200,213,238-242; bayes_opt/bayesian_optimization.py:124-130,238,403-407,440-443,490):
+`fit`, `predict(return_std/return_cov)`, `X_train_`, `n_features_in_`, `set_params/get_params`,
+`kernel`, `kernel_`, `alpha`, `normalize_y`, `n_restarts_optimizer`.  HipGPR subclasses sklearn's
+estimator so all of that keeps its meaning, and replaces the two numeric stages:
+
+  * fit: the theta search is sklearn's own code path (L-BFGS-B over `log_marginal_likelihood`, on the
+    host — SURVEY.md §8f-1 "next" row), restated here line by line from
+    sklearn/gaussian_process/_gpr.py:225-338 so that the shared RandomState is consumed identically;
+    the fixed-theta tail (_gpr.py:346-364: K + alpha I, Cholesky, alpha_) runs on the GPU.
+  * predict (fitted, mean/std): _gpr.py:443-494 on the GPU.
+
+Supported on the HIP path: Matern(nu=2.5) and RBF (optionally wrapped by bayes_opt's `wrap_kernel`,
+optionally scaled by a fixed-at-1 ConstantKernel as in sklearn's default), scalar `alpha`, 1-D targets.
+Anything else raises NotImplementedError — there is no CPU fallback in this class.
+"""
+from __future__ import annotations
+
+import warnings
+from operator import itemgetter
+
+import numpy as np
+from sklearn.base import clone
+from sklearn.gaussian_process import GaussianProcessRegressor
+from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern, Product
+from sklearn.utils import check_random_state
+
+from .engine import MATERN25, GpEngine
+from .engine import RBF as K_RBF
+
+_shared_engines: dict[int, GpEngine] = {}
+
+
+def shared_engine(device: int = 0) -> GpEngine:
+    """One context per device per process (created on first use; raises without a GPU)."""
+    if device not in _shared_engines:
+        _shared_engines[device] = GpEngine(device)
+    return _shared_engines[device]
+
+
+def describe_kernel(kernel):
+    """(kind, length_scale array) for a supported kernel, else raise NotImplementedError.
+
+    Accepts Matern(nu=2.5) / RBF, dynamic subclasses made by bayes_opt.parameter.wrap_kernel
+    (parameter.py:457-495; MRO WrappedKernel -> Matern -> RBF), and `ConstantKernel(1, "fixed") * k`
+    (sklearn's default kernel, _gpr.py:241-246).
+    """
+    k = kernel
+    if isinstance(k, Product):
+        c, inner = k.k1, k.k2
+        if not isinstance(c, ConstantKernel):
+            c, inner = k.k2, k.k1
+        if not (isinstance(c, ConstantKernel) and c.constant_value == 1.0 and c.constant_value_bounds == "fixed"):
+            raise NotImplementedError(f"HIP path supports only a fixed unit ConstantKernel factor, got {kernel!r}")
+        k = inner
+    if isinstance(k, Matern):
+        if k.nu != 2.5:
+            raise NotImplementedError(f"HIP path supports Matern(nu=2.5) only, got nu={k.nu}")
+        kind = MATERN25
+    elif isinstance(k, RBF):
+        kind = K_RBF
+    else:
+        raise NotImplementedError(f"HIP path supports Matern(nu=2.5) and RBF kernels, got {type(kernel).__name__}")
+    return kind, np.atleast_1d(np.asarray(k.length_scale, dtype=np.float64))
+
+
+class HipGPR(GaussianProcessRegressor):
+    """GaussianProcessRegressor whose fixed-theta fit and posterior run on the MI355X engine."""
+
+    def __init__(self, kernel=None, *, alpha=1e-10, optimizer="fmin_l_bfgs_b", n_restarts_optimizer=0,
+                 normalize_y=False, copy_X_train=True, n_targets=None, random_state=None,
+                 transform=None, engine=None, slot=0):
+        super().__init__(kernel=kernel, alpha=alpha, optimizer=optimizer,
+                         n_restarts_optimizer=n_restarts_optimizer, normalize_y=normalize_y,
+                         copy_X_train=copy_X_train, n_targets=n_targets, random_state=random_state)
+        self.transform = transform  # host-side input transform (None = identity, the all-float case)
+        self.engine = engine
+        self.slot = slot
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _engine(self) -> GpEngine:
+        if self.engine is None:
+            self.engine = shared_engine(0)
+        return self.engine
+
+    def _tx(self, X):
+        X = np.asarray(X, dtype=np.float64)
+        if self.transform is not None:
+            X = np.asarray(self.transform(X), dtype=np.float64)
+        return np.ascontiguousarray(X)
+
+    @classmethod
+    def from_sklearn(cls, gp: GaussianProcessRegressor, transform=None, engine=None, slot=0):
+        """Same hyper-parameters (and the same RandomState object) as an existing estimator."""
+        p = gp.get_params(deep=False)
+        return cls(kernel=p["kernel"], alpha=p["alpha"], optimizer=p["optimizer"],
+                   n_restarts_optimizer=p["n_restarts_optimizer"], normalize_y=p["normalize_y"],
+                   copy_X_train=p["copy_X_train"], n_targets=p.get("n_targets"),
+                   random_state=p["random_state"], transform=transform, engine=engine, slot=slot)
+
+    # lazily fetched parity attributes -------------------------------------------------------------
+    @property
+    def L_(self):
+        """Lower Cholesky factor, Fortran-ordered with a zero upper triangle like scipy's (gp.L_)."""
+        if "_L_cache" not in self.__dict__:
+            if not hasattr(self, "X_train_"):
+                raise AttributeError("L_")
+            self.__dict__["_L_cache"] = np.asfortranarray(self._engine().get_L(self.X_train_.shape[0], self.slot))
+        return self.__dict__["_L_cache"]
+
+    @L_.setter
+    def L_(self, v):
+        self.__dict__["_L_cache"] = v
+
+    @property
+    def alpha_(self):
+        if "_alpha_cache" not in self.__dict__:
+            if not hasattr(self, "X_train_"):
+                raise AttributeError("alpha_")
+            self.__dict__["_alpha_cache"] = self._engine().get_alpha(self.X_train_.shape[0], self.slot)
+        return self.__dict__["_alpha_cache"]
+
+    @alpha_.setter
+    def alpha_(self, v):
+        self.__dict__["_alpha_cache"] = v
+
+    # -- fit -------------------------------------------------------------------------------------
+    def fit(self, X, y):
+        """Fit; mirrors sklearn _gpr.py:225-365 with the fixed-theta tail on the GPU."""
+        if self.kernel is None:  # _gpr.py:241-246
+            self.kernel_ = ConstantKernel(1.0, constant_value_bounds="fixed") * RBF(1.0, length_scale_bounds="fixed")
+        else:
+            self.kernel_ = clone(self.kernel)
+        if np.iterable(self.alpha):
+            raise NotImplementedError("HIP path supports a scalar alpha only")
+        describe_kernel(self.kernel_)  # fail before any work on unsupported kernels
+        self._rng = check_random_state(self.random_state)
+
+        X = np.asarray(X, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64)
+        if X.ndim != 2:
+            raise ValueError(f"Expected 2D array, got {X.ndim}D array instead")
+        self._y_2d = y.ndim == 2
+        if self._y_2d:
+            if y.shape[1] != 1:
+                raise NotImplementedError("HIP path supports a single target")
+            y = y[:, 0]
+        if y.shape[0] != X.shape[0]:
+            raise ValueError(f"Found input variables with inconsistent numbers of samples: [{X.shape[0]}, {y.shape[0]}]")
+        self.n_features_in_ = X.shape[1]
+
+        if self.normalize_y:  # _gpr.py:272-277 + preprocessing/_data.py:107-110
+            self._y_train_mean = np.mean(y, axis=0)
+            std = np.std(y, axis=0)
+            self._y_train_std = 1.0 if std < 10 * np.finfo(np.float64).eps else std
+            y = (y - self._y_train_mean) / self._y_train_std
+        else:
+            self._y_train_mean = np.zeros(())
+            self._y_train_std = np.ones(())
+        self.X_train_ = np.copy(X) if self.copy_X_train else X
+        self.y_train_ = np.copy(y) if self.copy_X_train else y
+        self.__dict__.pop("_L_cache", None)
+        self.__dict__.pop("_alpha_cache", None)
+
+        if self.optimizer is not None and self.kernel_.n_dims > 0:  # _gpr.py:296-338 (host theta search)
+            def obj_func(theta, eval_gradient=True):
+                if eval_gradient:
+                    lml, grad = self.log_marginal_likelihood(theta, eval_gradient=True, clone_kernel=False)
+                    return -lml, -grad
+                return -self.log_marginal_likelihood(theta, clone_kernel=False)
+
+            optima = [self._constrained_optimization(obj_func, self.kernel_.theta, self.kernel_.bounds)]
+            if self.n_restarts_optimizer > 0:
+                if not np.isfinite(self.kernel_.bounds).all():
+                    raise ValueError("Multiple optimizer restarts (n_restarts_optimizer>0) requires that all bounds are finite.")
+                bounds = self.kernel_.bounds
+                for _ in range(self.n_restarts_optimizer):
+                    theta_initial = self._rng.uniform(bounds[:, 0], bounds[:, 1])
+                    optima.append(self._constrained_optimization(obj_func, theta_initial, bounds))
+            lml_values = list(map(itemgetter(1), optima))
+            self.kernel_.theta = optima[np.argmin(lml_values)][0]
+            self.kernel_._check_bounds_params()
+            self.log_marginal_likelihood_value_ = -np.min(lml_values)
+        else:
+            self.log_marginal_likelihood_value_ = None  # not evaluated on the fixed-theta path
+
+        kind, ls = describe_kernel(self.kernel_)
+        if ls.shape[0] not in (1, self.n_features_in_):
+            raise ValueError("Anisotropic kernel must have the same number of dimensions as data")
+        self._kind, self._ls = kind, ls
+        # _gpr.py:346-364 on the device (LinAlgError with sklearn's hint when K is not PD)
+        self._engine().fit(self._tx(self.X_train_), self.y_train_, kind, ls, float(self.alpha), slot=self.slot)
+        return self
+
+    # -- predict -----------------------------------------------------------------------------------
+    def predict(self, X, return_std=False, return_cov=False):
+        if return_std and return_cov:
+            raise RuntimeError("At most one of return_std or return_cov can be requested.")
+        if not hasattr(self, "X_train_") or return_cov:
+            # prior (unfitted) predictions and full covariances are not on the hot path: sklearn's own
+            # code handles them (for return_cov it reads the lazily fetched L_ / alpha_).
+            return super().predict(X, return_std=return_std, return_cov=return_cov)
+        X = np.asarray(X, dtype=np.float64)
+        if X.ndim != 2:
+            raise ValueError(f"Expected 2D array, got {X.ndim}D array instead")
+        if X.shape[1] != self.n_features_in_:
+            raise ValueError(f"X has {X.shape[1]} features, but HipGPR is expecting {self.n_features_in_} features as input.")
+        mean, std = self._engine().predict(self._tx(X), slot=self.slot, y_mean=float(self._y_train_mean),
+                                           y_std=float(self._y_train_std))
+        if return_std:
+            if np.any(std == 0.0):  # _gpr.py:479-485: sklearn warns when it clips negative variances
+                warnings.warn("Predicted variances smaller than 0. Setting those variances to 0.", stacklevel=2)
+            return mean, std
+        return mean
+
+    # engine-resident posterior for the fused acquisition path ----------------------------------
+    def posterior_resident(self):
+        """Run the posterior kernel over the engine's resident candidates, keeping mu/sd on the device."""
+        self._engine().posterior(self.slot, float(self._y_train_mean), float(self._y_train_std), fetch=False)

@@ -1,0 +1,63 @@
+"""CPU: the C-ABI library builds/loads, exports every symbol include/gpbo.h declares, and fails
+loudly (no fallback) when no GPU is present."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from bayesianoptimization_amd import _lib
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "gpbo.h")
+
+
+def _declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpbo_[A-Za-z0-9_]+)\s*\(", src)))
+
+
+def test_library_is_built_in_tree():
+    assert os.path.exists(_lib.LIB_PATH), "run `python -m bayesianoptimization_amd.build`"
+    assert os.path.dirname(_lib.LIB_PATH).endswith("bayesianoptimization_amd")
+
+
+def test_every_header_symbol_is_exported_and_bound():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in gpbo.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes prototype in _lib.SIGNATURES"
+    assert sorted(_lib.SIGNATURES) == declared
+
+
+def test_abi_version_and_load():
+    lib = _lib.load_library()
+    assert lib.gpbo_abi_version() == _lib.ABI_VERSION
+    hdr = open(HEADER).read()
+    assert f"#define GPBO_ABI_VERSION {_lib.ABI_VERSION}" in hdr
+
+
+def test_no_gpu_means_loud_failure():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    from bayesianoptimization_amd.engine import GpEngine
+
+    with pytest.raises(_lib.GpboError):
+        GpEngine(0)
+
+
+def test_missing_library_raises_import_error(tmp_path):
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load_library(str(tmp_path / "libgpbo.so"))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "bayesianoptimization_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+            assert "import torch" not in src, fn

@@ -1,0 +1,184 @@
+"""CPU: host-side mirror of the reference interface (space, acquisition orchestration, merge rules),
+checked against the reference itself when /root/reference is mounted."""
+import warnings
+
+import numpy as np
+import pytest
+
+from bayesianoptimization_amd import acquisition as A
+from bayesianoptimization_amd import workloads as W
+from bayesianoptimization_amd.distributed import merge_best, shard_range
+from bayesianoptimization_amd.space import FloatSpace, ensure_rng
+from oracle.refenv import have_reference, import_reference
+
+needs_ref = pytest.mark.skipif(not have_reference(), reason="reference not mounted (GPU box)")
+
+
+def test_ensure_rng():
+    assert isinstance(ensure_rng(None), np.random.RandomState)
+    r = np.random.RandomState(3)
+    assert ensure_rng(r) is r
+    assert ensure_rng(5).uniform() == np.random.RandomState(5).uniform()
+    with pytest.raises(TypeError):
+        ensure_rng("x")
+
+
+def test_shard_range_partitions_exactly():
+    for M in (1, 7, 128, 1 << 20, 1000003):
+        for G in (1, 2, 3, 8):
+            spans = [shard_range(M, G, r) for r in range(G)]
+            assert spans[0][0] == 0 and spans[-1][1] == M
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(G - 1))
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def test_merge_best_rules():
+    # lowest index among equal minima; -0.0 == 0.0
+    bi, bv, si, sv = merge_best([0.0, -0.0], [7, 3], [[0.0, 1.0], [-0.0, 2.0]], [[7, 8], [3, 4]], 3)
+    assert bi == 3 and list(si) == [3, 7, 8]
+    # first NaN wins arg-best, NaNs sort last among seeds, padding (-1) dropped
+    bi, bv, si, sv = merge_best([1.0, np.nan], [2, 50], [[1.0, np.nan], [np.nan, np.nan]], [[2, 9], [50, -1]], 4)
+    assert bi == 50 and np.isnan(bv) and list(si) == [2, 9, 50]
+    # merge equals a global sort
+    rng = np.random.RandomState(0)
+    ys = rng.randn(1000)
+    ys[rng.randint(0, 1000, 30)] = ys[5]  # ties
+    k = 10
+    parts = [(0, 400), (400, 1000)]
+    sv_, si_, bv_, bi_ = [], [], [], []
+    for s, e in parts:
+        o = np.lexsort((np.arange(s, e), ys[s:e]))[:k]
+        si_.append(o + s); sv_.append(ys[s:e][o]); bi_.append(o[0] + s); bv_.append(ys[s:e][o[0]])
+    bi, bv, si, sv = merge_best(bv_, bi_, sv_, si_, k)
+    ref = np.lexsort((np.arange(1000), ys))[:k]
+    assert bi == ref[0] and np.array_equal(si, ref)
+
+
+def test_floatspace_protocol_and_target_max():
+    sp = FloatSpace({"a": (0, 1), "b": (-2, 2)})
+    assert sp.empty and sp._target_max() is None
+    sp.register([0.5, 0.0], 1.0)
+    sp.register([0.5, 5.0], 9.0)  # out of bounds -> masked
+    assert len(sp) == 2 and sp._target_max() == 1.0
+    x = sp.random_sample(5, np.random.RandomState(1))
+    assert x.shape == (5, 2) and np.all(x[:, 1] >= -2)
+    assert sp.random_sample(0, 3).shape == (2,)
+
+
+@needs_ref
+def test_candidate_stream_equals_reference():
+    import_reference()
+    from bayes_opt.target_space import TargetSpace
+
+    for w in (W.C1, W.C2, W.C5S):
+        ts = TargetSpace(None, w.pbounds())
+        a = ts.random_sample(777, np.random.RandomState(7))
+        b = FloatSpace(w.pbounds()).random_sample(777, np.random.RandomState(7))
+        c = W.make_candidates(w.bounds_array(), 777, 7)
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+        assert np.array_equal(ts.bounds, FloatSpace(w.pbounds()).bounds)
+
+
+def _mk_spaces(w, n=40):
+    X, y, c = W.make_observations(w)
+    sp = FloatSpace(w.pbounds())
+    sp.register_bulk(X[:n], y[:n])
+    return sp, X[:n], y[:n]
+
+
+@needs_ref
+@pytest.mark.parametrize("kind", ["ucb", "ei", "poi"])
+@pytest.mark.parametrize("n_smart", [0, 3])
+def test_host_orchestration_equals_reference(kind, n_smart):
+    """Same GP object, same seeds: the restated suggest()/_acq_min/_smart_minimize give the SAME point
+    as bayes_opt's (non-fused path, plain sklearn GP), and consume the RandomState identically."""
+    import_reference()
+    from bayes_opt import acquisition as RA
+    from bayes_opt.target_space import TargetSpace
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import Matern
+
+    w = W.P1
+    sp, X, y = _mk_spaces(w)
+    ts = TargetSpace(None, w.pbounds())
+    for i in range(len(y)):
+        ts.register(X[i], y[i])
+    mine = {"ucb": A.UpperConfidenceBound(kappa=1.7, exploration_decay=0.9), "ei": A.ExpectedImprovement(xi=0.02),
+            "poi": A.ProbabilityOfImprovement(xi=0.02)}[kind]
+    ref = {"ucb": RA.UpperConfidenceBound(kappa=1.7, exploration_decay=0.9), "ei": RA.ExpectedImprovement(xi=0.02),
+           "poi": RA.ProbabilityOfImprovement(xi=0.02)}[kind]
+    r1, r2 = np.random.RandomState(11), np.random.RandomState(11)
+    gp1 = GaussianProcessRegressor(kernel=Matern(nu=2.5, length_scale=0.4), alpha=1e-6, normalize_y=True, optimizer=None)
+    gp2 = GaussianProcessRegressor(kernel=Matern(nu=2.5, length_scale=0.4), alpha=1e-6, normalize_y=True, optimizer=None)
+    for _ in range(2):
+        x1 = mine.suggest(gp1, sp, n_random=500, n_smart=n_smart, random_state=r1)
+        x2 = ref.suggest(gp2, ts, n_random=500, n_smart=n_smart, random_state=r2)
+        assert np.array_equal(x1, x2)
+    assert r1.uniform() == r2.uniform()  # identical stream position
+    assert mine.i == ref.i == 2
+    assert mine.get_acquisition_params() == ref.get_acquisition_params()
+
+
+def test_error_behaviour_matches_reference_contract():
+    sp = FloatSpace({"a": (0, 1)})
+    ucb = A.UpperConfidenceBound()
+    with pytest.raises(A.TargetSpaceEmptyError):
+        ucb.suggest(None, sp)
+    with pytest.raises(ValueError):
+        A.UpperConfidenceBound(kappa=-1)
+    with pytest.raises(ValueError):
+        A.ExpectedImprovement(xi=0.1, exploration_decay=1.5)
+    with pytest.raises(ValueError):
+        A.ExpectedImprovement(xi=0.1, exploration_decay_delay=-1)
+    with pytest.warns(DeprecationWarning):
+        A.UpperConfidenceBound(random_state=1)
+    ei = A.ExpectedImprovement(xi=0.1)
+    with pytest.raises(ValueError, match="y_max is not set"):
+        ei.base_acq(np.zeros(2), np.ones(2))
+
+    class Cons:  # any constraint makes UCB refuse (acquisition.py:524-529)
+        pass
+
+    sp2 = FloatSpace({"a": (0, 1)}, constraint=Cons())
+    sp2._params = np.zeros((1, 1)); sp2._target = np.zeros(1); sp2._constraint_values = np.zeros(1)
+    with pytest.raises(A.ConstraintNotSupportedError):
+        ucb.suggest(None, sp2)
+    sp.register([0.3], 1.0)
+    with pytest.raises(ValueError, match="Either n_random or n_smart"):
+        from sklearn.gaussian_process import GaussianProcessRegressor
+        ucb.suggest(GaussianProcessRegressor(), sp, n_random=0, n_smart=0)
+
+
+def test_mock_gp_duck_typing_and_seed_containment():
+    """tests/test_acquisition.py:90-132 of the reference: an analytic bowl, x_min must be among the seeds."""
+    class MockAcq(A.AcquisitionFunction):
+        def _get_acq(self, gp, constraint=None):
+            return lambda x: (3 - x[..., 0]) ** 2 + (1 - x[..., 1]) ** 2
+        def base_acq(self, mean, std):
+            pass
+
+    sp = FloatSpace({"x": (1, 4), "y": (0, 3)})
+    acq = MockAcq()
+    rs = np.random.RandomState(0)
+    x_min, min_acq, x_seeds = acq._random_sample_minimize(acq._get_acq(None), sp, rs, n_random=1000, n_x_seeds=5)
+    assert any(np.array_equal(x_min, s) for s in x_seeds)
+    best = acq._acq_min(acq._get_acq(None), sp, rs, n_random=1000, n_smart=5)
+    assert np.allclose(best, [3, 1], atol=1e-4)
+
+
+def test_hipgpr_fails_loudly_without_gpu():
+    from bayesianoptimization_amd import _lib
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    from sklearn.gaussian_process.kernels import Matern
+    from bayesianoptimization_amd.gpr import HipGPR, describe_kernel
+    from sklearn.gaussian_process.kernels import RationalQuadratic
+
+    gp = HipGPR(kernel=Matern(nu=2.5), alpha=1e-6, normalize_y=True, optimizer=None)
+    with pytest.raises(_lib.GpboError):
+        gp.fit(np.random.rand(5, 2), np.random.rand(5))
+    with pytest.raises(NotImplementedError):
+        describe_kernel(RationalQuadratic())
+    with pytest.raises(NotImplementedError):
+        describe_kernel(Matern(nu=1.5))

@@ -1,0 +1,118 @@
+"""CPU: pin the oracle (oracle/gp_oracle.py) against golden vectors produced by the reference itself
+(tests/golden/*.npz, written by oracle/gen_golden.py from bayes_opt 3.3.0 -> sklearn/scipy) and against
+scikit-learn directly."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from bayesianoptimization_amd import workloads as W
+from conftest import GOLDEN_DIR, load_golden, rel_err
+from oracle import gp_oracle as O
+
+SMALL = ["C1", "F1", "P1", "P2", "C5S", "C2"]
+
+
+def _fit_from_golden(name):
+    w = W.ALL[name]
+    g = load_golden(name)
+    X, y, c = W.make_observations(w)
+    gp = O.fit_fixed_theta(w.kernel, X, y, g["length_scale"], w.noise)
+    return w, g, X, y, c, gp
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_fit_matches_reference(name):
+    w, g, X, y, c, gp = _fit_from_golden(name)
+    assert abs(gp.y_mean - g["y_mean"]) <= 1e-15 * max(1, abs(g["y_mean"]))
+    assert abs(gp.y_std - g["y_std"]) <= 1e-15 * max(1, abs(g["y_std"]))
+    assert rel_err(gp.alpha, g["alpha"]) < 1e-9
+    assert rel_err(np.diag(gp.L), g["L_diag"]) < 1e-12
+    assert rel_err(gp.L[-1], g["L_lastrow"]) < 1e-11
+    if "L" in g:
+        assert rel_err(gp.L, g["L"]) < 1e-12
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_posterior_and_acquisition_match_reference(name):
+    w, g, X, y, c, gp = _fit_from_golden(name)
+    S = len(g["mu"])
+    Xc = W.make_candidates(w.bounds_array(), int(g["M_evaluated"]), 7)
+    mu, sd = O.predict(gp, Xc[:S])
+    assert rel_err(mu, g["mu"]) < 1e-9
+    assert rel_err(sd, g["sd"]) < 1e-9
+    cons = None
+    if w.constrained:
+        cgp = O.fit_fixed_theta(W.MATERN25, X, c, g["c_length_scale"], w.noise)
+        assert rel_err(cgp.alpha, g["c_alpha"]) < 1e-9
+        cmu, csd = O.predict(cgp, Xc[:S])
+        assert rel_err(cmu, g["c_mu"]) < 1e-9 and rel_err(csd, g["c_sd"]) < 1e-9
+        cons = ([cgp], [-np.inf], [w.constraint_ub])
+        assert rel_err(O.constraint_prob(*cons, Xc[:S]), g["p_c"]) < 1e-9
+    y_max = W.feasible_y_max(w, y, c)
+    if w.acq != W.UCB:
+        assert y_max == pytest.approx(float(g["y_max"]), abs=0)
+    ys = O.neg_acquisition(gp, Xc, w.acq, w.acq_param, y_max, cons)
+    assert rel_err(ys[:S], g["ys"]) < 1e-9
+    idx, val, seeds = O.arg_best(ys, 16)
+    assert idx == int(g["argmin"])
+    assert val == pytest.approx(float(g["min"]), rel=1e-9)
+    assert np.array_equal(seeds, g["topk_idx"])
+    # seam B1 with the random stage only: the suggestion is the arg-best candidate
+    nr = int(g["suggest_nsmart0_nrandom"])
+    assert np.array_equal(Xc[:nr][ys[:nr].argmin()], g["suggest_nsmart0_x"])
+
+
+def test_c3_sample_matches_reference():
+    """N=4096: the oracle on the first 1024 candidates of the golden sample (a few seconds)."""
+    w, g, X, y, c, gp = _fit_from_golden("C3")
+    Xc = W.make_candidates(w.bounds_array(), 1024, 7)
+    # make_candidates draws column by column, so a shorter draw is NOT a prefix: regenerate at full M
+    Xc_full = W.make_candidates(w.bounds_array(), w.M, 7)
+    assert not np.array_equal(Xc, Xc_full[:1024])
+    mu, sd = O.predict(gp, Xc_full[:1024])
+    assert rel_err(gp.alpha, g["alpha"]) < 1e-8
+    assert rel_err(mu, g["mu"][:1024]) < 1e-9
+    assert rel_err(sd, g["sd"][:1024]) < 1e-9
+    ys = O.neg_acquisition(gp, Xc_full[:1024], w.acq, w.acq_param)
+    assert rel_err(ys, g["ys"][:1024]) < 1e-9
+
+
+def test_oracle_against_sklearn_directly():
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF, Matern
+
+    rng = np.random.RandomState(5)
+    for kind, k in [(O.MATERN25, Matern(nu=2.5, length_scale=0.7)), (O.RBF, RBF(length_scale=[0.5, 0.9, 1.3]))]:
+        X = rng.uniform(size=(80, 3))
+        y = np.cos(X.sum(1)) + 0.01 * rng.randn(80)
+        sk = GaussianProcessRegressor(kernel=k, alpha=1e-6, normalize_y=True, optimizer=None).fit(X, y)
+        gp = O.fit_fixed_theta(kind, X, y, k.length_scale, 1e-6)
+        Xc = rng.uniform(size=(500, 3))
+        mu_s, sd_s = sk.predict(Xc, return_std=True)
+        mu, sd = O.predict(gp, Xc)
+        assert rel_err(gp.L, sk.L_) < 1e-13 and rel_err(gp.alpha, sk.alpha_) < 1e-10
+        assert rel_err(mu, mu_s) < 1e-11 and rel_err(sd, sd_s) < 1e-11
+
+
+def test_edge_semantics():
+    """NaN / sigma = 0 conventions the device must mirror."""
+    with np.errstate(all="ignore"):
+        assert np.isnan(O.base_acq_ei(np.array([1.0]), np.array([0.0]), 1.0, 0.0))[0]      # a = 0, sigma = 0
+        assert O.base_acq_ei(np.array([2.0]), np.array([0.0]), 1.0, 0.0)[0] == 1.0           # a > 0 -> a
+        assert O.base_acq_ei(np.array([0.0]), np.array([0.0]), 1.0, 0.0)[0] == 0.0           # a < 0 -> 0
+        assert O.base_acq_poi(np.array([2.0]), np.array([0.0]), 1.0, 0.0)[0] == 1.0
+    ys = np.array([3.0, np.nan, -1.0, np.nan, -1.0])
+    idx, val, seeds = O.arg_best(ys, 3)
+    assert idx == 1 and np.isnan(val)                      # first NaN wins argmin
+    assert list(seeds[:2]) == [2, 4] and seeds[2] == 0     # NaNs sort last
+    assert O.arg_best(np.array([0.0, -0.0]), 0)[0] == 0    # -0.0 == 0.0: first index
+
+
+def test_manifest_records_versions():
+    m = json.load(open(os.path.join(GOLDEN_DIR, "MANIFEST.json")))
+    v = m["_versions"]
+    assert v["bayes_opt"] == "3.3.0" and v["sklearn"] and v["scipy"] and v["numpy"]
+    for name in SMALL + ["C3", "C5"]:
+        assert name in m
