@@ -227,3 +227,20 @@ def test_virtual_rank_sharding_equals_single_pass(engine):
         m = merge_best(bv, bi, sv, si, 10)
         assert m[0] == full[0] and m[1] == full[1]
         assert np.array_equal(m[2], full[2]) and np.array_equal(m[3], full[3])
+
+
+def test_rccl_single_rank_roundtrip(engine):
+    """The RCCL transport (dlopen'ed librccl, ncclCommInitRank + ncclAllGather) with world_size = 1."""
+    from bayesianoptimization_amd.engine import GpEngine
+
+    uid = GpEngine.comm_unique_id()
+    assert len(uid) == 128
+    engine.comm_init(uid, 1, 0)
+    try:
+        vals = np.array([0.5, -1.25, np.nan, 3.0])
+        idxs = np.array([7, 1 << 40, 3, -1], dtype=np.int64)
+        av, ai = engine.comm_allgather_best(vals, idxs)
+        assert np.array_equal(av, vals, equal_nan=True) and np.array_equal(ai, idxs)
+    finally:
+        engine._lib.gpbo_comm_destroy(engine._h)
+        engine.world_size, engine.rank = 1, 0
