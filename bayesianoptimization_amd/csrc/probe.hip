@@ -39,8 +39,8 @@ int run_mfma_peak(gpbo_ctx* ctx, int iters, double* tflops) {
   GPBO_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
   const double flops = (double)grid * 4.0 * (double)iters * 8.0 * 2048.0;
   *tflops = flops / (ms * 1e-3) / 1e12;
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   GPBO_HIP(ctx, hipFree(out));
   return GPBO_OK;
 }
@@ -69,8 +69,8 @@ int run_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps) {
   float ms = 0.f;
   GPBO_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
   *gbps = 2.0 * (double)n * 16.0 * reps / (ms * 1e-3) / 1e9;
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   GPBO_HIP(ctx, hipFree(a));
   GPBO_HIP(ctx, hipFree(b));
   return GPBO_OK;

@@ -90,7 +90,10 @@ def test_acquisition_and_argbest_parity(engine, name, ls, cls):
         ys_o = O.neg_acquisition(oc["gp"], oc["Xc"], acq, param, oc["y_max"], oc["cons"])
         bi, bv, si, sv, ys = engine.acq_argbest(acq, param, oc["y_max"], lb, ub, k_seeds=12, return_values=True)
         scale = np.max(np.abs(ys_o))
-        assert np.max(np.abs(ys - ys_o)) <= TOL * scale
+        # RBF Gram matrices are far worse conditioned than Matern ones (P2: kappa(K) ~ 1e9 at alpha=1e-6),
+        # and both LAPACK and the device carry ~kappa*eps of rounding noise: 1e-7 there, 1e-9 otherwise.
+        tol = 1e-7 if w.kernel == W.RBF else TOL
+        assert np.max(np.abs(ys - ys_o)) <= tol * scale
         oi, ov, os_ = O.arg_best(ys_o, 12)
         assert bi == oi and np.array_equal(si, os_)
         assert bv == ys[bi] and np.array_equal(sv, ys[si])
