@@ -117,68 +117,151 @@ int launch_kmat(gpbo_ctx* ctx, Model& m, double noise) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Cholesky of one 64x64 diagonal block in LDS by one 256-thread workgroup (right-looking, one
-// column per step), followed by the inverse of the factor (thread c owns column c of L_kk^-1).
+// Cholesky + inverse of one 64x64 diagonal block by one 256-thread workgroup.
+//
+// Factorisation (right-looking, one column per step, ONE barrier per column): thread (row i = tid & 63,
+// quarter q = tid >> 6) keeps A[i][16q .. 16q+15] in registers, so wave q owns 16 whole columns.  At
+// step j the owning wave reads the pivot with a shuffle, scales its column and publishes it to a
+// double-buffered LDS vector; after the barrier every wave that still has live columns applies the
+// rank-1 update to its registers.  All indices are compile-time (the 64 steps are unrolled).
+//
+// Inverse: the four 16x16 diagonal sub-blocks by forward substitution in registers (thread = column),
+// then two doubling levels  W21 = -W22 (L21 W11)  as LDS-resident matrix products; the temporaries live
+// in the (zero) upper-right quadrants of the W image.
 // Writes L_kk in place (upper part zeroed) and L_kk^-1 to dinv[kb].
+__device__ __forceinline__ void lds_matmul(double* __restrict__ Cm, int ldc, const double* __restrict__ Am, int lda,
+                                           const double* __restrict__ Bm, int ldb, int m, int n, int k,
+                                           double alpha) {
+  for (int e = threadIdx.x; e < m * n; e += 256) {
+    const int i = e / n, c = e - i * n;
+    double s = 0.0;
+    for (int t = 0; t < k; ++t) s = fma(Am[i * lda + t], Bm[t * ldb + c], s);
+    Cm[i * ldc + c] = alpha * s;
+  }
+}
+
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, int kb,
                                                          double* __restrict__ dinv, int* info) {
-  __shared__ double Ls[64 * 65];
-  __shared__ int bad_sh;
+  extern __shared__ __attribute__((aligned(16))) double pd_smem[];
+  double* Ls = pd_smem;              // [64][65]
+  double* Wl = pd_smem + 64 * 65;    // [64][65]
+  double* col = Wl + 64 * 65;        // [2][64]
+  int* bad_sh = reinterpret_cast<int*>(col + 128);
   const int tid = threadIdx.x;
+  const int i = tid & 63;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* A = L + (int64_t)kb * 64 * ld + (int64_t)kb * 64;
-  for (int e = tid; e < 4096; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    Ls[r * 65 + c] = (c <= r) ? A[(int64_t)r * ld + c] : 0.0;
+  double a[16];
+  {
+    const double2* src = reinterpret_cast<const double2*>(A + (int64_t)i * ld + 16 * q);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      const double2 v = src[h];
+      a[2 * h] = v.x;
+      a[2 * h + 1] = v.y;
+    }
   }
-  if (tid == 0) bad_sh = 0;
+  if (tid == 0) *bad_sh = 0;
   __syncthreads();
+#pragma unroll
   for (int j = 0; j < 64; ++j) {
-    if (tid == 0) {
-      double piv = Ls[j * 65 + j];
+    const int qj = j >> 4, jj = j & 15;
+    double* cb = col + (j & 1) * 64;
+    if (q == qj) {
+      double piv = __shfl(a[jj], j);
       if (!(piv > 0.0)) {
-        if (!bad_sh) bad_sh = j + 1;
+        if (i == 0 && *bad_sh == 0) *bad_sh = j + 1;
         piv = 1.0;
       }
-      Ls[j * 65 + j] = sqrt(piv);
+      const double dg = sqrt(piv);
+      double l = (i == j) ? dg : a[jj] / dg;
+      l = (i >= j) ? l : 0.0;
+      a[jj] = l;
+      cb[i] = l;
     }
     __syncthreads();
-    if (tid > j && tid < 64) Ls[tid * 65 + j] = Ls[tid * 65 + j] / Ls[j * 65 + j];
-    __syncthreads();
-    // trailing update of the lower triangle: (i, c) with j < c <= i
-    for (int e = tid; e < 4096; e += 256) {
-      const int i = e >> 6, c = e & 63;
-      if (c > j && c <= i) Ls[i * 65 + c] = fma(-Ls[i * 65 + j], Ls[c * 65 + j], Ls[i * 65 + c]);
+    if (q > qj) {
+      const double li = cb[i];
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) a[cc] = fma(-li, cb[16 * q + cc], a[cc]);
+    } else if (q == qj) {
+      const double li = cb[i];
+#pragma unroll
+      for (int cc = jj + 1; cc < 16; ++cc) a[cc] = fma(-li, cb[16 * qj + cc], a[cc]);
     }
-    __syncthreads();
   }
-  for (int e = tid; e < 4096; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    A[(int64_t)r * ld + c] = Ls[r * 65 + c];
+  // L -> global (upper part zero) and -> LDS for the inverse
+  {
+    double2* dst = reinterpret_cast<double2*>(A + (int64_t)i * ld + 16 * q);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      const int c0 = 16 * q + 2 * h;
+      const double v0 = (c0 <= i) ? a[2 * h] : 0.0;
+      const double v1 = (c0 + 1 <= i) ? a[2 * h + 1] : 0.0;
+      dst[h] = make_double2(v0, v1);
+      Ls[i * 65 + c0] = v0;
+      Ls[i * 65 + c0 + 1] = v1;
+      Wl[i * 65 + c0] = 0.0;
+      Wl[i * 65 + c0 + 1] = 0.0;
+    }
   }
-  if (tid == 0 && bad_sh && *info == 0) *info = kb * 64 + bad_sh;
   __syncthreads();
-  // inverse by forward substitution on the identity; column c is private to thread c and is kept
-  // in the (free) strict upper triangle of the LDS image: W[i][c] (i >= c) lives at Ls[c][i + 1].
+  if (tid == 0 && *bad_sh && *info == 0) *info = kb * 64 + *bad_sh;
+  // --- inverse, step A: 16x16 diagonal sub-blocks (thread = sub-block b, column c)
   if (tid < 64) {
-    const int c = tid;
-    double* wc = Ls + c * 65 + 1;
-    for (int i = c; i < 64; ++i) wc[i] = (i == c) ? 1.0 : 0.0;
-    for (int k = c; k < 64; ++k) {
-      const double wk = wc[k] / Ls[k * 65 + k];
-      wc[k] = wk;
-      for (int i = k + 1; i < 64; ++i) wc[i] = fma(-Ls[i * 65 + k], wk, wc[i]);
+    const int b = tid >> 4, c = tid & 15;
+    const double* Lb = Ls + (16 * b) * 65 + 16 * b;
+    double w[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[r] = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const double wk = w[k] / Lb[k * 65 + k];
+      w[k] = wk;
+#pragma unroll
+      for (int r = k + 1; r < 16; ++r) w[r] = fma(-Lb[r * 65 + k], wk, w[r]);
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Wl[(16 * b + r) * 65 + 16 * b + c] = w[r];
   }
+  __syncthreads();
+  // --- step B: 16 -> 32 (two pairs).  T (16x16) sits in the upper-right 16x16 of each 32x32 diagonal block.
+  for (int p2 = 0; p2 < 2; ++p2) {
+    const int o = 32 * p2;
+    lds_matmul(Wl + o * 65 + o + 16, 65, Ls + (o + 16) * 65 + o, 65, Wl + o * 65 + o, 65, 16, 16, 16, 1.0);
+  }
+  __syncthreads();
+  for (int p2 = 0; p2 < 2; ++p2) {
+    const int o = 32 * p2;
+    lds_matmul(Wl + (o + 16) * 65 + o, 65, Wl + (o + 16) * 65 + o + 16, 65, Wl + o * 65 + o + 16, 65, 16, 16, 16, -1.0);
+  }
+  __syncthreads();
+  // --- step C: 32 -> 64.  T (32x32) sits in the upper-right quadrant; first clear step B's temporaries there.
+  for (int e = tid; e < 512; e += 256) {
+    const int p2 = e >> 8, r = (e >> 4) & 15, c = e & 15;
+    Wl[(32 * p2 + r) * 65 + 32 * p2 + 16 + c] = 0.0;
+  }
+  __syncthreads();
+  lds_matmul(Wl + 32, 65, Ls + 32 * 65, 65, Wl, 65, 32, 32, 32, 1.0);
+  __syncthreads();
+  lds_matmul(Wl + 32 * 65, 65, Wl + 32 * 65 + 32, 65, Wl + 32, 65, 32, 32, 32, -1.0);
   __syncthreads();
   double* D = dinv + (int64_t)kb * 64 * 64;
   for (int e = tid; e < 4096; e += 256) {
-    const int i = e >> 6, c = e & 63;
-    D[e] = (i >= c) ? Ls[c * 65 + i + 1] : 0.0;
+    const int r = e >> 6, c = e & 63;
+    D[e] = (c <= r) ? Wl[r * 65 + c] : 0.0;
   }
 }
 
 int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb) {
-  potrf_diag_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(m.L, m.NP, kb, m.dinv, ctx->info_dev);
+  constexpr size_t lds = (size_t)(2 * 64 * 65 + 128 + 2) * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_diag_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  potrf_diag_kernel<<<dim3(1), dim3(256), lds, ctx->stream>>>(m.L, m.NP, kb, m.dinv, ctx->info_dev);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
@@ -316,23 +399,44 @@ __global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restric
   if (lane == 0) t[i] = s;
 }
 
+// alpha = W^T t in two deterministic passes: (column block of 64) x (row split) partial sums, then a
+// fixed-order reduction over the row splits.
+constexpr int TRMV_SPLITS = 16;
+
 __global__ __launch_bounds__(256) void trmv_lower_t_kernel(const double* __restrict__ W,
                                                            const double* __restrict__ t,
-                                                           double* __restrict__ alpha, int64_t NP) {
+                                                           double* __restrict__ partial, int64_t NP) {
   __shared__ double red[4][64];
   const int ig = threadIdx.x >> 6, jl = threadIdx.x & 63;
   const int64_t j0 = (int64_t)blockIdx.x * 64;
+  const int64_t rows = NP - j0;                                   // rows j0 .. NP-1 hold non-zeros
+  const int64_t chunk = (rows + TRMV_SPLITS - 1) / TRMV_SPLITS;
+  const int64_t r0 = j0 + (int64_t)blockIdx.y * chunk;
+  const int64_t r1 = min(NP, r0 + chunk);
   double s = 0.0;
-  for (int64_t i = j0 + ig; i < NP; i += 4) s = fma(W[i * NP + j0 + jl], t[i], s);
+  for (int64_t i = r0 + ig; i < r1; i += 4) s = fma(W[i * NP + j0 + jl], t[i], s);
   red[ig][jl] = s;
   __syncthreads();
-  if (ig == 0) alpha[j0 + jl] = ((red[0][jl] + red[1][jl]) + red[2][jl]) + red[3][jl];
+  if (ig == 0) partial[(int64_t)blockIdx.y * NP + j0 + jl] = ((red[0][jl] + red[1][jl]) + red[2][jl]) + red[3][jl];
+}
+
+__global__ __launch_bounds__(256) void trmv_reduce_kernel(const double* __restrict__ partial,
+                                                          double* __restrict__ alpha, int64_t NP) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= NP) return;
+  double s = 0.0;
+#pragma unroll
+  for (int r = 0; r < TRMV_SPLITS; ++r) s += partial[(int64_t)r * NP + j];
+  alpha[j] = s;
 }
 
 int launch_trmv(gpbo_ctx* ctx, Model& m) {
   trmv_lower_kernel<<<dim3((unsigned)((m.NP + 3) / 4)), dim3(256), 0, ctx->stream>>>(m.W, m.yn, m.tvec, m.NP);
   GPBO_HIP(ctx, hipGetLastError());
-  trmv_lower_t_kernel<<<dim3((unsigned)(m.NP / 64)), dim3(256), 0, ctx->stream>>>(m.W, m.tvec, m.alpha, m.NP);
+  // m.tmp (>= NP*64 doubles) is free again after trtri
+  trmv_lower_t_kernel<<<dim3((unsigned)(m.NP / 64), TRMV_SPLITS), dim3(256), 0, ctx->stream>>>(m.W, m.tvec, m.tmp, m.NP);
+  GPBO_HIP(ctx, hipGetLastError());
+  trmv_reduce_kernel<<<dim3((unsigned)((m.NP + 255) / 256)), dim3(256), 0, ctx->stream>>>(m.tmp, m.alpha, m.NP);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }

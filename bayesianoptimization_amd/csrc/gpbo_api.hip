@@ -426,6 +426,12 @@ int gpbo_mfma_f64_peak(gpbo_ctx* ctx, int iters, double* tflops) {
   return run_mfma_peak(ctx, iters, tflops);
 }
 
+int gpbo_mfma_f64_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, double* out) {
+  if (!ctx || !out || iters < 1 || waves_per_simd < 1 || waves_per_simd > 8) return GPBO_ERR_INVALID;
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  return run_mfma_probe(ctx, iters, waves_per_simd, out);
+}
+
 int gpbo_hbm_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps) {
   if (!ctx || !gbps || bytes < (1 << 20)) return GPBO_ERR_INVALID;
   GPBO_HIP(ctx, hipSetDevice(ctx->device));

@@ -162,6 +162,7 @@ int launch_acq_argbest(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, 
 // probe.hip
 int run_mfma_peak(gpbo_ctx* ctx, int iters, double* tflops);
 int run_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);
+int run_mfma_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, double* out4);
 
 inline void ev_begin(gpbo_ctx* ctx, int slot) {
   EventPair& e = ctx->ev[slot];

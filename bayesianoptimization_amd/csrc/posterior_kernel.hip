@@ -19,6 +19,8 @@
 // posterior_finalize_kernel, so results are run-to-run deterministic.
 #include "gpbo_internal.h"
 
+#include <cstdlib>
+
 namespace gpbo {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -46,7 +48,7 @@ __device__ __forceinline__ double kernel_value_post(double d2) {
   }
 }
 
-template <int DP, int KERNEL, bool XC_LDS>
+template <int DP, int KERNEL, bool XC_LDS, int SCHED>
 __global__ __launch_bounds__(512, 2) void posterior_kernel(PostArgs p) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* Ks = smem;                                       // [2][POST_BK][KS_STRIDE]
@@ -89,9 +91,11 @@ __global__ __launch_bounds__(512, 2) void posterior_kernel(PostArgs p) {
   // --- MFMA role: 32 rows of W starting at slab_row0
   const int slab = r * (POST_ROWS / 32) + wave;
   const int slab_row0 = slab * 32;
-  const bool active = slab_row0 < NP;
+  const bool active = slab_row0 < NP;   // false only in a ragged last chunk (NP not a multiple of 256)
   const int64_t pairs = NP / 8;
-  const double2* wp = reinterpret_cast<const double2*>(p.Wp) + (int64_t)slab * pairs * 128 + lane;
+  // inactive waves stream a valid slab (NP/32 - 1) so the main loop stays branch-free; their sums are dropped
+  const int slab_ld = active ? slab : (NP / 32 - 1);
+  const double2* wp = reinterpret_cast<const double2*>(p.Wp) + (int64_t)slab_ld * pairs * 128 + lane;
 
   d4 acc[2][8];
 #pragma unroll
@@ -100,7 +104,9 @@ __global__ __launch_bounds__(512, 2) void posterior_kernel(PostArgs p) {
     for (int j = 0; j < 8; ++j) acc[t][j] = d4{0.0, 0.0, 0.0, 0.0};
   double mu_acc = 0.0;
 
-  auto gen4 = [&](int stage, int buf) {
+  // k* values of this thread's 4 train points of `stage` (pure VALU + scalar loads: no LDS access, so the
+  // scheduler is free to weave it between the MFMAs); gen_store publishes them to the stage tile.
+  auto gen_compute = [&](int stage, double (&kv)[4]) {
     const int j0 = stage * POST_BK + kg * 4;
     const double* xr = p.Xs + (int64_t)j0 * DP;  // wave-uniform -> scalar loads
     double d2[4] = {0.0, 0.0, 0.0, 0.0};
@@ -130,10 +136,13 @@ __global__ __launch_bounds__(512, 2) void posterior_kernel(PostArgs p) {
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const double kv = kernel_value_post<KERNEL>(d2[e]);
-      Ks[(buf * POST_BK + kg * 4 + e) * KS_STRIDE + c] = kv;
-      if (last) mu_acc = fma(kv, p.alpha[j0 + e], mu_acc);
+      kv[e] = kernel_value_post<KERNEL>(d2[e]);
+      mu_acc = fma(kv[e], p.alpha[j0 + e], mu_acc);  // only the last chunk's value is stored
     }
+  };
+  auto gen_store = [&](const double (&kv)[4], int buf) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Ks[(buf * POST_BK + kg * 4 + e) * KS_STRIDE + c] = kv[e];
   };
 
   double2 a_cur[2][2], a_nxt[2][2];
@@ -145,30 +154,70 @@ __global__ __launch_bounds__(512, 2) void posterior_kernel(PostArgs p) {
   };
 
   if (XC_LDS) __syncthreads();
-  gen4(0, 0);
-  if (active) loadA(0, a_cur);
+  {
+    double kv0[4];
+    gen_compute(0, kv0);
+    gen_store(kv0, 0);
+  }
+  loadA(0, a_cur);
   __syncthreads();
 
-  for (int s = 0; s < n_stages; ++s) {
+  auto mma_step = [&](int buf, int q) {
+    const double a0 = (q & 1) ? a_cur[q >> 1][0].y : a_cur[q >> 1][0].x;
+    const double a1 = (q & 1) ? a_cur[q >> 1][1].y : a_cur[q >> 1][1].x;
+    const double* kb = Ks + (buf * POST_BK + q * 4 + (lane >> 4)) * KS_STRIDE + (lane & 15);
+#pragma unroll
+    for (int jt = 0; jt < 8; ++jt) {
+      const double b = kb[jt * 16];
+      acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][jt], 0, 0, 0);
+      acc[1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][jt], 0, 0, 0);
+    }
+  };
+
+  // Loop 1: stages strictly left of this chunk's diagonal block — every wave multiplies, stage s+1 always
+  // exists; the body is one basic block so the scheduler interleaves the VALU generation with the MFMAs.
+  const int n_full = r * (POST_ROWS / POST_BK);
+  int s = 0;
+  for (; s < n_full; ++s) {
+    const int buf = s & 1;
+    double kv[4];
+    loadA(s + 1, a_nxt);
+    gen_compute(s + 1, kv);
+    mma_step(buf, 0);
+    mma_step(buf, 1);
+    mma_step(buf, 2);
+    mma_step(buf, 3);
+    gen_store(kv, buf ^ 1);   // after the last read of this iteration: no LDS ordering against the MFMA feeds
+    if constexpr (SCHED > 0) {
+      // ask the scheduler for "1 MFMA, then SCHED VALU" so the generation hides in the MFMA shadow
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, SCHED, 0);
+      }
+    }
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) a_cur[pp][t] = a_nxt[pp][t];
+    __syncthreads();
+  }
+  // Loop 2: the diagonal block of the chunk (<= 16 stages): a wave stops multiplying once the stage lies
+  // right of its 32-row slab (W is lower triangular there).
+  for (; s < n_stages; ++s) {
     const int buf = s & 1;
     const bool has_next = (s + 1 < n_stages);
-    const bool domma = active && (s * POST_BK <= slab_row0 + 31);
-    const bool domma_next = active && has_next && ((s + 1) * POST_BK <= slab_row0 + 31);
+    const bool domma = (s * POST_BK <= slab_row0 + 31);
+    const bool domma_next = has_next && ((s + 1) * POST_BK <= slab_row0 + 31);
     if (domma_next) loadA(s + 1, a_nxt);
+    if (has_next) {
+      double kv[4];
+      gen_compute(s + 1, kv);
+      gen_store(kv, buf ^ 1);
+    }
+    if (domma) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (domma) {
-        const double a0 = (q & 1) ? a_cur[q >> 1][0].y : a_cur[q >> 1][0].x;
-        const double a1 = (q & 1) ? a_cur[q >> 1][1].y : a_cur[q >> 1][1].x;
-        const double* kb = Ks + (buf * POST_BK + q * 4 + (lane >> 4)) * KS_STRIDE + (lane & 15);
-#pragma unroll
-        for (int jt = 0; jt < 8; ++jt) {
-          const double b = kb[jt * 16];
-          acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][jt], 0, 0, 0);
-          acc[1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][jt], 0, 0, 0);
-        }
-      }
-      if (q == 0 && has_next) gen4(s + 1, buf ^ 1);
+      for (int q = 0; q < 4; ++q) mma_step(buf, q);
     }
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp)
@@ -189,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void posterior_kernel(PostArgs p) {
       for (int rr = 0; rr < 4; ++rr) s = fma(acc[t][jt][rr], acc[t][jt][rr], s);
     s += __shfl_xor(s, 16);
     s += __shfl_xor(s, 32);
-    if (lane < 16) red[wave * POST_CANDS + jt * 16 + lane] = s;
+    if (lane < 16) red[wave * POST_CANDS + jt * 16 + lane] = active ? s : 0.0;
   }
   if (last) mured[kg * POST_CANDS + c] = mu_acc;
   __syncthreads();
@@ -222,10 +271,17 @@ __global__ __launch_bounds__(256) void posterior_finalize_kernel(const double* _
   mu[m] = y_std * mu_part[m] + y_mean;
 }
 
-template <int DP, int KERNEL, bool XC_LDS>
-static int launch_post_t(gpbo_ctx* ctx, const PostArgs& a, int64_t nblocks) {
+// Scheduling variant of the main loop: 0 = compiler default, 6 = "1 MFMA : 6 VALU" group hints (default).
+// GPBO_POST_SCHED=0 selects the unhinted build for A/B runs.
+static int post_sched_variant() {
+  const char* e = getenv("GPBO_POST_SCHED");   // read per launch so one process can A/B both builds
+  return (e && e[0] == '0') ? 0 : 6;
+}
+
+template <int DP, int KERNEL, bool XC_LDS, int SCHED>
+static int launch_post_s(gpbo_ctx* ctx, const PostArgs& a, int64_t nblocks) {
   size_t lds = (size_t)(2 * POST_BK * KS_STRIDE + (XC_LDS ? DP * POST_CANDS : 0)) * sizeof(double);
-  auto kern = posterior_kernel<DP, KERNEL, XC_LDS>;
+  auto kern = posterior_kernel<DP, KERNEL, XC_LDS, SCHED>;
   if (lds > 64 * 1024) {
     GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -233,6 +289,12 @@ static int launch_post_t(gpbo_ctx* ctx, const PostArgs& a, int64_t nblocks) {
   kern<<<dim3((unsigned)nblocks), dim3(512), lds, ctx->stream>>>(a);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
+}
+
+template <int DP, int KERNEL, bool XC_LDS>
+static int launch_post_t(gpbo_ctx* ctx, const PostArgs& a, int64_t nblocks) {
+  if (post_sched_variant() == 0) return launch_post_s<DP, KERNEL, XC_LDS, 0>(ctx, a, nblocks);
+  return launch_post_s<DP, KERNEL, XC_LDS, 6>(ctx, a, nblocks);
 }
 
 template <int KERNEL>

@@ -23,6 +23,68 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) 
   out[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// Same MFMA stream with in-kernel clocks: s_memtime (shader cycles) and s_memrealtime (100 MHz) bracket
+// the loop, so cycles per MFMA per SIMD and the sustained shader clock can be told apart.
+__global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, unsigned long long* clk, int iters) {
+  d4 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+  const double a = 1.0 + threadIdx.x * 1e-6, b = 0.5 - threadIdx.x * 1e-6;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+  out[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;   // forces completion of the MFMAs before the clocks
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    clk[2 * w] = c1 - c0;
+    clk[2 * w + 1] = r1 - r0;
+  }
+}
+
+int run_mfma_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, double* out4) {
+  const int grid = 256 * (waves_per_simd < 1 ? 1 : waves_per_simd);
+  double* out = nullptr;
+  unsigned long long* clk = nullptr;
+  GPBO_HIP(ctx, hipMalloc((void**)&out, (size_t)grid * 256 * sizeof(double)));
+  GPBO_HIP(ctx, hipMalloc((void**)&clk, (size_t)grid * 4 * 2 * sizeof(unsigned long long)));
+  hipEvent_t e0, e1;
+  GPBO_HIP(ctx, hipEventCreate(&e0));
+  GPBO_HIP(ctx, hipEventCreate(&e1));
+  mfma_probe_kernel<<<dim3(grid), dim3(256), 0, ctx->stream>>>(out, clk, 16);
+  GPBO_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  mfma_probe_kernel<<<dim3(grid), dim3(256), 0, ctx->stream>>>(out, clk, iters);
+  GPBO_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  GPBO_HIP(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  GPBO_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  const int nw = grid * 4;
+  std::string h((size_t)nw * 16, '\0');
+  GPBO_HIP(ctx, hipMemcpy(&h[0], clk, h.size(), hipMemcpyDeviceToHost));
+  const unsigned long long* c = (const unsigned long long*)h.data();
+  double cyc = 0.0, rt = 0.0;
+  for (int w = 0; w < nw; ++w) { cyc += (double)c[2 * w]; rt += (double)c[2 * w + 1]; }
+  cyc /= nw; rt /= nw;
+  const double mfma_per_simd = (double)iters * 8.0 * (waves_per_simd < 1 ? 1 : waves_per_simd);
+  out4[0] = (double)grid * 4.0 * iters * 8.0 * 2048.0 / (ms * 1e-3) / 1e12;   // TFLOP/s
+  out4[1] = cyc / mfma_per_simd;                                               // shader cycles per MFMA per SIMD
+  out4[2] = cyc / (rt / 100.0);                                                // shader MHz (s_memrealtime = 100 MHz)
+  out4[3] = ms;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  GPBO_HIP(ctx, hipFree(out));
+  GPBO_HIP(ctx, hipFree(clk));
+  return GPBO_OK;
+}
+
 int run_mfma_peak(gpbo_ctx* ctx, int iters, double* tflops) {
   const int grid = 256 * 2;  // 2 workgroups of 4 waves per CU -> 2 waves per SIMD
   double* out = nullptr;

@@ -158,6 +158,11 @@ class GpEngine:
         self._check(self._lib.gpbo_mfma_f64_peak(self._h, int(iters), C.byref(out)))
         return out.value
 
+    def mfma_f64_probe(self, iters=20000, waves_per_simd=1) -> dict:
+        out = np.zeros(4)
+        self._check(self._lib.gpbo_mfma_f64_probe(self._h, int(iters), int(waves_per_simd), dptr(out)))
+        return {"tflops": out[0], "cycles_per_mfma": out[1], "shader_mhz": out[2], "ms": out[3]}
+
     def hbm_copy_peak(self, nbytes=1 << 30) -> float:
         out = C.c_double(0.0)
         self._check(self._lib.gpbo_hbm_copy_peak(self._h, int(nbytes), C.byref(out)))

@@ -132,6 +132,9 @@ int gpbo_debug_gemm(gpbo_ctx* ctx, int m, int n, int k, double alpha, const doub
                     const double* B, int b_trans, double beta, double* C);
 /* Sustained v_mfma_f64_16x16x4_f64 rate in TFLOP/s over `iters` dependent-chain-free MFMAs. */
 int gpbo_mfma_f64_peak(gpbo_ctx* ctx, int iters, double* tflops);
+/* The same MFMA stream with in-kernel clocks. out[4] = { TFLOP/s, shader cycles per MFMA per SIMD,
+ * sustained shader clock in MHz (s_memtime / s_memrealtime), kernel milliseconds }. */
+int gpbo_mfma_f64_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, double* out);
 /* Streaming copy bandwidth in GB/s (read+write bytes) over a `bytes`-sized buffer. */
 int gpbo_hbm_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);
 

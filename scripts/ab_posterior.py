@@ -1,0 +1,40 @@
+"""Within-process interleaved A/B of the posterior kernel's scheduling variants (GPBO_POST_SCHED=0|6)
+plus fit timings, on C3 (and C2 for the latency regime).  Development aid; writes gpurun_out/ab.json."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bayesianoptimization_amd import workloads as W  # noqa: E402
+from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
+
+eng = GpEngine(0)
+out = {"probe_1wave": eng.mfma_f64_probe(20000, 1), "probe_2wave": eng.mfma_f64_probe(20000, 2),
+       "probe_4wave": eng.mfma_f64_probe(10000, 4)}
+print(out, flush=True)
+for name, M in (("C3", 1 << 19), ("C2", 1 << 16)):
+    w = W.ALL[name]
+    X, y, c = W.make_observations(w)
+    ym, ys = float(np.mean(y)), float(np.std(y))
+    yn = (y - ym) / ys
+    fits = []
+    for _ in range(3):
+        eng.fit(X, yn, w.kernel, w.length_scale, w.noise)
+        fits.append(eng.last_timings())
+    out[name + "_fit_ms"] = fits[-1]
+    eng.set_candidates(W.make_candidates(w.bounds_array(), M, 7))
+    res = {"0": [], "6": []}
+    for rnd in range(4):
+        for v in ("0", "6"):
+            os.environ["GPBO_POST_SCHED"] = v
+            mu, sd = eng.posterior(0, ym, ys)
+            res[v].append(eng.last_timings()["posterior_main"])
+            res[v + "_chk"] = float(mu.sum() + sd.sum())
+    out[name + "_post_ms"] = res
+    print(name, out[name + "_fit_ms"], res, flush=True)
+os.environ.pop("GPBO_POST_SCHED", None)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", "ab.json"), "w"), indent=1)
