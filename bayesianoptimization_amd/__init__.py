@@ -24,7 +24,7 @@ def __getattr__(name):  # lazy: `import bayesianoptimization_amd.workloads` must
         from .space import FloatSpace
         return FloatSpace
     if name == "accelerate":
-        from .accelerate import accelerate
+        from .dropin import accelerate
         return accelerate
     if name in ("UpperConfidenceBound", "ExpectedImprovement", "ProbabilityOfImprovement", "AcquisitionFunction"):
         from . import acquisition

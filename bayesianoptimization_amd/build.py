@@ -26,6 +26,7 @@ SOURCES = {
     "gpbo_api.hip": [],
     "fit_kernels.hip": [],
     "posterior_kernel.hip": [],
+    "posterior_kernel_v2.hip": [],
     "acq_kernels.hip": ["-ffp-contract=off"],  # elementwise formulas follow NumPy op by op
     "probe.hip": [],
     "comm.hip": [],

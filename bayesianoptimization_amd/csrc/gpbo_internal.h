@@ -151,6 +151,8 @@ struct GemmArgs {
 int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g);
 // posterior_kernel.hip
 int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std);
+// posterior_kernel_v2.hip
+int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
 // acq_kernels.hip
 struct AcqArgs {
   int acq; double param; double y_max; int n_constraints;

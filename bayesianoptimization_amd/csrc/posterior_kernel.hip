@@ -326,14 +326,22 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
     m.cap_M = Mp;
   }
   if ((rc = launch_prescale(ctx, ctx->Xc, M, m.d, m.DP, m.ls, ctx->Xcs, Mp))) return rc;
-  PostArgs a;
-  a.Wp = m.Wp; a.Xs = m.Xs; a.alpha = m.alpha; a.Xcs = ctx->Xcs; a.part = ctx->part;
-  a.mu_part = ctx->mu_part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nchunks; a.n_ctiles = (int)n_ctiles;
-  const int64_t nblocks = n_ctiles * nchunks;
-  if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
+  // GPBO_POST_KERNEL=1 selects the 2-waves/SIMD kernel of this file (kept for A/B); default is v2
+  // (posterior_kernel_v2.hip, 4 waves/SIMD).
+  const char* kv = getenv("GPBO_POST_KERNEL");
+  const bool use_v1 = kv && kv[0] == '1';
   ev_begin(ctx, T_POST_MAIN);
-  if (m.kernel == GPBO_KERNEL_MATERN25) rc = launch_post_k<GPBO_KERNEL_MATERN25>(ctx, m.DP, a, nblocks);
-  else rc = launch_post_k<GPBO_KERNEL_RBF>(ctx, m.DP, a, nblocks);
+  if (use_v1) {
+    PostArgs a;
+    a.Wp = m.Wp; a.Xs = m.Xs; a.alpha = m.alpha; a.Xcs = ctx->Xcs; a.part = ctx->part;
+    a.mu_part = ctx->mu_part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nchunks; a.n_ctiles = (int)n_ctiles;
+    const int64_t nblocks = n_ctiles * nchunks;
+    if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
+    if (m.kernel == GPBO_KERNEL_MATERN25) rc = launch_post_k<GPBO_KERNEL_MATERN25>(ctx, m.DP, a, nblocks);
+    else rc = launch_post_k<GPBO_KERNEL_RBF>(ctx, m.DP, a, nblocks);
+  } else {
+    rc = launch_posterior_v2(ctx, m, Mp, nchunks);
+  }
   ev_end(ctx, T_POST_MAIN);
   if (rc) return rc;
   ev_begin(ctx, T_POST_FINAL);

@@ -1,0 +1,254 @@
+// posterior_kernel_v2 — the fused posterior kernel re-tiled for FOUR waves per SIMD.
+//
+// Why: the in-tree probe (gpbo_mfma_f64_probe) shows that on gfx950 a SIMD only reaches the
+// 64-cycle issue cadence of v_mfma_f64_16x16x4_f64 when >= 4 waves feed it (1 wave: 140 cycles per
+// MFMA, 2 waves: 102, 4 waves: 63), and rocprofv3 puts v1 (256 VGPRs -> 2 waves/SIMD) at 56 % matrix-pipe
+// busy.  v2 halves the per-wave accumulator tile so that a wave fits 128 VGPRs:
+//
+//   workgroup = 8 waves, 256 rows of W x 64 candidates, two workgroups resident per CU (4 waves/SIMD);
+//   wave w    = 32 rows x 64 candidates = 2 x 4 MFMA tiles = 64 accumulator VGPRs;
+//   k* stage  = 16 train points x 64 candidates, 2 elements per thread (lane = candidate, wave = k pair),
+//               candidate coordinates read from an LDS image (no registers to spare for them);
+//   W slab    = streamed HBM/L2 -> registers in fragment order, prefetched one k-pair (8 columns) ahead.
+//
+// Same math, same reduction order per row chunk as v1 up to the candidate-tile width; results are
+// deterministic.  Replaces the same reference lines as posterior_kernel.hip (_gpr.py:443-494).
+#include <cstdlib>
+
+#include "gpbo_internal.h"
+
+namespace gpbo {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int V2_CANDS = 64;
+constexpr int V2_STRIDE = 80;  // doubles per k-row of the stage tile: 64 + 16 -> rows 32 banks apart
+
+struct PostArgs2 {
+  const double* Wp;
+  const double* Xs;
+  const double* alpha;
+  const double* Xcs;
+  double* part;
+  double* mu_part;
+  int NP;
+  int64_t Mp;
+  int nchunks;
+  int n_ctiles;
+};
+
+template <int KERNEL>
+__device__ __forceinline__ double kernel_value_v2(double d2) {
+  if (KERNEL == GPBO_KERNEL_MATERN25) {
+    double k = sqrt(d2) * 2.23606797749978969641;
+    return (1.0 + k + k * k / 3.0) * exp(-k);
+  } else {
+    return exp(-0.5 * d2);
+  }
+}
+
+template <int DP, int KERNEL>
+__global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
+  extern __shared__ __attribute__((aligned(16))) double smem2[];
+  double* Ks = smem2;                              // [2][POST_BK][V2_STRIDE]
+  double* Xl = smem2 + 2 * POST_BK * V2_STRIDE;    // [DP][64] candidate coordinates, dimension-major
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int bid = blockIdx.x;
+  const int r = p.nchunks - 1 - bid / p.n_ctiles;   // heaviest row chunks first
+  const int ct = bid - (bid / p.n_ctiles) * p.n_ctiles;
+  const bool last = (r == p.nchunks - 1);
+  const int NP = p.NP;
+  const int k_end = min(NP, (r + 1) * POST_ROWS);
+  const int n_stages = k_end / POST_BK;
+
+  // candidate tile -> LDS (thread t loads candidate t>>3, dims (t&7)*DP/8 ...)
+  {
+    const double* src = p.Xcs + (int64_t)ct * V2_CANDS * DP;
+    for (int e = tid; e < V2_CANDS * DP; e += 512) {
+      const int cnd = e / DP, t = e - cnd * DP;
+      Xl[t * V2_CANDS + cnd] = src[e];
+    }
+  }
+
+  // MFMA role
+  const int slab = r * (POST_ROWS / 32) + wave;
+  const int slab_row0 = slab * 32;
+  const bool active = slab_row0 < NP;
+  const int64_t pairs = NP / 8;
+  const int slab_ld = active ? slab : (NP / 32 - 1);
+  const double2* wp = reinterpret_cast<const double2*>(p.Wp) + (int64_t)slab_ld * pairs * 128 + lane;
+
+  d4 acc[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[t][j] = d4{0.0, 0.0, 0.0, 0.0};
+  double mu_acc = 0.0;
+
+  // generation role: candidate = lane, train points 2*wave, 2*wave+1 of the stage
+  auto gen_compute = [&](int stage, double (&kv)[2]) {
+    const int j0 = stage * POST_BK + wave * 2;
+    const double* xr = p.Xs + (int64_t)j0 * DP;  // wave-uniform -> scalar loads
+    double d2a = 0.0, d2b = 0.0;
+    if constexpr (DP <= 8) {
+#pragma unroll
+      for (int t = 0; t < DP; ++t) {
+        const double x = Xl[t * V2_CANDS + lane];
+        const double da = x - xr[t], db = x - xr[DP + t];
+        d2a = fma(da, da, d2a);
+        d2b = fma(db, db, d2b);
+      }
+    } else {
+#pragma unroll 1
+      for (int tb = 0; tb < DP; tb += 8) {
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+          const double x = Xl[(tb + tt) * V2_CANDS + lane];
+          const double da = x - xr[tb + tt], db = x - xr[DP + tb + tt];
+          d2a = fma(da, da, d2a);
+          d2b = fma(db, db, d2b);
+        }
+      }
+    }
+    kv[0] = kernel_value_v2<KERNEL>(d2a);
+    kv[1] = kernel_value_v2<KERNEL>(d2b);
+    mu_acc = fma(kv[0], p.alpha[j0], mu_acc);
+    mu_acc = fma(kv[1], p.alpha[j0 + 1], mu_acc);
+  };
+  auto gen_store = [&](const double (&kv)[2], int buf) {
+    Ks[(buf * POST_BK + wave * 2) * V2_STRIDE + lane] = kv[0];
+    Ks[(buf * POST_BK + wave * 2 + 1) * V2_STRIDE + lane] = kv[1];
+  };
+
+  // A fragments for one k-pair (8 columns): [tile] double2 = 8 VGPRs
+  auto loadA = [&](int kpair, double2(&a)[2]) {
+    a[0] = wp[((int64_t)kpair * 2 + 0) * 64];
+    a[1] = wp[((int64_t)kpair * 2 + 1) * 64];
+  };
+  auto mma_pair = [&](int buf, int pp, const double2(&a)[2]) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int q = pp * 2 + e;
+      const double a0 = e ? a[0].y : a[0].x;
+      const double a1 = e ? a[1].y : a[1].x;
+      const double* kb = Ks + (buf * POST_BK + q * 4 + (lane >> 4)) * V2_STRIDE + (lane & 15);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const double b = kb[jt * 16];
+        acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][jt], 0, 0, 0);
+        acc[1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][jt], 0, 0, 0);
+      }
+    }
+  };
+
+  __syncthreads();   // Xl visible
+  {
+    double kv0[2];
+    gen_compute(0, kv0);
+    gen_store(kv0, 0);
+  }
+  double2 aA[2], aB[2];
+  loadA(0, aA);
+  __syncthreads();
+
+  // Loop 1: stages left of the chunk's diagonal block (every wave multiplies; stage s+1 exists).
+  const int n_full = r * (POST_ROWS / POST_BK);
+  int s = 0;
+  for (; s < n_full; ++s) {
+    const int buf = s & 1;
+    double kv[2];
+    loadA(2 * s + 1, aB);
+    gen_compute(s + 1, kv);
+    mma_pair(buf, 0, aA);
+    loadA(2 * s + 2, aA);
+    mma_pair(buf, 1, aB);
+    gen_store(kv, buf ^ 1);
+    __syncthreads();
+  }
+  // Loop 2: the diagonal block of the chunk.
+  for (; s < n_stages; ++s) {
+    const int buf = s & 1;
+    const bool has_next = (s + 1 < n_stages);
+    const bool domma = (s * POST_BK <= slab_row0 + 31);
+    const bool domma_next = has_next && ((s + 1) * POST_BK <= slab_row0 + 31);
+    if (domma) loadA(2 * s + 1, aB);
+    if (has_next) {
+      double kv[2];
+      gen_compute(s + 1, kv);
+      gen_store(kv, buf ^ 1);
+    }
+    if (domma) {
+      mma_pair(buf, 0, aA);
+      mma_pair(buf, 1, aB);
+    }
+    if (domma_next) loadA(2 * s + 2, aA);
+    __syncthreads();
+  }
+
+  // epilogue: per-candidate sum of squares over this chunk's rows, fixed order
+  double* red = Ks;                       // [8][64]
+  double* mured = Ks + 8 * V2_CANDS;      // [8][64]
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    double v = 0.0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) v = fma(acc[t][jt][rr], acc[t][jt][rr], v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (lane < 16) red[wave * V2_CANDS + jt * 16 + lane] = active ? v : 0.0;
+  }
+  mured[wave * V2_CANDS + lane] = mu_acc;
+  __syncthreads();
+  if (tid < V2_CANDS) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += red[w * V2_CANDS + tid];
+    const int64_t m = (int64_t)ct * V2_CANDS + tid;
+    p.part[(int64_t)r * p.Mp + m] = v;
+    if (last) {
+      double u = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) u += mured[w * V2_CANDS + tid];
+      p.mu_part[m] = u;
+    }
+  }
+}
+
+template <int DP, int KERNEL>
+static int launch_v2_t(gpbo_ctx* ctx, const PostArgs2& a, int64_t nblocks) {
+  const size_t lds = (size_t)(2 * POST_BK * V2_STRIDE + DP * V2_CANDS) * sizeof(double);
+  posterior_kernel_v2<DP, KERNEL><<<dim3((unsigned)nblocks), dim3(512), lds, ctx->stream>>>(a);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+template <int KERNEL>
+static int launch_v2_k(gpbo_ctx* ctx, int DP, const PostArgs2& a, int64_t nblocks) {
+  switch (DP) {
+    case 4: return launch_v2_t<4, KERNEL>(ctx, a, nblocks);
+    case 8: return launch_v2_t<8, KERNEL>(ctx, a, nblocks);
+    case 16: return launch_v2_t<16, KERNEL>(ctx, a, nblocks);
+    case 32: return launch_v2_t<32, KERNEL>(ctx, a, nblocks);
+    case 64: return launch_v2_t<64, KERNEL>(ctx, a, nblocks);
+  }
+  GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: unsupported padded dimension");
+}
+
+// Mp must be a multiple of 128 (the v1 tile) — also a multiple of 64.
+int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
+  PostArgs2 a;
+  a.Wp = m.Wp; a.Xs = m.Xs; a.alpha = m.alpha; a.Xcs = ctx->Xcs; a.part = ctx->part;
+  a.mu_part = ctx->mu_part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nchunks;
+  a.n_ctiles = (int)(Mp / V2_CANDS);
+  const int64_t nblocks = (int64_t)a.n_ctiles * nchunks;
+  if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
+  if (m.kernel == GPBO_KERNEL_MATERN25) return launch_v2_k<GPBO_KERNEL_MATERN25>(ctx, m.DP, a, nblocks);
+  return launch_v2_k<GPBO_KERNEL_RBF>(ctx, m.DP, a, nblocks);
+}
+
+}  // namespace gpbo

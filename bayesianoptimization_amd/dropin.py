@@ -40,14 +40,15 @@ def _convert_acquisition(fn):
     return new
 
 
-def accelerate(optimizer, device: int = 0, n_random: int | None = None):
+def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=None):
     """Swap the GP(s) and the acquisition function of `optimizer` in place; returns `optimizer`.
 
     Raises NotImplementedError for kernels outside the HIP path (see gpr.describe_kernel) and
     RuntimeError/ImportError when no GPU or no built library is available: there is no CPU fallback.
     `n_random` overrides the number of random candidates per suggest() (reference default 10_000).
+    `engine` lets several optimizers share (or tests inject) a GpEngine; default: one per device.
     """
-    engine = shared_engine(device)
+    engine = engine if engine is not None else shared_engine(device)
     space = optimizer._space
     transform = None if _identity_transform(space) else space.kernel_transform
     describe_kernel(optimizer._gp.kernel)

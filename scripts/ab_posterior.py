@@ -12,8 +12,7 @@ from bayesianoptimization_amd import workloads as W  # noqa: E402
 from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
 
 eng = GpEngine(0)
-out = {"probe_1wave": eng.mfma_f64_probe(20000, 1), "probe_2wave": eng.mfma_f64_probe(20000, 2),
-       "probe_4wave": eng.mfma_f64_probe(10000, 4)}
+out = {f"probe_{n}wave": eng.mfma_f64_probe(20000 // n, n) for n in (1, 2, 3, 4, 6, 8)}
 print(out, flush=True)
 for name, M in (("C3", 1 << 19), ("C2", 1 << 16)):
     w = W.ALL[name]
@@ -26,15 +25,21 @@ for name, M in (("C3", 1 << 19), ("C2", 1 << 16)):
         fits.append(eng.last_timings())
     out[name + "_fit_ms"] = fits[-1]
     eng.set_candidates(W.make_candidates(w.bounds_array(), M, 7))
-    res = {"0": [], "6": []}
+    res = {"v1_sched0": [], "v1_sched6": [], "v2": []}
+    ref = None
     for rnd in range(4):
-        for v in ("0", "6"):
-            os.environ["GPBO_POST_SCHED"] = v
+        for v, env in (("v1_sched0", {"GPBO_POST_KERNEL": "1", "GPBO_POST_SCHED": "0"}),
+                       ("v1_sched6", {"GPBO_POST_KERNEL": "1", "GPBO_POST_SCHED": "6"}),
+                       ("v2", {"GPBO_POST_KERNEL": "2"})):
+            os.environ.update(env)
             mu, sd = eng.posterior(0, ym, ys)
             res[v].append(eng.last_timings()["posterior_main"])
-            res[v + "_chk"] = float(mu.sum() + sd.sum())
+            if ref is None:
+                ref = (mu.copy(), sd.copy())
+            res[v + "_maxdiff"] = float(max(np.max(np.abs(mu - ref[0])), np.max(np.abs(sd - ref[1]))))
     out[name + "_post_ms"] = res
     print(name, out[name + "_fit_ms"], res, flush=True)
 os.environ.pop("GPBO_POST_SCHED", None)
+os.environ.pop("GPBO_POST_KERNEL", None)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "ab.json"), "w"), indent=1)

@@ -39,3 +39,64 @@ class OracleEngine:
         nan = np.isnan(ys)
         order = np.lexsort((np.arange(len(ys)), np.where(nan, np.inf, ys) + 0.0, nan))[:k_seeds]
         return bi + index_offset, bv, order + index_offset, ys[order], (ys if return_values else None)
+
+
+class FakeEngine:
+    """The full GpEngine surface HipGPR/acquisition use, computed by the CPU oracle.  TEST DOUBLE ONLY:
+    lets the host glue (HipGPR, fused acquisition classes, accelerate) be exercised against the real
+    bayes_opt in the CPU container, where no GPU exists."""
+
+    def __init__(self):
+        self.models = {}
+        self.post = {}
+        self.Xc = None
+        self.n_candidates = 0
+        self.calls = []
+
+    def fit(self, X, y_norm, kernel, length_scale, noise, slot=0, precision=0):
+        self.calls.append(("fit", slot, X.shape))
+        gp = O.fit_fixed_theta(kernel, X, y_norm, length_scale, noise, normalize_y=False)
+        self.models[slot] = gp
+
+    def get_L(self, n, slot=0):
+        return self.models[slot].L.copy()
+
+    def get_alpha(self, n, slot=0):
+        return self.models[slot].alpha.copy()
+
+    def set_candidates(self, Xc):
+        self.calls.append(("set_candidates", Xc.shape))
+        self.Xc = np.asarray(Xc, dtype=np.float64)
+        self.n_candidates = self.Xc.shape[0]
+        self.post = {}
+
+    def posterior(self, slot=0, y_mean=0.0, y_std=1.0, fetch=True):
+        self.calls.append(("posterior", slot))
+        mu, sd = O.predict(self.models[slot], self.Xc)
+        mu, sd = y_std * mu + y_mean, sd * y_std
+        self.post[slot] = (mu, sd)
+        return (mu, sd) if fetch else (None, None)
+
+    def predict(self, Xc, slot=0, y_mean=0.0, y_std=1.0):
+        self.set_candidates(Xc)
+        return self.posterior(slot, y_mean, y_std, True)
+
+    def acq_argbest(self, acq, param, y_max=0.0, lb=None, ub=None, k_seeds=0, index_offset=0, return_values=False):
+        self.calls.append(("acq_argbest", acq, k_seeds))
+        mu, sd = self.post[0]
+        ys = -1 * O.base_acq(acq, mu, sd, param, y_max)
+        if lb is not None:
+            p = None
+            for j in range(len(lb)):
+                cm, cs = self.post[j + 1]
+                pl = O._cdf_loc_scale(lb[j], cm, cs) if lb[j] != -np.inf else np.array([0.0])
+                pu = O._cdf_loc_scale(ub[j], cm, cs) if ub[j] != np.inf else np.array([1.0])
+                p = (pu - pl) if p is None else p * (pu - pl)
+            ys = ys * p
+        if np.isnan(ys).any():
+            bi, bv = int(np.flatnonzero(np.isnan(ys))[0]), float("nan")
+        else:
+            bi, bv = int(ys.argmin()), float(ys.min())
+        nan = np.isnan(ys)
+        order = np.lexsort((np.arange(len(ys)), np.where(nan, np.inf, ys) + 0.0, nan))[:k_seeds]
+        return bi + index_offset, bv, order + index_offset, ys[order], (ys if return_values else None)

@@ -95,8 +95,18 @@ def test_acquisition_and_argbest_parity(engine, name, ls, cls):
         tol = 1e-7 if w.kernel == W.RBF else TOL
         assert np.max(np.abs(ys - ys_o)) <= tol * scale
         oi, ov, os_ = O.arg_best(ys_o, 12)
-        assert bi == oi and np.array_equal(si, os_)
+        assert bi == oi
         assert bv == ys[bi] and np.array_equal(sv, ys[si])
+        # argsort(ys)[:k]: identical indices unless values tie exactly (POI saturates at -1.0 on confident
+        # posteriors); NumPy's introsort leaves the order of equal keys unspecified, the device breaks ties
+        # by lowest index — so compare the selected VALUES always and the indices when the keys are distinct.
+        srt = np.sort(ys_o)
+        assert np.allclose(sv, srt[:12], rtol=tol, atol=tol * scale)
+        if np.all(np.diff(srt[:13]) > 4 * tol * scale):
+            assert np.array_equal(si, os_)
+        else:
+            nan = np.isnan(ys)
+            assert np.array_equal(si, np.lexsort((np.arange(len(ys)), np.where(nan, np.inf, ys), nan))[:12])
 
 
 def test_two_sided_and_multiple_constraints(engine):
