@@ -70,7 +70,15 @@ def load_library(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
+    explicit = path is not None
     path = path or LIB_PATH
+    if not os.path.exists(path) and not explicit:
+        # the library is git-ignored: on a fresh checkout build it in-tree once (hipcc cross-compiles)
+        try:
+            from .build import build
+            build(verbose=False)
+        except Exception as e:  # noqa: BLE001
+            raise ImportError(f"{path} not found and building it failed ({e}). There is no CPU fallback.") from e
     if not os.path.exists(path):
         raise ImportError(
             f"{path} not found: the HIP extension has not been built. Run "

@@ -120,13 +120,27 @@ def main():
     collective = "none"
     allgather = None
     if world > 1:
-        try:
-            ids = [GpEngine.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            eng.comm_init(ids[0], world, rank)
+        # RCCL bootstrap guarded by a watchdog: a hung ncclCommInitRank must not take the scaling run down.
+        import threading
+
+        ids = [GpEngine.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        state = {"ok": False, "err": None}
+
+        def _init():
+            try:
+                eng.comm_init(ids[0], world, rank)
+                state["ok"] = True
+            except Exception as e:  # noqa: BLE001
+                state["err"] = repr(e)
+
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("GPBO_RCCL_INIT_TIMEOUT", "120")))
+        if state["ok"]:
             collective = "rccl-allgather"
-        except Exception as e:  # keep the scaling run alive; say so in the JSON
-            log(f"[bench] RCCL init failed on rank {rank}: {e!r}; falling back to gloo for the 176-byte exchange")
+        else:
+            log(f"[bench] RCCL init failed/hung on rank {rank}: {state['err']}; using gloo for the 176-byte exchange")
             collective = "gloo-allgather(fallback)"
         flags = [None] * world
         dist.all_gather_object(flags, collective)
@@ -219,6 +233,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        if th.is_alive():  # a hung RCCL bootstrap thread: leave without running its destructors
+            sys.stdout.flush()
+            os._exit(0)
     eng.close()
 
 
