@@ -272,19 +272,20 @@ int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb) {
 //   C = alpha * A(m,k) * op(B) + beta * C ;  A row-major; B row-major (k,n), or (n,k) if b_trans.
 // Fragment layout (cdna_hip_programming.md §3): A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15],
 // D lane l, reg r = D[(l>>4) + 4r][l&15].
-template <bool BT>
+template <bool BT, bool AT>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   const int bn = blockIdx.x, bm = blockIdx.y, bz = blockIdx.z;
   if (g.lower_only && bn > bm) return;
   __shared__ double As[16][68];
   __shared__ double Bs[16][68];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const double* A = g.A + (int64_t)bz * g.strideA + (int64_t)bm * 64 * g.lda;
+  const double* A = g.A + (int64_t)bz * g.strideA + (AT ? (int64_t)bm * 64 : (int64_t)bm * 64 * g.lda);
   const double* B = g.B + (int64_t)bz * g.strideB + (BT ? (int64_t)bn * 64 * g.ldb : (int64_t)bn * 64);
   double* C = g.C + (int64_t)bz * g.strideC;
   int kbeg = 0, kend = g.k;
   if (g.a_lower) kend = min(kend, (bm + 1) * 64);
   if (g.b_lower) kbeg = bn * 64;
+  if (g.k_from_tile) kbeg = max(bm, bn) * 64;   // both operands vanish above their diagonal tiles
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   d4 acc[2][2];
 #pragma unroll
@@ -294,9 +295,16 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   const int arow = tid >> 2, akq = (tid & 3) * 4;
   const int brow = tid >> 4, bnq = (tid & 15) * 4;
   for (int k0 = kbeg; k0 < kend; k0 += 16) {
-    const double* ap = A + (int64_t)arow * g.lda + k0 + akq;
-    const double2 a01 = *reinterpret_cast<const double2*>(ap);
-    const double2 a23 = *reinterpret_cast<const double2*>(ap + 2);
+    double2 a01, a23;
+    if (AT) {
+      const double* ap = A + (int64_t)(k0 + brow) * g.lda + bnq;
+      a01 = *reinterpret_cast<const double2*>(ap);
+      a23 = *reinterpret_cast<const double2*>(ap + 2);
+    } else {
+      const double* ap = A + (int64_t)arow * g.lda + k0 + akq;
+      a01 = *reinterpret_cast<const double2*>(ap);
+      a23 = *reinterpret_cast<const double2*>(ap + 2);
+    }
     double2 b01, b23;
     if (BT) {
       const double* bp = B + (int64_t)arow * g.ldb + k0 + akq;
@@ -308,10 +316,17 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       b23 = *reinterpret_cast<const double2*>(bp + 2);
     }
     __syncthreads();
-    As[akq + 0][arow] = a01.x;
-    As[akq + 1][arow] = a01.y;
-    As[akq + 2][arow] = a23.x;
-    As[akq + 3][arow] = a23.y;
+    if (AT) {
+      As[brow][bnq + 0] = a01.x;
+      As[brow][bnq + 1] = a01.y;
+      As[brow][bnq + 2] = a23.x;
+      As[brow][bnq + 3] = a23.y;
+    } else {
+      As[akq + 0][arow] = a01.x;
+      As[akq + 1][arow] = a01.y;
+      As[akq + 2][arow] = a23.x;
+      As[akq + 3][arow] = a23.y;
+    }
     if (BT) {
       Bs[akq + 0][arow] = b01.x;
       Bs[akq + 1][arow] = b01.y;
@@ -356,10 +371,13 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g) {
   if (g.m <= 0 || g.n <= 0 || g.batch <= 0) return GPBO_OK;
   if (g.m % 64 || g.n % 64 || g.k % 16) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gemm: m,n must be multiples of 64 and k of 16");
   dim3 grid((unsigned)(g.n / 64), (unsigned)(g.m / 64), (unsigned)g.batch);
+  if (g.a_trans && g.b_trans) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gemm: a_trans with b_trans is not instantiated");
   if (g.b_trans)
-    gemm_f64_kernel<true><<<grid, dim3(256), 0, ctx->stream>>>(g);
+    gemm_f64_kernel<true, false><<<grid, dim3(256), 0, ctx->stream>>>(g);
+  else if (g.a_trans)
+    gemm_f64_kernel<false, true><<<grid, dim3(256), 0, ctx->stream>>>(g);
   else
-    gemm_f64_kernel<false><<<grid, dim3(256), 0, ctx->stream>>>(g);
+    gemm_f64_kernel<false, false><<<grid, dim3(256), 0, ctx->stream>>>(g);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }

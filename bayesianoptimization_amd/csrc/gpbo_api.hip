@@ -218,23 +218,25 @@ int gpbo_device_info(gpbo_ctx* ctx, char* buf, int buflen) {
   return GPBO_OK;
 }
 
-int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d,
-             int kernel, const double* length_scale, int n_ls, double noise, int precision,
-             int* info) {
+// Shared by gpbo_fit and gpbo_lml: validate, upload, K, Cholesky, W = L^-1, alpha — all queued on the
+// stream; the potrf info word is copied to pinned memory (valid after the next stream sync).
+static int factorize(gpbo_ctx* ctx, int slot, const char* who, const double* X, const double* y_norm, int64_t N,
+                     int d, int kernel, const double* length_scale, int n_ls, double noise, int precision,
+                     int** info_host) {
   int rc = check_slot(ctx, slot);
   if (rc) return rc;
-  if (info) *info = 0;
-  if (!X || !y_norm || !length_scale) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit: NULL input");
-  if (N < 1 || N > (1 << 16)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit: N out of range [1, 65536]");
-  if (d < 1 || d > GPBO_MAX_DIM) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "gpbo_fit: d out of range [1, 64]");
+  std::string w(who);
+  if (!X || !y_norm || !length_scale) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": NULL input");
+  if (N < 1 || N > (1 << 16)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": N out of range [1, 65536]");
+  if (d < 1 || d > GPBO_MAX_DIM) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, w + ": d out of range [1, 64]");
   if (kernel != GPBO_KERNEL_RBF && kernel != GPBO_KERNEL_MATERN25)
-    GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "gpbo_fit: kernel must be RBF or Matern(nu=2.5)");
-  if (n_ls != 1 && n_ls != d) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit: length_scale must have 1 or d entries");
-  if (precision != GPBO_F64) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "gpbo_fit: only float64 arithmetic is implemented");
+    GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, w + ": kernel must be RBF or Matern(nu=2.5)");
+  if (n_ls != 1 && n_ls != d) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": length_scale must have 1 or d entries");
+  if (precision != GPBO_F64) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, w + ": only float64 arithmetic is implemented");
   for (int t = 0; t < n_ls; ++t)
     if (!(length_scale[t] > 0.0) || !std::isfinite(length_scale[t]))
-      GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit: length_scale must be positive and finite");
-  if (!(noise >= 0.0)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit: noise must be >= 0");
+      GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": length_scale must be positive and finite");
+  if (!(noise >= 0.0)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": noise must be >= 0");
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
 
   Model& m = ctx->models[slot];
@@ -246,7 +248,6 @@ int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int
   m.N = N; m.NP = NP; m.d = d; m.DP = DP; m.kernel = kernel; m.precision = precision;
 
   ev_begin(ctx, T_FIT);
-  // inputs -> device
   double* ls_h = (double*)ctx->pinned;
   for (int t = 0; t < GPBO_MAX_DIM; ++t) ls_h[t] = (t < d) ? (n_ls == 1 ? length_scale[0] : length_scale[t]) : 1.0;
   GPBO_HIP(ctx, hipMemcpyAsync(m.ls, ls_h, GPBO_MAX_DIM * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -255,22 +256,32 @@ int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int
   GPBO_HIP(ctx, hipMemcpyAsync(m.yn, y_norm, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   GPBO_HIP(ctx, hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream));
   if ((rc = launch_prescale(ctx, m.tmp, N, d, DP, m.ls, m.Xs, NP))) return rc;
-  // K
   ev_begin(ctx, T_KMAT);
   if ((rc = launch_kmat(ctx, m, noise))) return rc;
   ev_end(ctx, T_KMAT);
   GPBO_HIP(ctx, hipMemcpyAsync(m.L, m.K, (size_t)NP * NP * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  // L
   ev_begin(ctx, T_CHOL);
   if ((rc = cholesky(ctx, m))) return rc;
   ev_end(ctx, T_CHOL);
   int* info_h = (int*)((char*)ctx->pinned + 1024);
   GPBO_HIP(ctx, hipMemcpyAsync(info_h, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  // W, alpha, packed W (issued before the info check resolves; harmless on failure)
+  // W and alpha are issued before the info check resolves (harmless on failure)
   ev_begin(ctx, T_TRTRI);
   if ((rc = trtri(ctx, m))) return rc;
   ev_end(ctx, T_TRTRI);
   if ((rc = launch_trmv(ctx, m))) return rc;
+  *info_host = info_h;
+  return GPBO_OK;
+}
+
+int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d,
+             int kernel, const double* length_scale, int n_ls, double noise, int precision,
+             int* info) {
+  if (info) *info = 0;
+  int* info_h = nullptr;
+  int rc = factorize(ctx, slot, "gpbo_fit", X, y_norm, N, d, kernel, length_scale, n_ls, noise, precision, &info_h);
+  if (rc) return rc;
+  Model& m = ctx->models[slot];
   if ((rc = launch_pack_w(ctx, m))) return rc;
   ev_end(ctx, T_FIT);
   GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -281,6 +292,51 @@ int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int
     GPBO_FAIL(ctx, GPBO_ERR_NOT_PD, b);
   }
   m.fitted = true;
+  return GPBO_OK;
+}
+
+int gpbo_lml(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d,
+             int kernel, const double* length_scale, int n_ls, double noise, int eval_gradient,
+             double* lml, double* grad, int* info) {
+  if (info) *info = 0;
+  if (!lml || (eval_gradient && !grad)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml: NULL output");
+  int* info_h = nullptr;
+  int rc = factorize(ctx, slot, "gpbo_lml", X, y_norm, N, d, kernel, length_scale, n_ls, noise, GPBO_F64, &info_h);
+  if (rc) return rc;
+  Model& m = ctx->models[slot];   // left "unfitted": its W is not packed for the posterior kernel
+  // device scratch for the scalars: red buffer (>= 2 + n_ls doubles)
+  {
+    char* p = (char*)ctx->red;
+    int64_t cap = ctx->cap_red;
+    if ((rc = ensure(ctx, &p, &cap, (int64_t)(8 + GPBO_MAX_DIM) * 8))) return rc;
+    ctx->red = p;
+    ctx->cap_red = cap;
+  }
+  double* scal = (double*)ctx->red;
+  if ((rc = launch_lml_terms(ctx, m, scal))) return rc;
+  if (eval_gradient) {
+    // K^-1 = W^T W (lower tiles) into the K buffer, then the trace reduction; partials go to m.tmp
+    GemmArgs g{};
+    g.m = (int)m.NP; g.n = (int)m.NP; g.k = (int)m.NP; g.alpha = 1.0; g.beta = 0.0;
+    g.A = m.W; g.lda = m.NP; g.a_trans = 1;
+    g.B = m.W; g.ldb = m.NP;
+    g.C = m.K; g.ldc = m.NP; g.batch = 1; g.lower_only = 1; g.k_from_tile = 1;
+    if ((rc = launch_gemm(ctx, g))) return rc;
+    if ((rc = launch_lml_grad(ctx, m, n_ls, m.K, m.tmp, scal + 2))) return rc;
+  }
+  ev_end(ctx, T_FIT);
+  double* out_h = (double*)((char*)ctx->pinned + 2048);
+  GPBO_HIP(ctx, hipMemcpyAsync(out_h, scal, (size_t)(2 + (eval_gradient ? n_ls : 0)) * sizeof(double),
+                               hipMemcpyDeviceToHost, ctx->stream));
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (*info_h != 0) {  // sklearn returns -inf and a zero gradient when K is not PD (_gpr.py:588-589)
+    if (info) *info = *info_h;
+    *lml = -INFINITY;
+    if (eval_gradient) for (int t = 0; t < n_ls; ++t) grad[t] = 0.0;
+    return GPBO_OK;
+  }
+  *lml = -0.5 * out_h[0] - out_h[1] - 0.5 * (double)N * 1.83787706640934548356;  // log(2 pi)
+  if (eval_gradient) for (int t = 0; t < n_ls; ++t) grad[t] = out_h[2 + t];
   return GPBO_OK;
 }
 
@@ -426,10 +482,10 @@ int gpbo_mfma_f64_peak(gpbo_ctx* ctx, int iters, double* tflops) {
   return run_mfma_peak(ctx, iters, tflops);
 }
 
-int gpbo_mfma_f64_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, double* out) {
+int gpbo_mfma_f64_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, double* out) {
   if (!ctx || !out || iters < 1 || waves_per_simd < 1 || waves_per_simd > 8) return GPBO_ERR_INVALID;
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
-  return run_mfma_probe(ctx, iters, waves_per_simd, out);
+  return run_mfma_probe(ctx, iters, waves_per_simd, mode, out);
 }
 
 int gpbo_hbm_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps) {

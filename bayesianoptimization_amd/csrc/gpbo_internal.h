@@ -147,6 +147,8 @@ struct GemmArgs {
   int lower_only;         // skip output tiles strictly above the diagonal (m == n)
   int a_lower;            // A is lower triangular (k == m): k-loop stops at the row tile's diagonal
   int b_lower;            // B is lower triangular (k == n, not transposed): k-loop starts at the column tile
+  int a_trans;            // A given as (k,m) row-major (C = A^T B)
+  int k_from_tile;        // k-loop starts at max(row tile, column tile): W^T W with W lower triangular
 };
 int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g);
 // posterior_kernel.hip
@@ -161,10 +163,13 @@ struct AcqArgs {
 };
 int launch_acq_argbest(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, int64_t offset,
                        int64_t* best_idx, double* best_val, int64_t* seed_idx, double* seed_val);
+// lml_kernels.hip
+int launch_lml_terms(gpbo_ctx* ctx, Model& m, double* out2_dev);
+int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, double* partial, double* grad_dev);
 // probe.hip
 int run_mfma_peak(gpbo_ctx* ctx, int iters, double* tflops);
 int run_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);
-int run_mfma_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, double* out4);
+int run_mfma_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, double* out4);
 
 inline void ev_begin(gpbo_ctx* ctx, int slot) {
   EventPair& e = ctx->ev[slot];

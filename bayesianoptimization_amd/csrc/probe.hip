@@ -25,6 +25,7 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) 
 
 // Same MFMA stream with in-kernel clocks: s_memtime (shader cycles) and s_memrealtime (100 MHz) bracket
 // the loop, so cycles per MFMA per SIMD and the sustained shader clock can be told apart.
+template <int MODE>  // 0: builtin (compiler picks VGPR accumulators); 1: inline asm with AGPR accumulators
 __global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, unsigned long long* clk, int iters) {
   d4 acc[8];
 #pragma unroll
@@ -34,8 +35,15 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, unsigned l
   const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   for (int i = 0; i < iters; ++i) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+    for (int j = 0; j < 8; ++j) {
+      if constexpr (MODE == 1) {
+        asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc[j]) : "v"(a), "v"(b));
+      } else {
+        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+      }
+    }
   }
+  if constexpr (MODE == 1) asm volatile("s_nop 15\n s_nop 15" ::: "memory");
   double s = 0.0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
@@ -50,7 +58,7 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, unsigned l
   }
 }
 
-int run_mfma_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, double* out4) {
+int run_mfma_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, double* out4) {
   const int grid = 256 * (waves_per_simd < 1 ? 1 : waves_per_simd);
   double* out = nullptr;
   unsigned long long* clk = nullptr;
@@ -59,9 +67,10 @@ int run_mfma_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, double* out4) {
   hipEvent_t e0, e1;
   GPBO_HIP(ctx, hipEventCreate(&e0));
   GPBO_HIP(ctx, hipEventCreate(&e1));
-  mfma_probe_kernel<<<dim3(grid), dim3(256), 0, ctx->stream>>>(out, clk, 16);
+  auto kern = mode == 1 ? mfma_probe_kernel<1> : mfma_probe_kernel<0>;
+  kern<<<dim3(grid), dim3(256), 0, ctx->stream>>>(out, clk, 16);
   GPBO_HIP(ctx, hipEventRecord(e0, ctx->stream));
-  mfma_probe_kernel<<<dim3(grid), dim3(256), 0, ctx->stream>>>(out, clk, iters);
+  kern<<<dim3(grid), dim3(256), 0, ctx->stream>>>(out, clk, iters);
   GPBO_HIP(ctx, hipEventRecord(e1, ctx->stream));
   GPBO_HIP(ctx, hipEventSynchronize(e1));
   float ms = 0.f;

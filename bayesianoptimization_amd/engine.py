@@ -78,6 +78,20 @@ class GpEngine:
                                 dptr(ls), int(ls.shape[0]), float(noise), int(precision), C.byref(info))
         self._check(rc, info.value)
 
+    def lml(self, X, y_norm, kernel: int, length_scale, noise: float, eval_gradient=True, slot: int = 0):
+        """(log marginal likelihood, d/dlog(length_scale)) at theta (sklearn _gpr.py:575-652). Clobbers the slot's fit."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        y_norm = np.ascontiguousarray(y_norm, dtype=np.float64).ravel()
+        ls = np.ascontiguousarray(np.atleast_1d(np.asarray(length_scale, dtype=np.float64)))
+        val = C.c_double(0.0)
+        grad = np.zeros(ls.shape[0])
+        info = C.c_int(0)
+        rc = self._lib.gpbo_lml(self._h, int(slot), dptr(X), dptr(y_norm), X.shape[0], X.shape[1], int(kernel),
+                                dptr(ls), int(ls.shape[0]), float(noise), int(bool(eval_gradient)), C.byref(val),
+                                dptr(grad), C.byref(info))
+        self._check(rc, info.value)
+        return (val.value, grad) if eval_gradient else val.value
+
     def _square(self, fn, slot, n):
         out = np.empty((n, n), dtype=np.float64)
         self._check(fn(self._h, int(slot), dptr(out)))
@@ -158,9 +172,9 @@ class GpEngine:
         self._check(self._lib.gpbo_mfma_f64_peak(self._h, int(iters), C.byref(out)))
         return out.value
 
-    def mfma_f64_probe(self, iters=20000, waves_per_simd=1) -> dict:
+    def mfma_f64_probe(self, iters=20000, waves_per_simd=1, mode=0) -> dict:
         out = np.zeros(4)
-        self._check(self._lib.gpbo_mfma_f64_probe(self._h, int(iters), int(waves_per_simd), dptr(out)))
+        self._check(self._lib.gpbo_mfma_f64_probe(self._h, int(iters), int(waves_per_simd), int(mode), dptr(out)))
         return {"tflops": out[0], "cycles_per_mfma": out[1], "shader_mhz": out[2], "ms": out[3]}
 
     def hbm_copy_peak(self, nbytes=1 << 30) -> float:

@@ -72,13 +72,16 @@ class HipGPR(GaussianProcessRegressor):
 
     def __init__(self, kernel=None, *, alpha=1e-10, optimizer="fmin_l_bfgs_b", n_restarts_optimizer=0,
                  normalize_y=False, copy_X_train=True, n_targets=None, random_state=None,
-                 transform=None, engine=None, slot=0):
+                 transform=None, engine=None, slot=0, lml_on_device="auto"):
         super().__init__(kernel=kernel, alpha=alpha, optimizer=optimizer,
                          n_restarts_optimizer=n_restarts_optimizer, normalize_y=normalize_y,
                          copy_X_train=copy_X_train, n_targets=n_targets, random_state=random_state)
         self.transform = transform  # host-side input transform (None = identity, the all-float case)
         self.engine = engine
         self.slot = slot
+        # theta search: evaluate log_marginal_likelihood(theta, eval_gradient=True) on the GPU (True), with
+        # sklearn's host code (False), or on the GPU from N >= 512 observations ("auto")
+        self.lml_on_device = lml_on_device
 
     # -- plumbing ------------------------------------------------------------------------------
     def _engine(self) -> GpEngine:
@@ -100,6 +103,42 @@ class HipGPR(GaussianProcessRegressor):
                    n_restarts_optimizer=p["n_restarts_optimizer"], normalize_y=p["normalize_y"],
                    copy_X_train=p["copy_X_train"], n_targets=p.get("n_targets"),
                    random_state=p["random_state"], transform=transform, engine=engine, slot=slot)
+
+    # -- log marginal likelihood ---------------------------------------------------------------------
+    def _device_lml_ok(self, kernel) -> bool:
+        if self.lml_on_device is False or not hasattr(self, "X_train_"):
+            return False
+        if self.lml_on_device == "auto" and self.X_train_.shape[0] < 512:
+            return False
+        if np.iterable(self.alpha):
+            return False
+        try:
+            _, ls = describe_kernel(kernel)
+        except NotImplementedError:
+            return False
+        free = [h for h in kernel.hyperparameters if not h.fixed]
+        return len(free) == 1 and free[0].name.endswith("length_scale") and kernel.n_dims == ls.shape[0]
+
+    def log_marginal_likelihood(self, theta=None, eval_gradient=False, clone_kernel=True):
+        """sklearn _gpr.py:537-652; with `theta` given and a supported kernel the value and the gradient
+        with respect to log(length_scale) are computed on the device (gpbo_lml), otherwise by sklearn."""
+        if theta is None or not self._device_lml_ok(self.kernel_):
+            return super().log_marginal_likelihood(theta, eval_gradient=eval_gradient, clone_kernel=clone_kernel)
+        if clone_kernel:
+            kernel = self.kernel_.clone_with_theta(theta)
+        else:
+            kernel = self.kernel_
+            kernel.theta = theta
+        kind, ls = describe_kernel(kernel)
+        out = self._engine().lml(self._tx(self.X_train_), self.y_train_, kind, ls, float(self.alpha),
+                                 eval_gradient=eval_gradient, slot=self.slot)
+        self.__dict__.pop("_L_cache", None)      # the slot's factorisation now belongs to this theta
+        self.__dict__.pop("_alpha_cache", None)
+        if not getattr(self, "_in_fit", False) and hasattr(self, "_kind"):
+            # called on a fitted model: gpbo_lml reused the slot's buffers, so restore the fit
+            self._engine().fit(self._tx(self.X_train_), self.y_train_, self._kind, self._ls, float(self.alpha),
+                               slot=self.slot)
+        return out
 
     # lazily fetched parity attributes -------------------------------------------------------------
     @property
@@ -165,7 +204,9 @@ class HipGPR(GaussianProcessRegressor):
         self.__dict__.pop("_L_cache", None)
         self.__dict__.pop("_alpha_cache", None)
 
-        if self.optimizer is not None and self.kernel_.n_dims > 0:  # _gpr.py:296-338 (host theta search)
+        self._in_fit = True
+        if self.optimizer is not None and self.kernel_.n_dims > 0:  # _gpr.py:296-338 (L-BFGS-B on the host;
+            # each objective evaluation runs on the device when _device_lml_ok)
             def obj_func(theta, eval_gradient=True):
                 if eval_gradient:
                     lml, grad = self.log_marginal_likelihood(theta, eval_gradient=True, clone_kernel=False)
@@ -187,6 +228,7 @@ class HipGPR(GaussianProcessRegressor):
         else:
             self.log_marginal_likelihood_value_ = None  # not evaluated on the fixed-theta path
 
+        self._in_fit = False
         kind, ls = describe_kernel(self.kernel_)
         if ls.shape[0] not in (1, self.n_features_in_):
             raise ValueError("Anisotropic kernel must have the same number of dimensions as data")

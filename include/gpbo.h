@@ -73,6 +73,16 @@ int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int
              int kernel, const double* length_scale, int n_ls, double noise, int precision,
              int* info);
 
+/* Log marginal likelihood and its gradient with respect to log(length_scale) at the given theta.
+ * Replaces one L-BFGS-B evaluation of GaussianProcessRegressor.log_marginal_likelihood(theta,
+ * eval_gradient=True) (_gpr.py:575-652; Matern/RBF gradients kernels.py:1764-1766, 1567-1582), the inner
+ * loop of the theta search in fit (_gpr.py:296-338).  grad has n_ls entries.  A non-PD kernel matrix gives
+ * *lml = -inf, zero gradient and *info = pivot index (status stays GPBO_OK), as sklearn does.
+ * Overwrites the slot's fit state (the slot must be re-fitted with gpbo_fit before gpbo_posterior). */
+int gpbo_lml(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d,
+             int kernel, const double* length_scale, int n_ls, double noise, int eval_gradient,
+             double* lml, double* grad, int* info);
+
 /* Parity accessors (tests): copy device state back as (N,N) row-major / (N,) float64. */
 int gpbo_get_K(gpbo_ctx* ctx, int slot, double* out);      /* kernel matrix incl. noise, full symmetric */
 int gpbo_get_L(gpbo_ctx* ctx, int slot, double* out);      /* lower Cholesky factor, upper zeroed (gp.L_) */
@@ -133,8 +143,9 @@ int gpbo_debug_gemm(gpbo_ctx* ctx, int m, int n, int k, double alpha, const doub
 /* Sustained v_mfma_f64_16x16x4_f64 rate in TFLOP/s over `iters` dependent-chain-free MFMAs. */
 int gpbo_mfma_f64_peak(gpbo_ctx* ctx, int iters, double* tflops);
 /* The same MFMA stream with in-kernel clocks. out[4] = { TFLOP/s, shader cycles per MFMA per SIMD,
- * sustained shader clock in MHz (s_memtime / s_memrealtime), kernel milliseconds }. */
-int gpbo_mfma_f64_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, double* out);
+ * sustained shader clock in MHz (s_memtime / s_memrealtime), kernel milliseconds }.
+ * mode 0: accumulators where the compiler puts them (VGPRs); mode 1: AGPR accumulators (inline asm). */
+int gpbo_mfma_f64_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, double* out);
 /* Streaming copy bandwidth in GB/s (read+write bytes) over a `bytes`-sized buffer. */
 int gpbo_hbm_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);
 

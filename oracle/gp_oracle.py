@@ -40,7 +40,7 @@ EI = 1
 POI = 2
 
 _SQRT5 = np.sqrt(5.0)
-_INV_SQRT_2PI = 1.0 / np.sqrt(2.0 * np.pi)
+_SQRT_2PI = np.sqrt(2.0 * np.pi)
 
 
 def kernel_matrix(kind: int, Xa: np.ndarray, Xb: np.ndarray | None, length_scale) -> np.ndarray:
@@ -114,7 +114,7 @@ def norm_cdf(x):
 
 
 def norm_pdf(x):
-    return np.exp(-(x**2) / 2.0) * _INV_SQRT_2PI
+    return np.exp(-(x**2) / 2.0) / _SQRT_2PI  # scipy/stats/_continuous_distns.py:360-362
 
 
 def base_acq_ucb(mean, std, kappa):
@@ -181,6 +181,39 @@ def arg_best(ys: np.ndarray, k: int = 0):
     idx = int(ys.argmin())
     seeds = np.argsort(ys)[:k] if k else np.empty(0, dtype=np.int64)
     return idx, float(ys.min()), seeds
+
+
+def log_marginal_likelihood(kind, X, y_norm, length_scale, noise=1e-6, eval_gradient=True):
+    """LML and d LML / d log(length_scale) at fixed theta, following sklearn _gpr.py:575-652 and the kernel
+    gradients kernels.py:1764-1766 (Matern nu=2.5) / :1567-1582 (RBF).  Non-PD K -> (-inf, zeros)."""
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y_norm, dtype=np.float64)
+    ls = np.atleast_1d(np.asarray(length_scale, dtype=np.float64))
+    K = kernel_matrix(kind, X, None, ls)
+    K[np.diag_indices_from(K)] += noise
+    try:
+        L = cholesky(K, lower=True, check_finite=False)
+    except np.linalg.LinAlgError:
+        return (-np.inf, np.zeros(ls.shape[0])) if eval_gradient else -np.inf
+    alpha = cho_solve((L, True), y, check_finite=False)
+    lml = -0.5 * float(y @ alpha) - np.log(np.diag(L)).sum() - K.shape[0] / 2 * np.log(2 * np.pi)
+    if not eval_gradient:
+        return lml
+    Xs = X / ls
+    D = (Xs[:, None, :] - Xs[None, :, :]) ** 2           # (N, N, d) squared scaled differences
+    d2 = D.sum(-1)
+    if kind == MATERN25:
+        tmp = np.sqrt(5 * d2)
+        g = 5.0 / 3.0 * (tmp + 1) * np.exp(-tmp)
+    else:
+        g = np.exp(-0.5 * d2)
+    K_inv = cho_solve((L, True), np.eye(K.shape[0]), check_finite=False)
+    inner = np.outer(alpha, alpha) - K_inv
+    if ls.shape[0] == 1:
+        grad = np.array([0.5 * np.sum(inner * g * d2)])
+    else:
+        grad = 0.5 * np.einsum("ij,ijt->t", inner * g, D)
+    return lml, grad
 
 
 def flops_per_candidate(N: int, d: int, n_gp: int = 1) -> float:

@@ -12,7 +12,7 @@ from bayesianoptimization_amd import workloads as W  # noqa: E402
 from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
 
 eng = GpEngine(0)
-out = {f"probe_{n}wave": eng.mfma_f64_probe(20000 // n, n) for n in (1, 2, 3, 4, 6, 8)}
+out = {f"probe_{n}wave_mode{m}": eng.mfma_f64_probe(20000 // n, n, m) for m in (0, 1) for n in (1, 2, 4, 8)}
 print(out, flush=True)
 for name, M in (("C3", 1 << 19), ("C2", 1 << 16)):
     w = W.ALL[name]
@@ -24,6 +24,24 @@ for name, M in (("C3", 1 << 19), ("C2", 1 << 16)):
         eng.fit(X, yn, w.kernel, w.length_scale, w.noise)
         fits.append(eng.last_timings())
     out[name + "_fit_ms"] = fits[-1]
+    import time
+    lm = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        val, grad = eng.lml(X, yn, w.kernel, w.length_scale, w.noise)
+        lm.append((time.perf_counter() - t0) * 1e3)
+    out[name + "_lml_wall_ms"] = lm
+    out[name + "_lml"] = [val, grad.tolist()]
+    if name == "C3":
+        from sklearn.gaussian_process import GaussianProcessRegressor
+        from sklearn.gaussian_process.kernels import Matern
+        sk = GaussianProcessRegressor(kernel=Matern(nu=2.5, length_scale=w.length_scale), alpha=w.noise,
+                                      normalize_y=True, optimizer=None).fit(X, y)
+        t0 = time.perf_counter()
+        v_s, g_s = sk.log_marginal_likelihood(sk.kernel_.theta, eval_gradient=True)
+        out["C3_lml_sklearn_s"] = time.perf_counter() - t0
+        out["C3_lml_sklearn"] = [float(v_s), g_s.tolist()]
+    eng.fit(X, yn, w.kernel, w.length_scale, w.noise)
     eng.set_candidates(W.make_candidates(w.bounds_array(), M, 7))
     res = {"v1_sched0": [], "v1_sched6": [], "v2": []}
     ref = None

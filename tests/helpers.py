@@ -58,6 +58,11 @@ class FakeEngine:
         gp = O.fit_fixed_theta(kernel, X, y_norm, length_scale, noise, normalize_y=False)
         self.models[slot] = gp
 
+    def lml(self, X, y_norm, kernel, length_scale, noise, eval_gradient=True, slot=0):
+        self.calls.append(("lml", slot))
+        self.models.pop(slot, None)   # like the device: the slot's fit is clobbered
+        return O.log_marginal_likelihood(kernel, X, y_norm, length_scale, noise, eval_gradient)
+
     def get_L(self, n, slot=0):
         return self.models[slot].L.copy()
 

@@ -257,3 +257,27 @@ def test_rccl_single_rank_roundtrip(engine):
     finally:
         engine._lib.gpbo_comm_destroy(engine._h)
         engine.world_size, engine.rank = 1, 0
+
+
+@pytest.mark.parametrize("N,d,kernel,ls", [
+    (60, 3, O.MATERN25, 0.7), (200, 5, O.RBF, 0.6), (130, 4, O.MATERN25, [0.4, 0.7, 1.0, 1.3]),
+    (257, 8, O.RBF, [0.8] * 8), (1, 2, O.MATERN25, 1.0), (700, 16, O.MATERN25, 1.5),
+])
+def test_lml_value_and_gradient_parity(engine, N, d, kernel, ls):
+    """gpbo_lml vs sklearn's log_marginal_likelihood(theta, eval_gradient=True) (_gpr.py:575-652) via the
+    oracle restatement: value 1e-10, gradient 1e-7 relative to its largest component."""
+    X, y = _data(N, d, seed=11)
+    yn, _, _ = O.normalize_targets(y)
+    lml_o, grad_o = O.log_marginal_likelihood(kernel, X, yn, ls, 1e-6)
+    lml, grad = engine.lml(X, yn, kernel, ls, 1e-6)
+    assert abs(lml - lml_o) <= 1e-10 * max(1.0, abs(lml_o))
+    assert np.max(np.abs(grad - grad_o)) <= 1e-7 * max(np.max(np.abs(grad_o)), 1e-12)
+    assert engine.lml(X, yn, kernel, ls, 1e-6, eval_gradient=False) == lml
+    with pytest.raises(_lib.GpboError):
+        engine.posterior(0)   # gpbo_lml leaves the slot unfitted
+
+
+def test_lml_not_pd_returns_minus_inf(engine):
+    X = np.array([[0.1, 0.2], [0.1, 0.2], [0.5, 0.5]])
+    lml, grad = engine.lml(X, np.zeros(3), O.RBF, 1.0, 0.0)
+    assert lml == -np.inf and np.all(grad == 0)

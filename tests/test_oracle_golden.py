@@ -96,6 +96,27 @@ def test_oracle_against_sklearn_directly():
         assert rel_err(mu, mu_s) < 1e-11 and rel_err(sd, sd_s) < 1e-11
 
 
+def test_oracle_lml_against_sklearn():
+    """LML value and gradient at a given theta (never optimiser end points)."""
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF, Matern
+
+    rng = np.random.RandomState(8)
+    X = rng.uniform(size=(70, 3))
+    y = np.sin(2 * X.sum(1)) + 0.05 * rng.randn(70)
+    for kind, k in [(O.MATERN25, Matern(nu=2.5, length_scale=0.7)), (O.RBF, RBF(length_scale=0.5)),
+                    (O.MATERN25, Matern(nu=2.5, length_scale=[0.5, 0.8, 1.1])), (O.RBF, RBF(length_scale=[0.4, 0.9, 1.3]))]:
+        sk = GaussianProcessRegressor(kernel=k, alpha=1e-6, normalize_y=True, optimizer=None).fit(X, y)
+        lml_s, grad_s = sk.log_marginal_likelihood(sk.kernel_.theta, eval_gradient=True)
+        lml, grad = O.log_marginal_likelihood(kind, X, sk.y_train_, k.length_scale, 1e-6)
+        assert abs(lml - lml_s) <= 1e-11 * abs(lml_s)
+        assert np.allclose(grad, grad_s, rtol=1e-8, atol=1e-10 * np.max(np.abs(grad_s)))
+    # non-PD: duplicate points, no jitter -> -inf, zero gradient (_gpr.py:588-589)
+    Xd = np.vstack([X[:3], X[:3]])
+    lml, grad = O.log_marginal_likelihood(O.RBF, Xd, np.zeros(6), 1.0, 0.0)
+    assert lml == -np.inf and np.all(grad == 0)
+
+
 def test_edge_semantics():
     """NaN / sigma = 0 conventions the device must mirror."""
     with np.errstate(all="ignore"):
