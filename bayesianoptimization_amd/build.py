@@ -27,6 +27,7 @@ SOURCES = {
     "fit_kernels.hip": [],
     "posterior_kernel.hip": [],
     "posterior_kernel_v2.hip": [],
+    "posterior_small.hip": [],
     "lml_kernels.hip": [],
     "acq_kernels.hip": ["-ffp-contract=off"],  # elementwise formulas follow NumPy op by op
     "probe.hip": [],

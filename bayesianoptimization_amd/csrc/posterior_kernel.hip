@@ -326,6 +326,20 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
     m.cap_M = Mp;
   }
   if ((rc = launch_prescale(ctx, ctx->Xc, M, m.d, m.DP, m.ls, ctx->Xcs, Mp))) return rc;
+  {
+    // latency path: a handful of candidates (HipGPR.predict from the host optimiser) -> batched GEMV
+    const char* sm = getenv("GPBO_POST_SMALL");
+    if (M <= 8 && !(sm && sm[0] == '0')) {
+      ev_begin(ctx, T_POST_MAIN);
+      rc = launch_posterior_small(ctx, m, (int)M, y_mean, y_std);
+      ev_end(ctx, T_POST_MAIN);
+      if (rc) return rc;
+      ev_begin(ctx, T_POST_FINAL);
+      ev_end(ctx, T_POST_FINAL);
+      m.M_post = M;
+      return GPBO_OK;
+    }
+  }
   // GPBO_POST_KERNEL=1 selects the 2-waves/SIMD kernel of this file (kept for A/B); default is v2
   // (posterior_kernel_v2.hip, 4 waves/SIMD).
   const char* kv = getenv("GPBO_POST_KERNEL");

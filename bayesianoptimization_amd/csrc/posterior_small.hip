@@ -1,0 +1,133 @@
+// Small-batch posterior (M <= 8 candidates): the latency path behind HipGPR.predict when the reference's
+// "smart" stage (bayes_opt/acquisition.py:322-420: L-BFGS-B with finite differences) asks for one point at
+// a time.  Same arithmetic as posterior_kernel_v2 (sklearn _gpr.py:443-494), organised as a memory-bound
+// batched GEMV over the row-major W = L^-1 (read once, ~N^2/2 * 8 B) instead of an MFMA GEMM:
+//   kstar_small_kernel : k*[c][k] for all train points (N x M values)
+//   gemv_small_kernel  : v[c][i] = sum_k W[i][k] k*[c][k], one wave per 4 rows, fixed shuffle tree
+//   finalize_small     : mu = y_std * (k* . alpha) + y_mean ; sd = sqrt(max(1 - sum_i v^2, 0)) * y_std
+#include "gpbo_internal.h"
+
+namespace gpbo {
+
+constexpr int SMALL_MAX = 8;
+
+template <int KERNEL>
+__device__ __forceinline__ double kernel_value_small(double d2) {
+  if (KERNEL == GPBO_KERNEL_MATERN25) {
+    double k = sqrt(d2) * 2.23606797749978969641;
+    return (1.0 + k + k * k / 3.0) * exp(-k);
+  } else {
+    return exp(-0.5 * d2);
+  }
+}
+
+template <int KERNEL>
+__global__ __launch_bounds__(256) void kstar_small_kernel(const double* __restrict__ Xs, const double* __restrict__ Xcs,
+                                                          int DP, int64_t NP, int M, double* __restrict__ ks) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= NP) return;
+  const double* xr = Xs + k * DP;
+  for (int c = 0; c < M; ++c) {
+    const double* xc = Xcs + (int64_t)c * DP;
+    double d2 = 0.0;
+    for (int t = 0; t < DP; ++t) {
+      const double df = xc[t] - xr[t];
+      d2 = fma(df, df, d2);
+    }
+    ks[(int64_t)c * NP + k] = kernel_value_small<KERNEL>(d2);
+  }
+}
+
+// vsq[c][i] = (sum_k W[i][k] ks[c][k])^2 for i < N (rows >= N contribute 0)
+template <int MS>
+__global__ __launch_bounds__(256) void gemv_small_kernel(const double* __restrict__ W, const double* __restrict__ ks,
+                                                         int64_t N, int64_t NP, double* __restrict__ vsq) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
+  if (i0 >= NP) return;
+  double acc[4][MS];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < MS; ++c) acc[r][c] = 0.0;
+  const int64_t kmax = min(NP, i0 + 4);   // W is lower triangular with an explicit zero upper part
+  for (int64_t k = lane; k < kmax; k += 64) {
+    double w[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = W[(i0 + r) * NP + k];
+#pragma unroll
+    for (int c = 0; c < MS; ++c) {
+      const double kv = ks[(int64_t)c * NP + k];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r][c] = fma(w[r], kv, acc[r][c]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < MS; ++c) {
+      double v = acc[r][c];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) vsq[(int64_t)c * NP + i0 + r] = (i0 + r < N) ? v * v : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void finalize_small_kernel(const double* __restrict__ vsq, const double* __restrict__ ks,
+                                                             const double* __restrict__ alpha, int64_t NP,
+                                                             double y_mean, double y_std, double* __restrict__ mu,
+                                                             double* __restrict__ sd) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double s = 0.0, m = 0.0;
+  for (int64_t i = threadIdx.x; i < NP; i += 256) {
+    s += vsq[(int64_t)c * NP + i];
+    m = fma(ks[(int64_t)c * NP + i], alpha[i], m);
+  }
+  double tot[2] = {s, m};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    double v = tot[q];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    tot[q] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+  }
+  if (threadIdx.x == 0) {
+    double var = 1.0 - tot[0];
+    if (var < 0.0) var = 0.0;
+    var = var * (y_std * y_std);
+    sd[c] = sqrt(var);
+    mu[c] = y_std * tot[1] + y_mean;
+  }
+}
+
+// Requires ctx->Xcs to hold the scaled candidates ([M][DP]); uses ctx->part as scratch (2 * M * NP doubles).
+int launch_posterior_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double y_std) {
+  if (M < 1 || M > SMALL_MAX) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "posterior_small: M out of range");
+  int rc;
+  if ((rc = ensure(ctx, &ctx->part, &ctx->cap_part, (int64_t)2 * SMALL_MAX * m.NP))) return rc;
+  double* ks = ctx->part;
+  double* vsq = ctx->part + (int64_t)SMALL_MAX * m.NP;
+  const unsigned kb = (unsigned)((m.NP + 255) / 256);
+  if (m.kernel == GPBO_KERNEL_MATERN25)
+    kstar_small_kernel<GPBO_KERNEL_MATERN25><<<dim3(kb), dim3(256), 0, ctx->stream>>>(m.Xs, ctx->Xcs, m.DP, m.NP, M, ks);
+  else
+    kstar_small_kernel<GPBO_KERNEL_RBF><<<dim3(kb), dim3(256), 0, ctx->stream>>>(m.Xs, ctx->Xcs, m.DP, m.NP, M, ks);
+  GPBO_HIP(ctx, hipGetLastError());
+  const unsigned gb = (unsigned)((m.NP / 4 + 3) / 4);
+  switch (M) {
+    case 1: gemv_small_kernel<1><<<dim3(gb), dim3(256), 0, ctx->stream>>>(m.W, ks, m.N, m.NP, vsq); break;
+    case 2: gemv_small_kernel<2><<<dim3(gb), dim3(256), 0, ctx->stream>>>(m.W, ks, m.N, m.NP, vsq); break;
+    case 3: case 4: gemv_small_kernel<4><<<dim3(gb), dim3(256), 0, ctx->stream>>>(m.W, ks, m.N, m.NP, vsq); break;
+    default: gemv_small_kernel<8><<<dim3(gb), dim3(256), 0, ctx->stream>>>(m.W, ks, m.N, m.NP, vsq); break;
+  }
+  GPBO_HIP(ctx, hipGetLastError());
+  finalize_small_kernel<<<dim3((unsigned)M), dim3(256), 0, ctx->stream>>>(vsq, ks, m.alpha, m.NP, y_mean, y_std, m.mu, m.sd);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+}  // namespace gpbo

@@ -203,12 +203,28 @@ def main():
                                    f"M={M} candidates per GPU, fixed length_scale={w.length_scale}, alpha={w.noise}, "
                                    "k_seeds=10; BASELINE.json configs[2]",
                        "N": w.N, "d": w.d, "M_per_gpu": M, "M_total": M * n_gpus, "collective": collective},
-            "roofline": {"bound": "mfma", "kernel": "posterior_kernel<16,Matern25>", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "posterior_kernel_v2<16,Matern25>", "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": None, "avg_launch_ms": main_ms, "flops_per_launch_algorithmic": fl},
             "step_breakdown_ms": {k_: v / steps for k_, v in kern_ms.items()},
             "best": {"index": int(best[0]), "value": float(best[1])},
         }
+        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this very command
+        # (scripts/profile_pmc.sh; FETCH_SIZE and WRITE_SIZE cannot share a pass), summarised in profiles/.
+        ppath = os.path.join(ROOT, "profiles", f"r01_pmc_{w.name}_v2.json")
+        if os.path.exists(ppath):
+            try:
+                pm = json.load(open(ppath))
+                key = [k_ for k_ in pm if "posterior_kernel_v2" in k_][0]
+                out["roofline"]["traffic"] = pm[key]["fetch_bytes_corrected_x2"] + pm[key]["write_bytes"]
+                out["roofline"]["traffic_note"] = (
+                    "HBM-side bytes per launch = 2*FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE from "
+                    f"profiles/{os.path.basename(ppath)}; algorithmic compulsory bytes = "
+                    f"{(w.d + 1) * 8 * M + w.N * w.N * 4:.3g}; the excess is W re-streamed per candidate tile "
+                    "(L2/Infinity-Cache resident, <1% of HBM bandwidth: the kernel is MFMA-bound)")
+                out["roofline"]["mfma_pipe_busy_frac_pmc"] = pm[key].get("mfma_pipe_busy_frac")
+            except Exception as e:  # noqa: BLE001
+                log(f"[bench] could not read {ppath}: {e!r}")
         gpath = os.path.join(ROOT, "tests", "golden", f"{w.name}.npz")
         if n_gpus == 1 and os.path.exists(gpath):
             g = np.load(gpath)
@@ -217,7 +233,8 @@ def main():
                              "min_rel_err": float(abs(best[1] - float(g["min"])) / abs(float(g["min"])))}
         if n_gpus == 1:
             try:
-                out["roofline"]["peak_measured"] = eng.mfma_f64_peak(20000)
+                # sustained v_mfma_f64_16x16x4_f64 rate with 8 waves/SIMD of independent accumulators
+                out["roofline"]["peak_measured"] = max(eng.mfma_f64_probe(2500, 8)["tflops"] for _ in range(2))
                 out["roofline"]["frac_of_measured_peak"] = achieved / out["roofline"]["peak_measured"]
             except Exception as e:
                 log(f"[bench] mfma peak probe failed: {e!r}")

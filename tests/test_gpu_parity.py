@@ -281,3 +281,30 @@ def test_lml_not_pd_returns_minus_inf(engine):
     X = np.array([[0.1, 0.2], [0.1, 0.2], [0.5, 0.5]])
     lml, grad = engine.lml(X, np.zeros(3), O.RBF, 1.0, 0.0)
     assert lml == -np.inf and np.all(grad == 0)
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("N,d,kernel,ls", [(150, 6, O.MATERN25, 0.8), (1030, 16, O.MATERN25, 1.5), (70, 2, O.RBF, 0.5)])
+def test_small_batch_path_equals_oracle_and_big_kernel(engine, M, N, d, kernel, ls):
+    """M <= 8 goes through the batched-GEMV latency path (posterior_small.hip): same results as the oracle
+    and as the MFMA kernel (GPBO_POST_SMALL=0) to rounding."""
+    import os
+
+    X, y = _data(N, d, seed=21)
+    gp = O.fit_fixed_theta(kernel, X, y, ls, 1e-6)
+    yn, ym, ys = O.normalize_targets(y)
+    engine.fit(X, yn, kernel, ls, 1e-6)
+    Xc = np.random.RandomState(22).uniform(size=(M, d))
+    Xc[0] = X[3]                                   # a training point: variance ~ alpha, the cancellation case
+    mu, sd = engine.predict(Xc, y_mean=ym, y_std=ys)
+    mu_o, sd_o = O.predict(gp, Xc)
+    tol = 1e-7 if kernel == O.RBF else 1e-9
+    assert np.max(np.abs(mu - mu_o)) <= tol * np.max(np.abs(mu_o))
+    assert np.max(np.abs(sd - sd_o)) <= tol * max(np.max(np.abs(sd_o)), 1e-3)
+    os.environ["GPBO_POST_SMALL"] = "0"
+    try:
+        mu_b, sd_b = engine.predict(Xc, y_mean=ym, y_std=ys)
+    finally:
+        os.environ.pop("GPBO_POST_SMALL")
+    assert np.max(np.abs(mu - mu_b)) <= 1e-10 * np.max(np.abs(mu_o))
+    assert np.max(np.abs(sd - sd_b)) <= 1e-9 * max(np.max(np.abs(sd_o)), 1e-3)
