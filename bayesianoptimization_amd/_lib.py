@@ -57,6 +57,7 @@ SIGNATURES = {
                                   C.c_int, C.c_double, _c_double_p]),
     "gpbo_mfma_f64_peak": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
     "gpbo_mfma_f64_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _c_double_p]),
+    "gpbo_hybrid_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_double_p]),
     "gpbo_hbm_copy_peak": (C.c_int, [C.c_void_p, C.c_int64, _c_double_p]),
 }
 

@@ -488,6 +488,12 @@ int gpbo_mfma_f64_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, 
   return run_mfma_probe(ctx, iters, waves_per_simd, mode, out);
 }
 
+int gpbo_hybrid_probe(gpbo_ctx* ctx, int iters, int cfg, double* out) {
+  if (!ctx || !out || iters < 1 || cfg < 0 || cfg > 4) return GPBO_ERR_INVALID;
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  return run_hybrid_probe(ctx, iters, cfg, out);
+}
+
 int gpbo_hbm_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps) {
   if (!ctx || !gbps || bytes < (1 << 20)) return GPBO_ERR_INVALID;
   GPBO_HIP(ctx, hipSetDevice(ctx->device));

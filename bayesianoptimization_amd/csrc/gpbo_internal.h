@@ -171,6 +171,7 @@ int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, doubl
 // probe.hip
 int run_mfma_peak(gpbo_ctx* ctx, int iters, double* tflops);
 int run_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);
+int run_hybrid_probe(gpbo_ctx* ctx, int iters, int cfg, double* out3);
 int run_mfma_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, double* out4);
 
 inline void ev_begin(gpbo_ctx* ctx, int slot) {

@@ -94,6 +94,76 @@ int run_mfma_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, doubl
   return GPBO_OK;
 }
 
+// Hybrid probe: per loop iteration a wave issues NM independent MFMAs and NV v_fma_f64 whose multiplier is a
+// wave-uniform double fetched with scalar loads (the shape of a VALU GEMM row update: acc_r += W[r][k] * k*[k][lane]).
+// Answers: how much fp64 VALU FMA throughput is available NEXT TO a saturated fp64 matrix pipe?
+template <int NM, int NV>
+__global__ __launch_bounds__(256) void hybrid_probe_kernel(const double* __restrict__ wsc, double* out, int iters) {
+  d4 acc[NM > 0 ? NM : 1];
+#pragma unroll
+  for (int j = 0; j < (NM > 0 ? NM : 1); ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+  double va[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) va[r] = 0.0;
+  const double a = 1.0 + threadIdx.x * 1e-6, b = 0.5 - threadIdx.x * 1e-6;
+  double kv = 1.0 + threadIdx.x * 1e-3;
+  for (int i = 0; i < iters; ++i) {
+    const double* wrow = wsc + (size_t)(i & 63) * 256;   // wave-uniform -> s_load
+#pragma unroll
+    for (int j = 0; j < NM; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) va[v & 15] = fma(wrow[v], kv, va[v & 15]);
+    kv += 1e-9;
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int j = 0; j < (NM > 0 ? NM : 1); ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += va[r];
+  out[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// out3 = { ms, MFMA TFLOP/s, VALU TFLOP/s } for config cfg: 0 = 16 MFMA only, 1 = 256 VALU only,
+// 2 = 16 MFMA + 256 VALU, 3 = 16 MFMA + 128 VALU, 4 = 8 MFMA + 256 VALU.  4 waves per SIMD.
+int run_hybrid_probe(gpbo_ctx* ctx, int iters, int cfg, double* out3) {
+  const int grid = 256 * 4;
+  double *out = nullptr, *wsc = nullptr;
+  GPBO_HIP(ctx, hipMalloc((void**)&out, (size_t)grid * 256 * sizeof(double)));
+  GPBO_HIP(ctx, hipMalloc((void**)&wsc, (size_t)64 * 256 * sizeof(double)));
+  std::string h((size_t)64 * 256 * 8, '\0');
+  double* hw = (double*)h.data();
+  for (int i = 0; i < 64 * 256; ++i) hw[i] = 1e-3 * ((i * 37) % 101 - 50);
+  GPBO_HIP(ctx, hipMemcpy(wsc, hw, h.size(), hipMemcpyHostToDevice));
+  hipEvent_t e0, e1;
+  GPBO_HIP(ctx, hipEventCreate(&e0));
+  GPBO_HIP(ctx, hipEventCreate(&e1));
+  int nm = 0, nv = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int it = pass == 0 ? 8 : iters;
+    if (pass == 1) GPBO_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    switch (cfg) {
+      case 0: nm = 16; nv = 0; hybrid_probe_kernel<16, 0><<<dim3(grid), dim3(256), 0, ctx->stream>>>(wsc, out, it); break;
+      case 1: nm = 0; nv = 256; hybrid_probe_kernel<0, 256><<<dim3(grid), dim3(256), 0, ctx->stream>>>(wsc, out, it); break;
+      case 2: nm = 16; nv = 256; hybrid_probe_kernel<16, 256><<<dim3(grid), dim3(256), 0, ctx->stream>>>(wsc, out, it); break;
+      case 3: nm = 16; nv = 128; hybrid_probe_kernel<16, 128><<<dim3(grid), dim3(256), 0, ctx->stream>>>(wsc, out, it); break;
+      default: nm = 8; nv = 256; hybrid_probe_kernel<8, 256><<<dim3(grid), dim3(256), 0, ctx->stream>>>(wsc, out, it); break;
+    }
+  }
+  GPBO_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  GPBO_HIP(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  GPBO_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  const double waves = (double)grid * 4.0;
+  out3[0] = ms;
+  out3[1] = waves * iters * nm * 2048.0 / (ms * 1e-3) / 1e12;
+  out3[2] = waves * iters * nv * 128.0 / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  GPBO_HIP(ctx, hipFree(out));
+  GPBO_HIP(ctx, hipFree(wsc));
+  return GPBO_OK;
+}
+
 int run_mfma_peak(gpbo_ctx* ctx, int iters, double* tflops) {
   const int grid = 256 * 2;  // 2 workgroups of 4 waves per CU -> 2 waves per SIMD
   double* out = nullptr;

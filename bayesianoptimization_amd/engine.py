@@ -177,6 +177,11 @@ class GpEngine:
         self._check(self._lib.gpbo_mfma_f64_probe(self._h, int(iters), int(waves_per_simd), int(mode), dptr(out)))
         return {"tflops": out[0], "cycles_per_mfma": out[1], "shader_mhz": out[2], "ms": out[3]}
 
+    def hybrid_probe(self, iters=2000, cfg=2) -> dict:
+        out = np.zeros(3)
+        self._check(self._lib.gpbo_hybrid_probe(self._h, int(iters), int(cfg), dptr(out)))
+        return {"ms": out[0], "mfma_tflops": out[1], "valu_tflops": out[2]}
+
     def hbm_copy_peak(self, nbytes=1 << 30) -> float:
         out = C.c_double(0.0)
         self._check(self._lib.gpbo_hbm_copy_peak(self._h, int(nbytes), C.byref(out)))

@@ -146,6 +146,10 @@ int gpbo_mfma_f64_peak(gpbo_ctx* ctx, int iters, double* tflops);
  * sustained shader clock in MHz (s_memtime / s_memrealtime), kernel milliseconds }.
  * mode 0: accumulators where the compiler puts them (VGPRs); mode 1: AGPR accumulators (inline asm). */
 int gpbo_mfma_f64_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, double* out);
+/* fp64 VALU FMA throughput next to the matrix pipe, 4 waves/SIMD. cfg 0: 16 MFMA per iteration only, 1: 256
+ * v_fma_f64 (scalar-operand) only, 2: 16 MFMA + 256 VALU, 3: 16 + 128, 4: 8 + 256.
+ * out[3] = { kernel ms, MFMA TFLOP/s, VALU TFLOP/s }. */
+int gpbo_hybrid_probe(gpbo_ctx* ctx, int iters, int cfg, double* out);
 /* Streaming copy bandwidth in GB/s (read+write bytes) over a `bytes`-sized buffer. */
 int gpbo_hbm_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);
 

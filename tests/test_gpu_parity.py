@@ -306,5 +306,7 @@ def test_small_batch_path_equals_oracle_and_big_kernel(engine, M, N, d, kernel, 
         mu_b, sd_b = engine.predict(Xc, y_mean=ym, y_std=ys)
     finally:
         os.environ.pop("GPBO_POST_SMALL")
-    assert np.max(np.abs(mu - mu_b)) <= 1e-10 * np.max(np.abs(mu_o))
-    assert np.max(np.abs(sd - sd_b)) <= 1e-9 * max(np.max(np.abs(sd_o)), 1e-3)
+    # the two device paths sum k*.alpha and |W k*|^2 in different orders: agreement is bounded by the same
+    # kappa(K)*eps noise as the comparison with LAPACK (RBF, N=70, d=2: kappa ~ 4e7, |alpha| ~ 1e5)
+    assert np.max(np.abs(mu - mu_b)) <= tol * np.max(np.abs(mu_o))
+    assert np.max(np.abs(sd - sd_b)) <= tol * max(np.max(np.abs(sd_o)), 1e-3)
