@@ -69,8 +69,10 @@ struct gpbo_ctx {
   int64_t cap_Xcs = 0;
   double* part = nullptr;  // [nchunks][Mp] partial |W k*|^2
   int64_t cap_part = 0;
-  double* mu_part = nullptr;  // [Mp]
+  double* mu_part = nullptr;  // [nchunks][Mp] (v3: one partial mean per 256-train-point chunk) or [Mp]
   int64_t cap_mu_part = 0;
+  double* kst = nullptr;   // materialised k* slab [NP][slab width] (posterior v3)
+  int64_t cap_kst = 0;
   double* ys = nullptr;    // [M] negated acquisition values
   int64_t cap_ys = 0;
   void* red = nullptr;     // reduction scratch
@@ -155,6 +157,7 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g);
 int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std);
 // posterior_kernel_v2.hip
 int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
+int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
 // acq_kernels.hip
 struct AcqArgs {
   int acq; double param; double y_max; int n_constraints;

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void posterior_kernel(PostArgs p) {
 // mu = y_std * (k* . alpha) + y_mean ; sd = sqrt(max(1 - sum_chunks part, 0) * y_std^2)
 __global__ __launch_bounds__(256) void posterior_finalize_kernel(const double* __restrict__ part,
                                                                  const double* __restrict__ mu_part,
-                                                                 int nchunks, int64_t Mp, int64_t M,
+                                                                 int nchunks, int n_mu, int64_t Mp, int64_t M,
                                                                  double y_mean, double y_std,
                                                                  double* __restrict__ mu,
                                                                  double* __restrict__ sd) {
@@ -268,7 +268,9 @@ __global__ __launch_bounds__(256) void posterior_finalize_kernel(const double* _
   if (var < 0.0) var = 0.0;          // _gpr.py:479-485 (NaN stays NaN, as in numpy)
   var = var * (y_std * y_std);
   sd[m] = sqrt(var);
-  mu[m] = y_std * mu_part[m] + y_mean;
+  double mun = 0.0;
+  for (int q = 0; q < n_mu; ++q) mun += mu_part[(int64_t)q * Mp + m];
+  mu[m] = y_std * mun + y_mean;
 }
 
 // Scheduling variant of the main loop: 0 = compiler default, 6 = "1 MFMA : 6 VALU" group hints (default).
@@ -316,7 +318,7 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
   int rc;
   if ((rc = ensure(ctx, &ctx->Xcs, &ctx->cap_Xcs, Mp * m.DP))) return rc;
   if ((rc = ensure(ctx, &ctx->part, &ctx->cap_part, (int64_t)nchunks * Mp))) return rc;
-  if ((rc = ensure(ctx, &ctx->mu_part, &ctx->cap_mu_part, Mp))) return rc;
+  if ((rc = ensure(ctx, &ctx->mu_part, &ctx->cap_mu_part, (int64_t)nchunks * Mp))) return rc;
   if (Mp > m.cap_M) {
     if (m.mu) { GPBO_HIP(ctx, hipFree(m.mu)); m.mu = nullptr; }
     if (m.sd) { GPBO_HIP(ctx, hipFree(m.sd)); m.sd = nullptr; }
@@ -344,6 +346,8 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
   // (posterior_kernel_v2.hip, 4 waves/SIMD).
   const char* kv = getenv("GPBO_POST_KERNEL");
   const bool use_v1 = kv && kv[0] == '1';
+  const bool use_v2 = kv && kv[0] == '2';   // fused generation (one kernel); default v3 = k* slab + GEMM
+  const int n_mu = (use_v1 || use_v2) ? 1 : nchunks;
   ev_begin(ctx, T_POST_MAIN);
   if (use_v1) {
     PostArgs a;
@@ -353,14 +357,16 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
     if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
     if (m.kernel == GPBO_KERNEL_MATERN25) rc = launch_post_k<GPBO_KERNEL_MATERN25>(ctx, m.DP, a, nblocks);
     else rc = launch_post_k<GPBO_KERNEL_RBF>(ctx, m.DP, a, nblocks);
-  } else {
+  } else if (use_v2) {
     rc = launch_posterior_v2(ctx, m, Mp, nchunks);
+  } else {
+    rc = launch_posterior_v3(ctx, m, Mp, nchunks);
   }
   ev_end(ctx, T_POST_MAIN);
   if (rc) return rc;
   ev_begin(ctx, T_POST_FINAL);
   posterior_finalize_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream>>>(
-      ctx->part, ctx->mu_part, nchunks, Mp, M, y_mean, y_std, m.mu, m.sd);
+      ctx->part, ctx->mu_part, nchunks, n_mu, Mp, M, y_mean, y_std, m.mu, m.sd);
   ev_end(ctx, T_POST_FINAL);
   GPBO_HIP(ctx, hipGetLastError());
   m.M_post = M;

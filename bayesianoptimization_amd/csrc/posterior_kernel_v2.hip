@@ -35,6 +35,9 @@ struct PostArgs2 {
   int64_t Mp;
   int nchunks;
   int n_ctiles;
+  const double* Kst;   // GEN == 2: materialised k* slab [NP][ldk], candidate-contiguous
+  int64_t ldk;
+  int64_t m0;          // first candidate of the slab (outputs are indexed m0 + local)
 };
 
 template <int KERNEL>
@@ -47,7 +50,11 @@ __device__ __forceinline__ double kernel_value_v2(double d2) {
   }
 }
 
-template <int DP, int KERNEL>
+// GEN = 1: k* generated in the kernel (fused).  GEN = 2: k* read from a slab materialised by
+// kstar_gen_kernel (the fp64 VALU work of the generation shares the FP64 datapath with the MFMAs — measured:
+// 31 % of the fused kernel's time at C3 — so paying it once per candidate instead of once per row chunk wins).
+// GEN = 0 is a timing-only ablation (k* replaced by a constant; results are wrong): GPBO_POST_ABLATE_GEN=1.
+template <int DP, int KERNEL, int GEN>
 __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   extern __shared__ __attribute__((aligned(16))) double smem2[];
   double* Ks = smem2;                              // [2][POST_BK][V2_STRIDE]
@@ -65,7 +72,7 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   const int n_stages = k_end / POST_BK;
 
   // candidate tile -> LDS (thread t loads candidate t>>3, dims (t&7)*DP/8 ...)
-  {
+  if constexpr (GEN != 2) {
     const double* src = p.Xcs + (int64_t)ct * V2_CANDS * DP;
     for (int e = tid; e < V2_CANDS * DP; e += 512) {
       const int cnd = e / DP, t = e - cnd * DP;
@@ -91,6 +98,17 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   // generation role: candidate = lane, train points 2*wave, 2*wave+1 of the stage
   auto gen_compute = [&](int stage, double (&kv)[2]) {
     const int j0 = stage * POST_BK + wave * 2;
+    if constexpr (GEN == 0) {
+      kv[0] = 1e-3 * lane;
+      kv[1] = 2e-3 * lane + stage;
+      return;
+    }
+    if constexpr (GEN == 2) {
+      const double* src = p.Kst + (int64_t)j0 * p.ldk + (int64_t)ct * V2_CANDS + lane;
+      kv[0] = src[0];
+      kv[1] = src[p.ldk];
+      return;
+    }
     const double* xr = p.Xs + (int64_t)j0 * DP;  // wave-uniform -> scalar loads
     double d2a = 0.0, d2b = 0.0;
     if constexpr (DP <= 8) {
@@ -208,9 +226,9 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
     double v = 0.0;
 #pragma unroll
     for (int w = 0; w < 8; ++w) v += red[w * V2_CANDS + tid];
-    const int64_t m = (int64_t)ct * V2_CANDS + tid;
+    const int64_t m = p.m0 + (int64_t)ct * V2_CANDS + tid;
     p.part[(int64_t)r * p.Mp + m] = v;
-    if (last) {
+    if (GEN != 2 && last) {
       double u = 0.0;
 #pragma unroll
       for (int w = 0; w < 8; ++w) u += mured[w * V2_CANDS + tid];
@@ -219,10 +237,107 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   }
 }
 
+// k* slab generation: thread = candidate (coordinates in registers), loop over a chunk of 256 train points
+// (scalar loads), coalesced stores to Kst[k][m]; also the partial means sum_k k*[k] alpha[k] per chunk.
+template <int DP, int KERNEL>
+__global__ __launch_bounds__(256) void kstar_gen_kernel(const double* __restrict__ Xs, const double* __restrict__ alpha,
+                                                        const double* __restrict__ Xcs, double* __restrict__ Kst,
+                                                        int64_t ldk, int NP, double* __restrict__ mu_part,
+                                                        int64_t Mp, int64_t m0) {
+  const int64_t ml = (int64_t)blockIdx.x * 256 + threadIdx.x;   // slab-local candidate
+  if (ml >= ldk) return;
+  const int k0 = blockIdx.y * POST_ROWS, k1 = min(NP, k0 + POST_ROWS);
+  double xc[DP];
+  const double* xcp = Xcs + (m0 + ml) * DP;
+#pragma unroll
+  for (int t = 0; t < DP; t += 2) {
+    const double2 v = *reinterpret_cast<const double2*>(xcp + t);
+    xc[t] = v.x;
+    xc[t + 1] = v.y;
+  }
+  double mu = 0.0;
+  for (int k = k0; k < k1; k += 2) {
+    const double* xr = Xs + (int64_t)k * DP;   // uniform -> scalar loads
+    double d2a = 0.0, d2b = 0.0;
+#pragma unroll
+    for (int t = 0; t < DP; ++t) {
+      const double da = xc[t] - xr[t], db = xc[t] - xr[DP + t];
+      d2a = fma(da, da, d2a);
+      d2b = fma(db, db, d2b);
+    }
+    const double ka = kernel_value_v2<KERNEL>(d2a), kb = kernel_value_v2<KERNEL>(d2b);
+    Kst[(int64_t)k * ldk + ml] = ka;
+    Kst[(int64_t)(k + 1) * ldk + ml] = kb;
+    mu = fma(ka, alpha[k], mu);
+    mu = fma(kb, alpha[k + 1], mu);
+  }
+  mu_part[(int64_t)blockIdx.y * Mp + m0 + ml] = mu;
+}
+
+template <int DP, int KERNEL>
+static int launch_gen_t(gpbo_ctx* ctx, Model& m, double* Kst, int64_t ldk, int64_t Mp, int64_t m0, int nchunks) {
+  dim3 grid((unsigned)((ldk + 255) / 256), (unsigned)nchunks);
+  kstar_gen_kernel<DP, KERNEL><<<grid, dim3(256), 0, ctx->stream>>>(m.Xs, m.alpha, ctx->Xcs, Kst, ldk, (int)m.NP,
+                                                                      ctx->mu_part, Mp, m0);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+template <int KERNEL>
+static int launch_gen_k(gpbo_ctx* ctx, Model& m, double* Kst, int64_t ldk, int64_t Mp, int64_t m0, int nchunks) {
+  switch (m.DP) {
+    case 4: return launch_gen_t<4, KERNEL>(ctx, m, Kst, ldk, Mp, m0, nchunks);
+    case 8: return launch_gen_t<8, KERNEL>(ctx, m, Kst, ldk, Mp, m0, nchunks);
+    case 16: return launch_gen_t<16, KERNEL>(ctx, m, Kst, ldk, Mp, m0, nchunks);
+    case 32: return launch_gen_t<32, KERNEL>(ctx, m, Kst, ldk, Mp, m0, nchunks);
+    case 64: return launch_gen_t<64, KERNEL>(ctx, m, Kst, ldk, Mp, m0, nchunks);
+  }
+  GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: unsupported padded dimension");
+}
+
+// Two-kernel pipeline per candidate slab: kstar_gen_kernel -> posterior_kernel_v2<.., GEN = 2>.
+// The slab width is bounded by a workspace budget (default 40 GB, GPBO_KSTAR_GB to override); mu partials
+// need nchunks x Mp doubles in ctx->mu_part (allocated by the caller).
+int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
+  double budget_gb = 40.0;
+  if (const char* e = getenv("GPBO_KSTAR_GB")) budget_gb = atof(e) > 0.0 ? atof(e) : budget_gb;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    const double avail = ((double)free_b + (double)ctx->cap_kst * 8.0) * 0.8 / 1e9;
+    if (avail < budget_gb) budget_gb = avail;
+  }
+  int64_t ms = (int64_t)(budget_gb * 1e9 / ((double)m.NP * 8.0));
+  ms = ms / 128 * 128;
+  if (ms < 128) GPBO_FAIL(ctx, GPBO_ERR_HIP, "posterior: not enough device memory for one k* slab");
+  if (ms > Mp) ms = Mp;
+  int rc;
+  if ((rc = ensure(ctx, &ctx->kst, &ctx->cap_kst, ms * m.NP))) return rc;
+  for (int64_t m0 = 0; m0 < Mp; m0 += ms) {
+    const int64_t ldk = (Mp - m0 < ms) ? (Mp - m0) : ms;
+    if (m.kernel == GPBO_KERNEL_MATERN25) rc = launch_gen_k<GPBO_KERNEL_MATERN25>(ctx, m, ctx->kst, ldk, Mp, m0, nchunks);
+    else rc = launch_gen_k<GPBO_KERNEL_RBF>(ctx, m, ctx->kst, ldk, Mp, m0, nchunks);
+    if (rc) return rc;
+    PostArgs2 a;
+    a.Wp = m.Wp; a.Xs = m.Xs; a.alpha = m.alpha; a.Xcs = ctx->Xcs; a.part = ctx->part;
+    a.mu_part = ctx->mu_part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nchunks;
+    a.n_ctiles = (int)(ldk / V2_CANDS); a.Kst = ctx->kst; a.ldk = ldk; a.m0 = m0;
+    const int64_t nblocks = (int64_t)a.n_ctiles * nchunks;
+    if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
+    const size_t lds = (size_t)(2 * POST_BK * V2_STRIDE) * sizeof(double);
+    posterior_kernel_v2<4, 0, 2><<<dim3((unsigned)nblocks), dim3(512), lds, ctx->stream>>>(a);
+    GPBO_HIP(ctx, hipGetLastError());
+  }
+  return GPBO_OK;
+}
+
 template <int DP, int KERNEL>
 static int launch_v2_t(gpbo_ctx* ctx, const PostArgs2& a, int64_t nblocks) {
   const size_t lds = (size_t)(2 * POST_BK * V2_STRIDE + DP * V2_CANDS) * sizeof(double);
-  posterior_kernel_v2<DP, KERNEL><<<dim3((unsigned)nblocks), dim3(512), lds, ctx->stream>>>(a);
+  const char* ab = getenv("GPBO_POST_ABLATE_GEN");
+  if (ab && ab[0] == '1')
+    posterior_kernel_v2<DP, KERNEL, 0><<<dim3((unsigned)nblocks), dim3(512), lds, ctx->stream>>>(a);
+  else
+    posterior_kernel_v2<DP, KERNEL, 1><<<dim3((unsigned)nblocks), dim3(512), lds, ctx->stream>>>(a);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
@@ -245,6 +360,7 @@ int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
   a.Wp = m.Wp; a.Xs = m.Xs; a.alpha = m.alpha; a.Xcs = ctx->Xcs; a.part = ctx->part;
   a.mu_part = ctx->mu_part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nchunks;
   a.n_ctiles = (int)(Mp / V2_CANDS);
+  a.Kst = nullptr; a.ldk = 0; a.m0 = 0;
   const int64_t nblocks = (int64_t)a.n_ctiles * nchunks;
   if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
   if (m.kernel == GPBO_KERNEL_MATERN25) return launch_v2_k<GPBO_KERNEL_MATERN25>(ctx, m.DP, a, nblocks);

@@ -12,9 +12,9 @@ from bayesianoptimization_amd import workloads as W  # noqa: E402
 from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
 
 eng = GpEngine(0)
-out = {f"probe_{n}wave_mode{m}": eng.mfma_f64_probe(20000 // n, n, m) for m in (0, 1) for n in (1, 2, 4, 8)}
+out = {}
 print(out, flush=True)
-for name, M in (("C3", 1 << 19), ("C2", 1 << 16)):
+for name, M in (("C3", 1 << 20), ("C2", 1 << 16)):
     w = W.ALL[name]
     X, y, c = W.make_observations(w)
     ym, ys = float(np.mean(y)), float(np.std(y))
@@ -43,12 +43,12 @@ for name, M in (("C3", 1 << 19), ("C2", 1 << 16)):
         out["C3_lml_sklearn"] = [float(v_s), g_s.tolist()]
     eng.fit(X, yn, w.kernel, w.length_scale, w.noise)
     eng.set_candidates(W.make_candidates(w.bounds_array(), M, 7))
-    res = {"v1_sched0": [], "v1_sched6": [], "v2": []}
+    res = {"v1_sched0": [], "v1_sched6": [], "v2": [], "v3": []}
     ref = None
     for rnd in range(4):
         for v, env in (("v1_sched0", {"GPBO_POST_KERNEL": "1", "GPBO_POST_SCHED": "0"}),
                        ("v1_sched6", {"GPBO_POST_KERNEL": "1", "GPBO_POST_SCHED": "6"}),
-                       ("v2", {"GPBO_POST_KERNEL": "2"})):
+                       ("v2", {"GPBO_POST_KERNEL": "2"}), ("v3", {"GPBO_POST_KERNEL": "3"})):
             os.environ.update(env)
             mu, sd = eng.posterior(0, ym, ys)
             res[v].append(eng.last_timings()["posterior_main"])
