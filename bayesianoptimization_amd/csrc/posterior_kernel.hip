@@ -346,7 +346,9 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
   // (posterior_kernel_v2.hip, 4 waves/SIMD).
   const char* kv = getenv("GPBO_POST_KERNEL");
   const bool use_v1 = kv && kv[0] == '1';
-  const bool use_v2 = kv && kv[0] == '2';   // fused generation (one kernel); default v3 = k* slab + GEMM
+  // v2 = fused generation (one kernel); v3 = k* slab + GEMM.  Default: v3 once k* would be regenerated by
+  // >= 3 row chunks (NP > 512), v2 below that (the second launch costs more than the regeneration saves).
+  const bool use_v2 = kv ? (kv[0] == '2') : (nchunks <= 2);
   const int n_mu = (use_v1 || use_v2) ? 1 : nchunks;
   ev_begin(ctx, T_POST_MAIN);
   if (use_v1) {
