@@ -233,13 +233,6 @@ def main():
             out["parity"] = {"argmin_equals_reference": bool(int(best[0]) == int(g["argmin"])),
                              "top10_equals_reference": bool(np.array_equal(best[2], g["topk_idx"][:10])),
                              "min_rel_err": float(abs(best[1] - float(g["min"])) / abs(float(g["min"])))}
-        if n_gpus == 1:
-            try:
-                # sustained v_mfma_f64_16x16x4_f64 rate with 8 waves/SIMD of independent accumulators
-                out["roofline"]["peak_measured"] = max(eng.mfma_f64_probe(2500, 8)["tflops"] for _ in range(2))
-                out["roofline"]["frac_of_measured_peak"] = achieved / out["roofline"]["peak_measured"]
-            except Exception as e:
-                log(f"[bench] mfma peak probe failed: {e!r}")
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
                 _, _, _, _, gpu_ys = eng.acq_argbest(w.acq, w.acq_param, 0.0 if y_max is None else y_max,
