@@ -1,0 +1,82 @@
+"""Device timings for every BASELINE.json config (one GPU; C4/C5 = one rank's shard of the 8-GPU job),
+with the CPU path (scikit-learn at the same theta, bounded sample, extrapolated linearly in M) beside it.
+Writes gpurun_out/config_table.json and a markdown table to stdout."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bayesianoptimization_amd import workloads as W  # noqa: E402
+from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
+from oracle import gp_oracle as O  # noqa: E402
+
+eng = GpEngine(0)
+rows = {}
+for name, shard in (("C1", 1), ("C2", 1), ("C3", 1), ("C4", 8), ("C5", 8)):
+    w = W.ALL[name]
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"{'C3' if name == 'C4' else name}.npz"))
+    ls = float(g["length_scale"][0])
+    X, y, c = W.make_observations(w)
+    M = w.M // shard
+    Xc = W.make_candidates(w.bounds_array(), M, 7)
+    yn, ym, ys = O.normalize_targets(y)
+    y_max = W.feasible_y_max(w, y, c)
+    n_gp = 2 if w.constrained else 1
+    r = {"N": w.N, "d": w.d, "M_per_gpu": M, "gps": n_gp, "arith": "f64"}
+    best = None
+    for rep in range(3):
+        t0 = time.perf_counter()
+        eng.fit(X, yn, w.kernel, ls, w.noise, slot=0)
+        fit_ms = eng.last_timings()["fit"]
+        lb = ub = None
+        if w.constrained:
+            cn, cm, cs = O.normalize_targets(c)
+            eng.fit(X, cn, W.MATERN25, float(g["c_length_scale"][0]), w.noise, slot=1)
+            fit_ms += eng.last_timings()["fit"]
+            lb, ub = [-np.inf], [w.constraint_ub]
+        if rep == 0:
+            eng.set_candidates(Xc)
+        eng.posterior(0, ym, ys, fetch=False)
+        post_ms = eng.last_timings()["posterior_main"]
+        if w.constrained:
+            eng.posterior(1, cm, cs, fetch=False)
+            post_ms += eng.last_timings()["posterior_main"]
+        bi, bv, si, sv, _ = eng.acq_argbest(w.acq, w.acq_param, y_max, lb, ub, k_seeds=10)
+        acq_ms = eng.last_timings()["acq_argbest"]
+        step_ms = (time.perf_counter() - t0) * 1e3
+        if best is None or step_ms < best[0]:
+            best = (step_ms, fit_ms, post_ms, acq_ms)
+    r["step_ms"], r["fit_ms"], r["posterior_ms"], r["acq_argbest_ms"] = best
+    r["cand_per_s"] = M / (best[0] * 1e-3)
+    fl = O.flops_per_candidate(w.N, w.d, n_gp) * M
+    r["posterior_tflops_algorithmic"] = fl / (best[2] * 1e-3) / 1e12
+    r["frac_of_78.6"] = r["posterior_tflops_algorithmic"] / 78.6
+    r["argbest"] = int(bi)
+    # CPU: sklearn at the same theta on a bounded sample
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF, Matern
+    chunk = min(M, 8192 if w.N <= 4096 else 2048)
+    k = RBF(length_scale=ls) if w.kernel == W.RBF else Matern(nu=2.5, length_scale=ls)
+    t0 = time.perf_counter(); sk = GaussianProcessRegressor(kernel=k, alpha=w.noise, normalize_y=True, optimizer=None).fit(X, y)
+    cpu_fit = time.perf_counter() - t0
+    t0 = time.perf_counter(); mu_s, sd_s = sk.predict(Xc[:chunk], return_std=True); cpu_chunk = time.perf_counter() - t0
+    r["cpu_fit_s"] = cpu_fit * n_gp
+    r["cpu_acq_cand_per_s"] = chunk / (cpu_chunk * n_gp)
+    r["cpu_step_s_extrapolated"] = cpu_fit * n_gp + cpu_chunk * n_gp * (M / chunk)
+    r["speedup_step"] = r["cpu_step_s_extrapolated"] / (best[0] * 1e-3)
+    mu, sd = eng.posterior(0, ym, ys)
+    r["parity_mu_sd_rel_on_cpu_sample"] = [float(np.max(np.abs(mu[:chunk] - mu_s)) / np.max(np.abs(mu_s))),
+                                           float(np.max(np.abs(sd[:chunk] - sd_s)) / np.max(np.abs(sd_s)))]
+    rows[name] = r
+    print(name, json.dumps(r), flush=True)
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "config_table.json"), "w"), indent=1)
+print("| config | N | d | M/GPU | GPs | step ms | fit ms | posterior ms | cand/s | TFLOP/s (frac of 78.6) | CPU cand/s | step speed-up |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+for n, r in rows.items():
+    print(f"| {n} | {r['N']} | {r['d']} | {r['M_per_gpu']} | {r['gps']} | {r['step_ms']:.2f} | {r['fit_ms']:.2f} | {r['posterior_ms']:.2f} | "
+          f"{r['cand_per_s']:.3g} | {r['posterior_tflops_algorithmic']:.1f} ({r['frac_of_78.6']:.2f}) | {r['cpu_acq_cand_per_s']:.3g} | {r['speedup_step']:.0f}x |")
