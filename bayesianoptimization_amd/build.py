@@ -28,6 +28,7 @@ SOURCES = {
     "posterior_kernel.hip": [],
     "posterior_kernel_v2.hip": [],
     "posterior_small.hip": [],
+    "posterior_kernel_f32.hip": [],
     "lml_kernels.hip": [],
     "acq_kernels.hip": ["-ffp-contract=off"],  # elementwise formulas follow NumPy op by op
     "probe.hip": [],

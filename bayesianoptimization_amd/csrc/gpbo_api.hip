@@ -29,6 +29,7 @@ static void free_model(Model& m) {
     if (*p) (void)hipFree(*p);
     *p = nullptr;
   }
+  if (m.Wp32) (void)hipFree(m.Wp32);
   m = Model();
 }
 
@@ -232,7 +233,7 @@ static int factorize(gpbo_ctx* ctx, int slot, const char* who, const double* X, 
   if (kernel != GPBO_KERNEL_RBF && kernel != GPBO_KERNEL_MATERN25)
     GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, w + ": kernel must be RBF or Matern(nu=2.5)");
   if (n_ls != 1 && n_ls != d) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": length_scale must have 1 or d entries");
-  if (precision != GPBO_F64) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, w + ": only float64 arithmetic is implemented");
+  if (precision != GPBO_F64 && precision != GPBO_F32) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, w + ": precision must be GPBO_F64 or GPBO_F32");
   for (int t = 0; t < n_ls; ++t)
     if (!(length_scale[t] > 0.0) || !std::isfinite(length_scale[t]))
       GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": length_scale must be positive and finite");
@@ -283,6 +284,10 @@ int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int
   if (rc) return rc;
   Model& m = ctx->models[slot];
   if ((rc = launch_pack_w(ctx, m))) return rc;
+  if (precision == GPBO_F32) {   // fp32 posterior: W rounded to fp32 in f32-MFMA fragment order (fit itself is fp64)
+    if ((rc = ensure(ctx, &m.Wp32, &m.cap_Wp32, m.NP * m.NP))) return rc;
+    if ((rc = launch_pack_w32(ctx, m))) return rc;
+  }
   ev_end(ctx, T_FIT);
   GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (*info_h != 0) {

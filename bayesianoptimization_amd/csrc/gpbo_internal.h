@@ -36,6 +36,8 @@ struct Model {
   double* L = nullptr;     // [NP][NP] Cholesky factor (lower triangle valid)
   double* W = nullptr;     // [NP][NP] L^-1 (upper triangle zero)
   double* Wp = nullptr;    // NP*NP doubles, MFMA-fragment packed W for the posterior kernel
+  float* Wp32 = nullptr;   // NP*NP floats, W rounded to fp32 in v_mfma_f32_16x16x4_f32 fragment order (precision F32)
+  int64_t cap_Wp32 = 0;
   double* dinv = nullptr;  // [NP/NB][NB][NB] inverses of the diagonal blocks of L
   double* tmp = nullptr;   // NP*NP/2 doubles workspace (trtri)
   double* yn = nullptr;    // [NP] normalised targets, zero padded
@@ -158,6 +160,9 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
 // posterior_kernel_v2.hip
 int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
 int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
+// posterior_kernel_f32.hip
+int launch_pack_w32(gpbo_ctx* ctx, Model& m);
+int launch_posterior_f32(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
 // acq_kernels.hip
 struct AcqArgs {
   int acq; double param; double y_max; int n_constraints;

@@ -349,9 +349,12 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
   // v2 = fused generation (one kernel); v3 = k* slab + GEMM.  Default: v3 once k* would be regenerated by
   // >= 3 row chunks (NP > 512), v2 below that (the second launch costs more than the regeneration saves).
   const bool use_v2 = kv ? (kv[0] == '2') : (nchunks <= 2);
-  const int n_mu = (use_v1 || use_v2) ? 1 : nchunks;
+  const bool use_f32 = (m.precision == GPBO_F32);   // fp32 slab + f32 MFMA GEMM (posterior_kernel_f32.hip)
+  const int n_mu = use_f32 ? nchunks : ((use_v1 || use_v2) ? 1 : nchunks);
   ev_begin(ctx, T_POST_MAIN);
-  if (use_v1) {
+  if (use_f32) {
+    rc = launch_posterior_f32(ctx, m, Mp, nchunks);
+  } else if (use_v1) {
     PostArgs a;
     a.Wp = m.Wp; a.Xs = m.Xs; a.alpha = m.alpha; a.Xcs = ctx->Xcs; a.part = ctx->part;
     a.mu_part = ctx->mu_part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nchunks; a.n_ctiles = (int)n_ctiles;

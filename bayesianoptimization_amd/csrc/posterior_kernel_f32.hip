@@ -1,0 +1,279 @@
+// fp32 posterior pipeline (precision = GPBO_F32; BASELINE.json configs[4] is quoted in fp32).
+//
+// The factorisation (K, L, W = L^-1, alpha) stays in fp64 — it is O(N^3) once per fit and its accuracy
+// decides everything downstream.  What runs in fp32 is the M-scaled part:
+//   kstar_gen_f32_kernel : k* evaluated in fp64 (distance, sqrt, exp) and ROUNDED to fp32 into the slab
+//                          [NP][slab] (half the HBM traffic of the fp64 slab); the means k*.alpha are
+//                          accumulated in fp64 before rounding, so mu keeps fp64 accuracy;
+//   posterior_kernel_f32 : V = W K*^T on v_mfma_f32_16x16x4_f32 (exact f32, 2x the fp64 matrix rate) with W
+//                          rounded to fp32 in fragment order; sum of squares in fp32 inside a 256-row chunk,
+//                          fp64 across lanes / waves / chunks.
+// Same decomposition as posterior_kernel_v2<GEN=2> (8 waves, wave = 32 rows x 64 candidates, 4 waves/SIMD),
+// with 32 train points per stage.  The reference has no fp32 path (everything is float64,
+// bayes_opt/target_space.py:95-96): this mode trades ~1e-3 relative accuracy on sigma for throughput and is
+// checked against the fp64 goldens with that tolerance (tests/test_gpu_f32.py).
+#include <cstdlib>
+
+#include "gpbo_internal.h"
+
+namespace gpbo {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int F32_CANDS = 64;
+constexpr int F32_BK = 32;
+constexpr int F32_STRIDE = 80;   // floats per k-row of the stage tile: 64 + 16 -> the two k-rows of a 32-lane group 16 banks apart
+
+struct PostArgsF32 {
+  const float* Wp;      // packed (pack_w32_kernel)
+  const float* Kst;     // [NP][ldk]
+  double* part;         // [nchunks][Mp]
+  int NP;
+  int64_t Mp;
+  int nchunks;
+  int n_ctiles;
+  int64_t ldk;
+  int64_t m0;
+};
+
+// W -> fp32 A fragments of v_mfma_f32_16x16x4_f32: for slab s (32 rows), k-quad q (16 columns), tile t (16 rows):
+// 64 lanes x 4 floats contiguous; lane l, element e holds W[32 s + 16 t + (l & 15)][16 q + 4 e + (l >> 4)].
+__global__ __launch_bounds__(256) void pack_w32_kernel(const double* __restrict__ W, float* __restrict__ Wp,
+                                                       int64_t N, int64_t NP) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= NP * NP) return;
+  const int e = (int)(idx & 3);
+  const int lane = (int)((idx >> 2) & 63);
+  const int t = (int)((idx >> 8) & 1);
+  const int64_t sq = idx >> 9;
+  const int64_t quads = NP / 16;
+  const int64_t s = sq / quads, q = sq - s * quads;
+  const int64_t row = 32 * s + 16 * t + (lane & 15);
+  const int64_t colx = 16 * q + 4 * e + (lane >> 4);
+  float v = 0.f;
+  if (row < N && colx < N && colx <= row) v = (float)W[row * NP + colx];
+  Wp[idx] = v;
+}
+
+int launch_pack_w32(gpbo_ctx* ctx, Model& m) {
+  const int64_t total = m.NP * m.NP;
+  pack_w32_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream>>>(m.W, m.Wp32, m.N, m.NP);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+template <int KERNEL>
+__device__ __forceinline__ double kernel_value_f32path(double d2) {
+  if (KERNEL == GPBO_KERNEL_MATERN25) {
+    double k = sqrt(d2) * 2.23606797749978969641;
+    return (1.0 + k + k * k / 3.0) * exp(-k);
+  } else {
+    return exp(-0.5 * d2);
+  }
+}
+
+template <int DP, int KERNEL>
+__global__ __launch_bounds__(256) void kstar_gen_f32_kernel(const double* __restrict__ Xs, const double* __restrict__ alpha,
+                                                            const double* __restrict__ Xcs, float* __restrict__ Kst,
+                                                            int64_t ldk, int NP, double* __restrict__ mu_part,
+                                                            int64_t Mp, int64_t m0) {
+  const int64_t ml = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (ml >= ldk) return;
+  const int k0 = blockIdx.y * POST_ROWS, k1 = min(NP, k0 + POST_ROWS);
+  double xc[DP];
+  const double* xcp = Xcs + (m0 + ml) * DP;
+#pragma unroll
+  for (int t = 0; t < DP; t += 2) {
+    const double2 v = *reinterpret_cast<const double2*>(xcp + t);
+    xc[t] = v.x;
+    xc[t + 1] = v.y;
+  }
+  double mu = 0.0;
+  for (int k = k0; k < k1; k += 2) {
+    const double* xr = Xs + (int64_t)k * DP;
+    double d2a = 0.0, d2b = 0.0;
+#pragma unroll
+    for (int t = 0; t < DP; ++t) {
+      const double da = xc[t] - xr[t], db = xc[t] - xr[DP + t];
+      d2a = fma(da, da, d2a);
+      d2b = fma(db, db, d2b);
+    }
+    const double ka = kernel_value_f32path<KERNEL>(d2a), kb = kernel_value_f32path<KERNEL>(d2b);
+    Kst[(int64_t)k * ldk + ml] = (float)ka;
+    Kst[(int64_t)(k + 1) * ldk + ml] = (float)kb;
+    mu = fma(ka, alpha[k], mu);
+    mu = fma(kb, alpha[k + 1], mu);
+  }
+  mu_part[(int64_t)blockIdx.y * Mp + m0 + ml] = mu;
+}
+
+__global__ __launch_bounds__(512, 4) void posterior_kernel_f32(PostArgsF32 p) {
+  __shared__ __attribute__((aligned(16))) float Ks[2 * F32_BK * F32_STRIDE];   // 20 KiB
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int bid = blockIdx.x;
+  const int r = p.nchunks - 1 - bid / p.n_ctiles;
+  const int ct = bid - (bid / p.n_ctiles) * p.n_ctiles;
+  const int NP = p.NP;
+  const int k_end = min(NP, (r + 1) * POST_ROWS);
+  const int n_stages = (k_end + F32_BK - 1) / F32_BK;   // NP is a multiple of 64, so k_end is a multiple of 32
+
+  const int slab = r * (POST_ROWS / 32) + wave;
+  const int slab_row0 = slab * 32;
+  const bool active = slab_row0 < NP;
+  const int64_t quads = NP / 16;
+  const int slab_ld = active ? slab : (NP / 32 - 1);
+  const f4* wp = reinterpret_cast<const f4*>(p.Wp) + (int64_t)slab_ld * quads * 128 + lane;
+
+  f4 acc[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[t][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+  // this thread's 4 slab elements of a stage: train points 4*wave .. 4*wave+3, candidate = lane
+  auto ld_stage = [&](int stage, float (&kv)[4]) {
+    const float* src = p.Kst + (int64_t)(stage * F32_BK + wave * 4) * p.ldk + (int64_t)ct * F32_CANDS + lane;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) kv[e] = src[(int64_t)e * p.ldk];
+  };
+  auto st_stage = [&](const float (&kv)[4], int buf) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Ks[(buf * F32_BK + wave * 4 + e) * F32_STRIDE + lane] = kv[e];
+  };
+  // A fragments of one k-quad (16 columns): [tile] float4 = 8 VGPRs
+  auto loadA = [&](int kquad, f4(&a)[2]) {
+    a[0] = wp[((int64_t)kquad * 2 + 0) * 64];
+    a[1] = wp[((int64_t)kquad * 2 + 1) * 64];
+  };
+  auto mma_quad = [&](int buf, int qq, const f4(&a)[2]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float* kb = Ks + (buf * F32_BK + qq * 16 + e * 4 + (lane >> 4)) * F32_STRIDE + (lane & 15);
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const float b = kb[jt * 16];
+        acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][e], b, acc[0][jt], 0, 0, 0);
+        acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][e], b, acc[1][jt], 0, 0, 0);
+      }
+    }
+  };
+
+  {
+    float kv0[4];
+    ld_stage(0, kv0);
+    st_stage(kv0, 0);
+  }
+  f4 aA[2], aB[2];
+  loadA(0, aA);
+  __syncthreads();
+
+  const int n_full = r * (POST_ROWS / F32_BK);
+  int s = 0;
+  for (; s < n_full; ++s) {
+    const int buf = s & 1;
+    float kv[4];
+    loadA(2 * s + 1, aB);
+    ld_stage(s + 1, kv);
+    mma_quad(buf, 0, aA);
+    loadA(2 * s + 2, aA);
+    mma_quad(buf, 1, aB);
+    st_stage(kv, buf ^ 1);
+    __syncthreads();
+  }
+  for (; s < n_stages; ++s) {
+    const int buf = s & 1;
+    const bool has_next = (s + 1 < n_stages);
+    const bool domma = (s * F32_BK <= slab_row0 + 31);
+    const bool domma_next = has_next && ((s + 1) * F32_BK <= slab_row0 + 31);
+    if (domma) loadA(2 * s + 1, aB);
+    float kv[4];
+    if (has_next) ld_stage(s + 1, kv);
+    if (domma) {
+      mma_quad(buf, 0, aA);
+      mma_quad(buf, 1, aB);
+    }
+    if (has_next) st_stage(kv, buf ^ 1);
+    if (domma_next) loadA(2 * s + 2, aA);
+    __syncthreads();
+  }
+
+  // epilogue: squares in fp32 per lane, everything beyond that in fp64, fixed order
+  double* red = reinterpret_cast<double*>(Ks);   // [8][64] doubles = 4 KiB
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt) {
+    float vs = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) vs = fmaf(acc[t][jt][rr], acc[t][jt][rr], vs);
+    double v = (double)vs;
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (lane < 16) red[wave * F32_CANDS + jt * 16 + lane] = active ? v : 0.0;
+  }
+  __syncthreads();
+  if (tid < F32_CANDS) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += red[w * F32_CANDS + tid];
+    p.part[(int64_t)r * p.Mp + p.m0 + (int64_t)ct * F32_CANDS + tid] = v;
+  }
+}
+
+template <int DP, int KERNEL>
+static int launch_gen32_t(gpbo_ctx* ctx, Model& m, float* Kst, int64_t ldk, int64_t Mp, int64_t m0, int nchunks) {
+  dim3 grid((unsigned)((ldk + 255) / 256), (unsigned)nchunks);
+  kstar_gen_f32_kernel<DP, KERNEL><<<grid, dim3(256), 0, ctx->stream>>>(m.Xs, m.alpha, ctx->Xcs, Kst, ldk, (int)m.NP,
+                                                                          ctx->mu_part, Mp, m0);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+template <int KERNEL>
+static int launch_gen32_k(gpbo_ctx* ctx, Model& m, float* Kst, int64_t ldk, int64_t Mp, int64_t m0, int nchunks) {
+  switch (m.DP) {
+    case 4: return launch_gen32_t<4, KERNEL>(ctx, m, Kst, ldk, Mp, m0, nchunks);
+    case 8: return launch_gen32_t<8, KERNEL>(ctx, m, Kst, ldk, Mp, m0, nchunks);
+    case 16: return launch_gen32_t<16, KERNEL>(ctx, m, Kst, ldk, Mp, m0, nchunks);
+    case 32: return launch_gen32_t<32, KERNEL>(ctx, m, Kst, ldk, Mp, m0, nchunks);
+    case 64: return launch_gen32_t<64, KERNEL>(ctx, m, Kst, ldk, Mp, m0, nchunks);
+  }
+  GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: unsupported padded dimension");
+}
+
+// fp32 pipeline per candidate slab; the slab buffer (ctx->kst, sized in doubles) is shared with the fp64 path.
+int launch_posterior_f32(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
+  double budget_gb = 40.0;
+  if (const char* e = getenv("GPBO_KSTAR_GB")) budget_gb = atof(e) > 0.0 ? atof(e) : budget_gb;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    const double avail = ((double)free_b + (double)ctx->cap_kst * 8.0) * 0.8 / 1e9;
+    if (avail < budget_gb) budget_gb = avail;
+  }
+  int64_t ms = (int64_t)(budget_gb * 1e9 / ((double)m.NP * 4.0));
+  ms = ms / 128 * 128;
+  if (ms < 128) GPBO_FAIL(ctx, GPBO_ERR_HIP, "posterior: not enough device memory for one k* slab");
+  if (ms > Mp) ms = Mp;
+  int rc;
+  if ((rc = ensure(ctx, &ctx->kst, &ctx->cap_kst, (ms * m.NP + 1) / 2))) return rc;
+  float* kst = reinterpret_cast<float*>(ctx->kst);
+  for (int64_t m0 = 0; m0 < Mp; m0 += ms) {
+    const int64_t ldk = (Mp - m0 < ms) ? (Mp - m0) : ms;
+    if (m.kernel == GPBO_KERNEL_MATERN25) rc = launch_gen32_k<GPBO_KERNEL_MATERN25>(ctx, m, kst, ldk, Mp, m0, nchunks);
+    else rc = launch_gen32_k<GPBO_KERNEL_RBF>(ctx, m, kst, ldk, Mp, m0, nchunks);
+    if (rc) return rc;
+    PostArgsF32 a;
+    a.Wp = m.Wp32; a.Kst = kst; a.part = ctx->part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nchunks;
+    a.n_ctiles = (int)(ldk / F32_CANDS); a.ldk = ldk; a.m0 = m0;
+    const int64_t nblocks = (int64_t)a.n_ctiles * nchunks;
+    if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
+    posterior_kernel_f32<<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
+    GPBO_HIP(ctx, hipGetLastError());
+  }
+  return GPBO_OK;
+}
+
+}  // namespace gpbo

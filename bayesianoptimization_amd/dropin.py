@@ -40,26 +40,27 @@ def _convert_acquisition(fn):
     return new
 
 
-def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=None):
+def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=None, precision: str = "f64"):
     """Swap the GP(s) and the acquisition function of `optimizer` in place; returns `optimizer`.
 
     Raises NotImplementedError for kernels outside the HIP path (see gpr.describe_kernel) and
     RuntimeError/ImportError when no GPU or no built library is available: there is no CPU fallback.
     `n_random` overrides the number of random candidates per suggest() (reference default 10_000).
+    `precision="f32"` keeps the fp64 factorisation but runs the posterior contraction in fp32 (2x matrix rate).
     `engine` lets several optimizers share (or tests inject) a GpEngine; default: one per device.
     """
     engine = engine if engine is not None else shared_engine(device)
     space = optimizer._space
     transform = None if _identity_transform(space) else space.kernel_transform
     describe_kernel(optimizer._gp.kernel)
-    optimizer._gp = HipGPR.from_sklearn(optimizer._gp, transform=transform, engine=engine, slot=0)
+    optimizer._gp = HipGPR.from_sklearn(optimizer._gp, transform=transform, engine=engine, slot=0, precision=precision)
     constraint = getattr(space, "_constraint", None)
     if constraint is not None:
         if len(constraint._model) > 7:
             raise NotImplementedError("at most 7 constraint GPs fit the engine's model slots")
         for j, m in enumerate(constraint._model):
             describe_kernel(m.kernel)
-            constraint._model[j] = HipGPR.from_sklearn(m, transform=transform, engine=engine, slot=j + 1)
+            constraint._model[j] = HipGPR.from_sklearn(m, transform=transform, engine=engine, slot=j + 1, precision=precision)
     optimizer._acquisition_function = _convert_acquisition(optimizer._acquisition_function)
     if n_random is not None and isinstance(optimizer._acquisition_function, A.AcquisitionFunction):
         optimizer._acquisition_function.default_n_random = int(n_random)

@@ -72,7 +72,7 @@ class HipGPR(GaussianProcessRegressor):
 
     def __init__(self, kernel=None, *, alpha=1e-10, optimizer="fmin_l_bfgs_b", n_restarts_optimizer=0,
                  normalize_y=False, copy_X_train=True, n_targets=None, random_state=None,
-                 transform=None, engine=None, slot=0, lml_on_device="auto"):
+                 transform=None, engine=None, slot=0, lml_on_device="auto", precision="f64"):
         super().__init__(kernel=kernel, alpha=alpha, optimizer=optimizer,
                          n_restarts_optimizer=n_restarts_optimizer, normalize_y=normalize_y,
                          copy_X_train=copy_X_train, n_targets=n_targets, random_state=random_state)
@@ -82,12 +82,19 @@ class HipGPR(GaussianProcessRegressor):
         # theta search: evaluate log_marginal_likelihood(theta, eval_gradient=True) on the GPU (True), with
         # sklearn's host code (False), or on the GPU from N >= 512 observations ("auto")
         self.lml_on_device = lml_on_device
+        # "f64" (reference arithmetic) or "f32": fp64 factorisation, fp32 posterior contraction (engine.F32)
+        self.precision = precision
 
     # -- plumbing ------------------------------------------------------------------------------
     def _engine(self) -> GpEngine:
         if self.engine is None:
             self.engine = shared_engine(0)
         return self.engine
+
+    def _precision_code(self) -> int:
+        if self.precision not in ("f64", "f32"):
+            raise ValueError("precision must be 'f64' or 'f32'")
+        return 1 if self.precision == "f32" else 0
 
     def _tx(self, X):
         X = np.asarray(X, dtype=np.float64)
@@ -96,13 +103,13 @@ class HipGPR(GaussianProcessRegressor):
         return np.ascontiguousarray(X)
 
     @classmethod
-    def from_sklearn(cls, gp: GaussianProcessRegressor, transform=None, engine=None, slot=0):
+    def from_sklearn(cls, gp: GaussianProcessRegressor, transform=None, engine=None, slot=0, precision="f64"):
         """Same hyper-parameters (and the same RandomState object) as an existing estimator."""
         p = gp.get_params(deep=False)
         return cls(kernel=p["kernel"], alpha=p["alpha"], optimizer=p["optimizer"],
                    n_restarts_optimizer=p["n_restarts_optimizer"], normalize_y=p["normalize_y"],
                    copy_X_train=p["copy_X_train"], n_targets=p.get("n_targets"),
-                   random_state=p["random_state"], transform=transform, engine=engine, slot=slot)
+                   random_state=p["random_state"], transform=transform, engine=engine, slot=slot, precision=precision)
 
     # -- log marginal likelihood ---------------------------------------------------------------------
     def _device_lml_ok(self, kernel) -> bool:
@@ -137,7 +144,7 @@ class HipGPR(GaussianProcessRegressor):
         if not getattr(self, "_in_fit", False) and hasattr(self, "_kind"):
             # called on a fitted model: gpbo_lml reused the slot's buffers, so restore the fit
             self._engine().fit(self._tx(self.X_train_), self.y_train_, self._kind, self._ls, float(self.alpha),
-                               slot=self.slot)
+                               slot=self.slot, precision=self._precision_code())
         return out
 
     # lazily fetched parity attributes -------------------------------------------------------------
@@ -234,7 +241,8 @@ class HipGPR(GaussianProcessRegressor):
             raise ValueError("Anisotropic kernel must have the same number of dimensions as data")
         self._kind, self._ls = kind, ls
         # _gpr.py:346-364 on the device (LinAlgError with sklearn's hint when K is not PD)
-        self._engine().fit(self._tx(self.X_train_), self.y_train_, kind, ls, float(self.alpha), slot=self.slot)
+        self._engine().fit(self._tx(self.X_train_), self.y_train_, kind, ls, float(self.alpha), slot=self.slot,
+                           precision=self._precision_code())
         return self
 
     # -- predict -----------------------------------------------------------------------------------

@@ -68,6 +68,8 @@ int gpbo_device_info(gpbo_ctx* ctx, char* buf, int buflen);
  * and additionally forms W = L^-1, the operator the posterior kernel applies to k*.
  * X: (N,d) row-major; y_norm: (N,) already normalised by the caller (_gpr.py:272-277);
  * length_scale: n_ls == 1 (isotropic) or n_ls == d (anisotropic).
+ * precision: GPBO_F64, or GPBO_F32 = the factorisation stays fp64 but gpbo_posterior rounds k* and W to fp32 and
+ * runs the N^2-per-candidate contraction on v_mfma_f32_16x16x4_f32 (sigma accurate to ~1e-3 relative; mu stays fp64).
  * On GPBO_ERR_NOT_PD, *info = 1-based index of the first non-positive pivot (LAPACK potrf info). */
 int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d,
              int kernel, const double* length_scale, int n_ls, double noise, int precision,

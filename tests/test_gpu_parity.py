@@ -186,7 +186,7 @@ def test_error_codes_map_to_python_exceptions(engine):
     with pytest.raises(NotImplementedError):
         engine.fit(X, y, 7, 1.0, 1e-6)                      # unknown kernel
     with pytest.raises(NotImplementedError):
-        engine.fit(X, y, O.RBF, 1.0, 1e-6, precision=1)     # fp32 arithmetic not implemented
+        engine.fit(X, y, O.RBF, 1.0, 1e-6, precision=7)     # unknown precision enum
     with pytest.raises(ValueError):
         engine.fit(X, y, O.RBF, [1.0, 2.0, 3.0], 1e-6)      # wrong length_scale size
     with pytest.raises(ValueError):
