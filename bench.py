@@ -31,6 +31,7 @@ from bayesianoptimization_amd.distributed import ShardedAcquisition  # noqa: E40
 from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet (matrix FP64); the guide lists no fp64 row
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate)
 
 
 def log(*a):
@@ -107,13 +108,20 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     w = W.ALL[args.config]
-    if w.dtype != "f64" or w.constrained:
-        raise SystemExit(f"config {w.name}: only single-GP float64 configs are wired into bench.py")
     X, y, c = W.make_observations(w)
     y_mean, y_std = float(np.mean(y)), float(np.std(y))
     yn = (y - y_mean) / y_std
     y_max = W.feasible_y_max(w, y, c)
-    M = w.M
+    # per-GPU candidate count: C3 = its own M; C4/C5 are quoted as 8-GPU jobs -> one eighth per GPU (weak scaling)
+    M = w.M // 8 if w.name in ("C4", "C5") else w.M
+    prec = 1 if w.dtype == "f32" else 0
+    n_gp = 2 if w.constrained else 1
+    if w.constrained:
+        c_mean, c_std = float(np.mean(c)), float(np.std(c))
+        cn = (c - c_mean) / c_std
+        lb_c, ub_c = [-np.inf], [w.constraint_ub]
+    else:
+        lb_c = ub_c = None
     Xc = W.make_candidates(w.bounds_array(), M, 7 + rank)  # rank r: shard r of a weak-scaled candidate set
 
     eng = GpEngine(local_rank)
@@ -158,10 +166,17 @@ def main():
     sh = ShardedAcquisition(eng, world, rank, allgather)
     sh.set_candidates_local(Xc, offset=rank * M)
 
+    post_ms = [0.0]
+
     def step():
-        eng.fit(X, yn, w.kernel, w.length_scale, w.noise, slot=0)
+        eng.fit(X, yn, w.kernel, w.length_scale, w.noise, slot=0, precision=prec)
         eng.posterior(0, y_mean, y_std, fetch=False)
-        return sh.argbest(w.acq, w.acq_param, 0.0 if y_max is None else y_max, k_seeds=10)
+        post_ms[0] = eng.last_timings()["posterior_main"]
+        if w.constrained:   # constraint GP in slot 1 (bayes_opt/constraint.py:132-151, 199-221)
+            eng.fit(X, cn, W.MATERN25, w.constraint_length_scale, w.noise, slot=1, precision=prec)
+            eng.posterior(1, c_mean, c_std, fetch=False)
+            post_ms[0] += eng.last_timings()["posterior_main"]
+        return sh.argbest(w.acq, w.acq_param, 0.0 if y_max is None else y_max, lb_c, ub_c, k_seeds=10)
 
     def barrier():
         eng.synchronize()
@@ -178,7 +193,8 @@ def main():
         best = step()
         tm = eng.last_timings()  # HIP events recorded on the engine's stream around each kernel group
         for k_ in kern_ms:
-            kern_ms[k_] += tm[k_]
+            kern_ms[k_] += tm[k_] * (n_gp if k_ in ("fit", "kmat", "cholesky", "trtri") else 1)
+        kern_ms["posterior_main"] += post_ms[0] - tm["posterior_main"]   # both GPs' posterior launches
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -192,19 +208,21 @@ def main():
         ms_per_step = elapsed / steps * 1e3
         value = n_gpus * M * steps / elapsed
         main_ms = kern_ms["posterior_main"] / steps
-        fl = flops_per_candidate(w.N, w.d) * M
+        fl = flops_per_candidate(w.N, w.d, n_gp) * M
         achieved = fl / (main_ms * 1e-3) / 1e12
+        peak = FP32_MFMA_PEAK_TFLOPS if prec else FP64_MFMA_PEAK_TFLOPS
         out = {
             "metric": "acquisition candidates/sec (suggest step: GP fit at fixed theta + posterior + acquisition + arg-best)",
             "value": value, "unit": "candidates/s", "n_gpus": n_gpus, "steps": steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f32" if prec else "f64", "data": "synthetic",
             "config": {"workload": f"{w.name}: d={w.d} N={w.N} {W.KERNEL_NAMES[w.kernel]} {W.ACQ_NAMES[w.acq]} "
-                                   f"M={M} candidates per GPU, fixed length_scale={w.length_scale}, alpha={w.noise}, "
-                                   "k_seeds=10; BASELINE.json configs[2]",
+                                   f"M={M} candidates per GPU, {n_gp} GP(s), fixed length_scale={w.length_scale}, "
+                                   f"alpha={w.noise}, k_seeds=10; BASELINE.json config {w.name}",
                        "N": w.N, "d": w.d, "M_per_gpu": M, "M_total": M * n_gpus, "collective": collective},
-            "roofline": {"bound": "mfma", "kernel": "kstar_gen_kernel<16,Matern25> + posterior_kernel_v2<GEN=2> (k* slab + MFMA GEMM)", "achieved": achieved,
-                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": ("kstar_gen_f32_kernel + posterior_kernel_f32" if prec else
+                                                     "kstar_gen_kernel + posterior_kernel_v2<GEN=2>") + " (k* slab + MFMA GEMM)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": None, "avg_launch_ms": main_ms, "flops_per_launch_algorithmic": fl},
             "step_breakdown_ms": {k_: v / steps for k_, v in kern_ms.items()},
             "best": {"index": int(best[0]), "value": float(best[1])},
@@ -228,12 +246,12 @@ def main():
             except Exception as e:  # noqa: BLE001
                 log(f"[bench] could not read {ppath}: {e!r}")
         gpath = os.path.join(ROOT, "tests", "golden", f"{w.name}.npz")
-        if n_gpus == 1 and os.path.exists(gpath):
+        if n_gpus == 1 and os.path.exists(gpath) and int(np.load(gpath)["M_evaluated"]) == M and not prec:
             g = np.load(gpath)
             out["parity"] = {"argmin_equals_reference": bool(int(best[0]) == int(g["argmin"])),
                              "top10_equals_reference": bool(np.array_equal(best[2], g["topk_idx"][:10])),
                              "min_rel_err": float(abs(best[1] - float(g["min"])) / abs(float(g["min"])))}
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not args.no_cpu_baseline and not w.constrained:
             try:
                 _, _, _, _, gpu_ys = eng.acq_argbest(w.acq, w.acq_param, 0.0 if y_max is None else y_max,
                                                      k_seeds=0, return_values=True)
