@@ -124,7 +124,10 @@ def main():
         lb_c = ub_c = None
     Xc = W.make_candidates(w.bounds_array(), M, 7 + rank)  # rank r: shard r of a weak-scaled candidate set
 
-    eng = GpEngine(local_rank)
+    # GPBO_BENCH_DEVICE pins every rank to one device (single-GPU rehearsal of the N > 1 flow; RCCL then
+    # refuses the duplicate GPU and the gloo fallback carries the 176-byte exchange)
+    dev = int(os.environ.get("GPBO_BENCH_DEVICE", local_rank))
+    eng = GpEngine(dev)
     collective = "none"
     allgather = None
     if world > 1:
