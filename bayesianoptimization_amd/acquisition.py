@@ -49,6 +49,47 @@ def _norm_pdf(x):
     return np.exp(-(x**2) / 2.0) / _SQRT_2PI  # scipy/stats/_continuous_distns.py:360-362
 
 
+_FD_EPS = 1e-8                       # scipy.optimize._lbfgsb_py._minimize_lbfgsb: eps=1e-8 -> abs_step
+_SQRT_EPS = np.finfo(np.float64).eps ** 0.5
+
+
+def _fd_value_and_grad(acq, bounds):
+    """value-and-gradient callable reproducing, in ONE batched acq() call per iteration, the forward
+    differences SciPy's L-BFGS-B forms one point at a time when `jac` is not given
+    (scipy/optimize/_numdiff.py: approx_derivative(method="2-point", abs_step=1e-8, bounds) ->
+    _adjust_scheme_to_bounds(..., "1-sided") -> _dense_difference): same steps, same divisions, so the
+    optimiser sees the same (f, g) and walks the same path as the reference's
+    `minimize(acq, x_try, bounds=..., method="L-BFGS-B")` (bayes_opt/acquisition.py:365-366)."""
+    lb, ub = bounds[:, 0].astype(float), bounds[:, 1].astype(float)
+
+    def fun(x):
+        x0 = np.asarray(x, dtype=np.float64)
+        d = x0.shape[0]
+        sign_x0 = (x0 >= 0).astype(float) * 2 - 1
+        h = np.full(d, _FD_EPS)
+        dx = (x0 + h) - x0
+        h = np.where(dx == 0, _SQRT_EPS * sign_x0 * np.maximum(1.0, np.abs(x0)), h)
+        if not np.all((lb == -np.inf) & (ub == np.inf)):
+            lower_dist, upper_dist = x0 - lb, ub - x0
+            xs = x0 + h
+            violated = (xs < lb) | (xs > ub)
+            fitting = np.abs(h) <= np.maximum(lower_dist, upper_dist)
+            h = h.copy()
+            h[violated & fitting] *= -1
+            forward = (upper_dist >= lower_dist) & ~fitting
+            h[forward] = upper_dist[forward]
+            backward = (upper_dist < lower_dist) & ~fitting
+            h[backward] = -lower_dist[backward]
+        pts = np.empty((d + 1, d))
+        pts[0] = x0
+        pts[1:] = x0 + np.diag(h)
+        ys = np.asarray(acq(pts), dtype=np.float64)
+        dxs = pts[1:][np.arange(d), np.arange(d)] - x0
+        return ys[0], (ys[1:] - ys[0]) / dxs
+
+    return fun
+
+
 def _fused_models(gp, constraint):
     """[target, constraint GPs...] if all are HipGPRs on one engine in slots 0..n, else None."""
     if not isinstance(gp, HipGPR) or gp.slot != 0:
@@ -70,6 +111,9 @@ class AcquisitionFunction(abc.ABC):
 
     #: default number of random candidates; the reference hard-codes 10_000 (acquisition.py:120)
     default_n_random = 10_000
+    #: with engine-backed GPs, form L-BFGS-B's finite-difference gradient in one batched device call per
+    #: iteration (d + 1 points) instead of d + 1 single-point calls; same numbers, ~d times fewer launches
+    batched_fd = True
     _acq_kind: int | None = None
 
     def __init__(self, random_state=None) -> None:
@@ -191,8 +235,13 @@ class AcquisitionFunction(abc.ABC):
         min_acq = None
         x_min = None
         if all(continuous_dimensions):
+            batched = self.batched_fd and getattr(self, "_fused", None) is not None
+            fg = _fd_value_and_grad(acq, continuous_bounds) if batched else None
             for x_try in x_seeds:
-                res = minimize(acq, x_try, bounds=continuous_bounds, method="L-BFGS-B")
+                if batched:
+                    res = minimize(fg, x_try, jac=True, bounds=continuous_bounds, method="L-BFGS-B")
+                else:
+                    res = minimize(acq, x_try, bounds=continuous_bounds, method="L-BFGS-B")
                 if not res.success:
                     continue
                 if min_acq is None or np.squeeze(res.fun) < min_acq:

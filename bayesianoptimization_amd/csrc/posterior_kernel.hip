@@ -331,7 +331,7 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
   {
     // latency path: a handful of candidates (HipGPR.predict from the host optimiser) -> batched GEMV
     const char* sm = getenv("GPBO_POST_SMALL");
-    if (M <= 8 && !(sm && sm[0] == '0')) {
+    if (M <= 72 && !(sm && sm[0] == '0')) {
       ev_begin(ctx, T_POST_MAIN);
       rc = launch_posterior_small(ctx, m, (int)M, y_mean, y_std);
       ev_end(ctx, T_POST_MAIN);

@@ -1,6 +1,6 @@
-// Small-batch posterior (M <= 8 candidates): the latency path behind HipGPR.predict when the reference's
-// "smart" stage (bayes_opt/acquisition.py:322-420: L-BFGS-B with finite differences) asks for one point at
-// a time.  Same arithmetic as posterior_kernel_v2 (sklearn _gpr.py:443-494), organised as a memory-bound
+// Small-batch posterior (M <= 72 candidates): the latency path behind HipGPR.predict when the reference's
+// "smart" stage (bayes_opt/acquisition.py:322-420: L-BFGS-B with finite differences) asks for one point — or,
+// with the batched finite-difference gradient of acquisition.py here, d + 1 points — at a time.  Same arithmetic as posterior_kernel_v2 (sklearn _gpr.py:443-494), organised as a memory-bound
 // batched GEMV over the row-major W = L^-1 (read once, ~N^2/2 * 8 B) instead of an MFMA GEMM:
 //   kstar_small_kernel : k*[c][k] for all train points (N x M values)
 //   gemv_small_kernel  : v[c][i] = sum_k W[i][k] k*[c][k], one wave per 4 rows, fixed shuffle tree
@@ -9,7 +9,7 @@
 
 namespace gpbo {
 
-constexpr int SMALL_MAX = 8;
+constexpr int SMALL_MAX = 72;   // d + 1 finite-difference points for d <= 64, plus slack
 
 template <int KERNEL>
 __device__ __forceinline__ double kernel_value_small(double d2) {
@@ -38,32 +38,32 @@ __global__ __launch_bounds__(256) void kstar_small_kernel(const double* __restri
   }
 }
 
-// vsq[c][i] = (sum_k W[i][k] ks[c][k])^2 for i < N (rows >= N contribute 0)
-template <int MS>
+// vsq[c][i] = (sum_k W[i][k] ks[c][k])^2 for i < N (rows >= N contribute 0); one wave per R rows, MS candidates.
+template <int MS, int R>
 __global__ __launch_bounds__(256) void gemv_small_kernel(const double* __restrict__ W, const double* __restrict__ ks,
                                                          int64_t N, int64_t NP, double* __restrict__ vsq) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
+  const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * R;
   if (i0 >= NP) return;
-  double acc[4][MS];
+  double acc[R][MS];
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int c = 0; c < MS; ++c) acc[r][c] = 0.0;
-  const int64_t kmax = min(NP, i0 + 4);   // W is lower triangular with an explicit zero upper part
+  const int64_t kmax = min(NP, i0 + R);   // W is lower triangular with an explicit zero upper part
   for (int64_t k = lane; k < kmax; k += 64) {
-    double w[4];
+    double w[R];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) w[r] = W[(i0 + r) * NP + k];
+    for (int r = 0; r < R; ++r) w[r] = W[(i0 + r) * NP + k];
 #pragma unroll
     for (int c = 0; c < MS; ++c) {
       const double kv = ks[(int64_t)c * NP + k];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r][c] = fma(w[r], kv, acc[r][c]);
+      for (int r = 0; r < R; ++r) acc[r][c] = fma(w[r], kv, acc[r][c]);
     }
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+  for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int c = 0; c < MS; ++c) {
       double v = acc[r][c];
@@ -71,6 +71,12 @@ __global__ __launch_bounds__(256) void gemv_small_kernel(const double* __restric
       for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
       if (lane == 0) vsq[(int64_t)c * NP + i0 + r] = (i0 + r < N) ? v * v : 0.0;
     }
+}
+
+template <int MS, int R>
+static void launch_gemv(gpbo_ctx* ctx, Model& m, const double* ks, double* vsq) {
+  const unsigned gb = (unsigned)((m.NP / R + 3) / 4);
+  gemv_small_kernel<MS, R><<<dim3(gb), dim3(256), 0, ctx->stream>>>(m.W, ks, m.N, m.NP, vsq);
 }
 
 __global__ __launch_bounds__(256) void finalize_small_kernel(const double* __restrict__ vsq, const double* __restrict__ ks,
@@ -108,21 +114,28 @@ __global__ __launch_bounds__(256) void finalize_small_kernel(const double* __res
 int launch_posterior_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double y_std) {
   if (M < 1 || M > SMALL_MAX) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "posterior_small: M out of range");
   int rc;
-  if ((rc = ensure(ctx, &ctx->part, &ctx->cap_part, (int64_t)2 * SMALL_MAX * m.NP))) return rc;
+  // scratch: ks and vsq, each (SMALL_MAX + 16) rows so that a padded last pass stays inside the allocation
+  const int64_t rows = SMALL_MAX + 16;
+  if ((rc = ensure(ctx, &ctx->part, &ctx->cap_part, (int64_t)2 * rows * m.NP))) return rc;
   double* ks = ctx->part;
-  double* vsq = ctx->part + (int64_t)SMALL_MAX * m.NP;
+  double* vsq = ctx->part + rows * m.NP;
   const unsigned kb = (unsigned)((m.NP + 255) / 256);
   if (m.kernel == GPBO_KERNEL_MATERN25)
     kstar_small_kernel<GPBO_KERNEL_MATERN25><<<dim3(kb), dim3(256), 0, ctx->stream>>>(m.Xs, ctx->Xcs, m.DP, m.NP, M, ks);
   else
     kstar_small_kernel<GPBO_KERNEL_RBF><<<dim3(kb), dim3(256), 0, ctx->stream>>>(m.Xs, ctx->Xcs, m.DP, m.NP, M, ks);
   GPBO_HIP(ctx, hipGetLastError());
-  const unsigned gb = (unsigned)((m.NP / 4 + 3) / 4);
-  switch (M) {
-    case 1: gemv_small_kernel<1><<<dim3(gb), dim3(256), 0, ctx->stream>>>(m.W, ks, m.N, m.NP, vsq); break;
-    case 2: gemv_small_kernel<2><<<dim3(gb), dim3(256), 0, ctx->stream>>>(m.W, ks, m.N, m.NP, vsq); break;
-    case 3: case 4: gemv_small_kernel<4><<<dim3(gb), dim3(256), 0, ctx->stream>>>(m.W, ks, m.N, m.NP, vsq); break;
-    default: gemv_small_kernel<8><<<dim3(gb), dim3(256), 0, ctx->stream>>>(m.W, ks, m.N, m.NP, vsq); break;
+  // passes of up to 16 candidates (the row order of the dot products does not depend on the pass width, so a
+  // candidate's result is bitwise the same whether it is evaluated alone or inside a batch)
+  for (int c0 = 0; c0 < M; c0 += 16) {
+    const int mc = (M - c0 < 16) ? (M - c0) : 16;
+    const double* ksp = ks + (int64_t)c0 * m.NP;
+    double* vp = vsq + (int64_t)c0 * m.NP;
+    if (mc == 1) launch_gemv<1, 4>(ctx, m, ksp, vp);
+    else if (mc == 2) launch_gemv<2, 4>(ctx, m, ksp, vp);
+    else if (mc <= 4) launch_gemv<4, 4>(ctx, m, ksp, vp);
+    else if (mc <= 8) launch_gemv<8, 4>(ctx, m, ksp, vp);
+    else launch_gemv<16, 2>(ctx, m, ksp, vp);
   }
   GPBO_HIP(ctx, hipGetLastError());
   finalize_small_kernel<<<dim3((unsigned)M), dim3(256), 0, ctx->stream>>>(vsq, ks, m.alpha, m.NP, y_mean, y_std, m.mu, m.sd);

@@ -167,3 +167,31 @@ def test_device_theta_search_matches_sklearn_optimum(engine):
     m1, s1 = sk.predict(Xc, return_std=True)
     m2, s2 = gp.predict(Xc, return_std=True)
     assert rel_err(m2, m1) < 1e-5 and rel_err(s2, s1) < 1e-5
+
+
+def test_batched_fd_smart_stage_is_bitwise_the_per_point_path(engine):
+    """The smart stage with one batched (d+1)-point device call per L-BFGS-B iteration returns exactly the point
+    of the reference-shaped per-point path (the small-batch kernel evaluates a candidate identically alone or in
+    a batch), with far fewer engine calls."""
+    w = W.P2
+    sp = _space(w)
+    res = {}
+    for batched in (True, False):
+        gp = HipGPR(kernel=RBF(length_scale=0.6), alpha=w.noise, normalize_y=True, optimizer=None, engine=engine)
+        fn = A.ExpectedImprovement(xi=0.01)
+        fn.batched_fd = batched
+        n0 = [0]
+        orig = engine.set_candidates
+
+        def counting(Xc, _o=orig, _n=n0):
+            _n[0] += 1
+            return _o(Xc)
+
+        engine.set_candidates = counting
+        try:
+            x = fn.suggest(gp, sp, n_random=2048, n_smart=5, random_state=np.random.RandomState(7))
+        finally:
+            del engine.set_candidates
+        res[batched] = (x, n0[0])
+    assert np.array_equal(res[True][0], res[False][0])
+    assert res[True][1] * 3 < res[False][1]

@@ -182,3 +182,33 @@ def test_hipgpr_fails_loudly_without_gpu():
         describe_kernel(RationalQuadratic())
     with pytest.raises(NotImplementedError):
         describe_kernel(Matern(nu=1.5))
+
+
+def test_batched_finite_differences_reproduce_scipy_lbfgsb():
+    """_fd_value_and_grad hands L-BFGS-B the forward differences SciPy would form itself (abs_step 1e-8, the
+    one-sided bound adjustment): same iterates bit for bit, ~d times fewer acquisition calls."""
+    from scipy.optimize import minimize
+
+    from bayesianoptimization_amd.acquisition import _fd_value_and_grad
+
+    rng = np.random.RandomState(0)
+    A = rng.randn(6, 6)
+    A = A @ A.T + np.eye(6)
+    b = rng.randn(6)
+
+    def f1(x):
+        return 0.5 * x @ A @ x - x @ b + np.sin(3 * x).sum()
+
+    calls = [0]
+
+    def acq(x):  # batch evaluation that is bitwise the per-point evaluation (as the device's small path is)
+        calls[0] += 1
+        return np.array([f1(r) for r in np.atleast_2d(x)])
+
+    bounds = np.array([[-1.0, 1.0]] * 6)
+    for x0 in (rng.uniform(-1, 1, 6), np.array([1.0, -1.0, 0.3, 1.0, 0, -1.0]), np.zeros(6)):
+        calls[0] = 0
+        r1 = minimize(f1, x0, bounds=bounds, method="L-BFGS-B")
+        r2 = minimize(_fd_value_and_grad(acq, bounds), x0, jac=True, bounds=bounds, method="L-BFGS-B")
+        assert np.array_equal(r1.x, r2.x) and r1.fun == r2.fun and r1.nit == r2.nit
+        assert calls[0] * 5 < r1.nfev
