@@ -14,9 +14,8 @@ namespace gpbo {
 
 constexpr int NB = 64;          // Cholesky / inverse block size (one MFMA GEMM tile edge)
 constexpr int POST_ROWS = 256;  // W rows owned by one posterior workgroup (8 waves x 32 rows)
-constexpr int POST_CANDS = 128; // candidates owned by one posterior workgroup
-constexpr int POST_BK = 16;     // train points (k) generated per LDS stage
-constexpr int KS_STRIDE = 144;  // doubles per k-row of the k* stage tile (128 + 16: 32-bank skew)
+constexpr int POST_CANDS = 128; // candidate padding granule (Mp = round_up(M, 128); kernels tile 64 candidates)
+constexpr int POST_BK = 16;     // train points (k) per LDS stage of the fp64 kernels
 
 enum TimingSlot {
   T_FIT = 0, T_POST_MAIN = 1, T_POST_FINAL = 2, T_ACQ = 3, T_KMAT = 4, T_CHOL = 5, T_TRTRI = 6, T_COUNT = 8

@@ -1,4 +1,5 @@
-// posterior_kernel_v2 — the fused posterior kernel re-tiled for FOUR waves per SIMD.
+// posterior_kernel_v2 — the posterior MFMA kernel tiled for FOUR waves per SIMD (v1, 2 waves/SIMD, is in the git
+// history), with the k* operand either generated in-kernel (GEN = 1) or read from a slab (GEN = 2, "v3").
 //
 // Why: the in-tree probe (gpbo_mfma_f64_probe) shows that on gfx950 a SIMD only reaches the
 // 64-cycle issue cadence of v_mfma_f64_16x16x4_f64 when >= 4 waves feed it (1 wave: 140 cycles per

@@ -1,5 +1,5 @@
-"""Within-process interleaved A/B of the posterior kernel's scheduling variants (GPBO_POST_SCHED=0|6)
-plus fit timings, on C3 (and C2 for the latency regime).  Development aid; writes gpurun_out/ab.json."""
+"""Within-process interleaved A/B of the posterior paths (GPBO_POST_KERNEL=2 fused | 3 slab+GEMM)
+plus fit / LML timings, on C3 (and C2 for the latency regime).  Development aid; writes gpurun_out/ab.json."""
 import json
 import os
 import sys
@@ -43,12 +43,10 @@ for name, M in (("C3", 1 << 20), ("C2", 1 << 16)):
         out["C3_lml_sklearn"] = [float(v_s), g_s.tolist()]
     eng.fit(X, yn, w.kernel, w.length_scale, w.noise)
     eng.set_candidates(W.make_candidates(w.bounds_array(), M, 7))
-    res = {"v1_sched0": [], "v1_sched6": [], "v2": [], "v3": []}
+    res = {"v2": [], "v3": []}
     ref = None
     for rnd in range(4):
-        for v, env in (("v1_sched0", {"GPBO_POST_KERNEL": "1", "GPBO_POST_SCHED": "0"}),
-                       ("v1_sched6", {"GPBO_POST_KERNEL": "1", "GPBO_POST_SCHED": "6"}),
-                       ("v2", {"GPBO_POST_KERNEL": "2"}), ("v3", {"GPBO_POST_KERNEL": "3"})):
+        for v, env in (("v2", {"GPBO_POST_KERNEL": "2"}), ("v3", {"GPBO_POST_KERNEL": "3"})):
             os.environ.update(env)
             mu, sd = eng.posterior(0, ym, ys)
             res[v].append(eng.last_timings()["posterior_main"])
