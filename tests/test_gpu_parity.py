@@ -310,3 +310,32 @@ def test_small_batch_path_equals_oracle_and_big_kernel(engine, M, N, d, kernel, 
     # kappa(K)*eps noise as the comparison with LAPACK (RBF, N=70, d=2: kappa ~ 4e7, |alpha| ~ 1e5)
     assert np.max(np.abs(mu - mu_b)) <= tol * np.max(np.abs(mu_o))
     assert np.max(np.abs(sd - sd_b)) <= tol * max(np.max(np.abs(sd_o)), 1e-3)
+
+
+def test_kstar_slab_loop_equals_single_slab(engine):
+    """The k* slab is bounded by a workspace budget; a candidate set larger than one slab is walked slab by slab.
+    Force ~7 slabs (GPBO_KSTAR_GB) and compare bitwise with the single-slab pass, in fp64 and fp32 modes."""
+    import os
+
+    from bayesianoptimization_amd.engine import F32, F64
+
+    N, d, M = 640, 6, 3000          # NP = 640 > 512 -> slab + GEMM path; Mp = 3072
+    X, y = _data(N, d, seed=41)
+    yn, ym, ys = O.normalize_targets(y)
+    Xc = np.random.RandomState(42).uniform(size=(M, d))
+    for prec in (F64, F32):
+        engine.fit(X, yn, O.MATERN25, 0.9, 1e-6, precision=prec)
+        engine.set_candidates(Xc)
+        mu1, sd1 = engine.posterior(0, ym, ys)
+        per_cand = 640 * (8 if prec == F64 else 4)
+        os.environ["GPBO_KSTAR_GB"] = repr(512 * per_cand / 1e9 * 1.01)    # room for 512 candidates per slab
+        try:
+            mu2, sd2 = engine.posterior(0, ym, ys)
+        finally:
+            os.environ.pop("GPBO_KSTAR_GB")
+        assert np.array_equal(mu1, mu2) and np.array_equal(sd1, sd2)
+    gp = O.fit_fixed_theta(O.MATERN25, X, y, 0.9, 1e-6)
+    mu_o, sd_o = O.predict(gp, Xc)
+    engine.fit(X, yn, O.MATERN25, 0.9, 1e-6)
+    mu, sd = engine.posterior(0, ym, ys)
+    assert rel_err(mu, mu_o) < TOL and rel_err(sd, sd_o) < TOL
