@@ -57,28 +57,16 @@ static int alloc_model(gpbo_ctx* ctx, Model& m, int64_t NP, int DP) {
   return GPBO_OK;
 }
 
-// Blocked right-looking Cholesky of m.L (lower), NB = 64, with one-step lookahead over two streams.
-// Step k: diag(k) [factor + invert the 64x64 diagonal block] -> panel(k) [L21 = A21 L11^-T as a GEMM with the
-// inverted block] -> trailing update A22 -= L21 L21^T, split into thin(k) (the first block column: what the NEXT
-// diagonal block and panel need) and rest(k) (everything to its right).  The dependency chain
-// diag -> panel -> thin -> diag ... stays on the main stream; rest(k) runs on the side stream concurrently with
-// thin(k), diag(k+1) and panel(k+1); thin(k+1) waits for rest(k) (they update the same tiles).
+// Blocked right-looking Cholesky of m.L (lower), NB = 64: diagonal block on one wave, panel and
+// trailing update on the MFMA GEMM.
 static int cholesky(gpbo_ctx* ctx, Model& m) {
   const int nblk = (int)(m.NP / NB);
   int rc;
-  hipStream_t sA = ctx->stream, sB = ctx->stream2;
-  const bool lookahead = sB != nullptr && nblk > 2;
-  if (lookahead) {   // the side stream must see everything queued so far on the main stream
-    GPBO_HIP(ctx, hipEventRecord(ctx->ev_panel[1], sA));
-    GPBO_HIP(ctx, hipStreamWaitEvent(sB, ctx->ev_panel[1], 0));
-  }
-  bool rest_pending = false;
   for (int kb = 0; kb < nblk; ++kb) {
     if ((rc = launch_potrf_diag(ctx, m, kb))) return rc;
     const int rem = (int)(m.NP - (int64_t)(kb + 1) * NB);
     if (rem == 0) break;
     double* panel = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)kb * NB;
-    double* trail = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)(kb + 1) * NB;
     GemmArgs g{};
     // panel: L21 = A21 * L11^-T  (in place)
     g.m = rem; g.n = NB; g.k = NB; g.alpha = 1.0; g.beta = 0.0;
@@ -86,39 +74,13 @@ static int cholesky(gpbo_ctx* ctx, Model& m) {
     g.B = m.dinv + (int64_t)kb * NB * NB; g.ldb = NB; g.strideB = 0; g.b_trans = 1;
     g.C = panel; g.ldc = m.NP; g.strideC = 0; g.batch = 1;
     if ((rc = launch_gemm(ctx, g))) return rc;
+    // trailing: A22 -= L21 L21^T (lower tiles only)
     GemmArgs s{};
-    s.k = NB; s.alpha = -1.0; s.beta = 1.0; s.lda = m.NP; s.ldb = m.NP; s.b_trans = 1; s.ldc = m.NP; s.batch = 1;
-    if (!lookahead) {   // trailing: A22 -= L21 L21^T (lower tiles only), one launch
-      s.m = rem; s.n = rem; s.A = panel; s.B = panel; s.C = trail; s.lower_only = 1;
-      if ((rc = launch_gemm(ctx, s))) return rc;
-      continue;
-    }
-    GPBO_HIP(ctx, hipEventRecord(ctx->ev_panel[kb & 1], sA));
-    // thin(k): first block column of the trailing matrix (all rem rows x 64 columns); after rest(k-1)
-    if (rest_pending) GPBO_HIP(ctx, hipStreamWaitEvent(sA, ctx->ev_rest[(kb - 1) & 1], 0));
-    s.m = rem; s.n = NB; s.A = panel; s.B = panel; s.C = trail; s.lower_only = 0;
+    s.m = rem; s.n = rem; s.k = NB; s.alpha = -1.0; s.beta = 1.0;
+    s.A = panel; s.lda = m.NP; s.B = panel; s.ldb = m.NP; s.b_trans = 1;
+    s.C = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)(kb + 1) * NB; s.ldc = m.NP;
+    s.batch = 1; s.lower_only = 1;
     if ((rc = launch_gemm(ctx, s))) return rc;
-    // rest(k): trailing[64:, 64:] on the side stream, after panel(k)
-    if (rem > NB) {
-      GPBO_HIP(ctx, hipStreamWaitEvent(sB, ctx->ev_panel[kb & 1], 0));
-      GemmArgs r2 = s;
-      r2.m = rem - NB; r2.n = rem - NB; r2.lower_only = 1;
-      r2.A = panel + (int64_t)NB * m.NP; r2.B = panel + (int64_t)NB * m.NP;
-      r2.C = trail + (int64_t)NB * m.NP + NB;
-      ctx->stream = sB;                      // launch_gemm launches on ctx->stream
-      rc = launch_gemm(ctx, r2);
-      ctx->stream = sA;
-      if (rc) return rc;
-      GPBO_HIP(ctx, hipEventRecord(ctx->ev_rest[kb & 1], sB));
-      rest_pending = true;
-    } else {
-      rest_pending = false;
-    }
-  }
-  if (lookahead && rest_pending) {
-    // join: nothing queued after this on the main stream may overtake the side stream
-    GPBO_HIP(ctx, hipEventRecord(ctx->ev_rest[0], sB));
-    GPBO_HIP(ctx, hipStreamWaitEvent(sA, ctx->ev_rest[0], 0));
   }
   return GPBO_OK;
 }
@@ -208,11 +170,6 @@ int gpbo_create(int device, gpbo_ctx** out) {
   ctx->device = device;
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
-  for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-    e = hipEventCreateWithFlags(&ctx->ev_panel[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->ev_rest[i], hipEventDisableTiming);
-  }
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->info_dev, sizeof(int));
   if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, 64 * 1024, hipHostMallocDefault);
   if (e != hipSuccess) {
@@ -238,11 +195,6 @@ int gpbo_destroy(gpbo_ctx* ctx) {
     if (e.a) (void)hipEventDestroy(e.a);
     if (e.b) (void)hipEventDestroy(e.b);
   }
-  for (int i = 0; i < 2; ++i) {
-    if (ctx->ev_panel[i]) (void)hipEventDestroy(ctx->ev_panel[i]);
-    if (ctx->ev_rest[i]) (void)hipEventDestroy(ctx->ev_rest[i]);
-  }
-  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return GPBO_OK;

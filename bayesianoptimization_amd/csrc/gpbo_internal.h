@@ -59,9 +59,6 @@ struct EventPair {
 struct gpbo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;       // side stream: Cholesky lookahead (bulk trailing update)
-  hipEvent_t ev_panel[2] = {nullptr, nullptr};
-  hipEvent_t ev_rest[2] = {nullptr, nullptr};
   std::string err;
   gpbo::Model models[GPBO_MAX_MODELS];
   // candidates
