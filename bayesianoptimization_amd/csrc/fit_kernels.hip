@@ -168,13 +168,25 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
     const int qj = j >> 4, jj = j & 15;
     double* cb = col + (j & 1) * 64;
     if (q == qj) {
-      double piv = __shfl(a[jj], j);
+      // pivot = a[jj] of lane j: the lane index is a compile-time constant here -> v_readlane, no LDS round trip
+      const unsigned long long pv = __double_as_longlong(a[jj]);
+      const unsigned plo = __builtin_amdgcn_readlane((int)(unsigned)pv, j);
+      const unsigned phi = __builtin_amdgcn_readlane((int)(unsigned)(pv >> 32), j);
+      double piv = __longlong_as_double(((unsigned long long)phi << 32) | plo);
       if (!(piv > 0.0)) {
         if (i == 0 && *bad_sh == 0) *bad_sh = j + 1;
         piv = 1.0;
       }
-      const double dg = sqrt(piv);
-      double l = (i == j) ? dg : a[jj] / dg;
+      // 1/sqrt(piv): v_rsq_f64 seed (2^-23) + two Newton steps, then sqrt = piv * rs with one correction;
+      // the column is scaled by the reciprocal (as LAPACK's dpotf2 does) instead of 64 divisions
+      double rs = __builtin_amdgcn_rsq(piv);
+      double e = fma(-piv * rs, rs, 1.0);
+      rs = fma(0.5 * rs, e, rs);
+      e = fma(-piv * rs, rs, 1.0);
+      rs = fma(0.5 * rs, e, rs);
+      double dg = piv * rs;
+      dg = fma(fma(-dg, dg, piv), 0.5 * rs, dg);
+      double l = (i == j) ? dg : a[jj] * rs;
       l = (i >= j) ? l : 0.0;
       a[jj] = l;
       cb[i] = l;
