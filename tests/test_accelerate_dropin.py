@@ -130,3 +130,45 @@ def test_predict_and_state_roundtrip(tmp_path):
         fresh.load_state(path)
         nxt2 = fresh.suggest()
     assert nxt == nxt2
+
+
+def test_hipgpr_device_lml_override_semantics():
+    """HipGPR.log_marginal_likelihood routes L-BFGS-B's objective to the engine (here the oracle-backed fake)
+    with sklearn's conventions: clone_kernel=False mutates kernel_.theta, theta=None returns the stored value,
+    unsupported kernels / lml_on_device=False fall through to sklearn's own code, a call on a fitted model
+    restores the fit, and the theta search reaches sklearn's optimum with the same RandomState consumption."""
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import ConstantKernel, Matern, RBF
+
+    from bayesianoptimization_amd.gpr import HipGPR
+
+    rng = np.random.RandomState(2)
+    X = rng.uniform(size=(40, 3))
+    y = np.sin(2 * X.sum(1))
+    eng = FakeEngine()
+    r1, r2 = np.random.RandomState(5), np.random.RandomState(5)
+    kw = dict(alpha=1e-6, normalize_y=True, n_restarts_optimizer=3)
+    sk = GaussianProcessRegressor(kernel=Matern(nu=2.5), random_state=r1, **kw).fit(X, y)
+    gp = HipGPR(kernel=Matern(nu=2.5), random_state=r2, engine=eng, lml_on_device=True, **kw).fit(X, y)
+    assert any(c[0] == "lml" for c in eng.calls) and eng.calls[-1][0] == "fit"
+    assert r1.uniform() == r2.uniform()
+    assert gp.log_marginal_likelihood_value_ == pytest.approx(sk.log_marginal_likelihood_value_, rel=1e-9)
+    assert gp.log_marginal_likelihood() == gp.log_marginal_likelihood_value_
+    th = np.log([0.7])
+    v_s, g_s = sk.log_marginal_likelihood(th, eval_gradient=True)
+    n_fit = sum(c[0] == "fit" for c in eng.calls)
+    v, g = gp.log_marginal_likelihood(th, eval_gradient=True)
+    assert v == pytest.approx(v_s, rel=1e-10) and np.allclose(g, g_s, rtol=1e-7)
+    assert sum(c[0] == "fit" for c in eng.calls) == n_fit + 1          # the slot's fit was restored
+    assert not np.allclose(gp.kernel_.theta, th)                          # clone_kernel=True: kernel_ untouched
+    gp.predict(X[:3], return_std=True)                                    # and the model still predicts
+    # anisotropic RBF under a fixed unit constant factor is supported; a free constant is not
+    gp2 = HipGPR(kernel=ConstantKernel(1.0, "fixed") * RBF([1.0, 1.0, 1.0]), engine=eng, lml_on_device=True,
+                 alpha=1e-6, optimizer=None).fit(X, y)
+    assert gp2._device_lml_ok(gp2.kernel_)
+    gp3 = HipGPR(kernel=Matern(nu=2.5), engine=eng, lml_on_device=False, alpha=1e-6, optimizer=None).fit(X, y)
+    n_lml = sum(c[0] == "lml" for c in eng.calls)
+    gp3.log_marginal_likelihood(th, eval_gradient=True)
+    assert sum(c[0] == "lml" for c in eng.calls) == n_lml
+    assert not HipGPR(kernel=Matern(nu=2.5), engine=eng, lml_on_device="auto", alpha=1e-6,
+                      optimizer=None).fit(X, y)._device_lml_ok(Matern(nu=2.5))   # auto: N < 512 stays on the host
