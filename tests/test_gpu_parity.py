@@ -200,6 +200,12 @@ def test_error_codes_map_to_python_exceptions(engine):
     engine.set_candidates(np.zeros((4, 2)))
     with pytest.raises(_lib.GpboError):
         engine.acq_argbest(O.UCB, 1.0)                       # posterior not run for these candidates
+    with pytest.raises(ValueError):
+        engine.set_candidates(np.zeros((0, 2)))              # empty candidate set (the host handles n_random == 0)
+    with pytest.raises(ValueError):
+        engine.fit(np.zeros((0, 2)), np.zeros(0), O.RBF, 1.0, 1e-6)   # no observations
+    with pytest.raises(NotImplementedError):
+        engine.fit(np.zeros((3, 65)), np.zeros(3), O.RBF, 1.0, 1e-6)  # d > 64
 
 
 def test_bitwise_determinism(engine):
