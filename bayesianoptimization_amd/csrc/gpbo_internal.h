@@ -112,6 +112,34 @@ void set_global_error(const std::string& s);
     return (code);                                                                           \
   } while (0)
 
+// k(d2) for the posterior-side k* generation (device only).  Same formulas as sklearn (kernels.py:1722-1724,
+// 1559-1560) with two cost cuts that stay within ~1 ulp: sqrt via v_rsq_f64 + Goldschmidt/Newton without the
+// subnormal rescaling (d2 is a sum of squares of O(1) numbers; exact 0 handled), and K^2/3 as K^2 * (1/3).
+// The fit-side kernel matrix (kmat_kernel) keeps the literal sqrt and division.
+#ifdef __HIPCC__
+__device__ __forceinline__ double gpbo_sqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  return x > 0.0 ? g : x;   // 0 -> 0 (rsq(0) = inf would give NaN), NaN -> NaN
+}
+template <int KERNEL>
+__device__ __forceinline__ double gpbo_kernel_value(double d2) {
+  if (KERNEL == GPBO_KERNEL_MATERN25) {
+    const double k = gpbo_sqrt_pos(d2) * 2.23606797749978969641;
+    return (1.0 + k + (k * k) * 0.33333333333333333333) * exp(-k);
+  } else {
+    return exp(-0.5 * d2);
+  }
+}
+#endif
+
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 inline int pad_dim(int d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : 64; }
 

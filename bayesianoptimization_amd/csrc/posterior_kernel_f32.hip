@@ -62,16 +62,6 @@ int launch_pack_w32(gpbo_ctx* ctx, Model& m) {
   return GPBO_OK;
 }
 
-template <int KERNEL>
-__device__ __forceinline__ double kernel_value_f32path(double d2) {
-  if (KERNEL == GPBO_KERNEL_MATERN25) {
-    double k = sqrt(d2) * 2.23606797749978969641;
-    return (1.0 + k + k * k / 3.0) * exp(-k);
-  } else {
-    return exp(-0.5 * d2);
-  }
-}
-
 template <int DP, int KERNEL>
 __global__ __launch_bounds__(256) void kstar_gen_f32_kernel(const double* __restrict__ Xs, const double* __restrict__ alpha,
                                                             const double* __restrict__ Xcs, float* __restrict__ Kst,
@@ -98,7 +88,7 @@ __global__ __launch_bounds__(256) void kstar_gen_f32_kernel(const double* __rest
       d2a = fma(da, da, d2a);
       d2b = fma(db, db, d2b);
     }
-    const double ka = kernel_value_f32path<KERNEL>(d2a), kb = kernel_value_f32path<KERNEL>(d2b);
+    const double ka = gpbo_kernel_value<KERNEL>(d2a), kb = gpbo_kernel_value<KERNEL>(d2b);
     Kst[(int64_t)k * ldk + ml] = (float)ka;
     Kst[(int64_t)(k + 1) * ldk + ml] = (float)kb;
     mu = fma(ka, alpha[k], mu);

@@ -41,16 +41,6 @@ struct PostArgs2 {
   int64_t m0;          // first candidate of the slab (outputs are indexed m0 + local)
 };
 
-template <int KERNEL>
-__device__ __forceinline__ double kernel_value_v2(double d2) {
-  if (KERNEL == GPBO_KERNEL_MATERN25) {
-    double k = sqrt(d2) * 2.23606797749978969641;
-    return (1.0 + k + k * k / 3.0) * exp(-k);
-  } else {
-    return exp(-0.5 * d2);
-  }
-}
-
 // GEN = 1: k* generated in the kernel (fused).  GEN = 2: k* read from a slab materialised by
 // kstar_gen_kernel (the fp64 VALU work of the generation shares the FP64 datapath with the MFMAs — measured:
 // 31 % of the fused kernel's time at C3 — so paying it once per candidate instead of once per row chunk wins).
@@ -132,8 +122,8 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
         }
       }
     }
-    kv[0] = kernel_value_v2<KERNEL>(d2a);
-    kv[1] = kernel_value_v2<KERNEL>(d2b);
+    kv[0] = gpbo_kernel_value<KERNEL>(d2a);
+    kv[1] = gpbo_kernel_value<KERNEL>(d2b);
     mu_acc = fma(kv[0], p.alpha[j0], mu_acc);
     mu_acc = fma(kv[1], p.alpha[j0 + 1], mu_acc);
   };
@@ -266,7 +256,7 @@ __global__ __launch_bounds__(256) void kstar_gen_kernel(const double* __restrict
       d2a = fma(da, da, d2a);
       d2b = fma(db, db, d2b);
     }
-    const double ka = kernel_value_v2<KERNEL>(d2a), kb = kernel_value_v2<KERNEL>(d2b);
+    const double ka = gpbo_kernel_value<KERNEL>(d2a), kb = gpbo_kernel_value<KERNEL>(d2b);
     Kst[(int64_t)k * ldk + ml] = ka;
     Kst[(int64_t)(k + 1) * ldk + ml] = kb;
     mu = fma(ka, alpha[k], mu);

@@ -12,16 +12,6 @@ namespace gpbo {
 constexpr int SMALL_MAX = 72;   // d + 1 finite-difference points for d <= 64, plus slack
 
 template <int KERNEL>
-__device__ __forceinline__ double kernel_value_small(double d2) {
-  if (KERNEL == GPBO_KERNEL_MATERN25) {
-    double k = sqrt(d2) * 2.23606797749978969641;
-    return (1.0 + k + k * k / 3.0) * exp(-k);
-  } else {
-    return exp(-0.5 * d2);
-  }
-}
-
-template <int KERNEL>
 __global__ __launch_bounds__(256) void kstar_small_kernel(const double* __restrict__ Xs, const double* __restrict__ Xcs,
                                                           int DP, int64_t NP, int M, double* __restrict__ ks) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -34,7 +24,7 @@ __global__ __launch_bounds__(256) void kstar_small_kernel(const double* __restri
       const double df = xc[t] - xr[t];
       d2 = fma(df, df, d2);
     }
-    ks[(int64_t)c * NP + k] = kernel_value_small<KERNEL>(d2);
+    ks[(int64_t)c * NP + k] = gpbo_kernel_value<KERNEL>(d2);
   }
 }
 
