@@ -114,6 +114,10 @@ class AcquisitionFunction(abc.ABC):
     #: with engine-backed GPs, form L-BFGS-B's finite-difference gradient in one batched device call per
     #: iteration (d + 1 points) instead of d + 1 single-point calls; same numbers, ~d times fewer launches
     batched_fd = True
+    #: THROUGHPUT MODE (off by default): draw the random-stage candidates on the device with a Philox generator
+    #: instead of space.random_sample(); removes the host sampling and the upload but is NOT the reference's
+    #: RandomState stream (two 31-bit integers are drawn from it as the device seed), so suggestions differ
+    device_sampling = False
     _acq_kind: int | None = None
 
     def __init__(self, random_state=None) -> None:
@@ -198,8 +202,11 @@ class AcquisitionFunction(abc.ABC):
     def _random_sample_minimize(self, acq, space, random_state, n_random: int, n_x_seeds: int = 0):  # :274-320
         if n_random == 0:
             return None, np.inf, space.random_sample(n_x_seeds, random_state=random_state)
-        x_tries = space.random_sample(n_random, random_state=random_state)
         fused = getattr(self, "_fused", None)
+        if (fused is not None and n_x_seeds <= 64 and self.device_sampling and fused[0].transform is None):
+            seed = int(random_state.randint(0, 2**31 - 1)) | (int(random_state.randint(0, 2**31 - 1)) << 31)
+            return self._device_minimize(fused, space, None, n_x_seeds, n_random=n_random, seed=seed)
+        x_tries = space.random_sample(n_random, random_state=random_state)
         if fused is not None and n_x_seeds <= 64:
             return self._device_minimize(fused, space, x_tries, n_x_seeds)
         ys = acq(x_tries)
@@ -212,11 +219,15 @@ class AcquisitionFunction(abc.ABC):
             x_seeds = []
         return x_min, min_acq, x_seeds
 
-    def _device_minimize(self, models, space, x_tries, n_x_seeds):
-        """The body of _random_sample_minimize after sampling, on the GPU (kernels K5-K8 of SURVEY.md §2.1)."""
+    def _device_minimize(self, models, space, x_tries, n_x_seeds, n_random=None, seed=None):
+        """The body of _random_sample_minimize after sampling, on the GPU (kernels K5-K8 of SURVEY.md §2.1).
+        x_tries=None: the candidates are generated on the device too (device_sampling)."""
         gp = models[0]
         eng = gp._engine()
-        eng.set_candidates(gp._tx(x_tries))
+        if x_tries is None:
+            eng.generate_candidates(n_random, space.bounds[:, 0], space.bounds[:, 1], seed)
+        else:
+            eng.set_candidates(gp._tx(x_tries))
         for m in models:
             m.posterior_resident()
         lb = ub = None
@@ -225,8 +236,12 @@ class AcquisitionFunction(abc.ABC):
         y_max = getattr(self, "y_max", None)
         bi, bv, si, _sv, _ = eng.acq_argbest(self._acq_kind, self._acq_param(), 0.0 if y_max is None else y_max,
                                              lb, ub, k_seeds=n_x_seeds)
+        si = si[si >= 0]
+        if x_tries is None:
+            rows = eng.get_candidate_rows(np.concatenate([[bi], si]), space.bounds.shape[0])
+            return rows[0], bv, (rows[1:] if n_x_seeds else [])
         x_min = x_tries[bi]
-        x_seeds = x_tries[si[si >= 0]] if n_x_seeds else []
+        x_seeds = x_tries[si] if n_x_seeds else []
         return x_min, bv, x_seeds
 
     def _smart_minimize(self, acq, space, x_seeds, random_state):  # acquisition.py:322-420

@@ -31,6 +31,7 @@ SOURCES = {
     "posterior_kernel_f32.hip": [],
     "lml_kernels.hip": [],
     "acq_kernels.hip": ["-ffp-contract=off"],  # elementwise formulas follow NumPy op by op
+    "candidates.hip": [],
     "probe.hip": [],
     "comm.hip": [],
 }

@@ -1,0 +1,109 @@
+// On-device candidate generation — a THROUGHPUT MODE, not stream-compatible with the
+// reference: TargetSpace.random_sample (bayes_opt/target_space.py:565-603) draws from NumPy's MT19937
+// RandomState on the host (92 ms for 2^20 x 16 on the GPU box's EPYC; index parity with the reference requires
+// exactly that stream, which stays the default).  Here a counter-based Philox4x32-10 generator produces the
+// (M, d) uniform matrix directly in HBM: no host sampling, no H2D copy.  Doubles are formed like NumPy's
+// random_sample: (a >> 5) * 2^26 + (b >> 6) over 2^53, then lo + (hi - lo) * u.
+#include "gpbo_internal.h"
+
+namespace gpbo {
+
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0;
+    const unsigned n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+    const unsigned n3 = (unsigned)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+
+// element index e = m * d + t; each Philox call yields two doubles (elements 2q, 2q+1)
+__global__ __launch_bounds__(256) void generate_candidates_kernel(double* __restrict__ Xc, int64_t total, int d,
+                                                                  const double* __restrict__ lohi,
+                                                                  unsigned long long seed) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t e0 = 2 * q;
+  if (e0 >= total) return;
+  unsigned c[4] = {(unsigned)q, (unsigned)((unsigned long long)q >> 32), 0u, 0u};
+  philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int64_t e = e0 + h;
+    if (e >= total) break;
+    const unsigned a = c[2 * h] >> 5, b = c[2 * h + 1] >> 6;
+    const double u = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    const int t = (int)(e % d);
+    Xc[e] = lohi[t] + (lohi[GPBO_MAX_DIM + t] - lohi[t]) * u;
+  }
+}
+
+__global__ void gather_rows_kernel(const double* __restrict__ Xc, int d, const int64_t* __restrict__ idx, int n,
+                                   int64_t M, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * d) return;
+  const int r = i / d, t = i - r * d;
+  const int64_t m = idx[r];
+  out[i] = (m >= 0 && m < M) ? Xc[m * d + t] : __longlong_as_double(0x7ff8000000000000LL);
+}
+
+}  // namespace gpbo
+
+using namespace gpbo;
+
+extern "C" int gpbo_generate_candidates(gpbo_ctx* ctx, int64_t M, int d, const double* lo, const double* hi,
+                                        uint64_t seed) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  if (!lo || !hi || M < 1 || d < 1 || d > GPBO_MAX_DIM) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "generate_candidates: bad arguments");
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, &ctx->Xc, &ctx->cap_Xc, M * d))) return rc;
+  {
+    char* p = (char*)ctx->red;
+    int64_t cap = ctx->cap_red;
+    if ((rc = ensure(ctx, &p, &cap, (int64_t)2 * GPBO_MAX_DIM * 8 + 4096))) return rc;
+    ctx->red = p;
+    ctx->cap_red = cap;
+  }
+  double* h = (double*)ctx->pinned;
+  for (int t = 0; t < d; ++t) { h[t] = lo[t]; h[GPBO_MAX_DIM + t] = hi[t]; }
+  GPBO_HIP(ctx, hipMemcpyAsync(ctx->red, h, 2 * GPBO_MAX_DIM * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  const int64_t total = M * d, nq = (total + 1) / 2;
+  generate_candidates_kernel<<<dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, ctx->stream>>>(
+      ctx->Xc, total, d, (const double*)ctx->red, (unsigned long long)seed);
+  GPBO_HIP(ctx, hipGetLastError());
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->M = M;
+  ctx->d_c = d;
+  for (auto& m : ctx->models) m.M_post = -1;
+  return GPBO_OK;
+}
+
+extern "C" int gpbo_get_candidate_rows(gpbo_ctx* ctx, const int64_t* idx, int n, double* out) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  if (!idx || !out || n < 1 || n > 4096) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "get_candidate_rows: bad arguments");
+  if (ctx->M < 1) GPBO_FAIL(ctx, GPBO_ERR_STATE, "get_candidate_rows: no candidates resident");
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  const int d = ctx->d_c;
+  int rc;
+  {
+    char* p = (char*)ctx->red;
+    int64_t cap = ctx->cap_red;
+    if ((rc = ensure(ctx, &p, &cap, (int64_t)n * 8 + (int64_t)n * d * 8 + 64))) return rc;
+    ctx->red = p;
+    ctx->cap_red = cap;
+  }
+  int64_t* didx = (int64_t*)ctx->red;
+  double* dout = (double*)((char*)ctx->red + (((size_t)n * 8 + 63) / 64) * 64);
+  GPBO_HIP(ctx, hipMemcpyAsync(didx, idx, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  gather_rows_kernel<<<dim3((unsigned)((n * d + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->Xc, d, didx, n, ctx->M, dout);
+  GPBO_HIP(ctx, hipGetLastError());
+  GPBO_HIP(ctx, hipMemcpyAsync(out, dout, (size_t)n * d * 8, hipMemcpyDeviceToHost, ctx->stream));
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GPBO_OK;
+}

@@ -119,6 +119,23 @@ class GpEngine:
         self._check(self._lib.gpbo_set_candidates(self._h, dptr(Xc), Xc.shape[0], Xc.shape[1]))
         self.n_candidates = Xc.shape[0]
 
+    def generate_candidates(self, M: int, lo, hi, seed: int):
+        """Throughput mode: M x d uniforms in [lo, hi) generated on the device (Philox); NOT the reference's stream."""
+        lo = np.ascontiguousarray(lo, dtype=np.float64).ravel()
+        hi = np.ascontiguousarray(hi, dtype=np.float64).ravel()
+        if lo.shape != hi.shape:
+            raise ValueError("lo and hi must have the same length")
+        self._check(self._lib.gpbo_generate_candidates(self._h, int(M), lo.shape[0], dptr(lo), dptr(hi),
+                                                       int(seed) & 0xFFFFFFFFFFFFFFFF))
+        self.n_candidates = int(M)
+        self._cand_dim = lo.shape[0]
+
+    def get_candidate_rows(self, idx, d: int):
+        idx = np.ascontiguousarray(np.atleast_1d(idx), dtype=np.int64)
+        out = np.empty((idx.shape[0], d))
+        self._check(self._lib.gpbo_get_candidate_rows(self._h, iptr(idx), idx.shape[0], dptr(out)))
+        return out
+
     def posterior(self, slot=0, y_mean=0.0, y_std=1.0, fetch=True):
         """mu, sd for the resident candidates (sklearn _gpr.py:443-494). fetch=False keeps them on device."""
         M = self.n_candidates

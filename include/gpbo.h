@@ -96,6 +96,15 @@ int gpbo_get_alpha(gpbo_ctx* ctx, int slot, double* out);  /* gp.alpha_ */
  * TargetSpace.random_sample target_space.py:565-603) and keep it resident in HBM. */
 int gpbo_set_candidates(gpbo_ctx* ctx, const double* Xc, int64_t M, int d);
 
+/* Throughput mode (NOT stream-compatible with the reference): fill the resident candidate matrix with
+ * M x d uniforms in [lo[t], hi[t]) from a counter-based Philox4x32-10 generator on the device, instead of
+ * TargetSpace.random_sample + upload (target_space.py:565-603).  Index parity with the reference needs the
+ * host RandomState stream (gpbo_set_candidates); this entry point removes the host sampling and the H2D copy. */
+int gpbo_generate_candidates(gpbo_ctx* ctx, int64_t M, int d, const double* lo, const double* hi, uint64_t seed);
+/* Copy n rows (by index) of the resident candidate matrix back to the host (x_min and the seeds,
+ * bayes_opt/acquisition.py:313-317); out is (n, d) row-major; out-of-range indices give NaN rows. */
+int gpbo_get_candidate_rows(gpbo_ctx* ctx, const int64_t* idx, int n, double* out);
+
 /* ---- posterior -------------------------------------------------------------------------- */
 /* Replaces GaussianProcessRegressor.predict(X, return_std=True) (_gpr.py:443-494; called from
  * bayes_opt/acquisition.py:205,216 and bayes_opt/constraint.py:200,213) for the resident

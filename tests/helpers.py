@@ -105,3 +105,32 @@ class FakeEngine:
         nan = np.isnan(ys)
         order = np.lexsort((np.arange(len(ys)), np.where(nan, np.inf, ys) + 0.0, nan))[:k_seeds]
         return bi + index_offset, bv, order + index_offset, ys[order], (ys if return_values else None)
+
+
+def philox4x32_10_uniform(M, d, lo, hi, seed):
+    """NumPy restatement of candidates.hip (Philox4x32-10, counter = pair index, key = 64-bit seed) -> (M, d)."""
+    total = M * d
+    nq = (total + 1) // 2
+    q = np.arange(nq, dtype=np.uint64)
+    c = [(q & np.uint64(0xFFFFFFFF)).astype(np.uint64), (q >> np.uint64(32)).astype(np.uint64),
+         np.zeros(nq, np.uint64), np.zeros(nq, np.uint64)]
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    m32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[1] ^ k0) & m32
+        n1 = p1 & m32
+        n2 = ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & m32
+        n3 = p0 & m32
+        c = [n0, n1, n2, n3]
+        k0 = (k0 + np.uint64(0x9E3779B9)) & m32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & m32
+    u = np.empty(2 * nq)
+    for h in range(2):
+        a = (c[2 * h] >> np.uint64(5)).astype(np.float64)
+        b = (c[2 * h + 1] >> np.uint64(6)).astype(np.float64)
+        u[h::2] = (a * 67108864.0 + b) / 9007199254740992.0
+    u = u[:total].reshape(M, d)
+    lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+    return lo + (hi - lo) * u

@@ -195,3 +195,32 @@ def test_batched_fd_smart_stage_is_bitwise_the_per_point_path(engine):
         res[batched] = (x, n0[0])
     assert np.array_equal(res[True][0], res[False][0])
     assert res[True][1] * 3 < res[False][1]
+
+
+def test_device_sampling_throughput_mode(engine):
+    """gpbo_generate_candidates: Philox4x32-10 on the device, checked bit for bit against a NumPy restatement
+    (known-answer), and used end to end by the fused acquisition (labelled non-parity: not the reference's
+    RandomState stream)."""
+    from helpers import philox4x32_10_uniform
+
+    lo, hi = np.array([0.0, -2.0, 3.0]), np.array([1.0, 2.0, 3.5])
+    M, seed = 10001, (123456789 << 31) | 987654321
+    engine.generate_candidates(M, lo, hi, seed)
+    ref = philox4x32_10_uniform(M, 3, lo, hi, seed)
+    rows = engine.get_candidate_rows(np.arange(0, M, 97), 3)
+    assert np.array_equal(rows, ref[::97])
+    assert np.all(ref >= lo) and np.all(ref < hi) and abs(ref[:, 0].mean() - 0.5) < 0.01
+    assert np.all(np.isnan(engine.get_candidate_rows([M + 5, -1], 3)))
+    # end to end: the fused random stage on device-generated candidates agrees with the same candidates uploaded
+    w = W.P1
+    sp = _space(w)
+    gp = HipGPR(kernel=Matern(nu=2.5, length_scale=0.4), alpha=w.noise, normalize_y=True, optimizer=None, engine=engine)
+    fn = A.UpperConfidenceBound(kappa=2.0)
+    fn.device_sampling = True
+    rs = np.random.RandomState(5)
+    x = fn.suggest(gp, sp, n_random=5000, n_smart=0, random_state=rs)
+    rs2 = np.random.RandomState(5)
+    seed2 = int(rs2.randint(0, 2**31 - 1)) | (int(rs2.randint(0, 2**31 - 1)) << 31)
+    Xc = philox4x32_10_uniform(5000, w.d, sp.bounds[:, 0], sp.bounds[:, 1], seed2)
+    m, s = gp.predict(Xc, return_std=True)
+    assert np.array_equal(x, Xc[np.argmin(-(m + 2.0 * s))])
