@@ -39,6 +39,15 @@ for name in ("C2", "C3"):
             x = fn.suggest(gp, sp, n_random=w.M, n_smart=n_smart, fit_gp=True, random_state=np.random.RandomState(7))
             ts.append((time.perf_counter() - t0) * 1e3)
         r[f"suggest_fixed_theta_nsmart{n_smart}_ms"] = ts
+    fn.device_sampling = True   # throughput mode: Philox candidates generated on the device (non-parity)
+    for n_smart in (0, 10):
+        ts = []
+        for rep in range(3):
+            t0 = time.perf_counter()
+            x = fn.suggest(gp, sp, n_random=w.M, n_smart=n_smart, fit_gp=True, random_state=np.random.RandomState(7))
+            ts.append((time.perf_counter() - t0) * 1e3)
+        r[f"suggest_device_sampling_nsmart{n_smart}_ms"] = ts
+    fn.device_sampling = False
     # single-point predict latency (what L-BFGS-B's finite differences call)
     xs = sp.random_sample(64, np.random.RandomState(1))
     t0 = time.perf_counter()
