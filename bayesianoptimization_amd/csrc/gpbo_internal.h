@@ -189,7 +189,7 @@ int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
 int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
 // posterior_kernel_f32.hip
 int launch_pack_w32(gpbo_ctx* ctx, Model& m);
-int launch_posterior_f32(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
+int launch_posterior_f32(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, int* part_chunks);
 // acq_kernels.hip
 struct AcqArgs {
   int acq; double param; double y_max; int n_constraints;

@@ -97,8 +97,13 @@ __global__ __launch_bounds__(256) void kstar_gen_f32_kernel(const double* __rest
   mu_part[(int64_t)blockIdx.y * Mp + m0 + ml] = mu;
 }
 
+// RT = 16-row MFMA tiles per wave: 2 (wave = 32 rows, workgroup chunk = 256 rows) or 4 (64 rows / 512 rows: half
+// the LDS B-fragment reads and slab re-reads per MFMA).  p.nchunks counts chunks of 8 * 16 * RT rows.
+template <int RT>
 __global__ __launch_bounds__(512, 4) void posterior_kernel_f32(PostArgsF32 p) {
   __shared__ __attribute__((aligned(16))) float Ks[2 * F32_BK * F32_STRIDE];   // 20 KiB
+  constexpr int WROWS = 16 * RT;          // rows per wave
+  constexpr int CROWS = 8 * WROWS;        // rows per workgroup chunk
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,19 +112,20 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32(PostArgsF32 p) {
   const int r = p.nchunks - 1 - bid / p.n_ctiles;
   const int ct = bid - (bid / p.n_ctiles) * p.n_ctiles;
   const int NP = p.NP;
-  const int k_end = min(NP, (r + 1) * POST_ROWS);
+  const int k_end = min(NP, (r + 1) * CROWS);
   const int n_stages = (k_end + F32_BK - 1) / F32_BK;   // NP is a multiple of 64, so k_end is a multiple of 32
 
-  const int slab = r * (POST_ROWS / 32) + wave;
-  const int slab_row0 = slab * 32;
-  const bool active = slab_row0 < NP;
+  const int wrow0 = r * CROWS + wave * WROWS;           // first row of this wave
+  const bool active = wrow0 < NP;
   const int64_t quads = NP / 16;
-  const int slab_ld = active ? slab : (NP / 32 - 1);
-  const f4* wp = reinterpret_cast<const f4*>(p.Wp) + (int64_t)slab_ld * quads * 128 + lane;
+  const int wrow_ld = active ? wrow0 : (NP - WROWS);    // inactive waves stream valid rows; their sums are dropped
+  // packed layout is per 32-row slab: [slab32][quad][tile2][lane] float4
+  const f4* wp0 = reinterpret_cast<const f4*>(p.Wp) + (int64_t)(wrow_ld / 32) * quads * 128 + lane;
+  const f4* wp1 = wp0 + quads * 128;                    // second 32-row slab (RT == 4)
 
-  f4 acc[2][4];
+  f4 acc[RT][4];
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[t][j] = f4{0.f, 0.f, 0.f, 0.f};
 
@@ -133,20 +139,24 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32(PostArgsF32 p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) Ks[(buf * F32_BK + wave * 4 + e) * F32_STRIDE + lane] = kv[e];
   };
-  // A fragments of one k-quad (16 columns): [tile] float4 = 8 VGPRs
-  auto loadA = [&](int kquad, f4(&a)[2]) {
-    a[0] = wp[((int64_t)kquad * 2 + 0) * 64];
-    a[1] = wp[((int64_t)kquad * 2 + 1) * 64];
+  // A fragments of one k-quad (16 columns): [tile] float4
+  auto loadA = [&](int kquad, f4(&a)[RT]) {
+    a[0] = wp0[((int64_t)kquad * 2 + 0) * 64];
+    a[1] = wp0[((int64_t)kquad * 2 + 1) * 64];
+    if constexpr (RT == 4) {
+      a[2] = wp1[((int64_t)kquad * 2 + 0) * 64];
+      a[3] = wp1[((int64_t)kquad * 2 + 1) * 64];
+    }
   };
-  auto mma_quad = [&](int buf, int qq, const f4(&a)[2]) {
+  auto mma_quad = [&](int buf, int qq, const f4(&a)[RT]) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float* kb = Ks + (buf * F32_BK + qq * 16 + e * 4 + (lane >> 4)) * F32_STRIDE + (lane & 15);
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
         const float b = kb[jt * 16];
-        acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0][e], b, acc[0][jt], 0, 0, 0);
-        acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1][e], b, acc[1][jt], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][e], b, acc[t][jt], 0, 0, 0);
       }
     }
   };
@@ -156,11 +166,11 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32(PostArgsF32 p) {
     ld_stage(0, kv0);
     st_stage(kv0, 0);
   }
-  f4 aA[2], aB[2];
+  f4 aA[RT], aB[RT];
   loadA(0, aA);
   __syncthreads();
 
-  const int n_full = r * (POST_ROWS / F32_BK);
+  const int n_full = r * (CROWS / F32_BK);
   int s = 0;
   for (; s < n_full; ++s) {
     const int buf = s & 1;
@@ -176,8 +186,8 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32(PostArgsF32 p) {
   for (; s < n_stages; ++s) {
     const int buf = s & 1;
     const bool has_next = (s + 1 < n_stages);
-    const bool domma = (s * F32_BK <= slab_row0 + 31);
-    const bool domma_next = has_next && ((s + 1) * F32_BK <= slab_row0 + 31);
+    const bool domma = (s * F32_BK <= wrow0 + WROWS - 1);
+    const bool domma_next = has_next && ((s + 1) * F32_BK <= wrow0 + WROWS - 1);
     if (domma) loadA(2 * s + 1, aB);
     float kv[4];
     if (has_next) ld_stage(s + 1, kv);
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32(PostArgsF32 p) {
   for (int jt = 0; jt < 4; ++jt) {
     float vs = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < RT; ++t)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) vs = fmaf(acc[t][jt][rr], acc[t][jt][rr], vs);
     double v = (double)vs;
@@ -235,7 +245,8 @@ static int launch_gen32_k(gpbo_ctx* ctx, Model& m, float* Kst, int64_t ldk, int6
 }
 
 // fp32 pipeline per candidate slab; the slab buffer (ctx->kst, sized in doubles) is shared with the fp64 path.
-int launch_posterior_f32(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
+int launch_posterior_f32(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, int* part_chunks) {
+  *part_chunks = nchunks;
   double budget_gb = 40.0;
   if (const char* e = getenv("GPBO_KSTAR_GB")) budget_gb = atof(e) > 0.0 ? atof(e) : budget_gb;
   size_t free_b = 0, total_b = 0;
@@ -256,12 +267,18 @@ int launch_posterior_f32(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
     else rc = launch_gen32_k<GPBO_KERNEL_RBF>(ctx, m, kst, ldk, Mp, m0, nchunks);
     if (rc) return rc;
     PostArgsF32 a;
-    a.Wp = m.Wp32; a.Kst = kst; a.part = ctx->part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nchunks;
+    a.Wp = m.Wp32; a.Kst = kst; a.part = ctx->part; a.NP = (int)m.NP; a.Mp = Mp;
     a.n_ctiles = (int)(ldk / F32_CANDS); a.ldk = ldk; a.m0 = m0;
-    const int64_t nblocks = (int64_t)a.n_ctiles * nchunks;
+    // wave tile: 64 rows (chunks of 512 rows) by default; GPBO_F32_RT=2 selects 32 rows (chunks of 256)
+    const char* e = getenv("GPBO_F32_RT");
+    const bool rt2 = (e && e[0] == '2') || m.NP < 512;
+    a.nchunks = rt2 ? nchunks : (int)((m.NP + 511) / 512);
+    const int64_t nblocks = (int64_t)a.n_ctiles * a.nchunks;
     if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
-    posterior_kernel_f32<<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
+    if (rt2) posterior_kernel_f32<2><<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
+    else posterior_kernel_f32<4><<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
     GPBO_HIP(ctx, hipGetLastError());
+    *part_chunks = a.nchunks;
   }
   return GPBO_OK;
 }
