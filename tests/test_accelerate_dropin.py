@@ -172,3 +172,28 @@ def test_hipgpr_device_lml_override_semantics():
     assert sum(c[0] == "lml" for c in eng.calls) == n_lml
     assert not HipGPR(kernel=Matern(nu=2.5), engine=eng, lml_on_device="auto", alpha=1e-6,
                       optimizer=None).fit(X, y)._device_lml_ok(Matern(nu=2.5))   # auto: N < 512 stays on the host
+
+
+def test_meta_acquisitions_run_through_the_seams():
+    """GPHedge and ConstantLiar (bayes_opt/acquisition.py:952-1360) stay reference code; after accelerate() they
+    reach the engine through the same seams (HipGPR.fit/predict), as SURVEY.md §2 scopes them."""
+    import_reference()
+    from bayes_opt import BayesianOptimization, acquisition
+
+    from bayesianoptimization_amd import accelerate
+    from bayesianoptimization_amd.gpr import HipGPR
+
+    for make in (lambda: acquisition.GPHedge([acquisition.UpperConfidenceBound(kappa=2.0),
+                                               acquisition.ExpectedImprovement(xi=0.01)]),
+                 lambda: acquisition.ConstantLiar(acquisition.UpperConfidenceBound(kappa=2.0))):
+        opt = BayesianOptimization(f=black_box, pbounds=PB, random_state=4, verbose=0, acquisition_function=make())
+        eng = FakeEngine()
+        accelerate(opt, engine=eng)
+        assert isinstance(opt._gp, HipGPR)
+        assert type(opt._acquisition_function).__module__.startswith("bayes_opt")   # meta policy untouched
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            opt.maximize(init_points=2, n_iter=2)
+        assert len(opt.space) == 4
+        kinds = {c[0] for c in eng.calls}
+        assert "fit" in kinds and ("posterior" in kinds or "set_candidates" in kinds)
