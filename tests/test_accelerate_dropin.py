@@ -197,3 +197,35 @@ def test_meta_acquisitions_run_through_the_seams():
         assert len(opt.space) == 4
         kinds = {c[0] for c in eng.calls}
         assert "fit" in kinds and ("posterior" in kinds or "set_candidates" in kinds)
+
+
+def test_integer_parameters_use_the_host_transform():
+    """Non-float parameters (bayes_opt/parameter.py:236-320): the engine sees kernel-transformed coordinates
+    (rounded integers) through HipGPR.transform, and the random stage still matches the reference exactly."""
+    import_reference()
+    from bayes_opt import BayesianOptimization
+
+    from bayesianoptimization_amd import accelerate
+
+    def f(x, k):
+        return -(x - 3) ** 2 - (k - 4) ** 2
+
+    pb = {"x": (2.0, 4.0), "k": (0, 10, int)}
+    ref = BayesianOptimization(f=f, pbounds=pb, random_state=9, verbose=0)
+    mine = BayesianOptimization(f=f, pbounds=pb, random_state=9, verbose=0)
+    eng = FakeEngine()
+    accelerate(mine, engine=eng)
+    assert mine._gp.transform is not None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for o in (ref, mine):
+            o.maximize(init_points=4, n_iter=0)
+        xr = ref._acquisition_function.suggest(ref._gp, ref._space, n_random=800, n_smart=0, random_state=ref._random_state)
+        xm = mine._acquisition_function.suggest(mine._gp, mine._space, n_random=800, n_smart=0, random_state=mine._random_state)
+    assert np.array_equal(xr, xm)
+    fit_X = [c for c in eng.calls if c[0] == "fit"]
+    assert fit_X and fit_X[-1][2] == (4, 2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mine.maximize(init_points=0, n_iter=2)      # mixed space: differential evolution smart stage on the host
+    assert len(mine.space) == 6
