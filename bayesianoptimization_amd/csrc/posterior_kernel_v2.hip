@@ -15,6 +15,7 @@
 // Same math, same reduction order per row chunk as v1 up to the candidate-tile width; results are
 // deterministic.  Replaces the same reference lines as posterior_kernel.hip (_gpr.py:443-494).
 #include <cstdlib>
+#include <type_traits>
 
 #include "gpbo_internal.h"
 
@@ -71,13 +72,18 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
     }
   }
 
-  // MFMA role
-  const int slab = r * (POST_ROWS / 32) + wave;
-  const int slab_row0 = slab * 32;
-  const bool active = slab_row0 < NP;
+  // MFMA role.  A chunk holds 16 tiles of 16 rows; wave w owns tiles w and 15 - w (not two adjacent ones):
+  // in the chunk's diagonal block a tile t only needs the stages up to its own rows, so the pairing gives
+  // every wave the same (t+1) + (16-t) = 17 tile-stages of work instead of 3 ... 31.
+  const int tileA = r * (POST_ROWS / 16) + wave;            // global 16-row tile index (the earlier one)
+  const int tileB = r * (POST_ROWS / 16) + 15 - wave;       // the later one
+  const int rowA0 = tileA * 16, rowB0 = tileB * 16;
+  const bool activeA = rowA0 < NP, activeB = rowB0 < NP;    // false only in a ragged last chunk
   const int64_t pairs = NP / 8;
-  const int slab_ld = active ? slab : (NP / 32 - 1);
-  const double2* wp = reinterpret_cast<const double2*>(p.Wp) + (int64_t)slab_ld * pairs * 128 + lane;
+  // packed W: [slab of 32 rows][k-pair][tile of 16 rows][lane] double2 ; inactive tiles stream tile 0 (dropped later)
+  const int tA = activeA ? tileA : 0, tB = activeB ? tileB : 0;
+  const double2* wpA = reinterpret_cast<const double2*>(p.Wp) + ((int64_t)(tA >> 1) * pairs * 2 + (tA & 1)) * 64 + lane;
+  const double2* wpB = reinterpret_cast<const double2*>(p.Wp) + ((int64_t)(tB >> 1) * pairs * 2 + (tB & 1)) * 64 + lane;
 
   d4 acc[2][4];
 #pragma unroll
@@ -134,10 +140,12 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
 
   // A fragments for one k-pair (8 columns): [tile] double2 = 8 VGPRs
   auto loadA = [&](int kpair, double2(&a)[2]) {
-    a[0] = wp[((int64_t)kpair * 2 + 0) * 64];
-    a[1] = wp[((int64_t)kpair * 2 + 1) * 64];
+    a[0] = wpA[(int64_t)kpair * 128];
+    a[1] = wpB[(int64_t)kpair * 128];
   };
-  auto mma_pair = [&](int buf, int pp, const double2(&a)[2]) {
+  // MODE 2: both tiles, 1: only the later tile (B), compile-time so that the hot loop stays one basic block
+  auto mma_pair = [&](int buf, int pp, const double2(&a)[2], auto mode) {
+    constexpr int MODE = decltype(mode)::value;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int q = pp * 2 + e;
@@ -147,11 +155,13 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
         const double b = kb[jt * 16];
-        acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][jt], 0, 0, 0);
+        if constexpr (MODE == 2) acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][jt], 0, 0, 0);
         acc[1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][jt], 0, 0, 0);
       }
     }
   };
+  using both_t = std::integral_constant<int, 2>;
+  using later_t = std::integral_constant<int, 1>;
 
   __syncthreads();   // Xl visible
   {
@@ -171,29 +181,34 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
     double kv[2];
     loadA(2 * s + 1, aB);
     gen_compute(s + 1, kv);
-    mma_pair(buf, 0, aA);
+    mma_pair(buf, 0, aA, both_t{});
     loadA(2 * s + 2, aA);
-    mma_pair(buf, 1, aB);
+    mma_pair(buf, 1, aB, both_t{});
     gen_store(kv, buf ^ 1);
     __syncthreads();
   }
-  // Loop 2: the diagonal block of the chunk.
+  // Loop 2: the diagonal block of the chunk.  Tile A (rows rowA0..+15) multiplies while the stage is not to the
+  // right of its rows, tile B likewise; B is the later tile, so the cases are both / B only / none.
   for (; s < n_stages; ++s) {
     const int buf = s & 1;
     const bool has_next = (s + 1 < n_stages);
-    const bool domma = (s * POST_BK <= slab_row0 + 31);
-    const bool domma_next = has_next && ((s + 1) * POST_BK <= slab_row0 + 31);
-    if (domma) loadA(2 * s + 1, aB);
+    const bool doA = (s * POST_BK <= rowA0 + 15);
+    const bool doB = (s * POST_BK <= rowB0 + 15);
+    const bool doB_next = has_next && ((s + 1) * POST_BK <= rowB0 + 15);
+    if (doB) loadA(2 * s + 1, aB);
     if (has_next) {
       double kv[2];
       gen_compute(s + 1, kv);
       gen_store(kv, buf ^ 1);
     }
-    if (domma) {
-      mma_pair(buf, 0, aA);
-      mma_pair(buf, 1, aB);
+    if (doA) {
+      mma_pair(buf, 0, aA, both_t{});
+      mma_pair(buf, 1, aB, both_t{});
+    } else if (doB) {
+      mma_pair(buf, 0, aA, later_t{});
+      mma_pair(buf, 1, aB, later_t{});
     }
-    if (domma_next) loadA(2 * s + 2, aA);
+    if (doB_next) loadA(2 * s + 2, aA);
     __syncthreads();
   }
 
@@ -204,12 +219,15 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   for (int jt = 0; jt < 4; ++jt) {
     double v = 0.0;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int rr = 0; rr < 4; ++rr) v = fma(acc[0][jt][rr], acc[0][jt][rr], v);
+    if (!activeA) v = 0.0;
+    double vb = 0.0;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) v = fma(acc[t][jt][rr], acc[t][jt][rr], v);
+    for (int rr = 0; rr < 4; ++rr) vb = fma(acc[1][jt][rr], acc[1][jt][rr], vb);
+    if (activeB) v += vb;
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
-    if (lane < 16) red[wave * V2_CANDS + jt * 16 + lane] = active ? v : 0.0;
+    if (lane < 16) red[wave * V2_CANDS + jt * 16 + lane] = v;
   }
   mured[wave * V2_CANDS + lane] = mu_acc;
   __syncthreads();
