@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   double mu_acc = 0.0;
 
   // generation role: candidate = lane, train points 2*wave, 2*wave+1 of the stage
-  auto gen_compute = [&](int stage, double (&kv)[2]) {
+  auto gen_compute = [&](int stage, double (&kv)[2], double mu_weight) {
     const int j0 = stage * POST_BK + wave * 2;
     if constexpr (GEN == 0) {
       kv[0] = 1e-3 * lane;
@@ -130,8 +130,9 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
     }
     kv[0] = gpbo_kernel_value<KERNEL>(d2a);
     kv[1] = gpbo_kernel_value<KERNEL>(d2b);
-    mu_acc = fma(kv[0], p.alpha[j0], mu_acc);
-    mu_acc = fma(kv[1], p.alpha[j0 + 1], mu_acc);
+    // mu_weight = 0 for the clamped (repeated) look-ahead of the last stage: it must not be counted twice
+    mu_acc = fma(kv[0] * mu_weight, p.alpha[j0], mu_acc);
+    mu_acc = fma(kv[1] * mu_weight, p.alpha[j0 + 1], mu_acc);
   };
   auto gen_store = [&](const double (&kv)[2], int buf) {
     Ks[(buf * POST_BK + wave * 2) * V2_STRIDE + lane] = kv[0];
@@ -166,51 +167,37 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   __syncthreads();   // Xl visible
   {
     double kv0[2];
-    gen_compute(0, kv0);
+    gen_compute(0, kv0, 1.0);
     gen_store(kv0, 0);
   }
   double2 aA[2], aB[2];
   loadA(0, aA);
   __syncthreads();
 
-  // Loop 1: stages left of the chunk's diagonal block (every wave multiplies; stage s+1 exists).
-  const int n_full = r * (POST_ROWS / POST_BK);
-  int s = 0;
-  for (; s < n_full; ++s) {
-    const int buf = s & 1;
+  // One stage = 16 train points.  MODE 2: both tiles multiply, 1: only the later tile, 0: none (the wave only
+  // feeds the stage tile).  The body is branch-free (the look-ahead indices are clamped instead of tested) so that
+  // loads, MFMAs and the LDS store of a stage stay in one basic block.
+  const int last_stage = n_stages - 1;
+  const int last_pair = (int)pairs - 1;
+  auto stage = [&](int st, auto mode) {
+    constexpr int MODE = decltype(mode)::value;
+    const int buf = st & 1;
     double kv[2];
-    loadA(2 * s + 1, aB);
-    gen_compute(s + 1, kv);
-    mma_pair(buf, 0, aA, both_t{});
-    loadA(2 * s + 2, aA);
-    mma_pair(buf, 1, aB, both_t{});
-    gen_store(kv, buf ^ 1);
+    if constexpr (MODE > 0) loadA(min(2 * st + 1, last_pair), aB);
+    gen_compute(min(st + 1, last_stage), kv, st < last_stage ? 1.0 : 0.0);
+    if constexpr (MODE > 0) mma_pair(buf, 0, aA, mode);
+    if constexpr (MODE > 0) loadA(min(2 * st + 2, last_pair), aA);
+    if constexpr (MODE > 0) mma_pair(buf, 1, aB, mode);
+    gen_store(kv, buf ^ 1);   // after the last LDS read of this stage (for st == last_stage nobody reads it)
     __syncthreads();
-  }
-  // Loop 2: the diagonal block of the chunk.  Tile A (rows rowA0..+15) multiplies while the stage is not to the
-  // right of its rows, tile B likewise; B is the later tile, so the cases are both / B only / none.
-  for (; s < n_stages; ++s) {
-    const int buf = s & 1;
-    const bool has_next = (s + 1 < n_stages);
-    const bool doA = (s * POST_BK <= rowA0 + 15);
-    const bool doB = (s * POST_BK <= rowB0 + 15);
-    const bool doB_next = has_next && ((s + 1) * POST_BK <= rowB0 + 15);
-    if (doB) loadA(2 * s + 1, aB);
-    if (has_next) {
-      double kv[2];
-      gen_compute(s + 1, kv);
-      gen_store(kv, buf ^ 1);
-    }
-    if (doA) {
-      mma_pair(buf, 0, aA, both_t{});
-      mma_pair(buf, 1, aB, both_t{});
-    } else if (doB) {
-      mma_pair(buf, 0, aA, later_t{});
-      mma_pair(buf, 1, aB, later_t{});
-    }
-    if (doB_next) loadA(2 * s + 2, aA);
-    __syncthreads();
-  }
+  };
+  // stages 0 .. sA: both tiles; sA+1 .. sB: the later tile only; beyond: none (W is lower triangular)
+  const int sA = min(last_stage, (rowA0 + 15) / POST_BK);
+  const int sB = min(last_stage, (rowB0 + 15) / POST_BK);
+  int s = 0;
+  for (; s <= sA; ++s) stage(s, both_t{});
+  for (; s <= sB; ++s) stage(s, later_t{});
+  for (; s <= last_stage; ++s) stage(s, std::integral_constant<int, 0>{});
 
   // epilogue: per-candidate sum of squares over this chunk's rows, fixed order
   double* red = Ks;                       // [8][64]
