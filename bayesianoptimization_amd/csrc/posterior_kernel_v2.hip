@@ -185,6 +185,9 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
     double kv[2];
     if constexpr (MODE > 0) loadA(min(2 * st + 1, last_pair), aB);
     gen_compute(min(st + 1, last_stage), kv, st < last_stage ? 1.0 : 0.0);
+    // slab mode: these are plain global loads — keep them at the top of the stage (a full stage of MFMAs hides
+    // their latency); without the fence hipcc sinks them next to their first use
+    if constexpr (GEN == 2) __builtin_amdgcn_sched_barrier(0);
     if constexpr (MODE > 0) mma_pair(buf, 0, aA, mode);
     if constexpr (MODE > 0) loadA(min(2 * st + 2, last_pair), aA);
     if constexpr (MODE > 0) mma_pair(buf, 1, aB, mode);
