@@ -27,6 +27,7 @@ from sklearn.base import clone
 from sklearn.gaussian_process import GaussianProcessRegressor
 from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern, Product
 from sklearn.utils import check_random_state
+from sklearn.utils.validation import validate_data
 
 from .engine import MATERN25, GpEngine
 from .engine import RBF as K_RBF
@@ -185,18 +186,16 @@ class HipGPR(GaussianProcessRegressor):
         describe_kernel(self.kernel_)  # fail before any work on unsupported kernels
         self._rng = check_random_state(self.random_state)
 
+        # sklearn's own input validation (_gpr.py:254-262): same ValueErrors for NaN/inf, wrong rank, length
+        # mismatch; sets n_features_in_
+        X, y = validate_data(self, X, y, multi_output=True, y_numeric=True, ensure_2d=True, dtype="numeric")
         X = np.asarray(X, dtype=np.float64)
         y = np.asarray(y, dtype=np.float64)
-        if X.ndim != 2:
-            raise ValueError(f"Expected 2D array, got {X.ndim}D array instead")
         self._y_2d = y.ndim == 2
         if self._y_2d:
             if y.shape[1] != 1:
                 raise NotImplementedError("HIP path supports a single target")
             y = y[:, 0]
-        if y.shape[0] != X.shape[0]:
-            raise ValueError(f"Found input variables with inconsistent numbers of samples: [{X.shape[0]}, {y.shape[0]}]")
-        self.n_features_in_ = X.shape[1]
 
         if self.normalize_y:  # _gpr.py:272-277 + preprocessing/_data.py:107-110
             self._y_train_mean = np.mean(y, axis=0)
@@ -253,11 +252,7 @@ class HipGPR(GaussianProcessRegressor):
             # prior (unfitted) predictions and full covariances are not on the hot path: sklearn's own
             # code handles them (for return_cov it reads the lazily fetched L_ / alpha_).
             return super().predict(X, return_std=return_std, return_cov=return_cov)
-        X = np.asarray(X, dtype=np.float64)
-        if X.ndim != 2:
-            raise ValueError(f"Expected 2D array, got {X.ndim}D array instead")
-        if X.shape[1] != self.n_features_in_:
-            raise ValueError(f"X has {X.shape[1]} features, but HipGPR is expecting {self.n_features_in_} features as input.")
+        X = np.asarray(validate_data(self, X, ensure_2d=True, dtype="numeric", reset=False), dtype=np.float64)  # _gpr.py:412
         mean, std = self._engine().predict(self._tx(X), slot=self.slot, y_mean=float(self._y_train_mean),
                                            y_std=float(self._y_train_std))
         if return_std:
