@@ -232,7 +232,7 @@ def main():
         }
         # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this very command
         # (scripts/profile_pmc.sh; FETCH_SIZE and WRITE_SIZE cannot share a pass), summarised in profiles/.
-        ppath = os.path.join(ROOT, "profiles", f"r01_pmc_{w.name}_v3.json")
+        ppath = os.path.join(ROOT, "profiles", f"r01_pmc_{w.name}_final.json")
         if os.path.exists(ppath):
             try:
                 pm = json.load(open(ppath))
