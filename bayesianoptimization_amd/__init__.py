@@ -18,15 +18,15 @@ def __getattr__(name):  # lazy: `import bayesianoptimization_amd.workloads` must
         from .gpr import HipGPR
         return HipGPR
     if name == "HipConstraintModel":
-        from .constraint import HipConstraintModel
+        from .constraint_model import HipConstraintModel
         return HipConstraintModel
     if name == "FloatSpace":
-        from .space import FloatSpace
+        from .float_space import FloatSpace
         return FloatSpace
     if name == "accelerate":
         from .dropin import accelerate
         return accelerate
     if name in ("UpperConfidenceBound", "ExpectedImprovement", "ProbabilityOfImprovement", "AcquisitionFunction"):
-        from . import acquisition
+        from . import fused_acquisition as acquisition
         return getattr(acquisition, name)
     raise AttributeError(name)

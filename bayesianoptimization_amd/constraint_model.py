@@ -2,7 +2,7 @@
 
 Mirrors bayes_opt/constraint.py:23-263 (`fit` :132-151, `predict` :153-221, `approx` :223-243,
 `allowed` :245-263).  Constraint j lives in engine slot j+1; `predict` on a host batch goes through
-HipGPR.predict, while the fused acquisition path (acquisition.py here) reads `_model`, `_lb`, `_ub`
+HipGPR.predict, while the fused acquisition path (fused_acquisition.py) reads `_model`, `_lb`, `_ub`
 and keeps every posterior on the device.
 """
 from __future__ import annotations

@@ -1,6 +1,6 @@
 // Small-batch posterior (M <= 72 candidates): the latency path behind HipGPR.predict when the reference's
 // "smart" stage (bayes_opt/acquisition.py:322-420: L-BFGS-B with finite differences) asks for one point — or,
-// with the batched finite-difference gradient of acquisition.py here, d + 1 points — at a time.  Same arithmetic as posterior_kernel_v2 (sklearn _gpr.py:443-494), organised as a memory-bound
+// with the batched finite-difference gradient of fused_acquisition.py, d + 1 points — at a time.  Same arithmetic as posterior_kernel_v2 (sklearn _gpr.py:443-494), organised as a memory-bound
 // batched GEMV over the row-major W = L^-1 (read once, ~N^2/2 * 8 B) instead of an MFMA GEMM:
 //   kstar_small_kernel : k*[c][k] for all train points (N x M values)
 //   gemv_small_kernel  : v[c][i] = sum_k W[i][k] k*[c][k], one wave per 4 rows, fixed shuffle tree

@@ -8,7 +8,7 @@ Everything else in the optimizer (space, queue, logging, state I/O) is untouched
 """
 from __future__ import annotations
 
-from . import acquisition as A
+from . import fused_acquisition as A
 from .gpr import HipGPR, describe_kernel, shared_engine
 
 

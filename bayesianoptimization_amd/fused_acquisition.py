@@ -1,0 +1,414 @@
+"""Acquisition policies whose random-search stage runs fused on the GPU (seam B1).
+
+Drop-in for `BayesianOptimization(acquisition_function=...)`.  The reference driver touches an acquisition object
+only through `suggest(gp=, target_space=, fit_gp=True, random_state=)` (bayes_opt/bayesian_optimization.py:329-331),
+`_fit_gp(gp, space)` (:236) and `get/set_acquisition_params` (:430, :471); subclasses and notebooks additionally
+rely on the override points `base_acq`, `_get_acq`, `_acq_min`, `_random_sample_minimize`, `_smart_minimize`
+(bayes_opt/acquisition.py:75-420).  This module keeps those names, argument meanings, error types/messages, the
+`i` counter, kappa/xi decay and — crucially — the order in which the shared RandomState is consumed, but is written
+independently of the reference and does not import it, so it also runs where bayes_opt is not installed.
+
+Device path: when the target GP (and every constraint GP) is a `HipGPR` on one engine, everything after candidate
+sampling in the random stage — posterior mean/std of M candidates, -acq(x) [* p_constraint], argmin, min,
+argsort[:k] (acquisition.py:311-317) — is one sequence of HIP kernels; only the arg-best record and the k seeds
+return to the host.  Any other `gp` object (duck-typed mocks, plain sklearn estimators) goes through the `_get_acq`
+closure on the host, as in the reference.  The local-search stage stays a host L-BFGS-B / differential evolution,
+with its finite-difference gradient evaluated as one device batch per iteration (`_fd_value_and_grad`).
+"""
+from __future__ import annotations
+
+import abc
+import warnings
+
+import numpy as np
+from scipy.optimize import minimize
+from scipy.special import ndtr
+
+from . import engine as E
+from .float_space import ensure_rng
+from .gpr import HipGPR
+
+try:  # raise the reference's own exception classes when it is installed, so `except` clauses keep working
+    from bayes_opt.exception import (ConstraintNotSupportedError, NoValidPointRegisteredError,
+                                     TargetSpaceEmptyError)
+except Exception:  # pragma: no cover - exercised on boxes without bayes_opt
+    class BayesianOptimizationError(Exception):
+        """Base class (bayes_opt/exception.py:14)."""
+
+    class ConstraintNotSupportedError(BayesianOptimizationError):
+        """bayes_opt/exception.py:22."""
+
+    class NoValidPointRegisteredError(BayesianOptimizationError):
+        """bayes_opt/exception.py:26."""
+
+    class TargetSpaceEmptyError(BayesianOptimizationError):
+        """bayes_opt/exception.py:30."""
+
+_SQRT_2PI = np.sqrt(2.0 * np.pi)
+_FD_EPS = 1e-8                       # scipy.optimize._lbfgsb_py._minimize_lbfgsb: eps=1e-8 -> abs_step
+_SQRT_EPS = np.finfo(np.float64).eps ** 0.5
+_MAX_DEVICE_SEEDS = 64               # GPBO_MAX_SEEDS
+
+
+def _norm_pdf(x):
+    return np.exp(-(x**2) / 2.0) / _SQRT_2PI  # scipy/stats/_continuous_distns.py:360-362
+
+
+def _fd_value_and_grad(acq, bounds):
+    """value-and-gradient callable reproducing, in ONE batched acq() call per iteration, the forward
+    differences SciPy's L-BFGS-B forms one point at a time when `jac` is not given
+    (scipy/optimize/_numdiff.py: approx_derivative(method="2-point", abs_step=1e-8, bounds) ->
+    _adjust_scheme_to_bounds(..., "1-sided") -> _dense_difference): same steps, same divisions, so the
+    optimiser sees the same (f, g) and walks the same path as the reference's
+    `minimize(acq, x_try, bounds=..., method="L-BFGS-B")` (bayes_opt/acquisition.py:365-366)."""
+    lb, ub = bounds[:, 0].astype(float), bounds[:, 1].astype(float)
+    unbounded = bool(np.all((lb == -np.inf) & (ub == np.inf)))
+
+    def fun(x):
+        x0 = np.asarray(x, dtype=np.float64)
+        d = x0.shape[0]
+        sign_x0 = (x0 >= 0).astype(float) * 2 - 1
+        h = np.full(d, _FD_EPS)
+        h = np.where((x0 + h) - x0 == 0, _SQRT_EPS * sign_x0 * np.maximum(1.0, np.abs(x0)), h)
+        if not unbounded:
+            room_below, room_above = x0 - lb, ub - x0
+            trial = x0 + h
+            outside = (trial < lb) | (trial > ub)
+            fits = np.abs(h) <= np.maximum(room_below, room_above)
+            h = h.copy()
+            h[outside & fits] *= -1
+            go_up = (room_above >= room_below) & ~fits
+            h[go_up] = room_above[go_up]
+            go_down = (room_above < room_below) & ~fits
+            h[go_down] = -room_below[go_down]
+        pts = np.empty((d + 1, d))
+        pts[0] = x0
+        pts[1:] = x0 + np.diag(h)
+        vals = np.asarray(acq(pts), dtype=np.float64)
+        steps = pts[1:][np.arange(d), np.arange(d)] - x0
+        return vals[0], (vals[1:] - vals[0]) / steps
+
+    return fun
+
+
+def _fused_models(gp, constraint):
+    """[target, constraint GPs...] if all are HipGPRs on one engine in slots 0..n, else None."""
+    if not isinstance(gp, HipGPR) or gp.slot != 0:
+        return None
+    chain = [gp]
+    members = [] if constraint is None else getattr(constraint, "_model", None)
+    if members is None or len(members) + 1 > 8:
+        return None
+    for slot, model in enumerate(members, start=1):
+        if not isinstance(model, HipGPR) or model.slot != slot or model._engine() is not gp._engine():
+            return None
+        chain.append(model)
+    return chain
+
+
+class AcquisitionFunction(abc.ABC):
+    """Interface of bayes_opt.acquisition.AcquisitionFunction (bayes_opt/acquisition.py:56-420)."""
+
+    #: default number of random candidates; the reference hard-codes 10_000 (acquisition.py:120)
+    default_n_random = 10_000
+    #: with engine-backed GPs, form L-BFGS-B's finite-difference gradient in one batched device call per
+    #: iteration (d + 1 points) instead of d + 1 single-point calls; same numbers, ~d times fewer launches
+    batched_fd = True
+    #: THROUGHPUT MODE (off by default): draw the random-stage candidates on the device with a Philox generator
+    #: instead of space.random_sample(); removes the host sampling and the upload but is NOT the reference's
+    #: RandomState stream (two 31-bit integers are drawn from it as the device seed), so suggestions differ
+    device_sampling = False
+    _acq_kind: int | None = None     # engine acquisition id of the stock policies; None = host formula only
+
+    def __init__(self, random_state=None) -> None:
+        if random_state is not None:
+            warnings.warn(
+                "Providing a random_state to an acquisition function during initialization is deprecated "
+                "and will be ignored. The random_state is instead provided automatically during the "
+                "suggest() call.", DeprecationWarning, stacklevel=2)
+        self.i = 0
+        self._fused = None
+
+    # ---- interface ----------------------------------------------------------------------------------
+    @abc.abstractmethod
+    def base_acq(self, *args, **kwargs):
+        """Acquisition value from the posterior mean and standard deviation."""
+
+    def _acq_param(self) -> float:
+        raise NotImplementedError
+
+    def get_acquisition_params(self):
+        raise NotImplementedError(
+            "Custom AcquisitionFunction subclasses must implement their own get_acquisition_params method.")
+
+    def set_acquisition_params(self, params):
+        raise NotImplementedError(
+            "Custom AcquisitionFunction subclasses must implement their own set_acquisition_params method.")
+
+    def _fit_gp(self, gp, target_space) -> None:
+        """Fit the target GP, then the constraint GPs, warnings silenced (acquisition.py:79-86)."""
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            gp.fit(target_space.params, target_space.target)
+            cons = target_space.constraint
+            if cons is not None:
+                cons.fit(target_space.params, target_space._constraint_values)
+
+    # ---- suggest ------------------------------------------------------------------------------------
+    def suggest(self, gp, target_space, n_random: int | None = None, n_smart: int = 10, fit_gp: bool = True,
+                random_state=None):
+        """Next point to probe (acquisition.py:116-169); `n_random=None` -> `default_n_random` (10_000 there)."""
+        rng = ensure_rng(random_state)
+        if len(target_space) == 0:
+            raise TargetSpaceEmptyError(
+                "Cannot suggest a point without previous samples. Use "
+                " target_space.random_sample() to generate a point and "
+                " target_space.probe(*) to evaluate it.")
+        self.i += 1
+        if fit_gp:
+            self._fit_gp(gp=gp, target_space=target_space)
+        objective = self._get_acq(gp=gp, constraint=target_space.constraint)
+        self._fused = None if self._acq_kind is None else _fused_models(gp, target_space.constraint)
+        try:
+            return self._acq_min(objective, target_space, n_smart=n_smart, random_state=rng,
+                                 n_random=self.default_n_random if n_random is None else n_random)
+        finally:
+            self._fused = None
+
+    def _get_acq(self, gp, constraint=None):
+        """Host objective x -> -acq(x) [* p_constraint(x)] for (M,d) or (d,) input (acquisition.py:171-219)."""
+        ndim = gp.X_train_.shape[1]
+
+        def objective(x):
+            batch = x.reshape(-1, ndim)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                mean, std = gp.predict(batch, return_std=True)
+                if constraint is None:
+                    return -1 * self.base_acq(mean, std)
+                feasible = constraint.predict(batch)
+            return -1 * self.base_acq(mean, std) * feasible
+
+        return objective
+
+    def _acq_min(self, acq, space, random_state, n_random: int = 10_000, n_smart: int = 10):
+        """Random stage, then local searches from its best points; the better of the two (acquisition.py:221-272)."""
+        if n_random == 0 and n_smart == 0:
+            raise ValueError("Either n_random or n_smart needs to be greater than 0.")
+        x_rand, f_rand, seeds = self._random_sample_minimize(acq, space, random_state,
+                                                             n_random=max(n_random, n_smart), n_x_seeds=n_smart)
+        if not n_smart:
+            return x_rand
+        x_loc, f_loc = self._smart_minimize(acq, space, x_seeds=seeds, random_state=random_state)
+        return x_loc if f_rand > f_loc else x_rand
+
+    def _random_sample_minimize(self, acq, space, random_state, n_random: int, n_x_seeds: int = 0):
+        """(x_min, min_acq, x_seeds) over `n_random` uniform candidates (acquisition.py:274-320)."""
+        if n_random == 0:
+            return None, np.inf, space.random_sample(n_x_seeds, random_state=random_state)
+        chain = getattr(self, "_fused", None) if n_x_seeds <= _MAX_DEVICE_SEEDS else None
+        if chain is not None and self.device_sampling and chain[0].transform is None:
+            seed = int(random_state.randint(0, 2**31 - 1)) | (int(random_state.randint(0, 2**31 - 1)) << 31)
+            return self._device_minimize(chain, space, None, n_x_seeds, n_random=n_random, seed=seed)
+        x_tries = space.random_sample(n_random, random_state=random_state)
+        if chain is not None:
+            return self._device_minimize(chain, space, x_tries, n_x_seeds)
+        values = acq(x_tries)
+        seeds = x_tries[np.argsort(values)[:n_x_seeds]] if n_x_seeds != 0 else []
+        return x_tries[values.argmin()], values.min(), seeds
+
+    def _device_minimize(self, models, space, x_tries, n_x_seeds, n_random=None, seed=None):
+        """The body of the random stage after sampling, on the GPU (kernels K5-K8 of SURVEY.md §2.1).
+        x_tries=None: the candidates are generated on the device too (device_sampling)."""
+        target = models[0]
+        eng = target._engine()
+        if x_tries is None:
+            eng.generate_candidates(n_random, space.bounds[:, 0], space.bounds[:, 1], seed)
+        else:
+            eng.set_candidates(target._tx(x_tries))
+        for model in models:
+            model.posterior_resident()
+        lb, ub = (space.constraint._lb, space.constraint._ub) if len(models) > 1 else (None, None)
+        y_max = getattr(self, "y_max", None)
+        best, best_val, picks, _vals, _ = eng.acq_argbest(self._acq_kind, self._acq_param(),
+                                                           0.0 if y_max is None else y_max, lb, ub,
+                                                           k_seeds=n_x_seeds)
+        picks = picks[picks >= 0]
+        if x_tries is None:
+            rows = eng.get_candidate_rows(np.concatenate([[best], picks]), space.bounds.shape[0])
+            return rows[0], best_val, (rows[1:] if n_x_seeds else [])
+        return x_tries[best], best_val, (x_tries[picks] if n_x_seeds else [])
+
+    # ---- local search -------------------------------------------------------------------------------
+    def _smart_minimize(self, acq, space, x_seeds, random_state):
+        """Local refinement of the seeds (acquisition.py:322-420): L-BFGS-B per seed when every parameter is
+        continuous, otherwise differential evolution (+ an L-BFGS-B polish of the continuous coordinates);
+        returns (x clipped to the bounds, value), or (NaNs, inf) if nothing converged."""
+        is_cont = space.continuous_dimensions
+        box = space.bounds[is_cont]
+        if all(is_cont):
+            winner = self._polish_seeds(acq, x_seeds, box)
+        else:
+            winner = self._evolve_mixed(acq, space, x_seeds, random_state, is_cont, box)
+        if winner is None:
+            return np.clip(np.full(space.bounds.shape[0], np.nan), space.bounds[:, 0], space.bounds[:, 1]), np.inf
+        x_best, f_best = winner
+        return np.clip(x_best, space.bounds[:, 0], space.bounds[:, 1]), f_best
+
+    def _polish_seeds(self, acq, x_seeds, box):
+        batched = self.batched_fd and getattr(self, "_fused", None) is not None
+        value_and_grad = _fd_value_and_grad(acq, box) if batched else None
+        winner = None
+        for start in x_seeds:
+            if batched:
+                res = minimize(value_and_grad, start, jac=True, bounds=box, method="L-BFGS-B")
+            else:
+                res = minimize(acq, start, bounds=box, method="L-BFGS-B")
+            if res.success and (winner is None or np.squeeze(res.fun) < winner[1]):
+                winner = (res.x, np.squeeze(res.fun))
+        return winner
+
+    def _evolve_mixed(self, acq, space, x_seeds, random_state, is_cont, box):
+        import scipy
+        from packaging import version
+        from scipy.optimize._differentialevolution import DifferentialEvolutionSolver  # as acquisition.py:32
+
+        population = space.random_sample(15 * len(space.bounds), random_state=random_state)
+        n_keep = min(len(x_seeds), len(population))
+        if n_keep > 0:
+            population[:n_keep] = x_seeds[:n_keep]
+        rng_kw = "seed" if version.parse(scipy.__version__) < version.parse("1.15.0") else "rng"
+        solver = DifferentialEvolutionSolver(func=acq, bounds=space.bounds, polish=False, init=population,
+                                             **{rng_kw: random_state})
+        found = solver.solve()
+        if not found.success:
+            raise RuntimeError(f"Differential evolution optimization failed. Message: {found.message}")
+        x_best, f_best = found.x, np.squeeze(found.fun)
+        if any(is_cont):
+            frozen = x_best.copy()
+
+            def along_continuous(z, frozen=frozen):
+                frozen[is_cont] = z
+                return acq(frozen)
+
+            res = minimize(along_continuous, x_best[is_cont], bounds=box)
+            if res.success and np.squeeze(res.fun) < f_best:
+                frozen[is_cont] = res.x
+                x_best, f_best = frozen, np.squeeze(res.fun)
+        return x_best, f_best
+
+
+class _DecayingParameter:
+    """kappa / xi schedule shared by the stock policies (acquisition.py:541-554, 721-734, 910-923)."""
+
+    _param_name = ""
+
+    def _init_decay(self, exploration_decay, exploration_decay_delay):
+        if exploration_decay is not None and not (0 < exploration_decay <= 1):
+            raise ValueError("exploration_decay must be greater than 0 and less than or equal to 1.")
+        if exploration_decay_delay is not None and (
+                not isinstance(exploration_decay_delay, int) or exploration_decay_delay < 0):
+            raise ValueError("exploration_decay_delay must be an integer greater than or equal to 0.")
+        self.exploration_decay = exploration_decay
+        self.exploration_decay_delay = exploration_decay_delay
+
+    def decay_exploration(self) -> None:
+        """Called at the end of every suggest(): multiply the parameter by the decay once the delay has passed."""
+        if self.exploration_decay is None:
+            return
+        if self.exploration_decay_delay is None or self.exploration_decay_delay <= self.i:
+            setattr(self, self._param_name, getattr(self, self._param_name) * self.exploration_decay)
+
+    def get_acquisition_params(self):
+        return {self._param_name: getattr(self, self._param_name), "exploration_decay": self.exploration_decay,
+                "exploration_decay_delay": self.exploration_decay_delay}
+
+    def set_acquisition_params(self, params):
+        setattr(self, self._param_name, params[self._param_name])
+        self.exploration_decay = params["exploration_decay"]
+        self.exploration_decay_delay = params["exploration_decay_delay"]
+
+    def _acq_param(self):
+        return float(getattr(self, self._param_name))
+
+
+class UpperConfidenceBound(_DecayingParameter, AcquisitionFunction):
+    """UCB(x) = mu(x) + kappa sigma(x)  (bayes_opt/acquisition.py:423-600)."""
+
+    _acq_kind = E.UCB
+    _param_name = "kappa"
+
+    def __init__(self, kappa: float = 2.576, exploration_decay=None, exploration_decay_delay=None,
+                 random_state=None) -> None:
+        if kappa < 0:
+            raise ValueError("kappa must be greater than or equal to 0.")
+        self._init_decay(exploration_decay, exploration_decay_delay)
+        AcquisitionFunction.__init__(self, random_state=random_state)
+        self.kappa = kappa
+
+    def base_acq(self, mean, std):
+        return mean + self.kappa * std
+
+    def suggest(self, gp, target_space, n_random=None, n_smart: int = 10, fit_gp: bool = True, random_state=None):
+        if target_space.constraint is not None:
+            raise ConstraintNotSupportedError(
+                f"Received constraints, but acquisition function {type(self)} "
+                "does not support constrained optimization.")
+        x = super().suggest(gp=gp, target_space=target_space, n_random=n_random, n_smart=n_smart, fit_gp=fit_gp,
+                            random_state=random_state)
+        self.decay_exploration()
+        return x
+
+
+class _ImprovementBased(_DecayingParameter, AcquisitionFunction):
+    """Shared by POI and EI: they need y_max = the best feasible, in-bounds observation."""
+
+    _param_name = "xi"
+
+    def __init__(self, xi: float, exploration_decay=None, exploration_decay_delay=None, random_state=None) -> None:
+        self._init_decay(exploration_decay, exploration_decay_delay)
+        AcquisitionFunction.__init__(self, random_state=random_state)
+        self.xi = xi
+        self.y_max = None
+
+    def _need_y_max(self):
+        if self.y_max is None:
+            raise ValueError("y_max is not set. If you are calling this method outside "
+                             "of suggest(), ensure y_max is set, or set it manually.")
+
+    def suggest(self, gp, target_space, n_random=None, n_smart: int = 10, fit_gp: bool = True, random_state=None):
+        incumbent = target_space._target_max()
+        if incumbent is None and not target_space.empty:
+            raise NoValidPointRegisteredError(
+                "Cannot suggest a point without an allowed point. Use "
+                "target_space.random_sample() to generate a point until "
+                " at least one point that satisfies the constraints is found.")
+        self.y_max = incumbent
+        x = super().suggest(gp=gp, target_space=target_space, n_random=n_random, n_smart=n_smart, fit_gp=fit_gp,
+                            random_state=random_state)
+        self.decay_exploration()
+        return x
+
+
+class ProbabilityOfImprovement(_ImprovementBased):
+    """POI(x) = Phi((mu - y_max - xi)/sigma)  (bayes_opt/acquisition.py:603-776)."""
+
+    _acq_kind = E.POI
+
+    def base_acq(self, mean, std):
+        self._need_y_max()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return ndtr((mean - self.y_max - self.xi) / std)
+
+
+class ExpectedImprovement(_ImprovementBased):
+    """EI(x) = a Phi(z) + sigma phi(z), a = mu - y_max - xi, z = a/sigma  (bayes_opt/acquisition.py:779-949)."""
+
+    _acq_kind = E.EI
+
+    def base_acq(self, mean, std):
+        self._need_y_max()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            a = mean - self.y_max - self.xi
+            z = a / std
+            return a * ndtr(z) + std * _norm_pdf(z)

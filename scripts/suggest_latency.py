@@ -14,11 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from sklearn.gaussian_process.kernels import Matern  # noqa: E402
 
-from bayesianoptimization_amd import acquisition as A  # noqa: E402
+from bayesianoptimization_amd import fused_acquisition as A  # noqa: E402
 from bayesianoptimization_amd import workloads as W  # noqa: E402
 from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
 from bayesianoptimization_amd.gpr import HipGPR  # noqa: E402
-from bayesianoptimization_amd.space import FloatSpace  # noqa: E402
+from bayesianoptimization_amd.float_space import FloatSpace  # noqa: E402
 
 warnings.simplefilter("ignore")
 eng = GpEngine(0)

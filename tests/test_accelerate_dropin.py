@@ -36,7 +36,7 @@ def _pair(seed=1, constraint=None, acq=None, acq2=None):
 
 
 def test_accelerate_swaps_gp_and_acquisition():
-    from bayesianoptimization_amd import acquisition as A
+    from bayesianoptimization_amd import fused_acquisition as A
     from bayesianoptimization_amd.gpr import HipGPR
 
     ref, mine, eng = _pair()
@@ -89,7 +89,7 @@ def test_constrained_ei_uses_all_slots():
     import_reference()
     from scipy.optimize import NonlinearConstraint
 
-    from bayesianoptimization_amd import acquisition as A
+    from bayesianoptimization_amd import fused_acquisition as A
     from bayesianoptimization_amd.gpr import HipGPR
 
     cons = NonlinearConstraint(lambda x, y: np.cos(x) * np.cos(y) - np.sin(x) * np.sin(y), -np.inf, 0.5)

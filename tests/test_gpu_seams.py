@@ -6,11 +6,11 @@ import pytest
 from sklearn.gaussian_process import GaussianProcessRegressor
 from sklearn.gaussian_process.kernels import RBF, Matern
 
-from bayesianoptimization_amd import acquisition as A
+from bayesianoptimization_amd import fused_acquisition as A
 from bayesianoptimization_amd import workloads as W
-from bayesianoptimization_amd.constraint import HipConstraintModel
+from bayesianoptimization_amd.constraint_model import HipConstraintModel
 from bayesianoptimization_amd.gpr import HipGPR
-from bayesianoptimization_amd.space import FloatSpace
+from bayesianoptimization_amd.float_space import FloatSpace
 from conftest import load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -121,7 +121,7 @@ def test_smart_stage_improves_and_stays_in_bounds(engine):
     fn.y_max = sp._target_max()
     fn._fit_gp(gp, sp)
     acq = fn._get_acq(gp)
-    from bayesianoptimization_amd.acquisition import _fused_models
+    from bayesianoptimization_amd.fused_acquisition import _fused_models
     fn._fused = _fused_models(gp, None)
     x_min, min_acq, seeds = fn._random_sample_minimize(acq, sp, np.random.RandomState(7), n_random=4096, n_x_seeds=10)
     assert any(np.array_equal(x_min, s) for s in seeds)

@@ -5,10 +5,10 @@ import warnings
 import numpy as np
 import pytest
 
-from bayesianoptimization_amd import acquisition as A
+from bayesianoptimization_amd import fused_acquisition as A
 from bayesianoptimization_amd import workloads as W
 from bayesianoptimization_amd.distributed import merge_best, shard_range
-from bayesianoptimization_amd.space import FloatSpace, ensure_rng
+from bayesianoptimization_amd.float_space import FloatSpace, ensure_rng
 from oracle.refenv import have_reference, import_reference
 
 needs_ref = pytest.mark.skipif(not have_reference(), reason="reference not mounted (GPU box)")
@@ -189,7 +189,7 @@ def test_batched_finite_differences_reproduce_scipy_lbfgsb():
     one-sided bound adjustment): same iterates bit for bit, ~d times fewer acquisition calls."""
     from scipy.optimize import minimize
 
-    from bayesianoptimization_amd.acquisition import _fd_value_and_grad
+    from bayesianoptimization_amd.fused_acquisition import _fd_value_and_grad
 
     rng = np.random.RandomState(0)
     A = rng.randn(6, 6)
