@@ -60,7 +60,7 @@ def _fingerprint() -> str:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    stamp = os.path.join(OBJDIR, "fingerprint")
+    stamp = LIB + ".fingerprint"   # next to the library, so the pair travels together
     fp = _fingerprint()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == fp:
         return LIB

@@ -200,6 +200,7 @@ int launch_acq_argbest(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, 
                        int64_t* best_idx, double* best_val, int64_t* seed_idx, double* seed_val);
 // posterior_small.hip
 int launch_posterior_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double y_std);
+int small_batch_limit(int64_t NP);   // largest M the GEMV path takes (posterior_small.hip)
 // lml_kernels.hip
 int launch_lml_terms(gpbo_ctx* ctx, Model& m, double* out2_dev);
 int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, double* partial, double* grad_dev);

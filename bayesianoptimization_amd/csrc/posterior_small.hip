@@ -1,4 +1,4 @@
-// Small-batch posterior (M <= 72 candidates): the latency path behind HipGPR.predict when the reference's
+// Small-batch posterior (M <= a few hundred candidates, see small_batch_limit): the latency path behind HipGPR.predict when the reference's
 // "smart" stage (bayes_opt/acquisition.py:322-420: L-BFGS-B with finite differences) asks for one point — or,
 // with the batched finite-difference gradient of fused_acquisition.py, d + 1 points — at a time.  Same arithmetic as posterior_kernel_v2 (sklearn _gpr.py:443-494), organised as a memory-bound
 // batched GEMV over the row-major W = L^-1 (read once, ~N^2/2 * 8 B) instead of an MFMA GEMM:
@@ -9,7 +9,26 @@
 
 namespace gpbo {
 
-constexpr int SMALL_MAX = 72;   // d + 1 finite-difference points for d <= 64, plus slack
+constexpr int SMALL_MAX = 1024;   // scratch bound: n_seeds * (d + 1) finite-difference points of a lockstep round
+
+// Largest batch the GEMV path takes before the MFMA path is the faster one.  The GEMV path re-reads W once per
+// pass of 16 candidates; the MFMA path's time is flat in M until its (row chunk x 64-candidate tile) grid fills
+// the chip, and is set by the longest row chunk on one CU.  Measured crossovers on MI355X
+// (profiles/r01_small_batch_latency.json, predict() latency incl. ~95 us of host/PCIe overhead):
+//   N = 512: ~60   N = 1024: ~550   N = 2048: ~300   N = 4096: ~130   N = 8192: ~70
+// (N <= 512 runs the single fused MFMA kernel, which is why its crossover is low.)  GPBO_SMALL_MAX overrides
+// the rule (A/B runs, and tests that pin one path).
+int small_batch_limit(int64_t NP) {
+  if (const char* e = getenv("GPBO_SMALL_MAX")) {
+    const long v = atol(e);
+    return (int)(v < 0 ? 0 : (v > SMALL_MAX ? SMALL_MAX : v));
+  }
+  if (NP <= 512) return 48;
+  if (NP <= 1024) return 512;
+  if (NP <= 2048) return 256;
+  if (NP <= 4096) return 128;
+  return 72;
+}
 
 template <int KERNEL>
 __global__ __launch_bounds__(256) void kstar_small_kernel(const double* __restrict__ Xs, const double* __restrict__ Xcs,
@@ -17,7 +36,8 @@ __global__ __launch_bounds__(256) void kstar_small_kernel(const double* __restri
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k >= NP) return;
   const double* xr = Xs + k * DP;
-  for (int c = 0; c < M; ++c) {
+  const int c_end = min(M, ((int)blockIdx.y + 1) * 16);
+  for (int c = (int)blockIdx.y * 16; c < c_end; ++c) {
     const double* xc = Xcs + (int64_t)c * DP;
     double d2 = 0.0;
     for (int t = 0; t < DP; ++t) {
@@ -35,6 +55,8 @@ __global__ __launch_bounds__(256) void gemv_small_kernel(const double* __restric
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * R;
   if (i0 >= NP) return;
+  ks += (int64_t)blockIdx.y * MS * NP;    // blockIdx.y = pass of MS candidates
+  vsq += (int64_t)blockIdx.y * MS * NP;
   double acc[R][MS];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -64,9 +86,9 @@ __global__ __launch_bounds__(256) void gemv_small_kernel(const double* __restric
 }
 
 template <int MS, int R>
-static void launch_gemv(gpbo_ctx* ctx, Model& m, const double* ks, double* vsq) {
+static void launch_gemv(gpbo_ctx* ctx, Model& m, const double* ks, double* vsq, int passes = 1) {
   const unsigned gb = (unsigned)((m.NP / R + 3) / 4);
-  gemv_small_kernel<MS, R><<<dim3(gb), dim3(256), 0, ctx->stream>>>(m.W, ks, m.N, m.NP, vsq);
+  gemv_small_kernel<MS, R><<<dim3(gb, (unsigned)passes), dim3(256), 0, ctx->stream>>>(m.W, ks, m.N, m.NP, vsq);
 }
 
 __global__ __launch_bounds__(256) void finalize_small_kernel(const double* __restrict__ vsq, const double* __restrict__ ks,
@@ -109,16 +131,18 @@ int launch_posterior_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double
   if ((rc = ensure(ctx, &ctx->part, &ctx->cap_part, (int64_t)2 * rows * m.NP))) return rc;
   double* ks = ctx->part;
   double* vsq = ctx->part + rows * m.NP;
-  const unsigned kb = (unsigned)((m.NP + 255) / 256);
+  const dim3 kgrid((unsigned)((m.NP + 255) / 256), (unsigned)((M + 15) / 16));
   if (m.kernel == GPBO_KERNEL_MATERN25)
-    kstar_small_kernel<GPBO_KERNEL_MATERN25><<<dim3(kb), dim3(256), 0, ctx->stream>>>(m.Xs, ctx->Xcs, m.DP, m.NP, M, ks);
+    kstar_small_kernel<GPBO_KERNEL_MATERN25><<<kgrid, dim3(256), 0, ctx->stream>>>(m.Xs, ctx->Xcs, m.DP, m.NP, M, ks);
   else
-    kstar_small_kernel<GPBO_KERNEL_RBF><<<dim3(kb), dim3(256), 0, ctx->stream>>>(m.Xs, ctx->Xcs, m.DP, m.NP, M, ks);
+    kstar_small_kernel<GPBO_KERNEL_RBF><<<kgrid, dim3(256), 0, ctx->stream>>>(m.Xs, ctx->Xcs, m.DP, m.NP, M, ks);
   GPBO_HIP(ctx, hipGetLastError());
   // passes of up to 16 candidates (the row order of the dot products does not depend on the pass width, so a
   // candidate's result is bitwise the same whether it is evaluated alone or inside a batch)
-  for (int c0 = 0; c0 < M; c0 += 16) {
-    const int mc = (M - c0 < 16) ? (M - c0) : 16;
+  const int full = M / 16;
+  if (full > 0) launch_gemv<16, 2>(ctx, m, ks, vsq, full);   // all full passes in one launch (grid.y)
+  if (M % 16) {
+    const int c0 = full * 16, mc = M - c0;
     const double* ksp = ks + (int64_t)c0 * m.NP;
     double* vp = vsq + (int64_t)c0 * m.NP;
     if (mc == 1) launch_gemv<1, 4>(ctx, m, ksp, vp);

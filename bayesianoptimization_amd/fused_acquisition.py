@@ -18,6 +18,7 @@ with its finite-difference gradient evaluated as one device batch per iteration 
 from __future__ import annotations
 
 import abc
+import threading
 import warnings
 
 import numpy as np
@@ -91,6 +92,101 @@ def _fd_value_and_grad(acq, bounds):
     return fun
 
 
+class _Lockstep:
+    """Merges the objective evaluations of several independent L-BFGS-B runs into shared device batches.
+
+    The reference polishes its seeds one after another (acquisition.py:364-374); the runs do not interact, so
+    they can advance together: every run lives in its own thread, a thread that needs function values parks
+    its points here, and once ALL live runs are parked the caller's thread evaluates the concatenation with a
+    single acq() call and hands each run its slice.  SciPy's optimiser code and the per-point arithmetic are
+    untouched, so every run visits the iterates it would visit alone; only the launch count drops (by the
+    number of seeds).  All device work stays on the thread that called `serve()`."""
+
+    class Abort(Exception):
+        pass
+
+    def __init__(self, acq, n_runs: int) -> None:
+        self._acq = acq
+        self._cv = threading.Condition()
+        self._parked: dict[int, np.ndarray] = {}
+        self._answers: dict[int, np.ndarray] = {}
+        self._live = n_runs
+        self._failure: BaseException | None = None
+        self.batches = 0
+
+    def ask(self, run: int, pts):
+        with self._cv:
+            self._parked[run] = np.array(pts, dtype=np.float64, copy=True)
+            self._cv.notify_all()
+            while run not in self._answers and self._failure is None:
+                self._cv.wait()
+            if self._failure is not None:
+                raise _Lockstep.Abort
+            return self._answers.pop(run)
+
+    def retire(self, run: int) -> None:
+        with self._cv:
+            self._live -= 1
+            self._cv.notify_all()
+
+    def serve(self) -> None:
+        with self._cv:
+            while True:
+                while self._live > 0 and len(self._parked) < self._live:
+                    self._cv.wait()
+                if self._live == 0:
+                    return
+                order = sorted(self._parked)
+                sizes = [len(self._parked[r]) for r in order]
+                try:
+                    values = np.asarray(self._acq(np.concatenate([self._parked[r] for r in order])),
+                                        dtype=np.float64)
+                except BaseException as exc:   # wake the runs so that their threads end, then re-raise here
+                    self._failure = exc
+                    self._parked.clear()
+                    self._cv.notify_all()
+                    raise
+                self.batches += 1
+                for r, chunk in zip(order, np.split(values, np.cumsum(sizes)[:-1])):
+                    self._answers[r] = chunk
+                self._parked.clear()
+                self._cv.notify_all()
+
+
+def _polish_in_lockstep(acq, x_seeds, box):
+    """[OptimizeResult per seed] of `minimize(fd(acq), seed, jac=True, bounds=box, method="L-BFGS-B")`, the
+    runs advanced together through `_Lockstep`."""
+    n = len(x_seeds)
+    hub = _Lockstep(acq, n)
+    results: list = [None] * n
+    errors: list = [None] * n
+
+    def run(idx, start):
+        try:
+            fun = _fd_value_and_grad(lambda pts: hub.ask(idx, pts), box)
+            results[idx] = minimize(fun, start, jac=True, bounds=box, method="L-BFGS-B")
+        except _Lockstep.Abort:
+            pass
+        except BaseException as exc:
+            errors[idx] = exc
+        finally:
+            hub.retire(idx)
+
+    threads = [threading.Thread(target=run, args=(i, np.array(x, dtype=np.float64)), daemon=True)
+               for i, x in enumerate(x_seeds)]
+    for t in threads:
+        t.start()
+    try:
+        hub.serve()
+    finally:
+        for t in threads:
+            t.join()
+    for exc in errors:
+        if exc is not None:
+            raise exc
+    return results
+
+
 def _fused_models(gp, constraint):
     """[target, constraint GPs...] if all are HipGPRs on one engine in slots 0..n, else None."""
     if not isinstance(gp, HipGPR) or gp.slot != 0:
@@ -114,6 +210,9 @@ class AcquisitionFunction(abc.ABC):
     #: with engine-backed GPs, form L-BFGS-B's finite-difference gradient in one batched device call per
     #: iteration (d + 1 points) instead of d + 1 single-point calls; same numbers, ~d times fewer launches
     batched_fd = True
+    #: with `batched_fd`, advance the L-BFGS-B runs of all seeds together so that each iteration of ALL runs is
+    #: one device batch (n_seeds * (d + 1) points) instead of one batch per run (`_Lockstep`)
+    lockstep = True
     #: THROUGHPUT MODE (off by default): draw the random-stage candidates on the device with a Philox generator
     #: instead of space.random_sample(); removes the host sampling and the upload but is NOT the reference's
     #: RandomState stream (two 31-bit integers are drawn from it as the device seed), so suggestions differ
@@ -259,11 +358,13 @@ class AcquisitionFunction(abc.ABC):
         batched = self.batched_fd and getattr(self, "_fused", None) is not None
         value_and_grad = _fd_value_and_grad(acq, box) if batched else None
         winner = None
-        for start in x_seeds:
-            if batched:
-                res = minimize(value_and_grad, start, jac=True, bounds=box, method="L-BFGS-B")
-            else:
-                res = minimize(acq, start, bounds=box, method="L-BFGS-B")
+        if batched and self.lockstep and len(x_seeds) > 1:
+            outcomes = _polish_in_lockstep(acq, x_seeds, box)
+        elif batched:
+            outcomes = (minimize(value_and_grad, start, jac=True, bounds=box, method="L-BFGS-B") for start in x_seeds)
+        else:
+            outcomes = (minimize(acq, start, bounds=box, method="L-BFGS-B") for start in x_seeds)
+        for res in outcomes:
             if res.success and (winner is None or np.squeeze(res.fun) < winner[1]):
                 winner = (res.x, np.squeeze(res.fun))
         return winner

@@ -39,6 +39,15 @@ for name in ("C2", "C3"):
             x = fn.suggest(gp, sp, n_random=w.M, n_smart=n_smart, fit_gp=True, random_state=np.random.RandomState(7))
             ts.append((time.perf_counter() - t0) * 1e3)
         r[f"suggest_fixed_theta_nsmart{n_smart}_ms"] = ts
+    fn.lockstep = False          # one L-BFGS-B run after another (round-1 behaviour before the lockstep hub)
+    ts = []
+    for rep in range(3):
+        t0 = time.perf_counter()
+        x_seq = fn.suggest(gp, sp, n_random=w.M, n_smart=10, fit_gp=True, random_state=np.random.RandomState(7))
+        ts.append((time.perf_counter() - t0) * 1e3)
+    r["suggest_fixed_theta_nsmart10_sequential_runs_ms"] = ts
+    fn.lockstep = True
+    r["lockstep_equals_sequential"] = bool(np.array_equal(x, x_seq))
     fn.device_sampling = True   # throughput mode: Philox candidates generated on the device (non-parity)
     for n_smart in (0, 10):
         ts = []

@@ -289,7 +289,7 @@ def test_lml_not_pd_returns_minus_inf(engine):
     assert lml == -np.inf and np.all(grad == 0)
 
 
-@pytest.mark.parametrize("M", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("M", [1, 2, 3, 5, 8, 17, 170])
 @pytest.mark.parametrize("N,d,kernel,ls", [(150, 6, O.MATERN25, 0.8), (1030, 16, O.MATERN25, 1.5), (70, 2, O.RBF, 0.5)])
 def test_small_batch_path_equals_oracle_and_big_kernel(engine, M, N, d, kernel, ls):
     """M <= 8 goes through the batched-GEMV latency path (posterior_small.hip): same results as the oracle
@@ -316,6 +316,27 @@ def test_small_batch_path_equals_oracle_and_big_kernel(engine, M, N, d, kernel, 
     # kappa(K)*eps noise as the comparison with LAPACK (RBF, N=70, d=2: kappa ~ 4e7, |alpha| ~ 1e5)
     assert np.max(np.abs(mu - mu_b)) <= tol * np.max(np.abs(mu_o))
     assert np.max(np.abs(sd - sd_b)) <= tol * max(np.max(np.abs(sd_o)), 1e-3)
+
+
+def test_small_batch_rows_do_not_depend_on_the_batch(engine):
+    """The GEMV path evaluates every candidate with the same instruction sequence whatever batch it arrives in
+    (pass width 1/2/4/8/16, pass index): a lockstep round of n_seeds * (d + 1) points returns, row for row, the
+    bits the per-run batches of d + 1 points return — what lets the merged L-BFGS-B runs retrace the separate ones."""
+    import os
+
+    N, d = 700, 9
+    X, y = _data(N, d, seed=51)
+    yn, ym, ys = O.normalize_targets(y)
+    engine.fit(X, yn, O.MATERN25, 1.1, 1e-6)
+    Xc = np.random.RandomState(52).uniform(size=(10 * (d + 1) + 3, d))
+    os.environ["GPBO_SMALL_MAX"] = "1024"
+    try:
+        mu_all, sd_all = engine.predict(Xc, y_mean=ym, y_std=ys)
+        for lo, hi in [(0, 1), (1, 3), (3, 13), (13, 30), (30, 103), (100, 103)]:
+            mu, sd = engine.predict(Xc[lo:hi], y_mean=ym, y_std=ys)
+            assert np.array_equal(mu, mu_all[lo:hi]) and np.array_equal(sd, sd_all[lo:hi])
+    finally:
+        os.environ.pop("GPBO_SMALL_MAX")
 
 
 def test_kstar_slab_loop_equals_single_slab(engine):

@@ -169,17 +169,20 @@ def test_device_theta_search_matches_sklearn_optimum(engine):
     assert rel_err(m2, m1) < 1e-5 and rel_err(s2, s1) < 1e-5
 
 
-def test_batched_fd_smart_stage_is_bitwise_the_per_point_path(engine):
-    """The smart stage with one batched (d+1)-point device call per L-BFGS-B iteration returns exactly the point
-    of the reference-shaped per-point path (the small-batch kernel evaluates a candidate identically alone or in
-    a batch), with far fewer engine calls."""
+def test_batched_fd_smart_stage_is_bitwise_the_per_point_path(engine, monkeypatch):
+    """The smart stage in its three shapes — all runs in lockstep (one device batch of n_seeds * (d + 1) points per
+    round), one batched (d + 1)-point call per L-BFGS-B iteration of each run, and the reference-shaped per-point
+    path — returns exactly the same point: the GEMV kernel evaluates a candidate identically alone or in any
+    batch (the path is pinned; across the GEMV/MFMA switch the agreement is to rounding, next test)."""
+    monkeypatch.setenv("GPBO_SMALL_MAX", "1024")
     w = W.P2
     sp = _space(w)
     res = {}
-    for batched in (True, False):
+    for mode in ("lockstep", "batched", "per_point"):
         gp = HipGPR(kernel=RBF(length_scale=0.6), alpha=w.noise, normalize_y=True, optimizer=None, engine=engine)
         fn = A.ExpectedImprovement(xi=0.01)
-        fn.batched_fd = batched
+        fn.batched_fd = mode != "per_point"
+        fn.lockstep = mode == "lockstep"
         n0 = [0]
         orig = engine.set_candidates
 
@@ -192,9 +195,29 @@ def test_batched_fd_smart_stage_is_bitwise_the_per_point_path(engine):
             x = fn.suggest(gp, sp, n_random=2048, n_smart=5, random_state=np.random.RandomState(7))
         finally:
             del engine.set_candidates
-        res[batched] = (x, n0[0])
-    assert np.array_equal(res[True][0], res[False][0])
-    assert res[True][1] * 3 < res[False][1]
+        res[mode] = (x, n0[0])
+    assert np.array_equal(res["batched"][0], res["per_point"][0])
+    assert np.array_equal(res["lockstep"][0], res["per_point"][0])
+    assert res["batched"][1] * 3 < res["per_point"][1]
+    assert res["lockstep"][1] * 2 < res["batched"][1]
+
+
+def test_lockstep_rounds_across_the_kernel_switch(engine):
+    """With the default dispatch a lockstep round may run on the MFMA path and a late round (few live runs) on
+    the GEMV path; values agree to rounding, so the polished point is the sequential one to optimiser precision."""
+    w = W.C2
+    sp = _space(w)
+    xs = {}
+    for lockstep in (True, False):
+        gp = HipGPR(kernel=Matern(nu=2.5, length_scale=w.length_scale), alpha=w.noise, normalize_y=True,
+                    optimizer=None, engine=engine)
+        fn = A.UpperConfidenceBound(kappa=2.576)
+        fn.lockstep = lockstep
+        xs[lockstep] = fn.suggest(gp, sp, n_random=4096, n_smart=10, random_state=np.random.RandomState(7))
+    acq = fn._get_acq(gp)
+    f_lock, f_seq = acq(xs[True])[0], acq(xs[False])[0]
+    assert abs(f_lock - f_seq) <= 1e-6 * abs(f_seq)
+    assert np.allclose(xs[True], xs[False], rtol=0, atol=1e-3)
 
 
 def test_device_sampling_throughput_mode(engine):

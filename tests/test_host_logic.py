@@ -212,3 +212,45 @@ def test_batched_finite_differences_reproduce_scipy_lbfgsb():
         r2 = minimize(_fd_value_and_grad(acq, bounds), x0, jac=True, bounds=bounds, method="L-BFGS-B")
         assert np.array_equal(r1.x, r2.x) and r1.fun == r2.fun and r1.nit == r2.nit
         assert calls[0] * 5 < r1.nfev
+
+
+def test_lockstep_runs_are_the_sequential_runs():
+    """_polish_in_lockstep advances all L-BFGS-B runs together (one merged batch per round) and every run ends
+    exactly where it ends alone; runs of different lengths retire without stalling the rest; an objective that
+    raises propagates to the caller."""
+    from scipy.optimize import minimize
+
+    from bayesianoptimization_amd.fused_acquisition import _fd_value_and_grad, _polish_in_lockstep
+
+    rng = np.random.RandomState(3)
+    A = rng.randn(5, 5)
+    A = A @ A.T + np.eye(5)
+
+    def f1(x):
+        return 0.5 * x @ A @ x + np.cos(4 * x).sum()
+
+    calls = []
+
+    def acq(x):
+        calls.append(len(x))
+        return np.array([f1(r) for r in np.atleast_2d(x)])
+
+    bounds = np.array([[-2.0, 2.0]] * 5)
+    seeds = np.vstack([rng.uniform(-2, 2, (7, 5)), np.full((1, 5), 2.0)])
+    alone = [minimize(_fd_value_and_grad(acq, bounds), s, jac=True, bounds=bounds, method="L-BFGS-B") for s in seeds]
+    n_alone = len(calls)
+    calls.clear()
+    together = _polish_in_lockstep(acq, seeds, bounds)
+    for a, b in zip(alone, together):
+        assert np.array_equal(a.x, b.x) and a.fun == b.fun and a.nit == b.nit and a.nfev == b.nfev
+    assert len(calls) == max(r.nfev for r in alone) and len(calls) * 3 < n_alone
+    assert calls[0] == len(seeds) * 6 and calls[-1] < calls[0]          # runs retire at different rounds
+
+    def broken(x):
+        if len(calls) > 3:
+            raise FloatingPointError("boom")
+        return acq(x)
+
+    calls.clear()
+    with pytest.raises(FloatingPointError):
+        _polish_in_lockstep(broken, seeds, bounds)
