@@ -472,6 +472,90 @@ int launch_trmv(gpbo_ctx* ctx, Model& m) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Rank-one growth of the factorisation (gpbo_fit_append): observation j joins a fitted model of j rows.
+//   append_kvec   : kv[i] = k(x_i, x_j) for i < j (the arithmetic of kmat_kernel, so K's new row is the row a
+//                   full fit would write), 0 for i >= j; also written to K[j][0..j-1], K[j][j] = 1 + noise
+//   trmv_lower    : l = W kv            (existing kernel; rows >= j give 0 because kv is 0 there)
+//   trmv_lower_t  : u = W^T l           (existing kernels)
+//   append_finish : lambda^2 = 1 + noise - sum l^2 (fixed tree); L[j][:] = [l, lambda]; W[j][:] = [-u/lambda, 1/lambda]
+template <int KERNEL>
+__global__ __launch_bounds__(256) void append_kvec_kernel(const double* __restrict__ Xs, int DP, int64_t j, int64_t NP,
+                                                          double noise, double* __restrict__ kv, double* __restrict__ K) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= NP) return;
+  double v = 0.0;
+  if (i < j) {
+    const double* xi = Xs + i * DP;
+    const double* xj = Xs + j * DP;
+    double d2 = 0.0;
+    for (int t = 0; t < DP; ++t) {
+      const double df = xj[t] - xi[t];
+      d2 = fma(df, df, d2);
+    }
+    v = kernel_value<KERNEL>(d2);
+    K[j * NP + i] = v;
+  } else if (i == j) {
+    K[j * NP + j] = 1.0 + noise;
+  }
+  kv[i] = v;
+}
+
+__global__ __launch_bounds__(256) void append_finish_kernel(const double* __restrict__ l, const double* __restrict__ u,
+                                                            int64_t j, int64_t NP, double noise, double* __restrict__ L,
+                                                            double* __restrict__ W, int* __restrict__ info) {
+  __shared__ double sh[4];
+  __shared__ double lam_sh;
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < j; i += 256) s = fma(l[i], l[i], s);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double piv = (1.0 + noise) - (((sh[0] + sh[1]) + sh[2]) + sh[3]);
+    double lam = 0.0;
+    if (piv > 0.0) lam = sqrt(piv);
+    else if (*info == 0) *info = (int)(j + 1);     // LAPACK potrf: order of the first non-positive minor
+    lam_sh = lam;
+  }
+  __syncthreads();
+  const double lam = lam_sh;
+  if (!(lam > 0.0)) return;
+  const double inv = 1.0 / lam;
+  for (int64_t i = threadIdx.x; i < j; i += 256) {
+    L[j * NP + i] = l[i];
+    W[j * NP + i] = -u[i] * inv;
+  }
+  if (threadIdx.x == 0) {
+    L[j * NP + j] = lam;
+    W[j * NP + j] = inv;
+  }
+}
+
+int launch_append_row(gpbo_ctx* ctx, Model& m, int64_t j) {
+  // scratch in m.tmp (>= NP * 64 doubles): [0, 16 NP) partials of W^T l, then kv, l, u
+  double* partial = m.tmp;
+  double* kv = m.tmp + (int64_t)TRMV_SPLITS * m.NP;
+  double* lv = kv + m.NP;
+  double* uv = lv + m.NP;
+  const unsigned vb = (unsigned)((m.NP + 255) / 256);
+  if (m.kernel == GPBO_KERNEL_MATERN25)
+    append_kvec_kernel<GPBO_KERNEL_MATERN25><<<dim3(vb), dim3(256), 0, ctx->stream>>>(m.Xs, m.DP, j, m.NP, m.noise, kv, m.K);
+  else
+    append_kvec_kernel<GPBO_KERNEL_RBF><<<dim3(vb), dim3(256), 0, ctx->stream>>>(m.Xs, m.DP, j, m.NP, m.noise, kv, m.K);
+  GPBO_HIP(ctx, hipGetLastError());
+  trmv_lower_kernel<<<dim3((unsigned)((m.NP + 3) / 4)), dim3(256), 0, ctx->stream>>>(m.W, kv, lv, m.NP);
+  GPBO_HIP(ctx, hipGetLastError());
+  trmv_lower_t_kernel<<<dim3((unsigned)(m.NP / 64), TRMV_SPLITS), dim3(256), 0, ctx->stream>>>(m.W, lv, partial, m.NP);
+  GPBO_HIP(ctx, hipGetLastError());
+  trmv_reduce_kernel<<<dim3(vb), dim3(256), 0, ctx->stream>>>(partial, uv, m.NP);
+  GPBO_HIP(ctx, hipGetLastError());
+  append_finish_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(lv, uv, j, m.NP, m.noise, m.L, m.W, ctx->info_dev);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Pack W into the order the posterior kernel's waves consume it: for row slab s (32 rows), k-pair p
 // (8 columns) and 16-row tile t, 64 lanes x 2 doubles contiguous (1 KiB): lane l, element e holds
 // W[32 s + 16 t + (l & 15)][8 p + 4 e + (l >> 4)] — the A fragment of v_mfma_f64_16x16x4_f64 for

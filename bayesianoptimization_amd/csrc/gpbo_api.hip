@@ -221,6 +221,30 @@ int gpbo_device_info(gpbo_ctx* ctx, char* buf, int buflen) {
 
 // Shared by gpbo_fit and gpbo_lml: validate, upload, K, Cholesky, W = L^-1, alpha — all queued on the
 // stream; the potrf info word is copied to pinned memory (valid after the next stream sync).
+// K, L, W = L^-1 and alpha from the device-resident scaled inputs m.Xs / targets m.yn (m.N, m.NP, m.kernel set).
+static int factor_resident(gpbo_ctx* ctx, Model& m, double noise, int** info_host) {
+  int rc;
+  const int64_t NP = m.NP;
+  m.noise = noise;
+  GPBO_HIP(ctx, hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream));
+  ev_begin(ctx, T_KMAT);
+  if ((rc = launch_kmat(ctx, m, noise))) return rc;
+  ev_end(ctx, T_KMAT);
+  GPBO_HIP(ctx, hipMemcpyAsync(m.L, m.K, (size_t)NP * NP * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  ev_begin(ctx, T_CHOL);
+  if ((rc = cholesky(ctx, m))) return rc;
+  ev_end(ctx, T_CHOL);
+  int* info_h = (int*)((char*)ctx->pinned + 1024);
+  GPBO_HIP(ctx, hipMemcpyAsync(info_h, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  // W and alpha are issued before the info check resolves (harmless on failure)
+  ev_begin(ctx, T_TRTRI);
+  if ((rc = trtri(ctx, m))) return rc;
+  ev_end(ctx, T_TRTRI);
+  if ((rc = launch_trmv(ctx, m))) return rc;
+  *info_host = info_h;
+  return GPBO_OK;
+}
+
 static int factorize(gpbo_ctx* ctx, int slot, const char* who, const double* X, const double* y_norm, int64_t N,
                      int d, int kernel, const double* length_scale, int n_ls, double noise, int precision,
                      int** info_host) {
@@ -255,36 +279,15 @@ static int factorize(gpbo_ctx* ctx, int slot, const char* who, const double* X, 
   GPBO_HIP(ctx, hipMemcpyAsync(m.tmp, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   GPBO_HIP(ctx, hipMemsetAsync(m.yn, 0, (size_t)NP * sizeof(double), ctx->stream));
   GPBO_HIP(ctx, hipMemcpyAsync(m.yn, y_norm, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  GPBO_HIP(ctx, hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream));
   if ((rc = launch_prescale(ctx, m.tmp, N, d, DP, m.ls, m.Xs, NP))) return rc;
-  ev_begin(ctx, T_KMAT);
-  if ((rc = launch_kmat(ctx, m, noise))) return rc;
-  ev_end(ctx, T_KMAT);
-  GPBO_HIP(ctx, hipMemcpyAsync(m.L, m.K, (size_t)NP * NP * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  ev_begin(ctx, T_CHOL);
-  if ((rc = cholesky(ctx, m))) return rc;
-  ev_end(ctx, T_CHOL);
-  int* info_h = (int*)((char*)ctx->pinned + 1024);
-  GPBO_HIP(ctx, hipMemcpyAsync(info_h, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  // W and alpha are issued before the info check resolves (harmless on failure)
-  ev_begin(ctx, T_TRTRI);
-  if ((rc = trtri(ctx, m))) return rc;
-  ev_end(ctx, T_TRTRI);
-  if ((rc = launch_trmv(ctx, m))) return rc;
-  *info_host = info_h;
-  return GPBO_OK;
+  return factor_resident(ctx, m, noise, info_host);
 }
 
-int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d,
-             int kernel, const double* length_scale, int n_ls, double noise, int precision,
-             int* info) {
-  if (info) *info = 0;
-  int* info_h = nullptr;
-  int rc = factorize(ctx, slot, "gpbo_fit", X, y_norm, N, d, kernel, length_scale, n_ls, noise, precision, &info_h);
-  if (rc) return rc;
-  Model& m = ctx->models[slot];
+// Tail shared by gpbo_fit and gpbo_fit_append: pack W for the posterior kernels, wait, resolve the pivot check.
+static int finish_fit(gpbo_ctx* ctx, Model& m, int* info_h, int* info) {
+  int rc;
   if ((rc = launch_pack_w(ctx, m))) return rc;
-  if (precision == GPBO_F32) {   // fp32 posterior: W rounded to fp32 in f32-MFMA fragment order (fit itself is fp64)
+  if (m.precision == GPBO_F32) {   // fp32 posterior: W rounded to fp32 in f32-MFMA fragment order (fit itself is fp64)
     if ((rc = ensure(ctx, &m.Wp32, &m.cap_Wp32, m.NP * m.NP))) return rc;
     if ((rc = launch_pack_w32(ctx, m))) return rc;
   }
@@ -298,6 +301,74 @@ int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int
   }
   m.fitted = true;
   return GPBO_OK;
+}
+
+int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d,
+             int kernel, const double* length_scale, int n_ls, double noise, int precision,
+             int* info) {
+  if (info) *info = 0;
+  int* info_h = nullptr;
+  int rc = factorize(ctx, slot, "gpbo_fit", X, y_norm, N, d, kernel, length_scale, n_ls, noise, precision, &info_h);
+  if (rc) return rc;
+  return finish_fit(ctx, ctx->models[slot], info_h, info);
+}
+
+int gpbo_fit_append(gpbo_ctx* ctx, int slot, const double* x_new, int64_t n_new, int d,
+                    const double* y_norm, int64_t n_total, int* info) {
+  if (info) *info = 0;
+  int rc = check_slot(ctx, slot);
+  if (rc) return rc;
+  Model& m = ctx->models[slot];
+  if (!m.fitted) GPBO_FAIL(ctx, GPBO_ERR_STATE, "gpbo_fit_append: slot has no fitted model (call gpbo_fit first)");
+  if (n_new < 0 || !y_norm || (n_new > 0 && !x_new)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit_append: NULL input or n_new < 0");
+  if (d != m.d) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit_append: d differs from the fitted model's");
+  if (n_total != m.N + n_new) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit_append: n_total must be N + n_new");
+  if (n_total > (1 << 16)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit_append: N out of range [1, 65536]");
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  m.fitted = false;
+  m.M_post = -1;
+  const int64_t N0 = m.N;
+  const int64_t NP_new = round_up(n_total, NB);
+  const bool rebuild = (NP_new != m.NP) || n_new > 16;
+  ev_begin(ctx, T_FIT);
+  if (NP_new > m.cap_NP) {
+    // grow the slot (25% head-room so that a maximize() loop reallocates rarely); the scaled inputs survive
+    double* keep = nullptr;
+    GPBO_HIP(ctx, hipMalloc((void**)&keep, (size_t)N0 * m.DP * sizeof(double)));
+    GPBO_HIP(ctx, hipMemcpyAsync(keep, m.Xs, (size_t)N0 * m.DP * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    double* ls_h = (double*)ctx->pinned;
+    GPBO_HIP(ctx, hipMemcpyAsync(ls_h, m.ls, GPBO_MAX_DIM * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int DP = m.DP;
+    if ((rc = alloc_model(ctx, m, round_up(NP_new + NP_new / 4, NB), DP))) { (void)hipFree(keep); return rc; }
+    GPBO_HIP(ctx, hipMemcpyAsync(m.ls, ls_h, GPBO_MAX_DIM * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    GPBO_HIP(ctx, hipMemcpyAsync(m.Xs, keep, (size_t)N0 * DP * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    GPBO_HIP(ctx, hipFree(keep));
+  }
+  // new rows: scaled into Xs[N0 .. NP_new) (zero padded), staged through ctx->Xcs-independent scratch (m.tvec is
+  // too small for d > 1, m.tmp is free between fits)
+  if (n_new > 0)
+    GPBO_HIP(ctx, hipMemcpyAsync(m.tmp, x_new, (size_t)n_new * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (NP_new > N0)
+    if ((rc = launch_prescale(ctx, m.tmp, n_new, d, m.DP, m.ls, m.Xs + N0 * m.DP, NP_new - N0))) return rc;
+  GPBO_HIP(ctx, hipMemsetAsync(m.yn, 0, (size_t)NP_new * sizeof(double), ctx->stream));
+  GPBO_HIP(ctx, hipMemcpyAsync(m.yn, y_norm, (size_t)n_total * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  int* info_h = nullptr;
+  if (rebuild) {
+    m.N = n_total;
+    m.NP = NP_new;
+    if ((rc = factor_resident(ctx, m, m.noise, &info_h))) return rc;
+  } else {
+    GPBO_HIP(ctx, hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream));
+    for (int64_t j = N0; j < n_total; ++j)
+      if ((rc = launch_append_row(ctx, m, j))) return rc;
+    m.N = n_total;
+    info_h = (int*)((char*)ctx->pinned + 1024);
+    GPBO_HIP(ctx, hipMemcpyAsync(info_h, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = launch_trmv(ctx, m))) return rc;
+  }
+  return finish_fit(ctx, m, info_h, info);
 }
 
 int gpbo_lml(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d,

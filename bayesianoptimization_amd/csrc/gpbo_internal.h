@@ -27,6 +27,7 @@ struct Model {
   int d = 0, DP = 0;       // input dimension, padded to {4,8,16,32,64}
   int kernel = 0;
   int precision = 0;
+  double noise = 0.0;      // value added to the diagonal of K at the last fit
   int64_t cap_NP = 0;      // allocated capacity (NP) of the square buffers
   int cap_DP = 0;
   double* ls = nullptr;    // [GPBO_MAX_DIM] length scale per dimension (device)
@@ -166,6 +167,7 @@ int launch_kmat(gpbo_ctx* ctx, Model& m, double noise);
 int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb);
 int launch_fill_w_diag(gpbo_ctx* ctx, Model& m);
 int launch_trmv(gpbo_ctx* ctx, Model& m);
+int launch_append_row(gpbo_ctx* ctx, Model& m, int64_t j);   // row j (== current m.N) from the prescaled m.Xs[j]
 int launch_pack_w(gpbo_ctx* ctx, Model& m);
 struct GemmArgs {
   int m, n, k;            // multiples of 64 / 64 / 16

@@ -74,9 +74,35 @@ class GpEngine:
             raise ValueError("X and y have inconsistent numbers of samples")
         ls = np.ascontiguousarray(np.atleast_1d(np.asarray(length_scale, dtype=np.float64)))
         info = C.c_int(0)
+        self._touch(slot)
         rc = self._lib.gpbo_fit(self._h, int(slot), dptr(X), dptr(y_norm), X.shape[0], X.shape[1], int(kernel),
                                 dptr(ls), int(ls.shape[0]), float(noise), int(precision), C.byref(info))
         self._check(rc, info.value)
+        return self._touch(slot)
+
+    def fit_append(self, x_new, y_norm, slot: int = 0):
+        """Grow the slot's fitted model by the rows `x_new` at unchanged kernel/length scale/noise (gpbo_fit_append);
+        `y_norm` = ALL normalised targets, old and new.  `x_new` may be empty (new targets for the same inputs)."""
+        y_norm = np.ascontiguousarray(y_norm, dtype=np.float64).ravel()
+        x_new = np.ascontiguousarray(x_new, dtype=np.float64)
+        if x_new.ndim != 2:
+            raise ValueError("x_new must be 2-D (n_new, n_features)")
+        info = C.c_int(0)
+        self._touch(slot)
+        rc = self._lib.gpbo_fit_append(self._h, int(slot), dptr(x_new) if x_new.shape[0] else None, x_new.shape[0],
+                                       x_new.shape[1], dptr(y_norm), y_norm.shape[0], C.byref(info))
+        self._check(rc, info.value)
+        return self._touch(slot)
+
+    def _touch(self, slot: int) -> int:
+        """Every call that rewrites a slot's factorisation bumps its serial; an estimator compares the serial it got
+        from its last fit with `fit_serial(slot)` to know whether the slot still holds ITS model."""
+        self._serial = getattr(self, "_serial", {})
+        self._serial[int(slot)] = self._serial.get(int(slot), 0) + 1
+        return self._serial[int(slot)]
+
+    def fit_serial(self, slot: int = 0) -> int:
+        return getattr(self, "_serial", {}).get(int(slot), 0)
 
     def lml(self, X, y_norm, kernel: int, length_scale, noise: float, eval_gradient=True, slot: int = 0):
         """(log marginal likelihood, d/dlog(length_scale)) at theta (sklearn _gpr.py:575-652). Clobbers the slot's fit."""
@@ -86,6 +112,7 @@ class GpEngine:
         val = C.c_double(0.0)
         grad = np.zeros(ls.shape[0])
         info = C.c_int(0)
+        self._touch(slot)
         rc = self._lib.gpbo_lml(self._h, int(slot), dptr(X), dptr(y_norm), X.shape[0], X.shape[1], int(kernel),
                                 dptr(ls), int(ls.shape[0]), float(noise), int(bool(eval_gradient)), C.byref(val),
                                 dptr(grad), C.byref(info))

@@ -73,7 +73,7 @@ class HipGPR(GaussianProcessRegressor):
 
     def __init__(self, kernel=None, *, alpha=1e-10, optimizer="fmin_l_bfgs_b", n_restarts_optimizer=0,
                  normalize_y=False, copy_X_train=True, n_targets=None, random_state=None,
-                 transform=None, engine=None, slot=0, lml_on_device="auto", precision="f64"):
+                 transform=None, engine=None, slot=0, lml_on_device="auto", precision="f64", incremental=True):
         super().__init__(kernel=kernel, alpha=alpha, optimizer=optimizer,
                          n_restarts_optimizer=n_restarts_optimizer, normalize_y=normalize_y,
                          copy_X_train=copy_X_train, n_targets=n_targets, random_state=random_state)
@@ -85,6 +85,9 @@ class HipGPR(GaussianProcessRegressor):
         self.lml_on_device = lml_on_device
         # "f64" (reference arithmetic) or "f32": fp64 factorisation, fp32 posterior contraction (engine.F32)
         self.precision = precision
+        # grow the device factorisation row by row (gpbo_fit_append, O(N^2) per new observation) when a fit repeats
+        # the previous one with observations appended and the kernel hyper-parameters unchanged
+        self.incremental = incremental
 
     # -- plumbing ------------------------------------------------------------------------------
     def _engine(self) -> GpEngine:
@@ -144,8 +147,8 @@ class HipGPR(GaussianProcessRegressor):
         self.__dict__.pop("_alpha_cache", None)
         if not getattr(self, "_in_fit", False) and hasattr(self, "_kind"):
             # called on a fitted model: gpbo_lml reused the slot's buffers, so restore the fit
-            self._engine().fit(self._tx(self.X_train_), self.y_train_, self._kind, self._ls, float(self.alpha),
-                               slot=self.slot, precision=self._precision_code())
+            self._held = None
+            self._device_fit_tail()
         return out
 
     # lazily fetched parity attributes -------------------------------------------------------------
@@ -240,9 +243,31 @@ class HipGPR(GaussianProcessRegressor):
             raise ValueError("Anisotropic kernel must have the same number of dimensions as data")
         self._kind, self._ls = kind, ls
         # _gpr.py:346-364 on the device (LinAlgError with sklearn's hint when K is not PD)
-        self._engine().fit(self._tx(self.X_train_), self.y_train_, kind, ls, float(self.alpha), slot=self.slot,
-                           precision=self._precision_code())
+        self._device_fit_tail()
         return self
+
+    def _device_fit_tail(self):
+        """gpbo_fit, or gpbo_fit_append when this fit extends the one the slot still holds (same theta, noise,
+        precision; the previous inputs are a prefix of the new ones) — SURVEY.md §8 f4.  The reference refits from
+        scratch on every maximize() iteration (bayesian_optimization.py:377-388); with optimizer=None that is the
+        same factorisation plus one row, which is what the append computes."""
+        eng = self._engine()
+        X, y = self.X_train_, self.y_train_
+        key = (self._kind, self._ls.tobytes(), float(self.alpha), self._precision_code())
+        held = self.__dict__.get("_held")
+        self._held = None
+        if (self.incremental and held is not None and held["key"] == key and held["engine"] is eng
+                and eng.fit_serial(self.slot) == held["serial"]):
+            X0 = held["X"]
+            n0 = X0.shape[0]
+            if n0 <= X.shape[0] and X0.shape[1] == X.shape[1] and np.array_equal(X0, X[:n0]):
+                serial = eng.fit_append(self._tx(X[n0:]) if X.shape[0] > n0 else np.empty((0, X.shape[1])), y,
+                                        slot=self.slot)
+                self._held = {"key": key, "engine": eng, "serial": serial, "X": X}
+                return
+        serial = eng.fit(self._tx(X), y, self._kind, self._ls, float(self.alpha), slot=self.slot,
+                         precision=self._precision_code())
+        self._held = {"key": key, "engine": eng, "serial": serial, "X": X}
 
     # -- predict -----------------------------------------------------------------------------------
     def predict(self, X, return_std=False, return_cov=False):

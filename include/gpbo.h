@@ -75,6 +75,20 @@ int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int
              int kernel, const double* length_scale, int n_ls, double noise, int precision,
              int* info);
 
+/* Append n_new observations to a fitted slot at UNCHANGED kernel, length scale and noise.
+ * Replaces re-running the whole fixed-theta fit (_gpr.py:346-364) on X u x_new, which is what the reference's
+ * maximize() loop does every iteration (bayes_opt/bayesian_optimization.py:377-388 -> acquisition.py:79-86) and what
+ * ConstantLiar's dummy refits do (acquisition.py:1130-1143).  Per new row j, O(j^2) instead of O(j^3):
+ *   k = k(X[:j], x_j);  l = W k;  lambda = sqrt(1 + noise - l.l);  L[j,:] = [l, lambda];
+ *   W[j,:] = [-(l^T W) / lambda, 1 / lambda]
+ * then alpha = W^T (W y_norm) for ALL targets.  y_norm: the n_total = N + n_new normalised targets (the
+ * normalisation of every target changes when one is added, _gpr.py:272-277).  n_new = 0 re-solves alpha for new
+ * targets only (same X; the dummy-target case).  When the rows do not fit the slot's 64-row padding, or n_new > 16,
+ * the factorisation is redone from the device-resident scaled inputs instead (same result as gpbo_fit).
+ * On GPBO_ERR_NOT_PD the slot is left unfitted and *info = 1-based index of the failing pivot. */
+int gpbo_fit_append(gpbo_ctx* ctx, int slot, const double* x_new, int64_t n_new, int d,
+                    const double* y_norm, int64_t n_total, int* info);
+
 /* Log marginal likelihood and its gradient with respect to log(length_scale) at the given theta.
  * Replaces one L-BFGS-B evaluation of GaussianProcessRegressor.log_marginal_likelihood(theta,
  * eval_gradient=True) (_gpr.py:575-652; Matern/RBF gradients kernels.py:1764-1766, 1567-1582), the inner

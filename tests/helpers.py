@@ -53,13 +53,35 @@ class FakeEngine:
         self.n_candidates = 0
         self.calls = []
 
+    def _touch(self, slot):
+        self.serial = getattr(self, "serial", {})
+        self.serial[slot] = self.serial.get(slot, 0) + 1
+        return self.serial[slot]
+
+    def fit_serial(self, slot=0):
+        return getattr(self, "serial", {}).get(slot, 0)
+
     def fit(self, X, y_norm, kernel, length_scale, noise, slot=0, precision=0):
         self.calls.append(("fit", slot, X.shape))
         gp = O.fit_fixed_theta(kernel, X, y_norm, length_scale, noise, normalize_y=False)
         self.models[slot] = gp
+        self.inputs = getattr(self, "inputs", {})
+        self.inputs[slot] = (np.array(X), kernel, length_scale, noise)
+        return self._touch(slot)
+
+    def fit_append(self, x_new, y_norm, slot=0):
+        self.calls.append(("fit_append", slot, x_new.shape))
+        if slot not in self.models:
+            raise RuntimeError("gpbo_fit_append: slot has no fitted model (call gpbo_fit first)")
+        X0, kernel, length_scale, noise = self.inputs[slot]
+        X = np.vstack([X0, x_new]) if x_new.shape[0] else X0
+        self.models[slot] = O.fit_fixed_theta(kernel, X, y_norm, length_scale, noise, normalize_y=False)
+        self.inputs[slot] = (X, kernel, length_scale, noise)
+        return self._touch(slot)
 
     def lml(self, X, y_norm, kernel, length_scale, noise, eval_gradient=True, slot=0):
         self.calls.append(("lml", slot))
+        self._touch(slot)
         self.models.pop(slot, None)   # like the device: the slot's fit is clobbered
         return O.log_marginal_likelihood(kernel, X, y_norm, length_scale, noise, eval_gradient)
 

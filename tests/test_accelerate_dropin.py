@@ -229,3 +229,44 @@ def test_integer_parameters_use_the_host_transform():
         warnings.simplefilter("ignore")
         mine.maximize(init_points=0, n_iter=2)      # mixed space: differential evolution smart stage on the host
     assert len(mine.space) == 6
+
+
+def test_refit_with_appended_rows_goes_through_fit_append():
+    """HipGPR.fit at fixed theta (optimizer=None) on the previous inputs plus new rows grows the held factorisation
+    (gpbo_fit_append) instead of refactorising; anything that invalidates the held model — another theta, a
+    changed earlier row, an LML evaluation on the slot, another estimator on the slot — falls back to gpbo_fit."""
+    from sklearn.gaussian_process.kernels import Matern
+
+    from bayesianoptimization_amd.gpr import HipGPR
+
+    rng = np.random.RandomState(0)
+    X = rng.uniform(size=(30, 3))
+    y = np.sin(X.sum(1))
+    eng = FakeEngine()
+    gp = HipGPR(kernel=Matern(nu=2.5, length_scale=0.7), alpha=1e-6, normalize_y=True, optimizer=None, engine=eng)
+
+    def last():
+        return [c[0] for c in eng.calls if c[0] in ("fit", "fit_append", "lml")][-1]
+
+    gp.fit(X[:20], y[:20]); assert last() == "fit"
+    gp.fit(X[:21], y[:21]); assert last() == "fit_append" and eng.calls[-1][2] == (1, 3)
+    gp.fit(X[:25], y[:25]); assert last() == "fit_append" and eng.calls[-1][2] == (4, 3)
+    gp.fit(X[:25], 2 * y[:25]); assert last() == "fit_append" and eng.calls[-1][2] == (0, 3)   # new targets only
+    fresh = HipGPR(kernel=Matern(nu=2.5, length_scale=0.7), alpha=1e-6, normalize_y=True, optimizer=None,
+                   engine=FakeEngine()).fit(X[:25], 2 * y[:25])
+    q = rng.uniform(size=(7, 3))
+    for a, b in zip(gp.predict(q, return_std=True), fresh.predict(q, return_std=True)):
+        assert np.allclose(a, b, rtol=1e-12, atol=1e-14)
+    assert np.allclose(gp.alpha_, fresh.alpha_, rtol=1e-10)
+    X2 = X.copy(); X2[3, 0] += 0.1
+    gp.fit(X2[:26], y[:26]); assert last() == "fit"                          # an earlier row changed
+    gp.fit(X2[:27], y[:27]); assert last() == "fit_append"
+    gp.log_marginal_likelihood(gp.kernel_.theta)                             # host LML: slot untouched
+    gp.fit(X2[:28], y[:28]); assert last() == "fit_append"
+    gp.set_params(kernel=Matern(nu=2.5, length_scale=0.9))
+    gp.fit(X2[:29], y[:29]); assert last() == "fit"                          # another theta
+    other = HipGPR(kernel=Matern(nu=2.5, length_scale=0.9), alpha=1e-6, normalize_y=True, optimizer=None, engine=eng)
+    other.fit(X2[:10], y[:10])
+    gp.fit(X2[:30], y[:30]); assert last() == "fit"                          # the slot was taken by someone else
+    gp.set_params(incremental=False)
+    gp.fit(X2[:30], y[:30]); assert last() == "fit"

@@ -247,3 +247,33 @@ def test_device_sampling_throughput_mode(engine):
     Xc = philox4x32_10_uniform(5000, w.d, sp.bounds[:, 0], sp.bounds[:, 1], seed2)
     m, s = gp.predict(Xc, return_std=True)
     assert np.array_equal(x, Xc[np.argmin(-(m + 2.0 * s))])
+
+
+def test_incremental_refit_in_a_maximize_loop(engine):
+    """optimizer=None: every suggest() refits on the observations so far.  With incremental=True the refits after
+    the first are gpbo_fit_append calls; the suggested points are those of from-scratch refits."""
+    w = W.C2
+    X, y, _ = W.make_observations(w)
+    picks = {}
+    for incremental in (True, False):
+        sp = FloatSpace(w.pbounds())
+        sp.register_bulk(X[:300], y[:300])
+        gp = HipGPR(kernel=Matern(nu=2.5, length_scale=w.length_scale), alpha=w.noise, normalize_y=True,
+                    optimizer=None, engine=engine, incremental=incremental)
+        fn = A.UpperConfidenceBound(kappa=2.576)
+        calls = []
+        orig_fit, orig_app = engine.fit, engine.fit_append
+        engine.fit = lambda *a, **k: (calls.append("fit"), orig_fit(*a, **k))[1]
+        engine.fit_append = lambda *a, **k: (calls.append("append"), orig_app(*a, **k))[1]
+        try:
+            out = []
+            for it in range(70):                                   # crosses a 64-row padding boundary
+                x = fn.suggest(gp, sp, n_random=2048, n_smart=0, random_state=np.random.RandomState(100 + it))
+                out.append(x)
+                sp.register(x, float(np.sin(3 * x.sum())))
+        finally:
+            del engine.fit, engine.fit_append
+        picks[incremental] = np.array(out)
+        assert calls.count("fit") == (1 if incremental else 70)
+        assert calls.count("append") == (69 if incremental else 0)
+    assert np.array_equal(picks[True], picks[False])
