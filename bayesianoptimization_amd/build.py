@@ -32,6 +32,7 @@ SOURCES = {
     "lml_kernels.hip": [],
     "acq_kernels.hip": ["-ffp-contract=off"],  # elementwise formulas follow NumPy op by op
     "candidates.hip": [],
+    "mt19937.hip": ["-ffp-contract=off"],      # lo + (hi - lo) * u as NumPy computes it
     "probe.hip": [],
     "comm.hip": [],
 }

@@ -187,7 +187,7 @@ int gpbo_destroy(gpbo_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   gpbo_comm_destroy(ctx);
   for (auto& m : ctx->models) free_model(m);
-  void* ptrs[] = {ctx->Xc, ctx->Xcs, ctx->part, ctx->mu_part, ctx->ys, ctx->red, ctx->info_dev, ctx->comm_buf, ctx->kst};
+  void* ptrs[] = {ctx->Xc, ctx->Xcs, ctx->part, ctx->mu_part, ctx->ys, ctx->red, ctx->info_dev, ctx->comm_buf, ctx->kst, ctx->stage};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -67,6 +67,8 @@ struct gpbo_ctx {
   int64_t cap_Xc = 0;      // capacity in doubles
   int64_t M = 0;
   int d_c = 0;
+  double* stage = nullptr; // [d][M] stream-order image of device-generated candidates (mt19937.hip)
+  int64_t cap_stage = 0;
   double* Xcs = nullptr;   // [Mp][DP] scaled/padded workspace
   int64_t cap_Xcs = 0;
   double* part = nullptr;  // [nchunks][Mp] partial |W k*|^2

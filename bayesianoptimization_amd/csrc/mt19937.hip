@@ -1,0 +1,205 @@
+// On-device candidate generation in INDEX-PARITY mode (first option): the (M, d) matrix
+// TargetSpace.random_sample (bayes_opt/target_space.py:593-600) fills column by column from NumPy's legacy
+// RandomState — FloatParameter.random_sample = random_state.uniform(lo, hi, M) (bayes_opt/parameter.py:86-87) —
+// is produced here from the SAME MT19937 state, bit for bit, and the advanced state goes back to the caller, so
+// the host RandomState continues exactly where the reference's would.  Removes the host sampling (91 ms at
+// M = 2^20, d = 16 on the GPU box's EPYC) and the 134 MB upload from a suggest() without leaving the reference's
+// candidate stream (candidates.hip's Philox generator is the other, non-parity, throughput mode).
+//
+// NumPy arithmetic restated (numpy/random/src/mt19937/mt19937.c, legacy distributions):
+//   regeneration  mt[k] = mt[(k+397) mod 624] ^ (y >> 1) ^ (y & 1 ? 0x9908b0df : 0),  y = (mt[k] & 0x80000000) | (mt[k+1] & 0x7fffffff)
+//   tempering     y ^= y >> 11;  y ^= (y << 7) & 0x9d2c5680;  y ^= (y << 15) & 0xefc60000;  y ^= y >> 18
+//   next_double   ((a >> 5) * 2^26 + (b >> 6)) / 2^53  from two consecutive outputs a, b
+//   uniform       lo + (hi - lo) * next_double          (no fused multiply-add: this unit is built -ffp-contract=off)
+//
+// MT19937 is a 624-word shift register with taps 0, 1 and 397: word k of the next block needs words at least 227
+// positions back, so a block regenerates in three data-parallel phases (k < 227, 227 <= k < 454, k >= 454).  The chain
+// over blocks is sequential — ONE workgroup walks it, double-buffered in LDS (the previous block stays readable while
+// the next is written): wave 0 regenerates (the three phases chained through registers, see the kernel), waves
+// 1..7 meanwhile temper the previous block's words into doubles and store them (312 per block); one workgroup
+// barrier per block.  The kernel is latency-bound by construction (53 k dependent blocks for 2^20 x 16 candidates).
+#include <cstdint>
+
+#include "gpbo_internal.h"
+
+namespace gpbo {
+
+constexpr int MT_N = 624, MT_M = 397;
+
+__device__ __forceinline__ unsigned mt_twist(unsigned cur, unsigned nxt, unsigned far) {
+  const unsigned y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+  return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+__device__ __forceinline__ unsigned mt_temper(unsigned y) {
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+// key_io: 624 state words (in: the caller's state, out: the last block touched); pos0: words of key_io already
+// consumed (0..624); T = M * d doubles written in STREAM order (out[t], i.e. the column-major [d][M] image of the
+// candidate matrix: coalesced stores; transpose_stream_kernel turns it into the row-major matrix afterwards);
+// n_blocks = regenerations needed.
+// Wave 0 regenerates block b + 1 while waves 1..7 temper and store
+// the doubles of block b; one workgroup barrier per block.
+__global__ __launch_bounds__(512) void mt19937_uniform_kernel(unsigned* __restrict__ key_io, int pos0, int64_t T,
+                                                              int64_t M, int d, int64_t n_blocks,
+                                                              const double* __restrict__ lohi, double* __restrict__ out,
+                                                              int skip) {   // skip: 1 = no emission, 2 = no regeneration (timing probes)
+  __shared__ unsigned buf[2][MT_N];
+  __shared__ double lohi_s[2 * GPBO_MAX_DIM];
+  __shared__ unsigned before[2];        // before[b & 1] = last word of block b - 1 (pairs that straddle two blocks)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const bool generator = tid < 64;
+  const int etid = tid - 64;            // 0..447 for the emitting waves: one double each per block (<= 312)
+  constexpr int LAG = MT_N - MT_M;      // 227
+  for (int k = tid; k < MT_N; k += 512) buf[0][k] = key_io[k];
+  if (tid == 0) before[0] = 0u;
+  if (tid < 2 * GPBO_MAX_DIM) lohi_s[tid] = lohi[tid];
+  __syncthreads();
+  int64_t col = 0, row = 0;        // position of the first double of the current block (uniform across lanes)
+  for (int64_t b = 0; b <= n_blocks; ++b) {
+    const unsigned* cur = buf[b & 1];
+    if (generator) {
+      if (b < n_blocks && !(skip & 2)) {
+        unsigned* nxt = buf[(b & 1) ^ 1];
+        if (lane == 0) before[(b & 1) ^ 1] = cur[MT_N - 1];
+        // Lane l owns words l + 64 s of each phase, so the far tap of phase B (word k - 227) is the word the SAME lane
+        // produced in phase A, and phase C's is its phase-B word: the three phases chain through registers.  Only
+        // the previous block is read from LDS — all loads first, one LDS round trip per block.
+        unsigned a0[4], a1[4], af[4], b0[4], b1[4], c0[3], c1[3];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int k = min(lane + 64 * s, LAG - 1);
+          a0[s] = cur[k]; a1[s] = cur[k + 1]; af[s] = cur[k + MT_M];
+          b0[s] = cur[LAG + k]; b1[s] = cur[LAG + k + 1];
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const int k = min(2 * LAG + lane + 64 * s, MT_N - 1);
+          c0[s] = cur[k]; c1[s] = cur[min(k + 1, MT_N - 1)];
+        }
+        unsigned vA[4], vB[4], vC[3];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          vA[s] = mt_twist(a0[s], a1[s], af[s]);     // k in [0, 227): all taps in the previous block
+          vB[s] = mt_twist(b0[s], b1[s], vA[s]);     // k in [227, 454): far tap = new word k - 227
+        }
+        const unsigned first = __builtin_amdgcn_readlane(vA[0], 0);   // the last word's "next" is new word 0
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const bool is_last = 2 * LAG + lane + 64 * s == MT_N - 1;
+          vC[s] = mt_twist(c0[s], is_last ? first : c1[s], vB[s]);   // k in [454, 624): far tap = new word k - 227
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          nxt[lane + 64 * s] = vA[s];
+          nxt[LAG + lane + 64 * s] = vB[s];
+        }
+        if (lane + 192 < LAG) {
+          nxt[lane + 192] = vA[3];
+          nxt[LAG + lane + 192] = vB[3];
+        }
+        nxt[2 * LAG + lane] = vC[0];
+        nxt[2 * LAG + lane + 64] = vC[1];
+        if (2 * LAG + lane + 128 < MT_N) nxt[2 * LAG + lane + 128] = vC[2];
+      }
+    } else if (!(skip & 1)) {
+      // doubles whose SECOND word lies in block b: virtual word index v = pos0 + n, second word v2 = pos0 + 2t + 1
+      const int64_t v_lo = (int64_t)MT_N * b, v_hi = v_lo + MT_N;            // [v_lo, v_hi)
+      const int64_t t_lo = (v_lo - pos0 - 1 >= 0) ? (v_lo - pos0) / 2 : 0;   // ceil((v_lo - pos0 - 1) / 2)
+      int64_t t_hi = (v_hi - pos0 - 2 >= 0) ? (v_hi - pos0 - 2) / 2 + 1 : 0; // exclusive
+      if (t_hi > T) t_hi = T;
+      const int cnt = (t_hi > t_lo) ? (int)(t_hi - t_lo) : 0;                // <= 312
+      const unsigned carry = before[b & 1];
+      const int cn = (col + 1 < d) ? (int)col + 1 : (int)col;               // a block spans at most two columns (M >= 320)
+      const double lo0 = lohi_s[col], rg0 = lohi_s[GPBO_MAX_DIM + col];
+      const double lo1 = lohi_s[cn], rg1 = lohi_s[GPBO_MAX_DIM + cn];
+      for (int o = etid; o < cnt; o += 448) {
+        const int i2 = (int)(pos0 + 2 * (t_lo + o) + 1 - v_lo);
+        const unsigned w2 = cur[i2];
+        const unsigned w1 = (i2 > 0) ? cur[i2 - 1] : carry;
+        const unsigned a = mt_temper(w1) >> 5, bb = mt_temper(w2) >> 6;
+        const double u = ((double)a * 67108864.0 + (double)bb) / 9007199254740992.0;
+        double lo_c, rg_c;
+        if (M >= 320) {
+          const bool nextcol = row + o >= M;
+          lo_c = nextcol ? lo1 : lo0;
+          rg_c = nextcol ? rg1 : rg0;
+        } else {
+          const int64_t c = col + (row + o) / M;
+          lo_c = lohi_s[c];
+          rg_c = lohi_s[GPBO_MAX_DIM + c];
+        }
+        out[t_lo + o] = lo_c + rg_c * u;                                      // lo + (hi - lo) * u
+      }
+      row += cnt;
+      if (M >= 320) {
+        if (row >= M) { row -= M; ++col; }
+      } else {
+        col += row / M;
+        row = row % M;
+      }
+    }
+    __syncthreads();
+  }
+  const unsigned* last = buf[n_blocks & 1];
+  for (int k = tid; k < MT_N; k += 512) key_io[k] = last[k];
+}
+
+// stream image S[c][r] (d x M) -> candidate matrix Xc[r][c] (M x d)
+__global__ __launch_bounds__(256) void transpose_stream_kernel(const double* __restrict__ S, int64_t M, int d,
+                                                               double* __restrict__ Xc) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= M) return;
+  for (int c = 0; c < d; ++c) Xc[r * d + c] = S[(int64_t)c * M + r];
+}
+
+}  // namespace gpbo
+
+using namespace gpbo;
+
+extern "C" int gpbo_generate_candidates_mt19937(gpbo_ctx* ctx, int64_t M, int d, const double* lo, const double* hi,
+                                                uint32_t* key, int* pos) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  if (!lo || !hi || !key || !pos || M < 1 || d < 1 || d > GPBO_MAX_DIM || *pos < 0 || *pos > MT_N)
+    GPBO_FAIL(ctx, GPBO_ERR_INVALID, "generate_candidates_mt19937: bad arguments");
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, &ctx->Xc, &ctx->cap_Xc, M * d))) return rc;
+  if ((rc = ensure(ctx, &ctx->stage, &ctx->cap_stage, M * d))) return rc;
+  {
+    char* p = (char*)ctx->red;
+    int64_t cap = ctx->cap_red;
+    if ((rc = ensure(ctx, &p, &cap, (int64_t)2 * GPBO_MAX_DIM * 8 + MT_N * 4 + 4096))) return rc;
+    ctx->red = p;
+    ctx->cap_red = cap;
+  }
+  double* h = (double*)ctx->pinned;                       // [lo | hi - lo | key]
+  for (int t = 0; t < d; ++t) { h[t] = lo[t]; h[GPBO_MAX_DIM + t] = hi[t] - lo[t]; }
+  unsigned* hkey = (unsigned*)(h + 2 * GPBO_MAX_DIM);
+  for (int k = 0; k < MT_N; ++k) hkey[k] = key[k];
+  const size_t head = 2 * GPBO_MAX_DIM * sizeof(double);
+  GPBO_HIP(ctx, hipMemcpyAsync(ctx->red, h, head + MT_N * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
+  unsigned* dkey = (unsigned*)((char*)ctx->red + head);
+  const int64_t T = M * d, words = 2 * T, avail = MT_N - *pos;
+  const int64_t n_blocks = (words > avail) ? (words - avail + MT_N - 1) / MT_N : 0;
+  mt19937_uniform_kernel<<<dim3(1), dim3(512), 0, ctx->stream>>>(dkey, *pos, T, M, d, n_blocks,
+                                                                  (const double*)ctx->red, ctx->stage,
+                                                                  getenv("GPBO_MT_PROBE") ? atoi(getenv("GPBO_MT_PROBE")) : 0);
+  GPBO_HIP(ctx, hipGetLastError());
+  transpose_stream_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->stage, M, d, ctx->Xc);
+  GPBO_HIP(ctx, hipGetLastError());
+  GPBO_HIP(ctx, hipMemcpyAsync(hkey, dkey, MT_N * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < MT_N; ++k) key[k] = hkey[k];
+  *pos = (words <= avail) ? (int)(*pos + words) : (int)((words - avail - 1) % MT_N + 1);
+  ctx->M = M;
+  ctx->d_c = d;
+  for (auto& m : ctx->models) m.M_post = -1;
+  return GPBO_OK;
+}

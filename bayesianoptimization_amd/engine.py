@@ -157,6 +157,27 @@ class GpEngine:
         self.n_candidates = int(M)
         self._cand_dim = lo.shape[0]
 
+    def generate_candidates_like(self, M: int, lo, hi, random_state):
+        """Index-parity mode: what `np.column_stack([random_state.uniform(lo[t], hi[t], M) for t in range(d)])`
+        would be, generated on the device from `random_state`'s MT19937 state; `random_state` (a legacy
+        np.random.RandomState) is advanced exactly as those draws would advance it."""
+        lo = np.ascontiguousarray(lo, dtype=np.float64).ravel()
+        hi = np.ascontiguousarray(hi, dtype=np.float64).ravel()
+        if lo.shape != hi.shape:
+            raise ValueError("lo and hi must have the same length")
+        if not np.all(np.isfinite(hi - lo)):
+            raise OverflowError("Range exceeds valid bounds")        # as RandomState.uniform
+        name, key, pos, has_gauss, cached = random_state.get_state(legacy=True)
+        if name != "MT19937":
+            raise TypeError("generate_candidates_like needs an MT19937 RandomState")
+        key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+        cpos = C.c_int(int(pos))
+        self._check(self._lib.gpbo_generate_candidates_mt19937(
+            self._h, int(M), lo.shape[0], dptr(lo), dptr(hi), key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cpos)))
+        random_state.set_state((name, key, cpos.value, has_gauss, cached))
+        self.n_candidates = int(M)
+        self._cand_dim = lo.shape[0]
+
     def get_candidate_rows(self, idx, d: int):
         idx = np.ascontiguousarray(np.atleast_1d(idx), dtype=np.int64)
         out = np.empty((idx.shape[0], d))

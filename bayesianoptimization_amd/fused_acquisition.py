@@ -187,6 +187,22 @@ def _polish_in_lockstep(acq, x_seeds, box):
     return results
 
 
+def _reference_stream_on_device(chain, space, random_state, n_random) -> bool:
+    """May the device reproduce `space.random_sample(n_random, random_state)`?  Yes when that call is one
+    `random_state.uniform(lo_j, hi_j, n_random)` per column in `space.bounds` order (target_space.py:593-600 with only
+    FloatParameters, parameter.py:86-87) on an MT19937 RandomState, the GPs take the raw coordinates, and the batch
+    is big enough to be worth a launch."""
+    if chain[0].transform is not None or n_random * space.bounds.shape[0] < 4096:
+        return False
+    if not isinstance(random_state, np.random.RandomState) or random_state.get_state()[0] != "MT19937":
+        return False
+    config = getattr(space, "_params_config", None)
+    if config is not None and not all(type(p).__name__ == "FloatParameter" for p in config.values()):
+        return False
+    sampler = getattr(type(space), "random_sample", None)
+    return getattr(sampler, "__module__", None) in ("bayes_opt.target_space", "bayesianoptimization_amd.float_space")
+
+
 def _fused_models(gp, constraint):
     """[target, constraint GPs...] if all are HipGPRs on one engine in slots 0..n, else None."""
     if not isinstance(gp, HipGPR) or gp.slot != 0:
@@ -213,10 +229,15 @@ class AcquisitionFunction(abc.ABC):
     #: with `batched_fd`, advance the L-BFGS-B runs of all seeds together so that each iteration of ALL runs is
     #: one device batch (n_seeds * (d + 1) points) instead of one batch per run (`_Lockstep`)
     lockstep = True
-    #: THROUGHPUT MODE (off by default): draw the random-stage candidates on the device with a Philox generator
-    #: instead of space.random_sample(); removes the host sampling and the upload but is NOT the reference's
-    #: RandomState stream (two 31-bit integers are drawn from it as the device seed), so suggestions differ
-    device_sampling = False
+    #: where the random-stage candidates are drawn when the GPs live on the engine:
+    #:   "auto"    (default) on the device in INDEX-PARITY mode — gpbo_generate_candidates_mt19937 walks the caller's
+    #:             MT19937 RandomState and returns it advanced, so candidates, suggestion and every later draw are
+    #:             bit for bit the reference's — whenever that applies (all-float space without input transform,
+    #:             legacy RandomState, >= 4096 values); otherwise on the host
+    #:   False     always space.random_sample() on the host + upload
+    #:   True      THROUGHPUT MODE: a Philox generator on the device; NOT the reference's stream (two 31-bit integers
+    #:             are drawn from it as the seed), so suggestions differ
+    device_sampling = "auto"
     _acq_kind: int | None = None     # engine acquisition id of the stock policies; None = host formula only
 
     def __init__(self, random_state=None) -> None:
@@ -306,9 +327,12 @@ class AcquisitionFunction(abc.ABC):
         if n_random == 0:
             return None, np.inf, space.random_sample(n_x_seeds, random_state=random_state)
         chain = getattr(self, "_fused", None) if n_x_seeds <= _MAX_DEVICE_SEEDS else None
-        if chain is not None and self.device_sampling and chain[0].transform is None:
+        if chain is not None and self.device_sampling is True and chain[0].transform is None:
             seed = int(random_state.randint(0, 2**31 - 1)) | (int(random_state.randint(0, 2**31 - 1)) << 31)
             return self._device_minimize(chain, space, None, n_x_seeds, n_random=n_random, seed=seed)
+        if chain is not None and self.device_sampling == "auto" and _reference_stream_on_device(chain, space,
+                                                                                               random_state, n_random):
+            return self._device_minimize(chain, space, None, n_x_seeds, n_random=n_random, stream=random_state)
         x_tries = space.random_sample(n_random, random_state=random_state)
         if chain is not None:
             return self._device_minimize(chain, space, x_tries, n_x_seeds)
@@ -316,12 +340,15 @@ class AcquisitionFunction(abc.ABC):
         seeds = x_tries[np.argsort(values)[:n_x_seeds]] if n_x_seeds != 0 else []
         return x_tries[values.argmin()], values.min(), seeds
 
-    def _device_minimize(self, models, space, x_tries, n_x_seeds, n_random=None, seed=None):
+    def _device_minimize(self, models, space, x_tries, n_x_seeds, n_random=None, seed=None, stream=None):
         """The body of the random stage after sampling, on the GPU (kernels K5-K8 of SURVEY.md §2.1).
-        x_tries=None: the candidates are generated on the device too (device_sampling)."""
+        x_tries=None: the candidates are generated on the device too — from `stream`'s MT19937 state (the
+        reference's candidates) or, with `seed`, by the Philox throughput generator."""
         target = models[0]
         eng = target._engine()
-        if x_tries is None:
+        if x_tries is None and stream is not None:
+            eng.generate_candidates_like(n_random, space.bounds[:, 0], space.bounds[:, 1], stream)
+        elif x_tries is None:
             eng.generate_candidates(n_random, space.bounds[:, 0], space.bounds[:, 1], seed)
         else:
             eng.set_candidates(target._tx(x_tries))

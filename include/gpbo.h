@@ -115,6 +115,13 @@ int gpbo_set_candidates(gpbo_ctx* ctx, const double* Xc, int64_t M, int d);
  * TargetSpace.random_sample + upload (target_space.py:565-603).  Index parity with the reference needs the
  * host RandomState stream (gpbo_set_candidates); this entry point removes the host sampling and the H2D copy. */
 int gpbo_generate_candidates(gpbo_ctx* ctx, int64_t M, int d, const double* lo, const double* hi, uint64_t seed);
+/* Index-parity mode: the SAME matrix TargetSpace.random_sample would return for an all-float space — column t =
+ * random_state.uniform(lo[t], hi[t], M) in key order (target_space.py:593-600, parameter.py:86-87) — generated on
+ * the device from the caller's MT19937 state (key[624], *pos as in RandomState.get_state()) and left resident; key
+ * and *pos come back advanced by the 2*M*d outputs consumed, so RandomState.set_state() continues the reference's
+ * stream.  Removes the host sampling and the upload without changing a single candidate. */
+int gpbo_generate_candidates_mt19937(gpbo_ctx* ctx, int64_t M, int d, const double* lo, const double* hi,
+                                     uint32_t* key, int* pos);
 /* Copy n rows (by index) of the resident candidate matrix back to the host (x_min and the seeds,
  * bayes_opt/acquisition.py:313-317); out is (n, d) row-major; out-of-range indices give NaN rows. */
 int gpbo_get_candidate_rows(gpbo_ctx* ctx, const int64_t* idx, int n, double* out);

@@ -39,6 +39,19 @@ for name in ("C2", "C3"):
             x = fn.suggest(gp, sp, n_random=w.M, n_smart=n_smart, fit_gp=True, random_state=np.random.RandomState(7))
             ts.append((time.perf_counter() - t0) * 1e3)
         r[f"suggest_fixed_theta_nsmart{n_smart}_ms"] = ts
+    fn.device_sampling = False   # host random_sample + upload (the path before the MT19937 device generator)
+    for n_smart in (0, 10):
+        ts = []
+        for rep in range(3):
+            t0 = time.perf_counter()
+            x_host = fn.suggest(gp, sp, n_random=w.M, n_smart=n_smart, fit_gp=True, random_state=np.random.RandomState(7))
+            ts.append((time.perf_counter() - t0) * 1e3)
+        r[f"suggest_host_sampling_nsmart{n_smart}_ms"] = ts
+    r["device_stream_equals_host_stream"] = bool(np.array_equal(x, x_host))
+    fn.device_sampling = "auto"
+    t0 = time.perf_counter()
+    eng.generate_candidates_like(w.M, sp.bounds[:, 0], sp.bounds[:, 1], np.random.RandomState(7))
+    r["device_mt19937_generation_ms"] = (time.perf_counter() - t0) * 1e3
     fn.lockstep = False          # one L-BFGS-B run after another (round-1 behaviour before the lockstep hub)
     ts = []
     for rep in range(3):
@@ -56,7 +69,7 @@ for name in ("C2", "C3"):
             x = fn.suggest(gp, sp, n_random=w.M, n_smart=n_smart, fit_gp=True, random_state=np.random.RandomState(7))
             ts.append((time.perf_counter() - t0) * 1e3)
         r[f"suggest_device_sampling_nsmart{n_smart}_ms"] = ts
-    fn.device_sampling = False
+    fn.device_sampling = "auto"
     # single-point predict latency (what L-BFGS-B's finite differences call)
     xs = sp.random_sample(64, np.random.RandomState(1))
     t0 = time.perf_counter()

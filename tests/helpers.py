@@ -97,6 +97,18 @@ class FakeEngine:
         self.n_candidates = self.Xc.shape[0]
         self.post = {}
 
+    def generate_candidates_like(self, M, lo, hi, random_state):
+        """What the device's index-parity generator returns: the reference's per-column draws (the kernel's block
+        walk itself is checked against NumPy in test_mt19937_block_walk_reproduces_randomstate_uniform)."""
+        self.calls.append(("generate_candidates_like", M))
+        self.Xc = np.column_stack([random_state.uniform(lo[t], hi[t], M) for t in range(len(lo))])
+        self.n_candidates = M
+        self.post = {}
+
+    def get_candidate_rows(self, idx, d):
+        idx = np.atleast_1d(np.asarray(idx, dtype=np.int64))
+        return self.Xc[idx]
+
     def posterior(self, slot=0, y_mean=0.0, y_std=1.0, fetch=True):
         self.calls.append(("posterior", slot))
         mu, sd = O.predict(self.models[slot], self.Xc)
@@ -156,3 +168,60 @@ def philox4x32_10_uniform(M, d, lo, hi, seed):
     u = u[:total].reshape(M, d)
     lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
     return lo + (hi - lo) * u
+
+
+def mt19937_device_mirror(key, pos0, M, d, lo, hi):
+    """Line-by-line NumPy mirror of mt19937_uniform_kernel (csrc/mt19937.hip): same block walk, same pairing of
+    words across block boundaries, same (row, col) bookkeeping.  Returns (Xc, key', pos').  Tests only."""
+    N_, M_ = 624, 397
+    key = np.array(key, dtype=np.uint32)
+    T = M * d
+    words, avail = 2 * T, N_ - pos0
+    n_blocks = (words - avail + N_ - 1) // N_ if words > avail else 0
+    Xc = np.full((M, d), np.nan)
+    rng_ = np.asarray(hi, dtype=np.float64) - np.asarray(lo, dtype=np.float64)
+
+    def twist(cur, nxt, far):
+        y = (cur & np.uint32(0x80000000)) | (nxt & np.uint32(0x7FFFFFFF))
+        return far ^ (y >> np.uint32(1)) ^ np.where(y & np.uint32(1), np.uint32(0x9908B0DF), np.uint32(0))
+
+    def temper(y):
+        y = y ^ (y >> np.uint32(11))
+        y = y ^ ((y << np.uint32(7)) & np.uint32(0x9D2C5680))
+        y = y ^ ((y << np.uint32(15)) & np.uint32(0xEFC60000))
+        return y ^ (y >> np.uint32(18))
+
+    buf = [key.copy(), np.zeros(N_, dtype=np.uint32)]
+    row = col = 0
+    for b in range(n_blocks + 1):
+        cur, prev = buf[b & 1], buf[(b & 1) ^ 1]
+        if b > 0:
+            k = np.arange(0, 227)
+            cur[k] = twist(prev[k], prev[k + 1], prev[k + M_])
+            k = np.arange(227, 454)
+            cur[k] = twist(prev[k], prev[k + 1], cur[k - 227])
+            k = np.arange(454, 624)
+            nxt = np.where(k == 623, cur[0], prev[np.minimum(k + 1, 623)])
+            cur[k] = twist(prev[k], nxt, cur[k - 227])
+        v_lo, v_hi = N_ * b, N_ * b + N_
+        t_lo = (v_lo - pos0) // 2 if v_lo - pos0 - 1 >= 0 else 0
+        t_hi = min(T, (v_hi - pos0 - 2) // 2 + 1 if v_hi - pos0 - 2 >= 0 else 0)
+        cnt = max(0, t_hi - t_lo)
+        if cnt:
+            o = np.arange(cnt)
+            t = t_lo + o
+            i2 = pos0 + 2 * t + 1 - v_lo
+            w2 = cur[i2]
+            w1 = np.where(i2 > 0, cur[np.maximum(i2 - 1, 0)], prev[623])
+            a = (temper(w1) >> np.uint32(5)).astype(np.float64)
+            bb = (temper(w2) >> np.uint32(6)).astype(np.float64)
+            u = (a * 67108864.0 + bb) / 9007199254740992.0
+            r = row + o
+            c = col + r // M
+            r = r % M
+            Xc[r, c] = np.asarray(lo)[c] + rng_[c] * u
+        row += cnt
+        col += row // M
+        row %= M
+    pos = pos0 + words if words <= avail else (words - avail - 1) % N_ + 1
+    return Xc, buf[n_blocks & 1].copy(), pos

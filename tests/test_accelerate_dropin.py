@@ -58,16 +58,17 @@ def test_maximize_trajectory_equals_reference_random_stage():
         o.maximize(init_points=3, n_iter=0)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        for _ in range(3):
-            xr = ref._acquisition_function.suggest(ref._gp, ref._space, n_random=2000, n_smart=0, fit_gp=True,
+        for n_random in (2000, 3000, 2500):     # 2 columns: 3000 and 2500 rows take the device-stream branch
+            xr = ref._acquisition_function.suggest(ref._gp, ref._space, n_random=n_random, n_smart=0, fit_gp=True,
                                                    random_state=ref._random_state)
-            xm = mine._acquisition_function.suggest(mine._gp, mine._space, n_random=2000, n_smart=0, fit_gp=True,
+            xm = mine._acquisition_function.suggest(mine._gp, mine._space, n_random=n_random, n_smart=0, fit_gp=True,
                                                     random_state=mine._random_state)
             assert np.array_equal(xr, xm)
             assert np.array_equal(ref._gp.kernel_.theta, mine._gp.kernel_.theta)
             for o, x in ((ref, xr), (mine, xm)):
                 o.probe(o._space.array_to_params(x), lazy=False)
     assert ref._random_state.uniform() == mine._random_state.uniform()
+    assert [c[1] for c in eng.calls if c[0] == "generate_candidates_like"] == [3000, 2500]
     kinds = [c[0] for c in eng.calls]
     assert "acq_argbest" in kinds and "posterior" in kinds        # the fused path was taken
 

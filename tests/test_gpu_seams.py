@@ -277,3 +277,39 @@ def test_incremental_refit_in_a_maximize_loop(engine):
         assert calls.count("fit") == (1 if incremental else 70)
         assert calls.count("append") == (69 if incremental else 0)
     assert np.array_equal(picks[True], picks[False])
+
+
+@pytest.mark.parametrize("M,d,burn", [(1, 1, 0), (311, 2, 1), (313, 3, 623), (5000, 7, 0), (70000, 16, 12345), (100, 64, 7)])
+def test_device_candidates_are_the_reference_stream(engine, M, d, burn):
+    """gpbo_generate_candidates_mt19937: the resident candidate matrix equals, bit for bit, the per-column
+    RandomState.uniform draws of TargetSpace.random_sample (target_space.py:593-600) from any stream position, and the
+    RandomState handed back continues the reference's stream."""
+    lo = np.linspace(-3.7, 2.0, d)
+    hi = lo + np.linspace(0.5, 11.3, d)
+    ref, dev = np.random.RandomState(42), np.random.RandomState(42)
+    for r in (ref, dev):
+        if burn:
+            r.randint(0, 2**31 - 1, size=burn)
+    want = np.column_stack([ref.uniform(lo[t], hi[t], M) for t in range(d)])
+    engine.generate_candidates_like(M, lo, hi, dev)
+    idx = np.unique(np.concatenate([np.arange(0, M, max(1, M // 1500)), [M - 1]]))
+    assert np.array_equal(engine.get_candidate_rows(idx, d), want[idx])
+    assert np.array_equal(dev.uniform(size=700), ref.uniform(size=700))
+    assert dev.standard_normal() == ref.standard_normal()
+
+
+def test_suggest_with_device_stream_is_the_host_stream_suggest(engine):
+    """device_sampling="auto" (candidates generated on the device from the caller's RandomState) and False (host
+    random_sample + upload) give the same suggestion and leave the RandomState at the same position."""
+    w = W.C2
+    sp = _space(w)
+    out = {}
+    for mode in ("auto", False):
+        gp = HipGPR(kernel=Matern(nu=2.5, length_scale=w.length_scale), alpha=w.noise, normalize_y=True,
+                    optimizer=None, engine=engine)
+        fn = A.UpperConfidenceBound(kappa=2.576)
+        fn.device_sampling = mode
+        rs = np.random.RandomState(11)
+        x = fn.suggest(gp, sp, n_random=30000, n_smart=4, random_state=rs)
+        out[mode] = (x, rs.uniform())
+    assert np.array_equal(out["auto"][0], out[False][0]) and out["auto"][1] == out[False][1]

@@ -254,3 +254,25 @@ def test_lockstep_runs_are_the_sequential_runs():
     calls.clear()
     with pytest.raises(FloatingPointError):
         _polish_in_lockstep(broken, seeds, bounds)
+
+
+@pytest.mark.parametrize("M,d,burn", [(1, 1, 0), (5, 3, 0), (311, 2, 1), (312, 2, 7), (313, 1, 623), (1000, 4, 624),
+                                      (2000, 16, 12345)])
+def test_mt19937_block_walk_reproduces_randomstate_uniform(M, d, burn):
+    """The block walk of csrc/mt19937.hip (mirrored in NumPy): bit-identical candidates to the reference's
+    per-column RandomState.uniform draws from any starting position (even/odd, fresh, mid-block), and the state
+    handed back continues the stream."""
+    from helpers import mt19937_device_mirror
+
+    lo = np.linspace(-3.7, 2.0, d)
+    hi = lo + np.linspace(0.5, 11.3, d)
+    ref = np.random.RandomState(42)
+    if burn:
+        ref.randint(0, 2**31 - 1, size=burn)         # one 32-bit output each: odd burn -> odd position
+    _, key, pos, hg, cg = ref.get_state()
+    Xc, key2, pos2 = mt19937_device_mirror(key, pos, M, d, lo, hi)
+    want = np.column_stack([ref.uniform(lo[t], hi[t], M) for t in range(d)])
+    assert np.array_equal(Xc, want)
+    cont = np.random.RandomState(0)
+    cont.set_state(("MT19937", key2, pos2, hg, cg))
+    assert np.array_equal(cont.uniform(size=700), ref.uniform(size=700))
