@@ -15,9 +15,9 @@
 // MT19937 is a 624-word shift register with taps 0, 1 and 397: word k of the next block needs words at least 227
 // positions back, so a block regenerates in three data-parallel phases (k < 227, 227 <= k < 454, k >= 454).  The chain
 // over blocks is sequential — ONE workgroup walks it, double-buffered in LDS (the previous block stays readable while
-// the next is written): wave 0 regenerates (the three phases chained through registers, see the kernel), waves
-// 1..7 meanwhile temper the previous block's words into doubles and store them (312 per block); one workgroup
-// barrier per block.  The kernel is latency-bound by construction (53 k dependent blocks for 2^20 x 16 candidates).
+// later ones are written): wave 0 regenerates (the three phases chained through registers, see mt_regenerate), waves
+// 1..7 meanwhile temper the previous group's words into doubles and store them (312 per block); one workgroup
+// barrier per group of four blocks.  The kernel is latency-bound by construction (53 k dependent blocks for 2^20 x 16 candidates).
 #include <cstdint>
 
 #include "gpbo_internal.h"
@@ -39,94 +39,123 @@ __device__ __forceinline__ unsigned mt_temper(unsigned y) {
   return y;
 }
 
+// Ordering of ONE wave's LDS traffic across its lanes: DS operations of a wave execute in issue order, so the hardware
+// needs nothing; the fences only stop the compiler from moving a lane's loads above the previous block's stores.
+#define GPBO_WAVE_SYNC()                                   \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+constexpr int MT_RING = 16;    // block buffers in LDS (power of two; the previous group and the last block before it stay readable)
+constexpr int MT_GROUP = 4;    // blocks regenerated (wave 0) / emitted (waves 1..7) between two workgroup barriers
+
+// Block `from` -> block `to` (both 624 words in LDS), by one wave.  Lane l owns words l + 64 s of each phase, so the
+// far tap of phase B (word k - 227) is the word the SAME lane produced in phase A, and phase C's is its phase-B word:
+// the three phases chain through registers and only the previous block is read from LDS — all loads first, one LDS
+// round trip per block.
+__device__ __forceinline__ void mt_regenerate(const unsigned* __restrict__ cur, unsigned* __restrict__ nxt, int lane) {
+  constexpr int LAG = MT_N - MT_M;      // 227
+  unsigned a0[4], a1[4], af[4], b0[4], b1[4], c0[3], c1[3];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int k = min(lane + 64 * s, LAG - 1);
+    a0[s] = cur[k]; a1[s] = cur[k + 1]; af[s] = cur[k + MT_M];
+    b0[s] = cur[LAG + k]; b1[s] = cur[LAG + k + 1];
+  }
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const int k = min(2 * LAG + lane + 64 * s, MT_N - 1);
+    c0[s] = cur[k]; c1[s] = cur[min(k + 1, MT_N - 1)];
+  }
+  unsigned vA[4], vB[4], vC[3];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    vA[s] = mt_twist(a0[s], a1[s], af[s]);     // k in [0, 227): all taps in the previous block
+    vB[s] = mt_twist(b0[s], b1[s], vA[s]);     // k in [227, 454): far tap = new word k - 227
+  }
+  const unsigned first = __builtin_amdgcn_readlane(vA[0], 0);   // the last word's "next" is new word 0
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const bool is_last = 2 * LAG + lane + 64 * s == MT_N - 1;
+    vC[s] = mt_twist(c0[s], is_last ? first : c1[s], vB[s]);   // k in [454, 624): far tap = new word k - 227
+  }
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    nxt[lane + 64 * s] = vA[s];
+    nxt[LAG + lane + 64 * s] = vB[s];
+  }
+  if (lane + 192 < LAG) {
+    nxt[lane + 192] = vA[3];
+    nxt[LAG + lane + 192] = vB[3];
+  }
+  nxt[2 * LAG + lane] = vC[0];
+  nxt[2 * LAG + lane + 64] = vC[1];
+  if (2 * LAG + lane + 128 < MT_N) nxt[2 * LAG + lane + 128] = vC[2];
+}
+
 // key_io: 624 state words (in: the caller's state, out: the last block touched); pos0: words of key_io already
 // consumed (0..624); T = M * d doubles written in STREAM order (out[t], i.e. the column-major [d][M] image of the
 // candidate matrix: coalesced stores; transpose_stream_kernel turns it into the row-major matrix afterwards);
-// n_blocks = regenerations needed.
-// Wave 0 regenerates block b + 1 while waves 1..7 temper and store
-// the doubles of block b; one workgroup barrier per block.
+// n_blocks = regenerations needed.  Block b lives in ring slot b % 16; per step wave 0 regenerates the next group of
+// four blocks while waves 1..7 temper and store the doubles of the previous group; one workgroup barrier per step.
 __global__ __launch_bounds__(512) void mt19937_uniform_kernel(unsigned* __restrict__ key_io, int pos0, int64_t T,
                                                               int64_t M, int d, int64_t n_blocks,
                                                               const double* __restrict__ lohi, double* __restrict__ out,
                                                               int skip) {   // skip: 1 = no emission, 2 = no regeneration (timing probes)
-  __shared__ unsigned buf[2][MT_N];
+  __shared__ unsigned ring[MT_RING][MT_N];
   __shared__ double lohi_s[2 * GPBO_MAX_DIM];
-  __shared__ unsigned before[2];        // before[b & 1] = last word of block b - 1 (pairs that straddle two blocks)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const bool generator = tid < 64;
   const int etid = tid - 64;            // 0..447 for the emitting waves: one double each per block (<= 312)
-  constexpr int LAG = MT_N - MT_M;      // 227
-  for (int k = tid; k < MT_N; k += 512) buf[0][k] = key_io[k];
-  if (tid == 0) before[0] = 0u;
+  for (int k = tid; k < MT_N; k += 512) ring[0][k] = key_io[k];
   if (tid < 2 * GPBO_MAX_DIM) lohi_s[tid] = lohi[tid];
   __syncthreads();
-  int64_t col = 0, row = 0;        // position of the first double of the current block (uniform across lanes)
-  for (int64_t b = 0; b <= n_blocks; ++b) {
-    const unsigned* cur = buf[b & 1];
+  int64_t col = 0, row = 0;        // position of the first double of the next block to emit (uniform across lanes)
+  const int64_t n_steps = (n_blocks + MT_GROUP - 1) / MT_GROUP;
+  for (int64_t step = 0; step <= n_steps; ++step) {
     if (generator) {
-      if (b < n_blocks && !(skip & 2)) {
-        unsigned* nxt = buf[(b & 1) ^ 1];
-        if (lane == 0) before[(b & 1) ^ 1] = cur[MT_N - 1];
-        // Lane l owns words l + 64 s of each phase, so the far tap of phase B (word k - 227) is the word the SAME lane
-        // produced in phase A, and phase C's is its phase-B word: the three phases chain through registers.  Only
-        // the previous block is read from LDS — all loads first, one LDS round trip per block.
-        unsigned a0[4], a1[4], af[4], b0[4], b1[4], c0[3], c1[3];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int k = min(lane + 64 * s, LAG - 1);
-          a0[s] = cur[k]; a1[s] = cur[k + 1]; af[s] = cur[k + MT_M];
-          b0[s] = cur[LAG + k]; b1[s] = cur[LAG + k + 1];
+      if (!(skip & 2)) {
+        for (int j = 1; j <= MT_GROUP; ++j) {
+          const int64_t b = step * MT_GROUP + j;          // block to produce, from block b - 1
+          if (b > n_blocks) break;
+          mt_regenerate(ring[(b - 1) % MT_RING], ring[b % MT_RING], lane);
+          GPBO_WAVE_SYNC();
         }
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const int k = min(2 * LAG + lane + 64 * s, MT_N - 1);
-          c0[s] = cur[k]; c1[s] = cur[min(k + 1, MT_N - 1)];
-        }
-        unsigned vA[4], vB[4], vC[3];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          vA[s] = mt_twist(a0[s], a1[s], af[s]);     // k in [0, 227): all taps in the previous block
-          vB[s] = mt_twist(b0[s], b1[s], vA[s]);     // k in [227, 454): far tap = new word k - 227
-        }
-        const unsigned first = __builtin_amdgcn_readlane(vA[0], 0);   // the last word's "next" is new word 0
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const bool is_last = 2 * LAG + lane + 64 * s == MT_N - 1;
-          vC[s] = mt_twist(c0[s], is_last ? first : c1[s], vB[s]);   // k in [454, 624): far tap = new word k - 227
-        }
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          nxt[lane + 64 * s] = vA[s];
-          nxt[LAG + lane + 64 * s] = vB[s];
-        }
-        if (lane + 192 < LAG) {
-          nxt[lane + 192] = vA[3];
-          nxt[LAG + lane + 192] = vB[3];
-        }
-        nxt[2 * LAG + lane] = vC[0];
-        nxt[2 * LAG + lane + 64] = vC[1];
-        if (2 * LAG + lane + 128 < MT_N) nxt[2 * LAG + lane + 128] = vC[2];
       }
     } else if (!(skip & 1)) {
-      // doubles whose SECOND word lies in block b: virtual word index v = pos0 + n, second word v2 = pos0 + 2t + 1
-      const int64_t v_lo = (int64_t)MT_N * b, v_hi = v_lo + MT_N;            // [v_lo, v_hi)
-      const int64_t t_lo = (v_lo - pos0 - 1 >= 0) ? (v_lo - pos0) / 2 : 0;   // ceil((v_lo - pos0 - 1) / 2)
-      int64_t t_hi = (v_hi - pos0 - 2 >= 0) ? (v_hi - pos0 - 2) / 2 + 1 : 0; // exclusive
+      // Doubles whose SECOND word lies in the previous group of blocks (block 0, the caller's state, in the first
+      // step).  Their stream indices t are contiguous, so the emitting lanes simply split [t_lo, t_hi); a double's
+      // two words sit at virtual positions v1 = pos0 + 2t and v1 + 1, located in the ring relative to b_first.
+      const int64_t b_first = (step == 0) ? 0 : (step - 1) * MT_GROUP + 1;
+      const int64_t b_last = (step == 0) ? 0 : min(n_blocks, (step - 1) * MT_GROUP + MT_GROUP);
+      const int64_t v_lo = (int64_t)MT_N * b_first, v_hi = (int64_t)MT_N * (b_last + 1);   // [v_lo, v_hi)
+      const int64_t t_lo = (v_lo - pos0 - 1 >= 0) ? (v_lo - pos0) / 2 : 0;                 // ceil((v_lo - pos0 - 1) / 2)
+      int64_t t_hi = (v_hi - pos0 - 2 >= 0) ? (v_hi - pos0 - 2) / 2 + 1 : 0;               // exclusive
       if (t_hi > T) t_hi = T;
-      const int cnt = (t_hi > t_lo) ? (int)(t_hi - t_lo) : 0;                // <= 312
-      const unsigned carry = before[b & 1];
-      const int cn = (col + 1 < d) ? (int)col + 1 : (int)col;               // a block spans at most two columns (M >= 320)
+      const int cnt = (t_hi > t_lo) ? (int)(t_hi - t_lo) : 0;                              // <= 4 * 312 + 1
+      const int rel0 = (int)(pos0 + 2 * t_lo - v_lo);                                      // first word of double t_lo: >= -1
+      const int slot0 = (int)(b_first & (MT_RING - 1));
+      const int cn = (col + 1 < d) ? (int)col + 1 : (int)col;      // a group spans at most two columns when M >= 1280
       const double lo0 = lohi_s[col], rg0 = lohi_s[GPBO_MAX_DIM + col];
       const double lo1 = lohi_s[cn], rg1 = lohi_s[GPBO_MAX_DIM + cn];
       for (int o = etid; o < cnt; o += 448) {
-        const int i2 = (int)(pos0 + 2 * (t_lo + o) + 1 - v_lo);
-        const unsigned w2 = cur[i2];
-        const unsigned w1 = (i2 > 0) ? cur[i2 - 1] : carry;
+        const int rel1 = rel0 + 2 * o, rel2 = rel1 + 1;
+        const int q2 = rel2 / MT_N;
+        const unsigned w2 = ring[(slot0 + q2) & (MT_RING - 1)][rel2 - q2 * MT_N];
+        unsigned w1;
+        if (rel1 < 0) {
+          w1 = ring[(slot0 + MT_RING - 1) & (MT_RING - 1)][MT_N - 1];
+        } else {
+          const int q1 = rel1 / MT_N;
+          w1 = ring[(slot0 + q1) & (MT_RING - 1)][rel1 - q1 * MT_N];
+        }
         const unsigned a = mt_temper(w1) >> 5, bb = mt_temper(w2) >> 6;
         const double u = ((double)a * 67108864.0 + (double)bb) / 9007199254740992.0;
         double lo_c, rg_c;
-        if (M >= 320) {
+        if (M >= 1280) {
           const bool nextcol = row + o >= M;
           lo_c = nextcol ? lo1 : lo0;
           rg_c = nextcol ? rg1 : rg0;
@@ -138,7 +167,7 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(unsigned* __restri
         out[t_lo + o] = lo_c + rg_c * u;                                      // lo + (hi - lo) * u
       }
       row += cnt;
-      if (M >= 320) {
+      if (M >= 1280) {
         if (row >= M) { row -= M; ++col; }
       } else {
         col += row / M;
@@ -147,7 +176,7 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(unsigned* __restri
     }
     __syncthreads();
   }
-  const unsigned* last = buf[n_blocks & 1];
+  const unsigned* last = ring[n_blocks % MT_RING];
   for (int k = tid; k < MT_N; k += 512) key_io[k] = last[k];
 }
 

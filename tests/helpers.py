@@ -171,7 +171,7 @@ def philox4x32_10_uniform(M, d, lo, hi, seed):
 
 
 def mt19937_device_mirror(key, pos0, M, d, lo, hi):
-    """Line-by-line NumPy mirror of mt19937_uniform_kernel (csrc/mt19937.hip): same block walk, same pairing of
+    """NumPy mirror of mt19937_uniform_kernel (csrc/mt19937.hip): same three-phase block walk, same pairing of
     words across block boundaries, same (row, col) bookkeeping.  Returns (Xc, key', pos').  Tests only."""
     N_, M_ = 624, 397
     key = np.array(key, dtype=np.uint32)
