@@ -60,7 +60,8 @@ for name in ("C2", "C3"):
         ts.append((time.perf_counter() - t0) * 1e3)
     r["suggest_fixed_theta_nsmart10_sequential_runs_ms"] = ts
     fn.lockstep = True
-    r["lockstep_equals_sequential"] = bool(np.array_equal(x, x_seq))
+    # bitwise only when one small-batch path is pinned (GPBO_SMALL_MAX); across the GEMV/MFMA switch: to rounding
+    r["lockstep_vs_sequential_max_abs_diff"] = float(np.max(np.abs(x - x_seq)))
     fn.device_sampling = True   # throughput mode: Philox candidates generated on the device (non-parity)
     for n_smart in (0, 10):
         ts = []
