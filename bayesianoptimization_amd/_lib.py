@@ -38,6 +38,8 @@ SIGNATURES = {
                                   C.POINTER(C.c_int)]),
     "gpbo_lml": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, C.c_int64, C.c_int, C.c_int, _c_double_p,
                            C.c_int, C.c_double, C.c_int, _c_double_p, _c_double_p, C.POINTER(C.c_int)]),
+    "gpbo_lml_batch": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, C.c_int64, C.c_int, C.c_int, _c_double_p,
+                                 C.c_int, C.c_double, C.c_int, _c_double_p, _c_double_p, C.POINTER(C.c_int)]),
     "gpbo_get_K": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
     "gpbo_get_L": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
     "gpbo_get_Linv": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),

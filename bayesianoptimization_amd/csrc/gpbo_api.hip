@@ -187,6 +187,9 @@ int gpbo_destroy(gpbo_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   gpbo_comm_destroy(ctx);
   for (auto& m : ctx->models) free_model(m);
+  for (auto& m : ctx->lml_model) free_model(m);
+  for (auto& st : ctx->lml_stream) if (st) (void)hipStreamDestroy(st);
+  for (auto& p : ctx->lml_scratch) if (p) (void)hipFree(p);
   void* ptrs[] = {ctx->Xc, ctx->Xcs, ctx->part, ctx->mu_part, ctx->ys, ctx->red, ctx->info_dev, ctx->comm_buf, ctx->kst, ctx->stage};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -245,11 +248,10 @@ static int factor_resident(gpbo_ctx* ctx, Model& m, double noise, int** info_hos
   return GPBO_OK;
 }
 
-static int factorize(gpbo_ctx* ctx, int slot, const char* who, const double* X, const double* y_norm, int64_t N,
+static int factorize(gpbo_ctx* ctx, Model& m, const char* who, const double* X, const double* y_norm, int64_t N,
                      int d, int kernel, const double* length_scale, int n_ls, double noise, int precision,
                      int** info_host) {
-  int rc = check_slot(ctx, slot);
-  if (rc) return rc;
+  int rc;
   std::string w(who);
   if (!X || !y_norm || !length_scale) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": NULL input");
   if (N < 1 || N > (1 << 16)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": N out of range [1, 65536]");
@@ -264,7 +266,6 @@ static int factorize(gpbo_ctx* ctx, int slot, const char* who, const double* X, 
   if (!(noise >= 0.0)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": noise must be >= 0");
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
 
-  Model& m = ctx->models[slot];
   m.fitted = false;
   m.M_post = -1;
   const int64_t NP = round_up(N, NB);
@@ -308,7 +309,9 @@ int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int
              int* info) {
   if (info) *info = 0;
   int* info_h = nullptr;
-  int rc = factorize(ctx, slot, "gpbo_fit", X, y_norm, N, d, kernel, length_scale, n_ls, noise, precision, &info_h);
+  int rc = check_slot(ctx, slot);
+  if (rc) return rc;
+  rc = factorize(ctx, ctx->models[slot], "gpbo_fit", X, y_norm, N, d, kernel, length_scale, n_ls, noise, precision, &info_h);
   if (rc) return rc;
   return finish_fit(ctx, ctx->models[slot], info_h, info);
 }
@@ -371,15 +374,13 @@ int gpbo_fit_append(gpbo_ctx* ctx, int slot, const double* x_new, int64_t n_new,
   return finish_fit(ctx, m, info_h, info);
 }
 
-int gpbo_lml(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d,
-             int kernel, const double* length_scale, int n_ls, double noise, int eval_gradient,
-             double* lml, double* grad, int* info) {
-  if (info) *info = 0;
-  if (!lml || (eval_gradient && !grad)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml: NULL output");
-  int* info_h = nullptr;
-  int rc = factorize(ctx, slot, "gpbo_lml", X, y_norm, N, d, kernel, length_scale, n_ls, noise, GPBO_F64, &info_h);
+// One log-marginal-likelihood evaluation enqueued on ctx->stream into model m; results land in the pinned words
+// *out_host (yT alpha, sum log L_ii, gradient...) and *info_host once the stream has drained.
+static int lml_enqueue(gpbo_ctx* ctx, Model& m, const double* X, const double* y_norm, int64_t N, int d, int kernel,
+                       const double* length_scale, int n_ls, double noise, int eval_gradient, double** out_host,
+                       int** info_host) {
+  int rc = factorize(ctx, m, "gpbo_lml", X, y_norm, N, d, kernel, length_scale, n_ls, noise, GPBO_F64, info_host);
   if (rc) return rc;
-  Model& m = ctx->models[slot];   // left "unfitted": its W is not packed for the posterior kernel
   // device scratch for the scalars: red buffer (>= 2 + n_ls doubles)
   {
     char* p = (char*)ctx->red;
@@ -404,15 +405,81 @@ int gpbo_lml(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int
   double* out_h = (double*)((char*)ctx->pinned + 2048);
   GPBO_HIP(ctx, hipMemcpyAsync(out_h, scal, (size_t)(2 + (eval_gradient ? n_ls : 0)) * sizeof(double),
                                hipMemcpyDeviceToHost, ctx->stream));
-  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out_host = out_h;
+  return GPBO_OK;
+}
+
+static void lml_finish(const double* out_h, const int* info_h, int64_t N, int n_ls, int eval_gradient, double* lml,
+                       double* grad, int* info) {
   if (*info_h != 0) {  // sklearn returns -inf and a zero gradient when K is not PD (_gpr.py:588-589)
     if (info) *info = *info_h;
     *lml = -INFINITY;
     if (eval_gradient) for (int t = 0; t < n_ls; ++t) grad[t] = 0.0;
-    return GPBO_OK;
+    return;
   }
   *lml = -0.5 * out_h[0] - out_h[1] - 0.5 * (double)N * 1.83787706640934548356;  // log(2 pi)
   if (eval_gradient) for (int t = 0; t < n_ls; ++t) grad[t] = out_h[2 + t];
+}
+
+int gpbo_lml(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d,
+             int kernel, const double* length_scale, int n_ls, double noise, int eval_gradient,
+             double* lml, double* grad, int* info) {
+  if (info) *info = 0;
+  if (!lml || (eval_gradient && !grad)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml: NULL output");
+  int rc = check_slot(ctx, slot);
+  if (rc) return rc;
+  int* info_h = nullptr;
+  double* out_h = nullptr;
+  // the slot is left "unfitted": its W is not packed for the posterior kernel
+  rc = lml_enqueue(ctx, ctx->models[slot], X, y_norm, N, d, kernel, length_scale, n_ls, noise, eval_gradient, &out_h, &info_h);
+  if (rc) return rc;
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  lml_finish(out_h, info_h, N, n_ls, eval_gradient, lml, grad, info);
+  return GPBO_OK;
+}
+
+int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_norm, int64_t N, int d, int kernel,
+                   const double* length_scales, int n_ls, double noise, int eval_gradient, double* lml, double* grad,
+                   int* info) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  if (n_theta < 1 || n_theta > GPBO_LML_BATCH_MAX) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: n_theta out of range [1, 8]");
+  if (!lml || !length_scales || (eval_gradient && !grad)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: NULL argument");
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  for (int i = 0; i < n_theta; ++i) {
+    if (!ctx->lml_stream[i]) GPBO_HIP(ctx, hipStreamCreateWithFlags(&ctx->lml_stream[i], hipStreamNonBlocking));
+    if (!ctx->lml_scratch[i]) GPBO_HIP(ctx, hipMalloc(&ctx->lml_scratch[i], 4096));
+  }
+  // every evaluation on its own stream, scratch model and scratch words; the engine stream and slots are untouched
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  hipStream_t stream0 = ctx->stream;
+  void* red0 = ctx->red; int64_t cap_red0 = ctx->cap_red;
+  int* info0 = ctx->info_dev;
+  void* pinned0 = ctx->pinned;
+  double* out_h[GPBO_LML_BATCH_MAX];
+  int* info_h[GPBO_LML_BATCH_MAX];
+  int rc = GPBO_OK;
+  ctx->no_timing = true;
+  for (int i = 0; i < n_theta && rc == GPBO_OK; ++i) {
+    ctx->stream = ctx->lml_stream[i];
+    ctx->red = (char*)ctx->lml_scratch[i] + 64;
+    ctx->cap_red = 4096 - 64;
+    ctx->info_dev = (int*)ctx->lml_scratch[i];
+    ctx->pinned = (char*)pinned0 + (size_t)(i + 1) * 4096;
+    rc = lml_enqueue(ctx, ctx->lml_model[i], X, y_norm, N, d, kernel, length_scales + (size_t)i * n_ls, n_ls, noise,
+                     eval_gradient, &out_h[i], &info_h[i]);
+  }
+  ctx->stream = stream0; ctx->red = red0; ctx->cap_red = cap_red0; ctx->info_dev = info0; ctx->pinned = pinned0;
+  ctx->no_timing = false;
+  for (int i = 0; i < n_theta; ++i) {
+    hipError_t e = hipStreamSynchronize(ctx->lml_stream[i]);
+    if (e != hipSuccess && rc == GPBO_OK) GPBO_HIP(ctx, e);
+  }
+  if (rc) return rc;
+  for (int i = 0; i < n_theta; ++i) {
+    if (info) info[i] = 0;
+    lml_finish(out_h[i], info_h[i], N, n_ls, eval_gradient, lml + i, eval_gradient ? grad + (size_t)i * n_ls : nullptr,
+               info ? info + i : nullptr);
+  }
   return GPBO_OK;
 }
 

@@ -62,6 +62,11 @@ struct gpbo_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   gpbo::Model models[GPBO_MAX_MODELS];
+  // gpbo_lml_batch: scratch models, streams and scratch words (info word at +0, scalars at +64), one set per lane
+  gpbo::Model lml_model[GPBO_LML_BATCH_MAX];
+  hipStream_t lml_stream[GPBO_LML_BATCH_MAX] = {};
+  void* lml_scratch[GPBO_LML_BATCH_MAX] = {};
+  bool no_timing = false;   // batch lanes do not touch the timing events
   // candidates
   double* Xc = nullptr;    // [M][d] raw
   int64_t cap_Xc = 0;      // capacity in doubles
@@ -215,12 +220,14 @@ int run_hybrid_probe(gpbo_ctx* ctx, int iters, int cfg, double* out3);
 int run_mfma_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, double* out4);
 
 inline void ev_begin(gpbo_ctx* ctx, int slot) {
+  if (ctx->no_timing) return;
   EventPair& e = ctx->ev[slot];
   if (!e.a) { (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); }
   (void)hipEventRecord(e.a, ctx->stream);
   e.used = false;
 }
 inline void ev_end(gpbo_ctx* ctx, int slot) {
+  if (ctx->no_timing) return;
   EventPair& e = ctx->ev[slot];
   (void)hipEventRecord(e.b, ctx->stream);
   e.used = true;

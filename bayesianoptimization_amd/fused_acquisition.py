@@ -27,6 +27,7 @@ from scipy.special import ndtr
 
 from . import engine as E
 from .float_space import ensure_rng
+from .lockstep import Lockstep as _Lockstep
 from .gpr import HipGPR
 
 try:  # raise the reference's own exception classes when it is installed, so `except` clauses keep working
@@ -90,67 +91,6 @@ def _fd_value_and_grad(acq, bounds):
         return vals[0], (vals[1:] - vals[0]) / steps
 
     return fun
-
-
-class _Lockstep:
-    """Merges the objective evaluations of several independent L-BFGS-B runs into shared device batches.
-
-    The reference polishes its seeds one after another (acquisition.py:364-374); the runs do not interact, so
-    they can advance together: every run lives in its own thread, a thread that needs function values parks
-    its points here, and once ALL live runs are parked the caller's thread evaluates the concatenation with a
-    single acq() call and hands each run its slice.  SciPy's optimiser code and the per-point arithmetic are
-    untouched, so every run visits the iterates it would visit alone; only the launch count drops (by the
-    number of seeds).  All device work stays on the thread that called `serve()`."""
-
-    class Abort(Exception):
-        pass
-
-    def __init__(self, acq, n_runs: int) -> None:
-        self._acq = acq
-        self._cv = threading.Condition()
-        self._parked: dict[int, np.ndarray] = {}
-        self._answers: dict[int, np.ndarray] = {}
-        self._live = n_runs
-        self._failure: BaseException | None = None
-        self.batches = 0
-
-    def ask(self, run: int, pts):
-        with self._cv:
-            self._parked[run] = np.array(pts, dtype=np.float64, copy=True)
-            self._cv.notify_all()
-            while run not in self._answers and self._failure is None:
-                self._cv.wait()
-            if self._failure is not None:
-                raise _Lockstep.Abort
-            return self._answers.pop(run)
-
-    def retire(self, run: int) -> None:
-        with self._cv:
-            self._live -= 1
-            self._cv.notify_all()
-
-    def serve(self) -> None:
-        with self._cv:
-            while True:
-                while self._live > 0 and len(self._parked) < self._live:
-                    self._cv.wait()
-                if self._live == 0:
-                    return
-                order = sorted(self._parked)
-                sizes = [len(self._parked[r]) for r in order]
-                try:
-                    values = np.asarray(self._acq(np.concatenate([self._parked[r] for r in order])),
-                                        dtype=np.float64)
-                except BaseException as exc:   # wake the runs so that their threads end, then re-raise here
-                    self._failure = exc
-                    self._parked.clear()
-                    self._cv.notify_all()
-                    raise
-                self.batches += 1
-                for r, chunk in zip(order, np.split(values, np.cumsum(sizes)[:-1])):
-                    self._answers[r] = chunk
-                self._parked.clear()
-                self._cv.notify_all()
 
 
 def _polish_in_lockstep(acq, x_seeds, box):

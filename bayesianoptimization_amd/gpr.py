@@ -73,7 +73,8 @@ class HipGPR(GaussianProcessRegressor):
 
     def __init__(self, kernel=None, *, alpha=1e-10, optimizer="fmin_l_bfgs_b", n_restarts_optimizer=0,
                  normalize_y=False, copy_X_train=True, n_targets=None, random_state=None,
-                 transform=None, engine=None, slot=0, lml_on_device="auto", precision="f64", incremental=True):
+                 transform=None, engine=None, slot=0, lml_on_device="auto", precision="f64", incremental=True,
+                 theta_lockstep=True):
         super().__init__(kernel=kernel, alpha=alpha, optimizer=optimizer,
                          n_restarts_optimizer=n_restarts_optimizer, normalize_y=normalize_y,
                          copy_X_train=copy_X_train, n_targets=n_targets, random_state=random_state)
@@ -88,6 +89,9 @@ class HipGPR(GaussianProcessRegressor):
         # grow the device factorisation row by row (gpbo_fit_append, O(N^2) per new observation) when a fit repeats
         # the previous one with observations appended and the kernel hyper-parameters unchanged
         self.incremental = incremental
+        # theta search with restarts: advance the independent L-BFGS-B runs together, their LML evaluations side by
+        # side on the device (gpbo_lml_batch); same iterates and same RandomState draws as one run after another
+        self.theta_lockstep = theta_lockstep
 
     # -- plumbing ------------------------------------------------------------------------------
     def _engine(self) -> GpEngine:
@@ -222,14 +226,20 @@ class HipGPR(GaussianProcessRegressor):
                     return -lml, -grad
                 return -self.log_marginal_likelihood(theta, clone_kernel=False)
 
-            optima = [self._constrained_optimization(obj_func, self.kernel_.theta, self.kernel_.bounds)]
+            # sklearn draws each restart's start right before running it (_gpr.py:325-334); the runs never touch the
+            # RandomState, so drawing all starts first consumes the stream identically
+            bounds = self.kernel_.bounds
+            starts = [self.kernel_.theta]
             if self.n_restarts_optimizer > 0:
-                if not np.isfinite(self.kernel_.bounds).all():
+                if not np.isfinite(bounds).all():
                     raise ValueError("Multiple optimizer restarts (n_restarts_optimizer>0) requires that all bounds are finite.")
-                bounds = self.kernel_.bounds
                 for _ in range(self.n_restarts_optimizer):
-                    theta_initial = self._rng.uniform(bounds[:, 0], bounds[:, 1])
-                    optima.append(self._constrained_optimization(obj_func, theta_initial, bounds))
+                    starts.append(self._rng.uniform(bounds[:, 0], bounds[:, 1]))
+            if (self.theta_lockstep and len(starts) > 1 and self.optimizer == "fmin_l_bfgs_b"
+                    and self._device_lml_ok(self.kernel_)):
+                optima = self._theta_search_lockstep(starts, bounds)
+            else:
+                optima = [self._constrained_optimization(obj_func, start, bounds) for start in starts]
             lml_values = list(map(itemgetter(1), optima))
             self.kernel_.theta = optima[np.argmin(lml_values)][0]
             self.kernel_._check_bounds_params()
@@ -245,6 +255,64 @@ class HipGPR(GaussianProcessRegressor):
         # _gpr.py:346-364 on the device (LinAlgError with sklearn's hint when K is not PD)
         self._device_fit_tail()
         return self
+
+    def _theta_search_lockstep(self, starts, bounds):
+        """[(theta_opt, -lml_opt)] of sklearn's `_constrained_optimization` from every start, the runs advanced together:
+        per round ONE gpbo_lml_batch call evaluates the theta each live run is asking for (up to 8 side by side; the
+        factorisations are latency-bound, so they overlap on the device).  Each run sees exactly the values it would see
+        alone (every lane of the batch is bitwise gpbo_lml)."""
+        from .lockstep import Lockstep
+
+        eng = self._engine()
+        X, y, noise = self._tx(self.X_train_), self.y_train_, float(self.alpha)
+        n_dims = len(starts[0])
+
+        def evaluate(thetas):
+            rows = np.empty((len(thetas), 1 + n_dims))
+            kinds, scales = [], []
+            for theta in thetas:
+                kind, ls = describe_kernel(self.kernel_.clone_with_theta(theta))
+                kinds.append(kind)
+                scales.append(ls)
+            for lo in range(0, len(thetas), 8):
+                part = eng.lml_batch(X, y, kinds[0], np.vstack(scales[lo:lo + 8]), noise, eval_gradient=True)
+                for j, (val, grad) in enumerate(part):
+                    rows[lo + j, 0] = val
+                    rows[lo + j, 1:] = grad
+            return rows
+
+        hub = Lockstep(evaluate, len(starts))
+        results, errors = [None] * len(starts), [None] * len(starts)
+
+        def run(idx, start):
+            def objective(theta, eval_gradient=True):
+                row = hub.ask(idx, np.asarray(theta, dtype=np.float64).reshape(1, -1))[0]
+                return (-row[0], -row[1:]) if eval_gradient else -row[0]
+
+            try:
+                results[idx] = self._constrained_optimization(objective, start, bounds)
+            except Lockstep.Abort:
+                pass
+            except BaseException as exc:
+                errors[idx] = exc
+            finally:
+                hub.retire(idx)
+
+        import threading
+
+        threads = [threading.Thread(target=run, args=(i, np.array(s, dtype=np.float64)), daemon=True)
+                   for i, s in enumerate(starts)]
+        for t in threads:
+            t.start()
+        try:
+            hub.serve()
+        finally:
+            for t in threads:
+                t.join()
+        for exc in errors:
+            if exc is not None:
+                raise exc
+        return results
 
     def _device_fit_tail(self):
         """gpbo_fit, or gpbo_fit_append when this fit extends the one the slot still holds (same theta, noise,

@@ -46,6 +46,7 @@ enum gpbo_precision { GPBO_F64 = 0, GPBO_F32 = 1 };
 #define GPBO_MAX_MODELS 8   /* slot 0 = target GP, slots 1.. = constraint GPs */
 #define GPBO_MAX_DIM 64
 #define GPBO_MAX_SEEDS 64
+#define GPBO_LML_BATCH_MAX 8 /* theta values one gpbo_lml_batch call evaluates side by side */
 
 typedef struct gpbo_ctx gpbo_ctx;
 
@@ -98,6 +99,15 @@ int gpbo_fit_append(gpbo_ctx* ctx, int slot, const double* x_new, int64_t n_new,
 int gpbo_lml(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d,
              int kernel, const double* length_scale, int n_ls, double noise, int eval_gradient,
              double* lml, double* grad, int* info);
+
+/* n_theta evaluations of gpbo_lml on the SAME (X, y_norm) at different length scales (length_scales: n_theta x n_ls,
+ * row-major), each on its own stream and scratch model so that the latency-bound factorisations overlap on the device.
+ * This is what the theta search's independent L-BFGS-B runs (the initial theta + n_restarts_optimizer restarts,
+ * _gpr.py:296-338) need when they advance together.  Results per theta as gpbo_lml (lml[i], grad[i * n_ls ...], info[i]);
+ * every lane computes exactly what gpbo_lml computes, bit for bit.  Model slots and their fits are not touched. */
+int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_norm, int64_t N, int d, int kernel,
+                   const double* length_scales, int n_ls, double noise, int eval_gradient, double* lml, double* grad,
+                   int* info);
 
 /* Parity accessors (tests): copy device state back as (N,N) row-major / (N,) float64. */
 int gpbo_get_K(gpbo_ctx* ctx, int slot, double* out);      /* kernel matrix incl. noise, full symmetric */

@@ -151,7 +151,7 @@ def test_hipgpr_device_lml_override_semantics():
     kw = dict(alpha=1e-6, normalize_y=True, n_restarts_optimizer=3)
     sk = GaussianProcessRegressor(kernel=Matern(nu=2.5), random_state=r1, **kw).fit(X, y)
     gp = HipGPR(kernel=Matern(nu=2.5), random_state=r2, engine=eng, lml_on_device=True, **kw).fit(X, y)
-    assert any(c[0] == "lml" for c in eng.calls) and eng.calls[-1][0] == "fit"
+    assert any(c[0] in ("lml", "lml_batch") for c in eng.calls) and eng.calls[-1][0] == "fit"
     assert r1.uniform() == r2.uniform()
     assert gp.log_marginal_likelihood_value_ == pytest.approx(sk.log_marginal_likelihood_value_, rel=1e-9)
     assert gp.log_marginal_likelihood() == gp.log_marginal_likelihood_value_
@@ -271,3 +271,28 @@ def test_refit_with_appended_rows_goes_through_fit_append():
     gp.fit(X2[:30], y[:30]); assert last() == "fit"                          # the slot was taken by someone else
     gp.set_params(incremental=False)
     gp.fit(X2[:30], y[:30]); assert last() == "fit"
+
+
+def test_theta_search_runs_in_lockstep_equal_the_sequential_runs():
+    """HipGPR.fit with restarts: the independent L-BFGS-B runs advanced together over batched LML evaluations
+    (gpbo_lml_batch) end at the same theta, the same LML and the same RandomState position as one run after another."""
+    from sklearn.gaussian_process.kernels import Matern
+
+    from bayesianoptimization_amd.gpr import HipGPR
+
+    rng = np.random.RandomState(4)
+    X = rng.uniform(size=(40, 3))
+    y = np.sin(3 * X.sum(1)) + 0.05 * rng.standard_normal(40)
+    fits = {}
+    for lockstep in (True, False):
+        eng = FakeEngine()
+        rs = np.random.RandomState(8)
+        gp = HipGPR(kernel=Matern(nu=2.5, length_scale=1.0), alpha=1e-6, normalize_y=True, n_restarts_optimizer=5,
+                    random_state=rs, engine=eng, lml_on_device=True, theta_lockstep=lockstep).fit(X, y)
+        fits[lockstep] = (gp.kernel_.theta.copy(), gp.log_marginal_likelihood_value_, rs.uniform(), eng.calls)
+    assert np.array_equal(fits[True][0], fits[False][0]) and fits[True][1] == fits[False][1]
+    assert fits[True][2] == fits[False][2]
+    batches = [c[1] for c in fits[True][3] if c[0] == "lml_batch"]
+    singles = [c for c in fits[False][3] if c[0] == "lml"]
+    assert batches and batches[0] == 6 and sum(batches) == len(singles) and len(batches) * 2 < len(singles)
+    assert not [c for c in fits[True][3] if c[0] == "lml"]

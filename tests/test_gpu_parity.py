@@ -451,3 +451,34 @@ def test_fit_append_long_run_stays_accurate(engine):
         yn, ym, ys = O.normalize_targets(y[:n])
         engine.fit_append(X[n - 1:n], yn)
     _assert_same_model(engine, X[:500], yn, O.MATERN25, 1.1, 1e-6, ym, ys, np.random.RandomState(66).uniform(size=(64, d)))
+
+
+@pytest.mark.parametrize("N,d,kernel", [(300, 4, O.MATERN25), (1030, 9, O.RBF)])
+def test_lml_batch_lanes_are_bitwise_gpbo_lml(engine, N, d, kernel):
+    """gpbo_lml_batch: every lane (own stream, own scratch model) returns the bits gpbo_lml returns for that theta;
+    anisotropic rows too; a non-PD lane reports -inf without disturbing its neighbours; the model slots keep their fits."""
+    X, y = _data(N, d, seed=71)
+    yn, ym, ys = O.normalize_targets(y)
+    engine.fit(X, yn, kernel, 1.0, 1e-6)
+    Xc = np.random.RandomState(72).uniform(size=(200, d))
+    before = engine.predict(Xc, y_mean=ym, y_std=ys)
+    scales = np.array([[0.3], [0.7], [1.0], [1.9], [4.0], [0.05], [11.0], [0.5]])
+    got = engine.lml_batch(X, yn, kernel, scales, 1e-6)
+    after = engine.predict(Xc, y_mean=ym, y_std=ys)
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    for (val, grad), ls in zip(got, scales):
+        v1, g1 = engine.lml(X, yn, kernel, ls, 1e-6)
+        assert val == v1 and np.array_equal(grad, g1)
+        if 0.2 <= ls[0] <= 2.0:     # the well-conditioned thetas also against the oracle (the others: cond(K) >> 1e10)
+            v_o, g_o = O.log_marginal_likelihood(kernel, X, yn, ls, 1e-6, True)
+            assert abs(val - v_o) <= (1e-9 if kernel == O.MATERN25 else 1e-6) * abs(v_o)
+    aniso = np.random.RandomState(73).uniform(0.4, 2.0, size=(3, d))
+    for (val, grad), ls in zip(engine.lml_batch(X, yn, kernel, aniso, 1e-6), aniso):
+        v1, g1 = engine.lml(X, yn, kernel, ls, 1e-6)
+        assert val == v1 and np.array_equal(grad, g1) and grad.shape == (d,)
+    Xdup = X.copy()
+    Xdup[1] = Xdup[0]
+    mixed = engine.lml_batch(Xdup, yn, O.RBF, np.array([[1.0], [0.8]]), 0.0)
+    assert all(v == -np.inf and np.all(g == 0) for v, g in mixed)
+    with pytest.raises(ValueError):
+        engine.lml_batch(X, yn, kernel, np.ones((9, 1)), 1e-6)

@@ -313,3 +313,17 @@ def test_suggest_with_device_stream_is_the_host_stream_suggest(engine):
         x = fn.suggest(gp, sp, n_random=30000, n_smart=4, random_state=rs)
         out[mode] = (x, rs.uniform())
     assert np.array_equal(out["auto"][0], out[False][0]) and out["auto"][1] == out[False][1]
+
+
+def test_theta_search_in_lockstep_on_the_device(engine):
+    """Default bayes_opt GP configuration (5 restarts), LML on the device: the lockstep search (gpbo_lml_batch) ends
+    at the same theta, LML value and RandomState position as the sequential one, bit for bit."""
+    w = W.F1
+    sp = _space(w)
+    out = {}
+    for lockstep in (True, False):
+        rs = np.random.RandomState(3)
+        gp = HipGPR(kernel=Matern(nu=2.5), alpha=1e-6, normalize_y=True, n_restarts_optimizer=5, random_state=rs,
+                    engine=engine, lml_on_device=True, theta_lockstep=lockstep).fit(sp.params, sp.target)
+        out[lockstep] = (gp.kernel_.theta.copy(), gp.log_marginal_likelihood_value_, rs.uniform())
+    assert np.array_equal(out[True][0], out[False][0]) and out[True][1:] == out[False][1:]
