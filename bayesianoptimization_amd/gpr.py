@@ -235,8 +235,9 @@ class HipGPR(GaussianProcessRegressor):
                     raise ValueError("Multiple optimizer restarts (n_restarts_optimizer>0) requires that all bounds are finite.")
                 for _ in range(self.n_restarts_optimizer):
                     starts.append(self._rng.uniform(bounds[:, 0], bounds[:, 1]))
+            # (each lockstep lane holds its own K, L, W: ~40 N^2 bytes per lane -> sequential beyond N = 16384)
             if (self.theta_lockstep and len(starts) > 1 and self.optimizer == "fmin_l_bfgs_b"
-                    and self._device_lml_ok(self.kernel_)):
+                    and self._device_lml_ok(self.kernel_) and self.X_train_.shape[0] <= 16384):
                 optima = self._theta_search_lockstep(starts, bounds)
             else:
                 optima = [self._constrained_optimization(obj_func, start, bounds) for start in starts]
