@@ -57,30 +57,54 @@ static int alloc_model(gpbo_ctx* ctx, Model& m, int64_t NP, int DP) {
   return GPBO_OK;
 }
 
-// Blocked right-looking Cholesky of m.L (lower), NB = 64: diagonal block on one wave, panel and
-// trailing update on the MFMA GEMM.
+// Blocked Cholesky of m.L (lower), two levels: 64-wide inner blocks (diagonal block factored and inverted by one
+// workgroup, panel solve = GEMM with the inverted block) inside CHOL_OUTER-wide outer panels.  Inside an outer panel the
+// rank-64 updates touch only the panel's own remaining columns; the rest of the matrix gets ONE rank-CHOL_OUTER update
+// per outer panel, so the trailing matrix is read and written N / CHOL_OUTER times instead of N / 64 times (the rank-64
+// update is HBM-bound on exactly that traffic).  GPBO_CHOL_OUTER=64 restores the one-level algorithm (A/B runs); default 512 (measured: N = 8192 13.2 -> 10.6 ms, N <= 4096 unchanged — there the chain of diagonal blocks is the critical path).
 static int cholesky(gpbo_ctx* ctx, Model& m) {
   const int nblk = (int)(m.NP / NB);
+  int outer = 512;
+  if (const char* e = getenv("GPBO_CHOL_OUTER")) outer = atoi(e);
+  if (outer < NB || outer % NB) outer = NB;
+  const int per_outer = outer / NB;
   int rc;
-  for (int kb = 0; kb < nblk; ++kb) {
-    if ((rc = launch_potrf_diag(ctx, m, kb))) return rc;
-    const int rem = (int)(m.NP - (int64_t)(kb + 1) * NB);
-    if (rem == 0) break;
-    double* panel = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)kb * NB;
-    GemmArgs g{};
-    // panel: L21 = A21 * L11^-T  (in place)
-    g.m = rem; g.n = NB; g.k = NB; g.alpha = 1.0; g.beta = 0.0;
-    g.A = panel; g.lda = m.NP; g.strideA = 0;
-    g.B = m.dinv + (int64_t)kb * NB * NB; g.ldb = NB; g.strideB = 0; g.b_trans = 1;
-    g.C = panel; g.ldc = m.NP; g.strideC = 0; g.batch = 1;
-    if ((rc = launch_gemm(ctx, g))) return rc;
-    // trailing: A22 -= L21 L21^T (lower tiles only)
-    GemmArgs s{};
-    s.m = rem; s.n = rem; s.k = NB; s.alpha = -1.0; s.beta = 1.0;
-    s.A = panel; s.lda = m.NP; s.B = panel; s.ldb = m.NP; s.b_trans = 1;
-    s.C = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)(kb + 1) * NB; s.ldc = m.NP;
-    s.batch = 1; s.lower_only = 1;
-    if ((rc = launch_gemm(ctx, s))) return rc;
+  for (int ob = 0; ob < nblk; ob += per_outer) {
+    const int oe = (ob + per_outer < nblk) ? ob + per_outer : nblk;      // inner blocks [ob, oe) form this outer panel
+    for (int kb = ob; kb < oe; ++kb) {
+      if ((rc = launch_potrf_diag(ctx, m, kb))) return rc;
+      const int rem = (int)(m.NP - (int64_t)(kb + 1) * NB);               // rows below the diagonal block
+      if (rem == 0) break;
+      double* panel = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)kb * NB;
+      GemmArgs g{};
+      // panel: L21 = A21 * L11^-T  (in place)
+      g.m = rem; g.n = NB; g.k = NB; g.alpha = 1.0; g.beta = 0.0;
+      g.A = panel; g.lda = m.NP; g.strideA = 0;
+      g.B = m.dinv + (int64_t)kb * NB * NB; g.ldb = NB; g.strideB = 0; g.b_trans = 1;
+      g.C = panel; g.ldc = m.NP; g.strideC = 0; g.batch = 1;
+      if ((rc = launch_gemm(ctx, g))) return rc;
+      // rank-64 update of the outer panel's remaining columns [kb + 1, oe): rows below, lower tiles only
+      const int wi = (oe - (kb + 1)) * NB;
+      if (wi > 0) {
+        GemmArgs s{};
+        s.m = rem; s.n = wi; s.k = NB; s.alpha = -1.0; s.beta = 1.0;
+        s.A = panel; s.lda = m.NP; s.B = panel; s.ldb = m.NP; s.b_trans = 1;
+        s.C = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)(kb + 1) * NB; s.ldc = m.NP;
+        s.batch = 1; s.lower_only = 1;
+        if ((rc = launch_gemm(ctx, s))) return rc;
+      }
+    }
+    // rank-(outer) update of everything right of the outer panel: A22 -= P P^T, P = L[oe.., ob..oe)
+    const int rem2 = (int)(m.NP - (int64_t)oe * NB);
+    if (rem2 > 0) {
+      const double* P = m.L + (int64_t)oe * NB * m.NP + (int64_t)ob * NB;
+      GemmArgs t{};
+      t.m = rem2; t.n = rem2; t.k = (oe - ob) * NB; t.alpha = -1.0; t.beta = 1.0;
+      t.A = P; t.lda = m.NP; t.B = P; t.ldb = m.NP; t.b_trans = 1;
+      t.C = m.L + (int64_t)oe * NB * m.NP + (int64_t)oe * NB; t.ldc = m.NP;
+      t.batch = 1; t.lower_only = 1;
+      if ((rc = launch_gemm(ctx, t))) return rc;
+    }
   }
   return GPBO_OK;
 }
@@ -343,7 +367,10 @@ int gpbo_fit_append(gpbo_ctx* ctx, int slot, const double* x_new, int64_t n_new,
     GPBO_HIP(ctx, hipMemcpyAsync(ls_h, m.ls, GPBO_MAX_DIM * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int DP = m.DP;
+    const Model old = m;   // alloc_model resets the descriptor along with the buffers
     if ((rc = alloc_model(ctx, m, round_up(NP_new + NP_new / 4, NB), DP))) { (void)hipFree(keep); return rc; }
+    m.N = old.N; m.NP = old.NP; m.d = old.d; m.DP = old.DP; m.kernel = old.kernel; m.precision = old.precision;
+    m.noise = old.noise;
     GPBO_HIP(ctx, hipMemcpyAsync(m.ls, ls_h, GPBO_MAX_DIM * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     GPBO_HIP(ctx, hipMemcpyAsync(m.Xs, keep, (size_t)N0 * DP * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));

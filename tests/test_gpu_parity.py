@@ -440,9 +440,13 @@ def test_fit_append_f32_mode_and_errors(engine):
         engine.fit_append(X[50:51], np.zeros(51))              # gpbo_lml clobbered the slot
 
 
-def test_fit_append_long_run_stays_accurate(engine):
+def test_fit_append_long_run_stays_accurate():
     """300 consecutive single-row appends (crossing the padding several times, i.e. mixing rank-one growth with
-    rebuilds) do not drift: the final model is the from-scratch model to the usual tolerance."""
+    rebuilds and, on this FRESH context whose slot starts at 256 rows of capacity, reallocations) do not drift: the
+    final model is the from-scratch model to the usual tolerance."""
+    from bayesianoptimization_amd.engine import GpEngine
+
+    engine = GpEngine(0)
     d = 6
     X, y = _data(500, d, seed=65)
     n = 200
