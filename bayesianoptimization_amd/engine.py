@@ -21,6 +21,10 @@ TIMING_NAMES = ("fit", "posterior_main", "posterior_finalize", "acq_argbest", "k
 
 
 class GpEngine:
+    """One engine context = one GPU, one HIP stream, 8 model slots (0 = target GP, 1.. = constraint GPs) and one resident
+    candidate matrix.  Calls are synchronous from the host's point of view unless noted (`posterior(fetch=False)` only
+    enqueues); a context is not thread-safe — the lockstep helpers keep every device call on the serving thread."""
+
     def __init__(self, device: int = 0):
         self._lib = _lib.load_library()
         h = C.c_void_p()
@@ -32,6 +36,7 @@ class GpEngine:
         self.n_candidates = 0
         self.world_size = 1
         self.rank = 0
+        self._serial: dict[int, int] = {}    # slot -> number of times its factorisation was rewritten
 
     # -- lifecycle ---------------------------------------------------------------------------
     def close(self):
@@ -112,12 +117,11 @@ class GpEngine:
     def _touch(self, slot: int) -> int:
         """Every call that rewrites a slot's factorisation bumps its serial; an estimator compares the serial it got
         from its last fit with `fit_serial(slot)` to know whether the slot still holds ITS model."""
-        self._serial = getattr(self, "_serial", {})
         self._serial[int(slot)] = self._serial.get(int(slot), 0) + 1
         return self._serial[int(slot)]
 
     def fit_serial(self, slot: int = 0) -> int:
-        return getattr(self, "_serial", {}).get(int(slot), 0)
+        return self._serial.get(int(slot), 0)
 
     def lml(self, X, y_norm, kernel: int, length_scale, noise: float, eval_gradient=True, slot: int = 0):
         """(log marginal likelihood, d/dlog(length_scale)) at theta (sklearn _gpr.py:575-652). Clobbers the slot's fit."""
