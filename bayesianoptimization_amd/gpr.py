@@ -325,7 +325,8 @@ class HipGPR(GaussianProcessRegressor):
         key = (self._kind, self._ls.tobytes(), float(self.alpha), self._precision_code())
         held = self.__dict__.get("_held")
         self._held = None
-        if (self.incremental and held is not None and held["key"] == key and held["engine"] is eng
+        # (copy_X_train=False keeps the caller's array: an in-place edit would go unnoticed, so no appends then)
+        if (self.incremental and self.copy_X_train and held is not None and held["key"] == key and held["engine"] is eng
                 and eng.fit_serial(self.slot) == held["serial"]):
             X0 = held["X"]
             n0 = X0.shape[0]
