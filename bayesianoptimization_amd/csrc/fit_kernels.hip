@@ -119,11 +119,12 @@ int launch_kmat(gpbo_ctx* ctx, Model& m, double noise) {
 // ------------------------------------------------------------------------------------------------
 // Cholesky + inverse of one 64x64 diagonal block by one 256-thread workgroup.
 //
-// Factorisation (right-looking, one column per step, ONE barrier per column): thread (row i = tid & 63,
-// quarter q = tid >> 6) keeps A[i][16q .. 16q+15] in registers, so wave q owns 16 whole columns.  At
-// step j the owning wave reads the pivot with a shuffle, scales its column and publishes it to a
-// double-buffered LDS vector; after the barrier every wave that still has live columns applies the
-// rank-1 update to its registers.  All indices are compile-time (the 64 steps are unrolled).
+// Factorisation (right-looking, one column per step, NO workgroup barrier): thread (row i = tid & 63, quarter
+// q = tid >> 6) keeps A[i][16q .. 16q+15] in registers, so wave q owns 16 whole columns.  A wave first applies the
+// columns left of its own as the owning waves publish them (column-major LDS image + a release/acquire counter it
+// polls), then factors its 16 columns inside the wave — pivot and pivot-row entries by v_readlane — publishing
+// each column the moment it is final.  Every element still receives its rank-1 updates in column order, so the
+// result does not depend on the timing.  All indices are compile-time (the 16 steps are unrolled).
 //
 // Inverse: the four 16x16 diagonal sub-blocks by forward substitution in registers (thread = column),
 // then two doubling levels  W21 = -W22 (L21 W11)  as LDS-resident matrix products; the temporaries live
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
   extern __shared__ __attribute__((aligned(16))) double pd_smem[];
   double* Ls = pd_smem;              // [64][65]
   double* Wl = pd_smem + 64 * 65;    // [64][65]
-  double* col = Wl + 64 * 65;        // [2][64]
+  double* col = Wl + 64 * 65;        // [64] reciprocals of the diagonal of L (+ 64 spare)
   int* bad_sh = reinterpret_cast<int*>(col + 128);
   const int tid = threadIdx.x;
   const int i = tid & 63;
@@ -161,14 +162,36 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
       a[2 * h + 1] = v.y;
     }
   }
-  if (tid == 0) *bad_sh = 0;
+  // Column-major image of the finished columns (colbuf[j][i] = L[i][j]) in the LDS the inverse uses later, and the
+  // number of columns published so far.  No workgroup barrier inside the factorisation: a wave first CONSUMES the
+  // columns left of its own 16 as they appear (polling `ready`), then factors its own 16 columns entirely inside the
+  // wave (pivot and the entries of the pivot row by v_readlane), publishing each column as soon as it is final — so
+  // the critical path is the 64 pivots themselves, and the rank-1 updates of the other waves trail one column behind.
+  double* colbuf = Wl;
+  int* ready = bad_sh + 1;
+  if (tid == 0) { *bad_sh = 0; *ready = 0; }
   __syncthreads();
+  {
+    const int need = 16 * q;
+    int applied = 0;
+    while (applied < need) {
+      int avail = __hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (avail <= applied) {
+        __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      if (avail > need) avail = need;
+      for (int k = applied; k < avail; ++k) {
+        const double li = colbuf[k * 64 + i];
+        const double* prow = colbuf + k * 64 + 16 * q;      // L[16q + cc][k]: the same address for every lane
 #pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    const int qj = j >> 4, jj = j & 15;
-    double* cb = col + (j & 1) * 64;
-    if (q == qj) {
-      // pivot = a[jj] of lane j: the lane index is a compile-time constant here -> v_readlane, no LDS round trip
+        for (int cc = 0; cc < 16; ++cc) a[cc] = fma(-li, prow[cc], a[cc]);
+      }
+      applied = avail;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = 16 * q + jj;
       const unsigned long long pv = __double_as_longlong(a[jj]);
       const unsigned plo = __builtin_amdgcn_readlane((int)(unsigned)pv, j);
       const unsigned phi = __builtin_amdgcn_readlane((int)(unsigned)(pv >> 32), j);
@@ -189,19 +212,22 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
       double l = (i == j) ? dg : a[jj] * rs;
       l = (i >= j) ? l : 0.0;
       a[jj] = l;
-      cb[i] = l;
-    }
-    __syncthreads();
-    if (q > qj) {
-      const double li = cb[i];
+      colbuf[j * 64 + i] = l;
+      if (i == 0) {
+        col[j] = rs;    // 1 / L[j][j] for the inverse below (saves its 16 dependent fp64 divisions per thread)
+        __hip_atomic_store(ready, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      // this wave's remaining columns: L[16q + cc][j] sits in lane 16q + cc of `l`
+      const unsigned long long lv = __double_as_longlong(l);
 #pragma unroll
-      for (int cc = 0; cc < 16; ++cc) a[cc] = fma(-li, cb[16 * q + cc], a[cc]);
-    } else if (q == qj) {
-      const double li = cb[i];
-#pragma unroll
-      for (int cc = jj + 1; cc < 16; ++cc) a[cc] = fma(-li, cb[16 * qj + cc], a[cc]);
+      for (int cc = jj + 1; cc < 16; ++cc) {
+        const unsigned llo = __builtin_amdgcn_readlane((int)(unsigned)lv, 16 * q + cc);
+        const unsigned lhi = __builtin_amdgcn_readlane((int)(unsigned)(lv >> 32), 16 * q + cc);
+        a[cc] = fma(-l, __longlong_as_double(((unsigned long long)lhi << 32) | llo), a[cc]);
+      }
     }
   }
+  __syncthreads();
   // L -> global (upper part zero) and -> LDS for the inverse
   {
     double2* dst = reinterpret_cast<double2*>(A + (int64_t)i * ld + 16 * q);
@@ -228,7 +254,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
     for (int r = 0; r < 16; ++r) w[r] = (r == c) ? 1.0 : 0.0;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-      const double wk = w[k] / Lb[k * 65 + k];
+      const double wk = w[k] * col[16 * b + k];
       w[k] = wk;
 #pragma unroll
       for (int r = k + 1; r < 16; ++r) w[r] = fma(-Lb[r * 65 + k], wk, w[r]);
@@ -266,7 +292,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
 }
 
 int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb) {
-  constexpr size_t lds = (size_t)(2 * 64 * 65 + 128 + 2) * sizeof(double);
+  constexpr size_t lds = (size_t)(2 * 64 * 65 + 128 + 2) * sizeof(double);   // Ls, Wl (= colbuf), spare, flags
   static bool attr_set = false;
   if (!attr_set) {
     GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_diag_kernel),
