@@ -455,6 +455,7 @@ def test_fit_append_long_run_stays_accurate():
         yn, ym, ys = O.normalize_targets(y[:n])
         engine.fit_append(X[n - 1:n], yn)
     _assert_same_model(engine, X[:500], yn, O.MATERN25, 1.1, 1e-6, ym, ys, np.random.RandomState(66).uniform(size=(64, d)))
+    engine.close()
 
 
 @pytest.mark.parametrize("N,d,kernel", [(300, 4, O.MATERN25), (1030, 9, O.RBF)])
