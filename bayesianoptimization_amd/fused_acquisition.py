@@ -26,6 +26,7 @@ from scipy.optimize import minimize
 from scipy.special import ndtr
 
 from . import engine as E
+from . import lbfgsb_lockstep
 from .float_space import ensure_rng
 from .lockstep import Lockstep as _Lockstep
 from .gpr import HipGPR
@@ -167,7 +168,9 @@ class AcquisitionFunction(abc.ABC):
     #: iteration (d + 1 points) instead of d + 1 single-point calls; same numbers, ~d times fewer launches
     batched_fd = True
     #: with `batched_fd`, advance the L-BFGS-B runs of all seeds together so that each iteration of ALL runs is
-    #: one device batch (n_seeds * (d + 1) points) instead of one batch per run (`_Lockstep`)
+    #: one device batch (n_seeds * (d + 1) points) instead of one batch per run.  True: SciPy's reverse-communication
+    #: routine driven directly on one thread (lbfgsb_lockstep.py) when the installed SciPy is the one it was written
+    #: against, else one thread per run around the public `minimize` (`_Lockstep`); "threads" forces the latter
     lockstep = True
     #: where the random-stage candidates are drawn when the GPs live on the engine:
     #:   "auto"    (default) on the device in INDEX-PARITY mode — gpbo_generate_candidates_mt19937 walks the caller's
@@ -326,7 +329,10 @@ class AcquisitionFunction(abc.ABC):
         value_and_grad = _fd_value_and_grad(acq, box) if batched else None
         winner = None
         if batched and self.lockstep and len(x_seeds) > 1:
-            outcomes = _polish_in_lockstep(acq, x_seeds, box)
+            if self.lockstep != "threads" and lbfgsb_lockstep.driver_available() and not np.any(box[:, 0] == box[:, 1]):
+                outcomes = lbfgsb_lockstep.minimize_many(acq, x_seeds, box)     # SciPy's setulb driven directly
+            else:
+                outcomes = _polish_in_lockstep(acq, x_seeds, box)               # public API only: one thread per run
         elif batched:
             outcomes = (minimize(value_and_grad, start, jac=True, bounds=box, method="L-BFGS-B") for start in x_seeds)
         else:

@@ -1,0 +1,166 @@
+"""Several SciPy L-BFGS-B minimisations advanced together over ONE batched objective, on one thread.
+
+The reference polishes the best random candidates one after another with
+`scipy.optimize.minimize(acq, x_try, bounds=..., method="L-BFGS-B")` (bayes_opt/acquisition.py:364-374); every function
+value there is one `gp.predict` call.  SciPy's L-BFGS-B is a reverse-communication routine: `setulb(...)` returns whenever
+it needs f and g at the current x.  This module drives that routine itself for all seeds: each round it steps every live
+run up to its next request, evaluates ALL requested points (and their finite-difference neighbours) with one call of the
+batched objective — one device launch — and hands the values back.  The optimiser arithmetic is SciPy's own compiled
+`setulb`, called with exactly the arguments `scipy.optimize._lbfgsb_py._minimize_lbfgsb` passes (same work arrays, `factr`,
+`pgtol`, `maxcor`, `maxls`, iteration/evaluation limits), and the forward differences are the ones `approx_derivative`
+forms (see `forward_difference_points`), so every run visits the iterates `minimize` would visit and ends in the same
+`OptimizeResult` fields.  What disappears is Python: `ScalarFunction`, `MemoizeJac`, bound standardisation and (compared
+with `lockstep.Lockstep`) one thread per run.
+
+`setulb` is private SciPy API.  `driver_available()` checks the module layout and the version this was written
+against (1.15.x); anything else falls back to the thread-based `lockstep.Lockstep`, which only uses public API.
+tests/test_host_logic.py::test_lbfgsb_driver_equals_scipy_minimize pins the equivalence bit for bit.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.optimize import OptimizeResult
+
+_FD_EPS = 1e-8                              # _minimize_lbfgsb: eps=1e-8 -> approx_derivative(abs_step=1e-8)
+_SQRT_EPS = np.finfo(np.float64).eps ** 0.5
+
+_TASK_FG, _TASK_NEW_X, _TASK_CONVERGENCE, _TASK_STOP = 3, 1, 4, 5
+
+
+def _setulb():
+    try:
+        import scipy
+        from scipy.optimize import _lbfgsb_py
+    except Exception:   # pragma: no cover
+        return None
+    major_minor = tuple(int(p) for p in scipy.__version__.split(".")[:2])
+    fn = getattr(getattr(_lbfgsb_py, "_lbfgsb", None), "setulb", None)
+    doc = getattr(fn, "__doc__", "") or ""
+    if fn is None or major_minor != (1, 15) or "ln_task" not in doc:
+        return None
+    return fn
+
+
+def driver_available() -> bool:
+    return _setulb() is not None
+
+
+def forward_difference_points(X0, lb, ub):
+    """For every row x0 of X0 (S, d): the d + 1 points at which SciPy evaluates the objective to form L-BFGS-B's
+    gradient when `jac` is absent — x0 and x0 + h_t e_t with `approx_derivative(method="2-point", abs_step=1e-8,
+    bounds=(lb, ub))`'s steps, including `_adjust_scheme_to_bounds(..., "1-sided")` (scipy/optimize/_numdiff.py).
+    Returns (pts (S, d + 1, d), steps (S, d)) with steps = the ACTUAL differences (x0_t + h_t) - x0_t, as
+    `_dense_difference` uses them."""
+    X0 = np.asarray(X0, dtype=np.float64)
+    sign = (X0 >= 0).astype(np.float64) * 2 - 1
+    h = np.full_like(X0, _FD_EPS)
+    h = np.where((X0 + h) - X0 == 0, _SQRT_EPS * sign * np.maximum(1.0, np.abs(X0)), h)
+    if not np.all((lb == -np.inf) & (ub == np.inf)):
+        below, above = X0 - lb, ub - X0
+        trial = X0 + h
+        outside = (trial < lb) | (trial > ub)
+        fits = np.abs(h) <= np.maximum(below, above)
+        h = np.where(outside & fits, -h, h)
+        h = np.where((above >= below) & ~fits, above, h)
+        h = np.where((above < below) & ~fits, -below, h)
+    S, d = X0.shape
+    pts = np.repeat(X0[:, None, :], d + 1, axis=1)
+    idx = np.arange(d)
+    pts[:, idx + 1, idx] = X0 + h
+    steps = pts[:, idx + 1, idx] - X0
+    return pts, steps
+
+
+class _Run:
+    __slots__ = ("x", "f", "g", "wa", "iwa", "task", "ln_task", "lsave", "isave", "dsave", "nit", "nfev", "done",
+                 "x_seen", "f_seen", "g_seen")
+
+    def __init__(self, x0, n, m):
+        self.x = np.array(x0, dtype=np.float64)
+        self.f = np.array(0.0, dtype=np.int32)        # as _minimize_lbfgsb initialises them
+        self.g = np.zeros((n,), dtype=np.int32)
+        self.wa = np.zeros(2 * m * n + 5 * n + 11 * m * m + 8 * m, np.float64)
+        self.iwa = np.zeros(3 * n, dtype=np.int32)
+        self.task = np.zeros(2, dtype=np.int32)
+        self.ln_task = np.zeros(2, dtype=np.int32)
+        self.lsave = np.zeros(4, dtype=np.int32)
+        self.isave = np.zeros(44, dtype=np.int32)
+        self.dsave = np.zeros(29, dtype=np.float64)
+        self.nit = 0
+        self.nfev = 0
+        self.done = False
+        self.x_seen = None       # the point of the last evaluation and its (f, g): ScalarFunction's one-entry cache
+        self.f_seen = self.g_seen = None
+
+
+def minimize_many(acq, starts, box, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000, maxiter=15000,
+                  maxls=20):
+    """[OptimizeResult(x, fun, jac, nit, nfev, status, success)] of
+    `scipy.optimize.minimize(acq_single, start, bounds=box, method="L-BFGS-B")` for every start, where `acq` maps a
+    batch of points (P, d) to their P values and `acq_single(x) = acq(x[None])[0]`."""
+    setulb = _setulb()
+    if setulb is None:
+        raise RuntimeError("scipy's L-BFGS-B reverse-communication routine is not available in the expected form")
+    box = np.asarray(box, dtype=np.float64)
+    lb, ub = box[:, 0].copy(), box[:, 1].copy()
+    n = box.shape[0]
+    if np.any(lb > ub):
+        raise ValueError("LBFGSB - one of the lower bounds is greater than an upper bound.")
+    if np.any(lb == ub):
+        raise ValueError("minimize_many does not handle fixed variables (lb == ub); use scipy.optimize.minimize")
+    factr = ftol / np.finfo(float).eps
+    low_bnd, upper_bnd = np.zeros(n), np.zeros(n)
+    nbd = np.zeros(n, np.int32)
+    for t in range(n):
+        has_l, has_u = not np.isinf(lb[t]), not np.isinf(ub[t])
+        if has_l:
+            low_bnd[t] = lb[t]
+        if has_u:
+            upper_bnd[t] = ub[t]
+        nbd[t] = {(False, False): 0, (True, False): 1, (True, True): 2, (False, True): 3}[has_l, has_u]
+
+    runs = [_Run(np.clip(np.asarray(s, dtype=np.float64).ravel(), lb, ub), n, maxcor) for s in starts]
+
+    def step(run):
+        """Advance one run to its next f/g request at a NEW point (returns True) or to its end (False)."""
+        while True:
+            run.g = run.g.astype(np.float64)
+            setulb(maxcor, run.x, low_bnd, upper_bnd, nbd, run.f, run.g, factr, gtol, run.wa, run.iwa, run.task,
+                   run.lsave, run.isave, run.dsave, maxls, run.ln_task)
+            if run.task[0] == _TASK_FG:
+                if run.x_seen is not None and np.array_equal(run.x, run.x_seen):
+                    run.f, run.g = run.f_seen, run.g_seen      # ScalarFunction answers a repeated x from its cache
+                    continue
+                return True
+            if run.task[0] == _TASK_NEW_X:
+                run.nit += 1
+                if run.nit >= maxiter:
+                    run.task[0], run.task[1] = _TASK_STOP, 504
+                elif run.nfev > maxfun:
+                    run.task[0], run.task[1] = _TASK_STOP, 502
+                continue
+            run.done = True
+            return False
+
+    live = [r for r in runs if step(r)]
+    while live:
+        X0 = np.array([r.x for r in live])
+        pts, steps = forward_difference_points(X0, lb, ub)
+        vals = np.asarray(acq(pts.reshape(-1, n)), dtype=np.float64).reshape(len(live), n + 1)
+        grads = (vals[:, 1:] - vals[:, :1]) / steps
+        for r, v, g in zip(live, vals[:, 0], grads):
+            r.f, r.g = v, g
+            r.x_seen, r.f_seen, r.g_seen = r.x.copy(), v, g
+            r.nfev += n + 1          # as ScalarFunction counts: the point and its d finite-difference neighbours
+        live = [r for r in live if step(r)]
+
+    out = []
+    for r in runs:
+        if r.task[0] == _TASK_CONVERGENCE:
+            status = 0
+        elif r.nfev > maxfun or r.nit >= maxiter:
+            status = 1
+        else:
+            status = 2
+        out.append(OptimizeResult(x=r.x, fun=r.f, jac=r.g, nit=r.nit, nfev=r.nfev, status=status, success=status == 0))
+    return out

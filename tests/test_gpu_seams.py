@@ -170,19 +170,19 @@ def test_device_theta_search_matches_sklearn_optimum(engine):
 
 
 def test_batched_fd_smart_stage_is_bitwise_the_per_point_path(engine, monkeypatch):
-    """The smart stage in its three shapes — all runs in lockstep (one device batch of n_seeds * (d + 1) points per
-    round), one batched (d + 1)-point call per L-BFGS-B iteration of each run, and the reference-shaped per-point
+    """The smart stage in its shapes — all runs in lockstep (one device batch of n_seeds * (d + 1) points per
+    round; SciPy's setulb driven directly, or one thread per run around the public minimize), one batched (d + 1)-point call per L-BFGS-B iteration of each run, and the reference-shaped per-point
     path — returns exactly the same point: the GEMV kernel evaluates a candidate identically alone or in any
     batch (the path is pinned; across the GEMV/MFMA switch the agreement is to rounding, next test)."""
     monkeypatch.setenv("GPBO_SMALL_MAX", "1024")
     w = W.P2
     sp = _space(w)
     res = {}
-    for mode in ("lockstep", "batched", "per_point"):
+    for mode in ("lockstep", "threads", "batched", "per_point"):
         gp = HipGPR(kernel=RBF(length_scale=0.6), alpha=w.noise, normalize_y=True, optimizer=None, engine=engine)
         fn = A.ExpectedImprovement(xi=0.01)
         fn.batched_fd = mode != "per_point"
-        fn.lockstep = mode == "lockstep"
+        fn.lockstep = {"lockstep": True, "threads": "threads"}.get(mode, False)   # True: SciPy's setulb driven directly
         n0 = [0]
         orig = engine.set_candidates
 
@@ -198,6 +198,8 @@ def test_batched_fd_smart_stage_is_bitwise_the_per_point_path(engine, monkeypatc
         res[mode] = (x, n0[0])
     assert np.array_equal(res["batched"][0], res["per_point"][0])
     assert np.array_equal(res["lockstep"][0], res["per_point"][0])
+    assert np.array_equal(res["threads"][0], res["per_point"][0]), (res["threads"], res["per_point"])
+    assert res["threads"][1] == res["lockstep"][1], (res["threads"][1], res["lockstep"][1])
     assert res["batched"][1] * 3 < res["per_point"][1]
     assert res["lockstep"][1] * 2 < res["batched"][1]
 

@@ -276,3 +276,56 @@ def test_mt19937_block_walk_reproduces_randomstate_uniform(M, d, burn):
     cont = np.random.RandomState(0)
     cont.set_state(("MT19937", key2, pos2, hg, cg))
     assert np.array_equal(cont.uniform(size=700), ref.uniform(size=700))
+
+
+def test_lbfgsb_driver_equals_scipy_minimize():
+    """lbfgsb_lockstep.minimize_many drives SciPy's setulb for all starts at once over a batched objective; every run
+    ends in the OptimizeResult `minimize(f, x0, bounds=..., method="L-BFGS-B")` (no jac: the reference's call,
+    bayes_opt/acquisition.py:366) returns — x, fun, jac, nit, nfev, status — bit for bit, including starts on the bounds,
+    active bounds at the optimum, half-open and unbounded boxes."""
+    from scipy.optimize import minimize
+
+    from bayesianoptimization_amd import lbfgsb_lockstep as LL
+
+    assert LL.driver_available()          # scipy 1.15.x in this image; elsewhere the threaded path is used
+    rng = np.random.RandomState(11)
+    A = rng.randn(6, 6)
+    A = A @ A.T + np.eye(6)
+    b = rng.randn(6)
+
+    def f1(x):
+        return 0.5 * x @ A @ x - x @ b + np.sin(3 * x).sum()
+
+    batches = []
+
+    def acq(P):
+        batches.append(len(P))
+        return np.array([f1(r) for r in P])
+
+    boxes = [np.array([[-1.0, 1.0]] * 6), np.array([[-0.2, 0.3]] * 6),
+             np.array([[-np.inf, 0.5], [-1.0, np.inf], [-np.inf, np.inf], [-1, 1], [0.0, np.inf], [-np.inf, 0.0]])]
+    for box in boxes:
+        lo = np.where(np.isinf(box[:, 0]), -2.0, box[:, 0])
+        hi = np.where(np.isinf(box[:, 1]), 2.0, box[:, 1])
+        starts = np.vstack([rng.uniform(lo, hi, size=(7, 6)), lo[None], hi[None], np.zeros((1, 6))])
+        batches.clear()
+        got = LL.minimize_many(acq, starts, box)
+        for x0, r in zip(starts, got):
+            ref = minimize(f1, x0, bounds=box, method="L-BFGS-B")
+            assert np.array_equal(r.x, ref.x) and r.fun == ref.fun and np.array_equal(r.jac, ref.jac)
+            assert (r.nit, r.nfev, r.status, r.success) == (ref.nit, ref.nfev, ref.status, ref.success)
+        assert len(batches) == max(r.nfev for r in got) // 7 and batches[0] == len(starts) * 7
+
+
+def test_forward_difference_points_match_the_per_seed_closure():
+    from bayesianoptimization_amd import lbfgsb_lockstep as LL
+    from bayesianoptimization_amd.fused_acquisition import _fd_value_and_grad
+
+    rng = np.random.RandomState(12)
+    box = np.array([[0.0, 1.0], [-3.0, 3.0], [2.0, 4.0], [-np.inf, np.inf]])
+    X0 = np.vstack([rng.uniform([0, -3, 2, -5], [1, 3, 4, 5], size=(6, 4)), [0.0, -3.0, 4.0, 0.0], [1.0, 3.0, 2.0, 1e9]])
+    pts, steps = LL.forward_difference_points(X0, box[:, 0], box[:, 1])
+    for x0, P, h in zip(X0, pts, steps):
+        seen = []
+        _fd_value_and_grad(lambda q: (seen.append(q.copy()), np.zeros(len(q)))[1], box)(x0)
+        assert np.array_equal(seen[0], P) and np.array_equal(h, P[1:][np.arange(4), np.arange(4)] - x0)
