@@ -282,6 +282,23 @@ class HipGPR(GaussianProcessRegressor):
                     rows[lo + j, 1:] = grad
             return rows
 
+        from . import lbfgsb_lockstep
+
+        if lbfgsb_lockstep.driver_available() and not np.any(bounds[:, 0] == bounds[:, 1]):
+            # SciPy's setulb driven for all runs on this thread; what sklearn's _constrained_optimization does around
+            # `minimize(obj_func, theta0, method="L-BFGS-B", jac=True, bounds=bounds)` (_gpr.py:656-668) follows it
+            from sklearn.utils.optimize import _check_optimize_result
+
+            def value_and_grad(thetas):
+                rows = evaluate(thetas)
+                return -rows[:, 0], -rows[:, 1:]
+
+            optima = []
+            for res in lbfgsb_lockstep.minimize_many_with_grad(value_and_grad, starts, bounds):
+                _check_optimize_result("lbfgs", res)
+                optima.append((res.x, res.fun))
+            return optima
+
         hub = Lockstep(evaluate, len(starts))
         results, errors = [None] * len(starts), [None] * len(starts)
 

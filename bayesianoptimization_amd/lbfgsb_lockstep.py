@@ -93,11 +93,17 @@ class _Run:
         self.f_seen = self.g_seen = None
 
 
-def minimize_many(acq, starts, box, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000, maxiter=15000,
-                  maxls=20):
-    """[OptimizeResult(x, fun, jac, nit, nfev, status, success)] of
-    `scipy.optimize.minimize(acq_single, start, bounds=box, method="L-BFGS-B")` for every start, where `acq` maps a
-    batch of points (P, d) to their P values and `acq_single(x) = acq(x[None])[0]`."""
+def _messages():
+    try:
+        from scipy.optimize._lbfgsb_py import status_messages, task_messages
+        return status_messages, task_messages
+    except Exception:   # pragma: no cover
+        return {}, {}
+
+
+def _drive(evaluate, evals_per_request, starts, box, maxcor, ftol, gtol, maxfun, maxiter, maxls):
+    """The loop of `_minimize_lbfgsb` for all starts at once.  evaluate(X (S, n)) -> (f (S,), g (S, n)) for the S runs
+    that asked this round; evals_per_request = what ScalarFunction adds to nfev per evaluated point."""
     setulb = _setulb()
     if setulb is None:
         raise RuntimeError("scipy's L-BFGS-B reverse-communication routine is not available in the expected form")
@@ -107,7 +113,7 @@ def minimize_many(acq, starts, box, maxcor=10, ftol=2.2204460492503131e-09, gtol
     if np.any(lb > ub):
         raise ValueError("LBFGSB - one of the lower bounds is greater than an upper bound.")
     if np.any(lb == ub):
-        raise ValueError("minimize_many does not handle fixed variables (lb == ub); use scipy.optimize.minimize")
+        raise ValueError("fixed variables (lb == ub) are not handled here; use scipy.optimize.minimize")
     factr = ftol / np.finfo(float).eps
     low_bnd, upper_bnd = np.zeros(n), np.zeros(n)
     nbd = np.zeros(n, np.int32)
@@ -144,16 +150,14 @@ def minimize_many(acq, starts, box, maxcor=10, ftol=2.2204460492503131e-09, gtol
 
     live = [r for r in runs if step(r)]
     while live:
-        X0 = np.array([r.x for r in live])
-        pts, steps = forward_difference_points(X0, lb, ub)
-        vals = np.asarray(acq(pts.reshape(-1, n)), dtype=np.float64).reshape(len(live), n + 1)
-        grads = (vals[:, 1:] - vals[:, :1]) / steps
-        for r, v, g in zip(live, vals[:, 0], grads):
+        fs, gs = evaluate(np.array([r.x for r in live]))
+        for r, v, g in zip(live, fs, gs):
             r.f, r.g = v, g
             r.x_seen, r.f_seen, r.g_seen = r.x.copy(), v, g
-            r.nfev += n + 1          # as ScalarFunction counts: the point and its d finite-difference neighbours
+            r.nfev += evals_per_request
         live = [r for r in live if step(r)]
 
+    status_messages, task_messages = _messages()
     out = []
     for r in runs:
         if r.task[0] == _TASK_CONVERGENCE:
@@ -162,5 +166,38 @@ def minimize_many(acq, starts, box, maxcor=10, ftol=2.2204460492503131e-09, gtol
             status = 1
         else:
             status = 2
-        out.append(OptimizeResult(x=r.x, fun=r.f, jac=r.g, nit=r.nit, nfev=r.nfev, status=status, success=status == 0))
+        message = f"{status_messages.get(int(r.task[0]), r.task[0])}: {task_messages.get(int(r.task[1]), r.task[1])}"
+        out.append(OptimizeResult(x=r.x, fun=r.f, jac=r.g, nit=r.nit, nfev=r.nfev, status=status, message=message,
+                                  success=status == 0))
     return out
+
+
+def minimize_many(acq, starts, box, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000, maxiter=15000,
+                  maxls=20):
+    """[OptimizeResult(x, fun, jac, nit, nfev, status, message, success)] of
+    `scipy.optimize.minimize(acq_single, start, bounds=box, method="L-BFGS-B")` (no `jac`: forward differences) for
+    every start, where `acq` maps a batch of points (P, d) to their P values and `acq_single(x) = acq(x[None])[0]`."""
+    box = np.asarray(box, dtype=np.float64)
+    lb, ub = box[:, 0], box[:, 1]
+    n = box.shape[0]
+
+    def evaluate(X0):
+        pts, steps = forward_difference_points(X0, lb, ub)
+        vals = np.asarray(acq(pts.reshape(-1, n)), dtype=np.float64).reshape(len(X0), n + 1)
+        return vals[:, 0], (vals[:, 1:] - vals[:, :1]) / steps
+
+    # ScalarFunction counts the point and its d finite-difference neighbours
+    return _drive(evaluate, n + 1, starts, box, maxcor, ftol, gtol, maxfun, maxiter, maxls)
+
+
+def minimize_many_with_grad(value_and_grad, starts, box, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5,
+                            maxfun=15000, maxiter=15000, maxls=20):
+    """The same for an objective that returns its gradient: [OptimizeResult] of
+    `scipy.optimize.minimize(fg_single, start, jac=True, bounds=box, method="L-BFGS-B")` for every start, where
+    `value_and_grad` maps a batch X (S, n) to (f (S,), g (S, n)) — scikit-learn's theta search with restarts
+    (sklearn/gaussian_process/_gpr.py:296-338, 656-668) over `gpbo_lml_batch`."""
+    def evaluate(X):
+        f, g = value_and_grad(X)
+        return np.asarray(f, dtype=np.float64), np.asarray(g, dtype=np.float64).reshape(len(X), -1)
+
+    return _drive(evaluate, 1, starts, box, maxcor, ftol, gtol, maxfun, maxiter, maxls)

@@ -273,7 +273,7 @@ def test_refit_with_appended_rows_goes_through_fit_append():
     gp.fit(X2[:30], y[:30]); assert last() == "fit"
 
 
-def test_theta_search_runs_in_lockstep_equal_the_sequential_runs():
+def test_theta_search_runs_in_lockstep_equal_the_sequential_runs(monkeypatch):
     """HipGPR.fit with restarts: the independent L-BFGS-B runs advanced together over batched LML evaluations
     (gpbo_lml_batch) end at the same theta, the same LML and the same RandomState position as one run after another."""
     from sklearn.gaussian_process.kernels import Matern
@@ -283,15 +283,21 @@ def test_theta_search_runs_in_lockstep_equal_the_sequential_runs():
     rng = np.random.RandomState(4)
     X = rng.uniform(size=(40, 3))
     y = np.sin(3 * X.sum(1)) + 0.05 * rng.standard_normal(40)
+    from bayesianoptimization_amd import lbfgsb_lockstep
+
     fits = {}
-    for lockstep in (True, False):
+    for lockstep in (True, "threads", False):
+        if lockstep == "threads":       # the public-API fallback: one thread per run around sklearn's own optimiser call
+            monkeypatch.setattr(lbfgsb_lockstep, "driver_available", lambda: False)
         eng = FakeEngine()
         rs = np.random.RandomState(8)
         gp = HipGPR(kernel=Matern(nu=2.5, length_scale=1.0), alpha=1e-6, normalize_y=True, n_restarts_optimizer=5,
-                    random_state=rs, engine=eng, lml_on_device=True, theta_lockstep=lockstep).fit(X, y)
+                    random_state=rs, engine=eng, lml_on_device=True, theta_lockstep=bool(lockstep)).fit(X, y)
         fits[lockstep] = (gp.kernel_.theta.copy(), gp.log_marginal_likelihood_value_, rs.uniform(), eng.calls)
-    assert np.array_equal(fits[True][0], fits[False][0]) and fits[True][1] == fits[False][1]
-    assert fits[True][2] == fits[False][2]
+    for mode in (True, "threads"):
+        assert np.array_equal(fits[mode][0], fits[False][0]) and fits[mode][1] == fits[False][1]
+        assert fits[mode][2] == fits[False][2]
+    assert [c for c in fits["threads"][3] if c[0] == "lml_batch"] == [c for c in fits[True][3] if c[0] == "lml_batch"]
     batches = [c[1] for c in fits[True][3] if c[0] == "lml_batch"]
     singles = [c for c in fits[False][3] if c[0] == "lml"]
     assert batches and batches[0] == 6 and sum(batches) == len(singles) and len(batches) * 2 < len(singles)

@@ -329,3 +329,30 @@ def test_forward_difference_points_match_the_per_seed_closure():
         seen = []
         _fd_value_and_grad(lambda q: (seen.append(q.copy()), np.zeros(len(q)))[1], box)(x0)
         assert np.array_equal(seen[0], P) and np.array_equal(h, P[1:][np.arange(4), np.arange(4)] - x0)
+
+
+def test_lbfgsb_driver_with_gradient_equals_scipy_minimize():
+    """minimize_many_with_grad == scipy.optimize.minimize(fg, x0, jac=True, bounds=..., method="L-BFGS-B") per start (the
+    call of sklearn's theta search, _gpr.py:656-668): x, fun, jac, nit, nfev, status, message bit for bit."""
+    from scipy.optimize import minimize
+
+    from bayesianoptimization_amd import lbfgsb_lockstep as LL
+
+    rng = np.random.RandomState(13)
+    A = rng.randn(4, 4)
+    A = A @ A.T + np.eye(4)
+    b = rng.randn(4)
+
+    def fg(x):
+        return 0.5 * x @ A @ x - x @ b + np.cos(2 * x).sum(), A @ x - b - 2 * np.sin(2 * x)
+
+    def batch(X):
+        out = [fg(x) for x in X]
+        return np.array([o[0] for o in out]), np.array([o[1] for o in out])
+
+    box = np.array([[-11.5, 11.5], [-1.0, 0.2], [0.0, 3.0], [-0.5, 0.5]])
+    starts = rng.uniform(box[:, 0], box[:, 1], size=(6, 4))
+    for x0, r in zip(starts, LL.minimize_many_with_grad(batch, starts, box)):
+        ref = minimize(fg, x0, jac=True, bounds=box, method="L-BFGS-B")
+        assert np.array_equal(r.x, ref.x) and r.fun == ref.fun and np.array_equal(r.jac, ref.jac)
+        assert (r.nit, r.nfev, r.status, r.success, r.message) == (ref.nit, ref.nfev, ref.status, ref.success, ref.message)
