@@ -214,6 +214,9 @@ int gpbo_destroy(gpbo_ctx* ctx) {
   for (auto& m : ctx->lml_model) free_model(m);
   for (auto& st : ctx->lml_stream) if (st) (void)hipStreamDestroy(st);
   for (auto& p : ctx->lml_scratch) if (p) (void)hipFree(p);
+  for (auto& ln : ctx->lml_lane) if (ln.exec) (void)hipGraphExecDestroy(ln.exec);
+  if (ctx->lml_X) (void)hipFree(ctx->lml_X);
+  if (ctx->lml_y) (void)hipFree(ctx->lml_y);
   void* ptrs[] = {ctx->Xc, ctx->Xcs, ctx->part, ctx->mu_part, ctx->ys, ctx->red, ctx->info_dev, ctx->comm_buf, ctx->kst, ctx->stage};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -272,12 +275,13 @@ static int factor_resident(gpbo_ctx* ctx, Model& m, double noise, int** info_hos
   return GPBO_OK;
 }
 
-static int factorize(gpbo_ctx* ctx, Model& m, const char* who, const double* X, const double* y_norm, int64_t N,
-                     int d, int kernel, const double* length_scale, int n_ls, double noise, int precision,
-                     int** info_host) {
+// Argument checks, buffers and descriptor of a fit; the scaled length scales go to the pinned staging words.  Nothing
+// is enqueued (so this part stays outside a stream capture).
+static int prepare_model(gpbo_ctx* ctx, Model& m, const char* who, bool have_inputs, int64_t N, int d, int kernel,
+                         const double* length_scale, int n_ls, double noise, int precision) {
   int rc;
   std::string w(who);
-  if (!X || !y_norm || !length_scale) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": NULL input");
+  if (!have_inputs || !length_scale) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": NULL input");
   if (N < 1 || N > (1 << 16)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": N out of range [1, 65536]");
   if (d < 1 || d > GPBO_MAX_DIM) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, w + ": d out of range [1, 64]");
   if (kernel != GPBO_KERNEL_RBF && kernel != GPBO_KERNEL_MATERN25)
@@ -296,16 +300,37 @@ static int factorize(gpbo_ctx* ctx, Model& m, const char* who, const double* X, 
   const int DP = pad_dim(d);
   if ((rc = alloc_model(ctx, m, NP, DP))) return rc;
   m.N = N; m.NP = NP; m.d = d; m.DP = DP; m.kernel = kernel; m.precision = precision;
-
-  ev_begin(ctx, T_FIT);
   double* ls_h = (double*)ctx->pinned;
   for (int t = 0; t < GPBO_MAX_DIM; ++t) ls_h[t] = (t < d) ? (n_ls == 1 ? length_scale[0] : length_scale[t]) : 1.0;
-  GPBO_HIP(ctx, hipMemcpyAsync(m.ls, ls_h, GPBO_MAX_DIM * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  GPBO_HIP(ctx, hipMemcpyAsync(m.tmp, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  return GPBO_OK;
+}
+
+// The fit enqueued on ctx->stream: inputs from the host (X, y_norm) or already on the device (X_dev raw (N, d), y_dev),
+// then K, L, W, alpha.  With device inputs every operation is capturable into a hipGraph.
+static int enqueue_factor(gpbo_ctx* ctx, Model& m, const double* X, const double* y_norm, const double* X_dev,
+                          const double* y_dev, double noise, int** info_host) {
+  int rc;
+  const int64_t N = m.N, NP = m.NP;
+  ev_begin(ctx, T_FIT);
+  GPBO_HIP(ctx, hipMemcpyAsync(m.ls, ctx->pinned, GPBO_MAX_DIM * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   GPBO_HIP(ctx, hipMemsetAsync(m.yn, 0, (size_t)NP * sizeof(double), ctx->stream));
-  GPBO_HIP(ctx, hipMemcpyAsync(m.yn, y_norm, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  if ((rc = launch_prescale(ctx, m.tmp, N, d, DP, m.ls, m.Xs, NP))) return rc;
+  if (X_dev) {
+    GPBO_HIP(ctx, hipMemcpyAsync(m.yn, y_dev, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = launch_prescale(ctx, X_dev, N, m.d, m.DP, m.ls, m.Xs, NP))) return rc;
+  } else {
+    GPBO_HIP(ctx, hipMemcpyAsync(m.tmp, X, (size_t)N * m.d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    GPBO_HIP(ctx, hipMemcpyAsync(m.yn, y_norm, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_prescale(ctx, m.tmp, N, m.d, m.DP, m.ls, m.Xs, NP))) return rc;
+  }
   return factor_resident(ctx, m, noise, info_host);
+}
+
+static int factorize(gpbo_ctx* ctx, Model& m, const char* who, const double* X, const double* y_norm, int64_t N,
+                     int d, int kernel, const double* length_scale, int n_ls, double noise, int precision,
+                     int** info_host) {
+  int rc = prepare_model(ctx, m, who, X && y_norm, N, d, kernel, length_scale, n_ls, noise, precision);
+  if (rc) return rc;
+  return enqueue_factor(ctx, m, X, y_norm, nullptr, nullptr, noise, info_host);
 }
 
 // Tail shared by gpbo_fit and gpbo_fit_append: pack W for the posterior kernels, wait, resolve the pivot check.
@@ -401,13 +426,10 @@ int gpbo_fit_append(gpbo_ctx* ctx, int slot, const double* x_new, int64_t n_new,
   return finish_fit(ctx, m, info_h, info);
 }
 
-// One log-marginal-likelihood evaluation enqueued on ctx->stream into model m; results land in the pinned words
-// *out_host (yT alpha, sum log L_ii, gradient...) and *info_host once the stream has drained.
-static int lml_enqueue(gpbo_ctx* ctx, Model& m, const double* X, const double* y_norm, int64_t N, int d, int kernel,
-                       const double* length_scale, int n_ls, double noise, int eval_gradient, double** out_host,
-                       int** info_host) {
-  int rc = factorize(ctx, m, "gpbo_lml", X, y_norm, N, d, kernel, length_scale, n_ls, noise, GPBO_F64, info_host);
-  if (rc) return rc;
+// The part of a log-marginal-likelihood evaluation that follows the factorisation, enqueued on ctx->stream: the scalar
+// terms, K^-1 = W^T W and the gradient reduction, and the copy of the results to the pinned words *out_host.
+static int lml_tail(gpbo_ctx* ctx, Model& m, int n_ls, int eval_gradient, double** out_host) {
+  int rc;
   // device scratch for the scalars: red buffer (>= 2 + n_ls doubles)
   {
     char* p = (char*)ctx->red;
@@ -434,6 +456,16 @@ static int lml_enqueue(gpbo_ctx* ctx, Model& m, const double* X, const double* y
                                hipMemcpyDeviceToHost, ctx->stream));
   *out_host = out_h;
   return GPBO_OK;
+}
+
+// One log-marginal-likelihood evaluation enqueued on ctx->stream into model m; results land in the pinned words
+// *out_host (yT alpha, sum log L_ii, gradient...) and *info_host once the stream has drained.
+static int lml_enqueue(gpbo_ctx* ctx, Model& m, const double* X, const double* y_norm, int64_t N, int d, int kernel,
+                       const double* length_scale, int n_ls, double noise, int eval_gradient, double** out_host,
+                       int** info_host) {
+  int rc = factorize(ctx, m, "gpbo_lml", X, y_norm, N, d, kernel, length_scale, n_ls, noise, GPBO_F64, info_host);
+  if (rc) return rc;
+  return lml_tail(ctx, m, n_ls, eval_gradient, out_host);
 }
 
 static void lml_finish(const double* out_h, const int* info_h, int64_t N, int n_ls, int eval_gradient, double* lml,
@@ -470,30 +502,86 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
                    int* info) {
   if (!ctx) return GPBO_ERR_INVALID;
   if (n_theta < 1 || n_theta > GPBO_LML_BATCH_MAX) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: n_theta out of range [1, 8]");
-  if (!lml || !length_scales || (eval_gradient && !grad)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: NULL argument");
+  if (!lml || !length_scales || !X || !y_norm || (eval_gradient && !grad))
+    GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: NULL argument");
+  if (N < 1 || N > (1 << 16) || d < 1 || d > GPBO_MAX_DIM) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: N or d out of range");
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
   for (int i = 0; i < n_theta; ++i) {
     if (!ctx->lml_stream[i]) GPBO_HIP(ctx, hipStreamCreateWithFlags(&ctx->lml_stream[i], hipStreamNonBlocking));
     if (!ctx->lml_scratch[i]) GPBO_HIP(ctx, hipMalloc(&ctx->lml_scratch[i], 4096));
   }
-  // every evaluation on its own stream, scratch model and scratch words; the engine stream and slots are untouched
+  // the inputs go to the device once; every lane reads them from there
+  int rc;
+  if ((rc = ensure(ctx, &ctx->lml_X, &ctx->cap_lml_X, N * d))) return rc;
+  if ((rc = ensure(ctx, &ctx->lml_y, &ctx->cap_lml_y, N))) return rc;
   GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  GPBO_HIP(ctx, hipMemcpy(ctx->lml_X, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice));
+  GPBO_HIP(ctx, hipMemcpy(ctx->lml_y, y_norm, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+  static const bool graphs_allowed = !(getenv("GPBO_LML_GRAPH") && getenv("GPBO_LML_GRAPH")[0] == '0');
+
+  // Every evaluation on its own stream, scratch model and scratch words; the engine stream and the model slots are
+  // untouched.  An evaluation is ~60 short kernels, i.e. launch-bound for N below a few thousand: the second time a
+  // lane sees the same problem shape its sequence is captured into a hipGraph and from then on replayed with ONE launch
+  // (theta enters through the pinned length-scale words the graph's first copy node reads).
   hipStream_t stream0 = ctx->stream;
   void* red0 = ctx->red; int64_t cap_red0 = ctx->cap_red;
   int* info0 = ctx->info_dev;
   void* pinned0 = ctx->pinned;
   double* out_h[GPBO_LML_BATCH_MAX];
   int* info_h[GPBO_LML_BATCH_MAX];
-  int rc = GPBO_OK;
+  rc = GPBO_OK;
   ctx->no_timing = true;
   for (int i = 0; i < n_theta && rc == GPBO_OK; ++i) {
+    LmlLane& lane = ctx->lml_lane[i];
+    Model& m = ctx->lml_model[i];
     ctx->stream = ctx->lml_stream[i];
     ctx->red = (char*)ctx->lml_scratch[i] + 64;
     ctx->cap_red = 4096 - 64;
     ctx->info_dev = (int*)ctx->lml_scratch[i];
     ctx->pinned = (char*)pinned0 + (size_t)(i + 1) * 4096;
-    rc = lml_enqueue(ctx, ctx->lml_model[i], X, y_norm, N, d, kernel, length_scales + (size_t)i * n_ls, n_ls, noise,
-                     eval_gradient, &out_h[i], &info_h[i]);
+    rc = prepare_model(ctx, m, "gpbo_lml_batch", true, N, d, kernel, length_scales + (size_t)i * n_ls, n_ls, noise, GPBO_F64);
+    if (rc) break;
+    out_h[i] = (double*)((char*)ctx->pinned + 2048);
+    info_h[i] = (int*)((char*)ctx->pinned + 1024);
+    const bool same = lane.seen && lane.N == N && lane.d == d && lane.kernel == kernel && lane.n_ls == n_ls &&
+                      lane.eval_gradient == eval_gradient && lane.noise == noise && lane.X == ctx->lml_X &&
+                      lane.y == ctx->lml_y && lane.K == m.K;
+    if (same && lane.exec) {
+      hipError_t e = hipGraphLaunch(lane.exec, ctx->stream);
+      if (e != hipSuccess) GPBO_HIP(ctx, e);
+      continue;
+    }
+    if (lane.exec) { (void)hipGraphExecDestroy(lane.exec); lane.exec = nullptr; }
+    if (same && graphs_allowed && !ctx->lml_graph_off) {
+      // second sighting of this shape: capture, instantiate, launch
+      hipGraph_t graph = nullptr;
+      double* oh = nullptr; int* ih = nullptr;
+      hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+      int crc = GPBO_ERR_HIP;
+      if (e == hipSuccess) {
+        crc = enqueue_factor(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, &ih);
+        if (crc == GPBO_OK) crc = lml_tail(ctx, m, n_ls, eval_gradient, &oh);
+        e = hipStreamEndCapture(ctx->stream, &graph);
+      }
+      if (e == hipSuccess && crc == GPBO_OK && graph &&
+          hipGraphInstantiate(&lane.exec, graph, nullptr, nullptr, 0) == hipSuccess && lane.exec) {
+        (void)hipGraphDestroy(graph);
+        e = hipGraphLaunch(lane.exec, ctx->stream);
+        if (e != hipSuccess) GPBO_HIP(ctx, e);
+        continue;
+      }
+      // capture is not available for this sequence on this runtime: stay with direct launches from now on
+      if (graph) (void)hipGraphDestroy(graph);
+      if (lane.exec) { (void)hipGraphExecDestroy(lane.exec); lane.exec = nullptr; }
+      (void)hipGetLastError();
+      ctx->lml_graph_off = true;
+    }
+    double* oh = nullptr; int* ih = nullptr;
+    rc = enqueue_factor(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, &ih);
+    if (rc == GPBO_OK) rc = lml_tail(ctx, m, n_ls, eval_gradient, &oh);
+    lane.seen = (rc == GPBO_OK);
+    lane.N = N; lane.d = d; lane.kernel = kernel; lane.n_ls = n_ls; lane.eval_gradient = eval_gradient; lane.noise = noise;
+    lane.X = ctx->lml_X; lane.y = ctx->lml_y; lane.K = m.K;
   }
   ctx->stream = stream0; ctx->red = red0; ctx->cap_red = cap_red0; ctx->info_dev = info0; ctx->pinned = pinned0;
   ctx->no_timing = false;

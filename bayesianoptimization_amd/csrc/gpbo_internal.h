@@ -50,6 +50,16 @@ struct Model {
   int64_t M_post = -1;     // number of candidates mu/sd are valid for (-1: none)
 };
 
+// One gpbo_lml_batch lane: the problem shape it last ran and, from the second run on, the captured launch sequence.
+struct LmlLane {
+  hipGraphExec_t exec = nullptr;
+  bool seen = false;
+  int64_t N = 0;
+  int d = 0, kernel = 0, n_ls = 0, eval_gradient = 0;
+  double noise = 0.0;
+  const void* X = nullptr; const void* y = nullptr; const void* K = nullptr;
+};
+
 struct EventPair {
   hipEvent_t a = nullptr, b = nullptr;
   bool used = false;
@@ -67,6 +77,10 @@ struct gpbo_ctx {
   hipStream_t lml_stream[GPBO_LML_BATCH_MAX] = {};
   void* lml_scratch[GPBO_LML_BATCH_MAX] = {};
   bool no_timing = false;   // batch lanes do not touch the timing events
+  gpbo::LmlLane lml_lane[GPBO_LML_BATCH_MAX];
+  double* lml_X = nullptr; int64_t cap_lml_X = 0;   // the batch's raw inputs, uploaded once per call
+  double* lml_y = nullptr; int64_t cap_lml_y = 0;
+  bool lml_graph_off = false;   // stream capture failed once: direct launches only
   // candidates
   double* Xc = nullptr;    // [M][d] raw
   int64_t cap_Xc = 0;      // capacity in doubles

@@ -477,6 +477,15 @@ def test_lml_batch_lanes_are_bitwise_gpbo_lml(engine, N, d, kernel):
         if 0.2 <= ls[0] <= 2.0:     # the well-conditioned thetas also against the oracle (the others: cond(K) >> 1e10)
             v_o, g_o = O.log_marginal_likelihood(kernel, X, yn, ls, 1e-6, True)
             assert abs(val - v_o) <= (1e-9 if kernel == O.MATERN25 else 1e-6) * abs(v_o)
+    # the same shape again: the second call captures each lane's launch sequence into a hipGraph, later calls replay
+    # it — new thetas enter through the pinned length-scale words; still bitwise gpbo_lml, for fewer lanes too
+    for rep in range(4):
+        sc = np.random.RandomState(80 + rep).uniform(0.3, 3.0, size=(8 if rep < 3 else 5, 1))
+        for (val, grad), ls in zip(engine.lml_batch(X, yn, kernel, sc, 1e-6), sc):
+            v1, g1 = engine.lml(X, yn, kernel, ls, 1e-6)
+            assert val == v1 and np.array_equal(grad, g1)
+    vals_only = engine.lml_batch(X, yn, kernel, scales[:3], 1e-6, eval_gradient=False)
+    assert [v for v, _ in vals_only] == [v for v, _ in got[:3]]
     aniso = np.random.RandomState(73).uniform(0.4, 2.0, size=(3, d))
     for (val, grad), ls in zip(engine.lml_batch(X, yn, kernel, aniso, 1e-6), aniso):
         v1, g1 = engine.lml(X, yn, kernel, ls, 1e-6)
