@@ -112,6 +112,21 @@ def make_candidates(bounds: np.ndarray, M: int, random_state) -> np.ndarray:
     return data
 
 
+def normalize_targets(y):
+    """(y_norm, mean, std) as GaussianProcessRegressor.fit(normalize_y=True) forms them (_gpr.py:272-277; a zero std
+    becomes 1, preprocessing/_data.py:107-110)."""
+    y = np.asarray(y, dtype=np.float64)
+    mean, std = float(np.mean(y)), float(np.std(y))
+    if std < 10 * np.finfo(np.float64).eps:
+        std = 1.0
+    return (y - mean) / std, mean, std
+
+
+def flops_per_candidate(N: int, d: int, n_gp: int = 1) -> float:
+    """F_cand = N^2 + (3d + 12) N per GP."""
+    return float(n_gp) * (float(N) * N + (3 * d + 12) * float(N))
+
+
 def feasible_y_max(w: Workload, y, c):
     """y_max as TargetSpace._target_max (target_space.py:605-622): max over feasible, in-bounds points."""
     if c is None:

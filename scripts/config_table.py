@@ -12,7 +12,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bayesianoptimization_amd import workloads as W  # noqa: E402
 from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
-from oracle import gp_oracle as O  # noqa: E402
 
 eng = GpEngine(0)
 rows = {}
@@ -23,7 +22,7 @@ for name, shard in (("C1", 1), ("C2", 1), ("C3", 1), ("C4", 8), ("C5", 8)):
     X, y, c = W.make_observations(w)
     M = w.M // shard
     Xc = W.make_candidates(w.bounds_array(), M, 7)
-    yn, ym, ys = O.normalize_targets(y)
+    yn, ym, ys = W.normalize_targets(y)
     y_max = W.feasible_y_max(w, y, c)
     n_gp = 2 if w.constrained else 1
     r = {"N": w.N, "d": w.d, "M_per_gpu": M, "gps": n_gp, "arith": "f64"}
@@ -34,7 +33,7 @@ for name, shard in (("C1", 1), ("C2", 1), ("C3", 1), ("C4", 8), ("C5", 8)):
         fit_ms = eng.last_timings()["fit"]
         lb = ub = None
         if w.constrained:
-            cn, cm, cs = O.normalize_targets(c)
+            cn, cm, cs = W.normalize_targets(c)
             eng.fit(X, cn, W.MATERN25, float(g["c_length_scale"][0]), w.noise, slot=1)
             fit_ms += eng.last_timings()["fit"]
             lb, ub = [-np.inf], [w.constraint_ub]
@@ -52,7 +51,7 @@ for name, shard in (("C1", 1), ("C2", 1), ("C3", 1), ("C4", 8), ("C5", 8)):
             best = (step_ms, fit_ms, post_ms, acq_ms)
     r["step_ms"], r["fit_ms"], r["posterior_ms"], r["acq_argbest_ms"] = best
     r["cand_per_s"] = M / (best[0] * 1e-3)
-    fl = O.flops_per_candidate(w.N, w.d, n_gp) * M
+    fl = W.flops_per_candidate(w.N, w.d, n_gp) * M
     r["posterior_tflops_algorithmic"] = fl / (best[2] * 1e-3) / 1e12
     r["frac_of_78.6"] = r["posterior_tflops_algorithmic"] / 78.6
     r["argbest"] = int(bi)

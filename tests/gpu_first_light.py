@@ -1,6 +1,6 @@
 """First-light diagnostics on a real MI355X: layout probe, peaks, parity vs the oracle, timings.
 
-    python scripts/gpu_first_light.py [--big]      (writes gpurun_out/first_light.json)
+    python tests/gpu_first_light.py [--big]      (writes gpurun_out/first_light.json)
 Development aid (not part of the product or the test-suite); uses the oracle as the checker.
 """
 import json
