@@ -61,3 +61,30 @@ def test_product_never_imports_the_oracle():
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
             assert "import torch" not in src, fn
+
+
+def test_oracle_is_only_reachable_from_the_allowed_places():
+    """Besides tests/: only bench.py's cpu_baseline leg and __graft_entry__ (build of the checker, smoke) may touch
+    oracle/; the measurement scripts and the package may not."""
+    import ast
+    import glob
+
+    def importers(path):
+        tree = ast.parse(open(path).read())
+        hits = []
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                hits.append(node)
+        return tree, hits
+
+    for path in glob.glob(os.path.join(ROOT, "scripts", "*.py")) + glob.glob(os.path.join(ROOT, "bayesianoptimization_amd", "*.py")):
+        assert not importers(path)[1], path
+    tree, hits = importers(os.path.join(ROOT, "bench.py"))
+    baseline = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "cpu_baseline")
+    inside = {id(n) for n in ast.walk(baseline)}
+    assert hits and all(id(h) in inside for h in hits)
