@@ -39,6 +39,16 @@ class GpEngine:
         self._serial: dict[int, int] = {}    # slot -> number of times its factorisation was rewritten
 
     # -- lifecycle ---------------------------------------------------------------------------
+    def __deepcopy__(self, memo):
+        # a context is a device resource, not data: estimators that get deep-copied (sklearn.base.clone, bayes_opt's
+        # ConstantLiar copying a constrained target space) keep pointing at the same engine
+        return self
+
+    __copy__ = lambda self: self  # noqa: E731
+
+    def __reduce__(self):
+        raise TypeError("GpEngine holds a GPU context and cannot be pickled; create one per process (GpEngine(device))")
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.gpbo_destroy(self._h)

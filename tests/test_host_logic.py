@@ -356,3 +356,31 @@ def test_lbfgsb_driver_with_gradient_equals_scipy_minimize():
         ref = minimize(fg, x0, jac=True, bounds=box, method="L-BFGS-B")
         assert np.array_equal(r.x, ref.x) and r.fun == ref.fun and np.array_equal(r.jac, ref.jac)
         assert (r.nit, r.nfev, r.status, r.success, r.message) == (ref.nit, ref.nfev, ref.status, ref.success, ref.message)
+
+
+def test_engine_is_shared_by_copies_and_not_picklable():
+    """sklearn.base.clone / copy.deepcopy of an estimator (bayes_opt's ConstantLiar deep-copies a constrained target
+    space, constraint GPs included) must not duplicate the device context behind it."""
+    import copy
+    import pickle
+
+    from sklearn.base import clone
+    from sklearn.gaussian_process.kernels import Matern
+
+    from bayesianoptimization_amd.engine import GpEngine
+    from bayesianoptimization_amd.gpr import HipGPR
+
+    class Handleless(GpEngine):            # no GPU here: skip context creation, keep the copy semantics
+        def __init__(self):
+            self._h = None
+            self._serial = {}
+
+    eng = Handleless()
+    assert copy.deepcopy(eng) is eng and copy.copy(eng) is eng
+    gp = HipGPR(kernel=Matern(nu=2.5), engine=eng, slot=3, precision="f32", incremental=False, theta_lockstep=False)
+    twin = clone(gp)
+    assert twin.engine is eng and twin.slot == 3 and twin.precision == "f32"
+    assert twin.incremental is False and twin.theta_lockstep is False
+    assert copy.deepcopy(gp).engine is eng
+    with pytest.raises(TypeError):
+        pickle.dumps(eng)
