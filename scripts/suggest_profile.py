@@ -27,12 +27,12 @@ sp.register_bulk(X, y)
 fn = A.UpperConfidenceBound(kappa=2.576)
 gp = HipGPR(kernel=Matern(nu=2.5, length_scale=w.length_scale), alpha=w.noise, normalize_y=True, optimizer=None, engine=eng)
 for _ in range(2):
-    fn.suggest(gp, sp, n_random=w.M, n_smart=0, fit_gp=True, random_state=np.random.RandomState(7))
+    fn.suggest(gp, sp, n_random=w.M, n_smart=int(os.environ.get("NSMART", "0")), fit_gp=True, random_state=np.random.RandomState(7))
 pr = cProfile.Profile()
 t0 = time.perf_counter()
 pr.enable()
-fn.suggest(gp, sp, n_random=w.M, n_smart=0, fit_gp=True, random_state=np.random.RandomState(7))
+fn.suggest(gp, sp, n_random=w.M, n_smart=int(os.environ.get("NSMART", "0")), fit_gp=True, random_state=np.random.RandomState(7))
 pr.disable()
 print("wall ms", (time.perf_counter() - t0) * 1e3)
 print("device timings", eng.last_timings())
-pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
