@@ -17,9 +17,11 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // X / length_scale into a zero-padded [n_pad][DP] image (true division, as numpy does).
 __global__ void prescale_kernel(const double* __restrict__ X, int64_t n, int d, int DP,
                                 const double* __restrict__ ls, double* __restrict__ out,
-                                int64_t total) {
+                                int64_t total, int64_t lane_stride) {
   int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
+  ls += (int64_t)blockIdx.y * lane_stride;     // lane mode: X is shared, length scales and output are per lane
+  out += (int64_t)blockIdx.y * lane_stride;
   int64_t row = idx / DP;
   int t = (int)(idx - row * DP);
   double v = 0.0;
@@ -32,7 +34,8 @@ int launch_prescale(gpbo_ctx* ctx, const double* X, int64_t n, int d, int DP, co
   int64_t total = n_pad * DP;
   if (total == 0) return GPBO_OK;
   int64_t blocks = (total + 255) / 256;
-  prescale_kernel<<<dim3((unsigned)blocks), dim3(256), 0, ctx->stream>>>(X, n, d, DP, ls, out, total);
+  prescale_kernel<<<dim3((unsigned)blocks, (unsigned)ctx->lanes), dim3(256), 0, ctx->stream>>>(X, n, d, DP, ls, out, total,
+                                                                                             ctx->lane_stride);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
@@ -53,9 +56,12 @@ __device__ __forceinline__ double kernel_value(double d2) {
 // point tiles staged k-major in LDS.  HBM-write bound: N^2/2 * 8 B.
 template <int KERNEL>
 __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ Xs, int DP, int64_t N,
-                                                   int64_t NP, double noise, double* __restrict__ K) {
+                                                   int64_t NP, double noise, double* __restrict__ K,
+                                                   int64_t lane_stride) {
   const int bj = blockIdx.x, bi = blockIdx.y;
   if (bj > bi) return;
+  Xs += (int64_t)blockIdx.z * lane_stride;
+  K += (int64_t)blockIdx.z * lane_stride;
   extern __shared__ __attribute__((aligned(16))) double kmat_smem[];
   double* XiT = kmat_smem;            // [DP][64]
   double* XjT = kmat_smem + DP * 64;  // [DP][64]
@@ -106,12 +112,12 @@ __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ Xs
 }
 
 int launch_kmat(gpbo_ctx* ctx, Model& m, double noise) {
-  dim3 grid((unsigned)(m.NP / 64), (unsigned)(m.NP / 64));
+  dim3 grid((unsigned)(m.NP / 64), (unsigned)(m.NP / 64), (unsigned)ctx->lanes);
   const size_t lds = (size_t)2 * m.DP * 64 * sizeof(double);
   if (m.kernel == GPBO_KERNEL_MATERN25)
-    kmat_kernel<GPBO_KERNEL_MATERN25><<<grid, dim3(256), lds, ctx->stream>>>(m.Xs, m.DP, m.N, m.NP, noise, m.K);
+    kmat_kernel<GPBO_KERNEL_MATERN25><<<grid, dim3(256), lds, ctx->stream>>>(m.Xs, m.DP, m.N, m.NP, noise, m.K, ctx->lane_stride);
   else
-    kmat_kernel<GPBO_KERNEL_RBF><<<grid, dim3(256), lds, ctx->stream>>>(m.Xs, m.DP, m.N, m.NP, noise, m.K);
+    kmat_kernel<GPBO_KERNEL_RBF><<<grid, dim3(256), lds, ctx->stream>>>(m.Xs, m.DP, m.N, m.NP, noise, m.K, ctx->lane_stride);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
@@ -142,7 +148,10 @@ __device__ __forceinline__ void lds_matmul(double* __restrict__ Cm, int ldc, con
 }
 
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, int kb,
-                                                         double* __restrict__ dinv, int* info) {
+                                                         double* __restrict__ dinv, int* info, int64_t lane_stride) {
+  L += (int64_t)blockIdx.x * lane_stride;
+  dinv += (int64_t)blockIdx.x * lane_stride;
+  info += (int64_t)blockIdx.x * lane_stride * 2;      // the info word lives in the lane's slab too (ints: 2 per double)
   extern __shared__ __attribute__((aligned(16))) double pd_smem[];
   double* Ls = pd_smem;              // [64][65]
   double* Wl = pd_smem + 64 * 65;    // [64][65]
@@ -299,7 +308,8 @@ int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  potrf_diag_kernel<<<dim3(1), dim3(256), lds, ctx->stream>>>(m.L, m.NP, kb, m.dinv, ctx->info_dev);
+  potrf_diag_kernel<<<dim3((unsigned)ctx->lanes), dim3(256), lds, ctx->stream>>>(m.L, m.NP, kb, m.dinv, ctx->info_dev,
+                                                                                   ctx->lane_stride);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
@@ -312,14 +322,16 @@ int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb) {
 // D lane l, reg r = D[(l>>4) + 4r][l&15].
 template <bool BT, bool AT>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
-  const int bn = blockIdx.x, bm = blockIdx.y, bz = blockIdx.z;
+  const int bn = blockIdx.x, bm = blockIdx.y;
+  const int zl = blockIdx.z / g.batch, bz = blockIdx.z - zl * g.batch;   // lane mode: z = lane * batch + b
   if (g.lower_only && bn > bm) return;
   __shared__ double As[16][68];
   __shared__ double Bs[16][68];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const double* A = g.A + (int64_t)bz * g.strideA + (AT ? (int64_t)bm * 64 : (int64_t)bm * 64 * g.lda);
-  const double* B = g.B + (int64_t)bz * g.strideB + (BT ? (int64_t)bn * 64 * g.ldb : (int64_t)bn * 64);
-  double* C = g.C + (int64_t)bz * g.strideC;
+  const int64_t lo = (int64_t)zl * g.lane_stride;
+  const double* A = g.A + lo + (int64_t)bz * g.strideA + (AT ? (int64_t)bm * 64 : (int64_t)bm * 64 * g.lda);
+  const double* B = g.B + lo + (int64_t)bz * g.strideB + (BT ? (int64_t)bn * 64 * g.ldb : (int64_t)bn * 64);
+  double* C = g.C + lo + (int64_t)bz * g.strideC;
   int kbeg = 0, kend = g.k;
   if (g.a_lower) kend = min(kend, (bm + 1) * 64);
   if (g.b_lower) kbeg = bn * 64;
@@ -405,10 +417,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       }
 }
 
-int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g) {
-  if (g.m <= 0 || g.n <= 0 || g.batch <= 0) return GPBO_OK;
+int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
+  if (g_in.m <= 0 || g_in.n <= 0 || g_in.batch <= 0) return GPBO_OK;
+  GemmArgs g = g_in;
+  g.lanes = ctx->lanes;
+  g.lane_stride = ctx->lane_stride;
   if (g.m % 64 || g.n % 64 || g.k % 16) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gemm: m,n must be multiples of 64 and k of 16");
-  dim3 grid((unsigned)(g.n / 64), (unsigned)(g.m / 64), (unsigned)g.batch);
+  dim3 grid((unsigned)(g.n / 64), (unsigned)(g.m / 64), (unsigned)(g.batch * g.lanes));
   if (g.a_trans && g.b_trans) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gemm: a_trans with b_trans is not instantiated");
   if (g.b_trans)
     gemm_f64_kernel<true, false><<<grid, dim3(256), 0, ctx->stream>>>(g);
@@ -423,8 +438,10 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g) {
 // ------------------------------------------------------------------------------------------------
 // W := blockdiag(dinv) (W has been zero-filled).
 __global__ __launch_bounds__(256) void fill_w_diag_kernel(const double* __restrict__ dinv,
-                                                          double* __restrict__ W, int64_t NP) {
+                                                          double* __restrict__ W, int64_t NP, int64_t lane_stride) {
   const int kb = blockIdx.x;
+  dinv += (int64_t)blockIdx.y * lane_stride;
+  W += (int64_t)blockIdx.y * lane_stride;
   const double* D = dinv + (int64_t)kb * 4096;
   for (int e = threadIdx.x; e < 4096; e += 256) {
     int r = e >> 6, c = e & 63;
@@ -433,8 +450,13 @@ __global__ __launch_bounds__(256) void fill_w_diag_kernel(const double* __restri
 }
 
 int launch_fill_w_diag(gpbo_ctx* ctx, Model& m) {
-  GPBO_HIP(ctx, hipMemsetAsync(m.W, 0, (size_t)m.NP * m.NP * sizeof(double), ctx->stream));
-  fill_w_diag_kernel<<<dim3((unsigned)(m.NP / 64)), dim3(256), 0, ctx->stream>>>(m.dinv, m.W, m.NP);
+  if (ctx->lanes == 1)
+    GPBO_HIP(ctx, hipMemsetAsync(m.W, 0, (size_t)m.NP * m.NP * sizeof(double), ctx->stream));
+  else
+    GPBO_HIP(ctx, hipMemset2DAsync(m.W, (size_t)ctx->lane_stride * sizeof(double), 0, (size_t)m.NP * m.NP * sizeof(double),
+                                   (size_t)ctx->lanes, ctx->stream));
+  fill_w_diag_kernel<<<dim3((unsigned)(m.NP / 64), (unsigned)ctx->lanes), dim3(256), 0, ctx->stream>>>(m.dinv, m.W, m.NP,
+                                                                                                      ctx->lane_stride);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
@@ -443,10 +465,13 @@ int launch_fill_w_diag(gpbo_ctx* ctx, Model& m) {
 // t = W y (one wave per row, fixed shuffle tree) and alpha = W^T t (64 columns per workgroup).
 __global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restrict__ W,
                                                          const double* __restrict__ y,
-                                                         double* __restrict__ t, int64_t NP) {
+                                                         double* __restrict__ t, int64_t NP, int64_t lane_stride) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + wave;
   if (i >= NP) return;
+  W += (int64_t)blockIdx.y * lane_stride;
+  y += (int64_t)blockIdx.y * lane_stride;
+  t += (int64_t)blockIdx.y * lane_stride;
   const double* row = W + i * NP;
   double s = 0.0;
   for (int64_t j = lane; j <= i; j += 64) s = fma(row[j], y[j], s);
@@ -461,8 +486,12 @@ constexpr int TRMV_SPLITS = 16;
 
 __global__ __launch_bounds__(256) void trmv_lower_t_kernel(const double* __restrict__ W,
                                                            const double* __restrict__ t,
-                                                           double* __restrict__ partial, int64_t NP) {
+                                                           double* __restrict__ partial, int64_t NP,
+                                                           int64_t lane_stride) {
   __shared__ double red[4][64];
+  W += (int64_t)blockIdx.z * lane_stride;
+  t += (int64_t)blockIdx.z * lane_stride;
+  partial += (int64_t)blockIdx.z * lane_stride;
   const int ig = threadIdx.x >> 6, jl = threadIdx.x & 63;
   const int64_t j0 = (int64_t)blockIdx.x * 64;
   const int64_t rows = NP - j0;                                   // rows j0 .. NP-1 hold non-zeros
@@ -477,9 +506,12 @@ __global__ __launch_bounds__(256) void trmv_lower_t_kernel(const double* __restr
 }
 
 __global__ __launch_bounds__(256) void trmv_reduce_kernel(const double* __restrict__ partial,
-                                                          double* __restrict__ alpha, int64_t NP) {
+                                                          double* __restrict__ alpha, int64_t NP,
+                                                          int64_t lane_stride) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= NP) return;
+  partial += (int64_t)blockIdx.y * lane_stride;
+  alpha += (int64_t)blockIdx.y * lane_stride;
   double s = 0.0;
 #pragma unroll
   for (int r = 0; r < TRMV_SPLITS; ++r) s += partial[(int64_t)r * NP + j];
@@ -487,12 +519,14 @@ __global__ __launch_bounds__(256) void trmv_reduce_kernel(const double* __restri
 }
 
 int launch_trmv(gpbo_ctx* ctx, Model& m) {
-  trmv_lower_kernel<<<dim3((unsigned)((m.NP + 3) / 4)), dim3(256), 0, ctx->stream>>>(m.W, m.yn, m.tvec, m.NP);
+  const unsigned lanes = (unsigned)ctx->lanes;
+  const int64_t ls = ctx->lane_stride;
+  trmv_lower_kernel<<<dim3((unsigned)((m.NP + 3) / 4), lanes), dim3(256), 0, ctx->stream>>>(m.W, m.yn, m.tvec, m.NP, ls);
   GPBO_HIP(ctx, hipGetLastError());
   // m.tmp (>= NP*64 doubles) is free again after trtri
-  trmv_lower_t_kernel<<<dim3((unsigned)(m.NP / 64), TRMV_SPLITS), dim3(256), 0, ctx->stream>>>(m.W, m.tvec, m.tmp, m.NP);
+  trmv_lower_t_kernel<<<dim3((unsigned)(m.NP / 64), TRMV_SPLITS, lanes), dim3(256), 0, ctx->stream>>>(m.W, m.tvec, m.tmp, m.NP, ls);
   GPBO_HIP(ctx, hipGetLastError());
-  trmv_reduce_kernel<<<dim3((unsigned)((m.NP + 255) / 256)), dim3(256), 0, ctx->stream>>>(m.tmp, m.alpha, m.NP);
+  trmv_reduce_kernel<<<dim3((unsigned)((m.NP + 255) / 256), lanes), dim3(256), 0, ctx->stream>>>(m.tmp, m.alpha, m.NP, ls);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
@@ -570,11 +604,11 @@ int launch_append_row(gpbo_ctx* ctx, Model& m, int64_t j) {
   else
     append_kvec_kernel<GPBO_KERNEL_RBF><<<dim3(vb), dim3(256), 0, ctx->stream>>>(m.Xs, m.DP, j, m.NP, m.noise, kv, m.K);
   GPBO_HIP(ctx, hipGetLastError());
-  trmv_lower_kernel<<<dim3((unsigned)((m.NP + 3) / 4)), dim3(256), 0, ctx->stream>>>(m.W, kv, lv, m.NP);
+  trmv_lower_kernel<<<dim3((unsigned)((m.NP + 3) / 4)), dim3(256), 0, ctx->stream>>>(m.W, kv, lv, m.NP, 0);
   GPBO_HIP(ctx, hipGetLastError());
-  trmv_lower_t_kernel<<<dim3((unsigned)(m.NP / 64), TRMV_SPLITS), dim3(256), 0, ctx->stream>>>(m.W, lv, partial, m.NP);
+  trmv_lower_t_kernel<<<dim3((unsigned)(m.NP / 64), TRMV_SPLITS), dim3(256), 0, ctx->stream>>>(m.W, lv, partial, m.NP, 0);
   GPBO_HIP(ctx, hipGetLastError());
-  trmv_reduce_kernel<<<dim3(vb), dim3(256), 0, ctx->stream>>>(partial, uv, m.NP);
+  trmv_reduce_kernel<<<dim3(vb), dim3(256), 0, ctx->stream>>>(partial, uv, m.NP, 0);
   GPBO_HIP(ctx, hipGetLastError());
   append_finish_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(lv, uv, j, m.NP, m.noise, m.L, m.W, ctx->info_dev);
   GPBO_HIP(ctx, hipGetLastError());

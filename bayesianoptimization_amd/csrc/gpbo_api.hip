@@ -211,10 +211,9 @@ int gpbo_destroy(gpbo_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   gpbo_comm_destroy(ctx);
   for (auto& m : ctx->models) free_model(m);
-  for (auto& m : ctx->lml_model) free_model(m);
   for (auto& st : ctx->lml_stream) if (st) (void)hipStreamDestroy(st);
-  for (auto& p : ctx->lml_scratch) if (p) (void)hipFree(p);
   for (auto& ln : ctx->lml_lane) if (ln.exec) (void)hipGraphExecDestroy(ln.exec);
+  if (ctx->lml_slab) (void)hipFree(ctx->lml_slab);
   if (ctx->lml_X) (void)hipFree(ctx->lml_X);
   if (ctx->lml_y) (void)hipFree(ctx->lml_y);
   void* ptrs[] = {ctx->Xc, ctx->Xcs, ctx->part, ctx->mu_part, ctx->ys, ctx->red, ctx->info_dev, ctx->comm_buf, ctx->kst, ctx->stage};
@@ -251,21 +250,50 @@ int gpbo_device_info(gpbo_ctx* ctx, char* buf, int buflen) {
 
 // Shared by gpbo_fit and gpbo_lml: validate, upload, K, Cholesky, W = L^-1, alpha — all queued on the
 // stream; the potrf info word is copied to pinned memory (valid after the next stream sync).
+// Copies/fills that act on one buffer of EVERY lane (lane mode: the buffers of lane l sit l * lane_stride doubles
+// behind lane 0's; host staging areas are arrays with `host_pitch` bytes per lane).
+static hipError_t lane_memset(gpbo_ctx* ctx, void* p, size_t bytes) {
+  if (ctx->lanes == 1) return hipMemsetAsync(p, 0, bytes, ctx->stream);
+  return hipMemset2DAsync(p, (size_t)ctx->lane_stride * sizeof(double), 0, bytes, (size_t)ctx->lanes, ctx->stream);
+}
+static hipError_t lane_copy_d2d(gpbo_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (ctx->lanes == 1) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+  const size_t pitch = (size_t)ctx->lane_stride * sizeof(double);
+  return hipMemcpy2DAsync(dst, pitch, src, pitch, bytes, (size_t)ctx->lanes, hipMemcpyDeviceToDevice, ctx->stream);
+}
+static hipError_t lane_h2d(gpbo_ctx* ctx, void* dst, const void* src_host, size_t host_pitch, size_t bytes) {
+  if (ctx->lanes == 1) return hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream);
+  return hipMemcpy2DAsync(dst, (size_t)ctx->lane_stride * sizeof(double), src_host, host_pitch, bytes, (size_t)ctx->lanes,
+                          hipMemcpyHostToDevice, ctx->stream);
+}
+static hipError_t lane_d2h(gpbo_ctx* ctx, void* dst_host, size_t host_pitch, const void* src, size_t bytes) {
+  if (ctx->lanes == 1) return hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+  return hipMemcpy2DAsync(dst_host, host_pitch, src, (size_t)ctx->lane_stride * sizeof(double), bytes, (size_t)ctx->lanes,
+                          hipMemcpyDeviceToHost, ctx->stream);
+}
+
+// Host staging layout inside one 4 KiB pinned region (single lane) — lane mode uses per-lane pitches over several
+// regions: length scales [64] doubles at +0, potrf info word at +1024, LML scalars at +2048.
+constexpr size_t PIN_LS_PITCH = GPBO_MAX_DIM * sizeof(double);
+constexpr size_t PIN_INFO_PITCH = 8;
+constexpr size_t PIN_OUT_PITCH = (2 + GPBO_MAX_DIM) * sizeof(double);
+constexpr size_t PIN_LANE_WINDOW = 16384, PIN_LANE_INFO = 4096, PIN_LANE_OUT = 8192;   // lane-mode window inside ctx->pinned
+
 // K, L, W = L^-1 and alpha from the device-resident scaled inputs m.Xs / targets m.yn (m.N, m.NP, m.kernel set).
 static int factor_resident(gpbo_ctx* ctx, Model& m, double noise, int** info_host) {
   int rc;
   const int64_t NP = m.NP;
   m.noise = noise;
-  GPBO_HIP(ctx, hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream));
+  GPBO_HIP(ctx, lane_memset(ctx, ctx->info_dev, sizeof(int)));
   ev_begin(ctx, T_KMAT);
   if ((rc = launch_kmat(ctx, m, noise))) return rc;
   ev_end(ctx, T_KMAT);
-  GPBO_HIP(ctx, hipMemcpyAsync(m.L, m.K, (size_t)NP * NP * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  GPBO_HIP(ctx, lane_copy_d2d(ctx, m.L, m.K, (size_t)NP * NP * sizeof(double)));
   ev_begin(ctx, T_CHOL);
   if ((rc = cholesky(ctx, m))) return rc;
   ev_end(ctx, T_CHOL);
-  int* info_h = (int*)((char*)ctx->pinned + 1024);
-  GPBO_HIP(ctx, hipMemcpyAsync(info_h, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  int* info_h = (int*)((char*)ctx->pinned + (ctx->lanes == 1 ? 1024 : PIN_LANE_INFO));   // lane mode: one word per PIN_INFO_PITCH
+  GPBO_HIP(ctx, lane_d2h(ctx, info_h, PIN_INFO_PITCH, ctx->info_dev, sizeof(int)));
   // W and alpha are issued before the info check resolves (harmless on failure)
   ev_begin(ctx, T_TRTRI);
   if ((rc = trtri(ctx, m))) return rc;
@@ -312,10 +340,12 @@ static int enqueue_factor(gpbo_ctx* ctx, Model& m, const double* X, const double
   int rc;
   const int64_t N = m.N, NP = m.NP;
   ev_begin(ctx, T_FIT);
-  GPBO_HIP(ctx, hipMemcpyAsync(m.ls, ctx->pinned, GPBO_MAX_DIM * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  GPBO_HIP(ctx, hipMemsetAsync(m.yn, 0, (size_t)NP * sizeof(double), ctx->stream));
+  GPBO_HIP(ctx, lane_h2d(ctx, m.ls, ctx->pinned, PIN_LS_PITCH, GPBO_MAX_DIM * sizeof(double)));
+  GPBO_HIP(ctx, lane_memset(ctx, m.yn, (size_t)NP * sizeof(double)));
   if (X_dev) {
-    GPBO_HIP(ctx, hipMemcpyAsync(m.yn, y_dev, (size_t)N * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    for (int l = 0; l < ctx->lanes; ++l)     // every lane gets the same targets
+      GPBO_HIP(ctx, hipMemcpyAsync(m.yn + (int64_t)l * ctx->lane_stride, y_dev, (size_t)N * sizeof(double),
+                                   hipMemcpyDeviceToDevice, ctx->stream));
     if ((rc = launch_prescale(ctx, X_dev, N, m.d, m.DP, m.ls, m.Xs, NP))) return rc;
   } else {
     GPBO_HIP(ctx, hipMemcpyAsync(m.tmp, X, (size_t)N * m.d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
@@ -451,9 +481,8 @@ static int lml_tail(gpbo_ctx* ctx, Model& m, int n_ls, int eval_gradient, double
     if ((rc = launch_lml_grad(ctx, m, n_ls, m.K, m.tmp, scal + 2))) return rc;
   }
   ev_end(ctx, T_FIT);
-  double* out_h = (double*)((char*)ctx->pinned + 2048);
-  GPBO_HIP(ctx, hipMemcpyAsync(out_h, scal, (size_t)(2 + (eval_gradient ? n_ls : 0)) * sizeof(double),
-                               hipMemcpyDeviceToHost, ctx->stream));
+  double* out_h = (double*)((char*)ctx->pinned + (ctx->lanes == 1 ? 2048 : PIN_LANE_OUT));   // lane mode: PIN_OUT_PITCH bytes per lane
+  GPBO_HIP(ctx, lane_d2h(ctx, out_h, PIN_OUT_PITCH, scal, (size_t)(2 + (eval_gradient ? n_ls : 0)) * sizeof(double)));
   *out_host = out_h;
   return GPBO_OK;
 }
@@ -504,96 +533,136 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
   if (n_theta < 1 || n_theta > GPBO_LML_BATCH_MAX) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: n_theta out of range [1, 8]");
   if (!lml || !length_scales || !X || !y_norm || (eval_gradient && !grad))
     GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: NULL argument");
-  if (N < 1 || N > (1 << 16) || d < 1 || d > GPBO_MAX_DIM) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: N or d out of range");
+  if (N < 1 || N > (1 << 16)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: N out of range [1, 65536]");
+  if (d < 1 || d > GPBO_MAX_DIM) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "gpbo_lml_batch: d out of range [1, 64]");
+  if (kernel != GPBO_KERNEL_RBF && kernel != GPBO_KERNEL_MATERN25)
+    GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "gpbo_lml_batch: kernel must be RBF or Matern(nu=2.5)");
+  if (n_ls != 1 && n_ls != d) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: length_scale must have 1 or d entries");
+  if (!(noise >= 0.0)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: noise must be >= 0");
+  for (int64_t t = 0; t < (int64_t)n_theta * n_ls; ++t)
+    if (!(length_scales[t] > 0.0) || !std::isfinite(length_scales[t]))
+      GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: length_scale must be positive and finite");
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
-  for (int i = 0; i < n_theta; ++i) {
-    if (!ctx->lml_stream[i]) GPBO_HIP(ctx, hipStreamCreateWithFlags(&ctx->lml_stream[i], hipStreamNonBlocking));
-    if (!ctx->lml_scratch[i]) GPBO_HIP(ctx, hipMalloc(&ctx->lml_scratch[i], 4096));
-  }
-  // the inputs go to the device once; every lane reads them from there
+  if (!ctx->lml_stream[0]) GPBO_HIP(ctx, hipStreamCreateWithFlags(&ctx->lml_stream[0], hipStreamNonBlocking));
+
+  // One slab, one layout per lane: every kernel of the evaluation runs ONCE for all lanes (lane = a grid dimension,
+  // lane l's buffers l * stride doubles behind lane 0's) — the command processor sees ~60 dispatches per batch, not
+  // ~60 per theta.  Model slots and their fits are not touched.
+  const int64_t NP = round_up(N, NB);
+  const int DP = pad_dim(d);
+  auto up = [](int64_t v) { return round_up(v, 32); };
+  int64_t off = 0;
+  const int64_t o_ls = off;    off += up(GPBO_MAX_DIM);
+  const int64_t o_Xs = off;    off += up(NP * DP);
+  const int64_t o_K = off;     off += up(NP * NP);
+  const int64_t o_L = off;     off += up(NP * NP);
+  const int64_t o_W = off;     off += up(NP * NP);
+  const int64_t o_dinv = off;  off += up((NP / NB) * NB * NB);
+  const int64_t o_tmp = off;   off += up(std::max<int64_t>(NP * NP / 2, NP * (int64_t)GPBO_MAX_DIM));
+  const int64_t o_yn = off;    off += up(NP);
+  const int64_t o_tvec = off;  off += up(NP);
+  const int64_t o_alpha = off; off += up(NP);
+  const int64_t o_scal = off;  off += up(8 + GPBO_MAX_DIM);
+  const int64_t o_info = off;  off += 32;
+  const int64_t stride = off;
   int rc;
+  if ((rc = ensure(ctx, &ctx->lml_slab, &ctx->cap_lml_slab, stride * n_theta))) return rc;
   if ((rc = ensure(ctx, &ctx->lml_X, &ctx->cap_lml_X, N * d))) return rc;
   if ((rc = ensure(ctx, &ctx->lml_y, &ctx->cap_lml_y, N))) return rc;
   GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   GPBO_HIP(ctx, hipMemcpy(ctx->lml_X, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice));
   GPBO_HIP(ctx, hipMemcpy(ctx->lml_y, y_norm, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
-  static const bool graphs_allowed = !(getenv("GPBO_LML_GRAPH") && getenv("GPBO_LML_GRAPH")[0] == '0');
+  double* base = ctx->lml_slab;
+  Model m;     // a view of lane 0 (not owning)
+  m.N = N; m.NP = NP; m.d = d; m.DP = DP; m.kernel = kernel; m.precision = GPBO_F64; m.noise = noise;
+  m.ls = base + o_ls; m.Xs = base + o_Xs; m.K = base + o_K; m.L = base + o_L; m.W = base + o_W;
+  m.dinv = base + o_dinv; m.tmp = base + o_tmp; m.yn = base + o_yn; m.tvec = base + o_tvec; m.alpha = base + o_alpha;
 
-  // Every evaluation on its own stream, scratch model and scratch words; the engine stream and the model slots are
-  // untouched.  An evaluation is ~60 short kernels, i.e. launch-bound for N below a few thousand: the second time a
-  // lane sees the same problem shape its sequence is captured into a hipGraph and from then on replayed with ONE launch
-  // (theta enters through the pinned length-scale words the graph's first copy node reads).
+  // theta enters through the pinned length-scale words ([lane][64]) that the sequence's first copy reads
+  char* window = (char*)ctx->pinned + PIN_LANE_WINDOW;
+  double* ls_h = (double*)window;
+  for (int l = 0; l < n_theta; ++l)
+    for (int t = 0; t < GPBO_MAX_DIM; ++t)
+      ls_h[l * GPBO_MAX_DIM + t] = (t < d) ? (n_ls == 1 ? length_scales[l] : length_scales[(int64_t)l * n_ls + t]) : 1.0;
+
+  static const bool graphs_allowed = !(getenv("GPBO_LML_GRAPH") && getenv("GPBO_LML_GRAPH")[0] == '0');
   hipStream_t stream0 = ctx->stream;
   void* red0 = ctx->red; int64_t cap_red0 = ctx->cap_red;
   int* info0 = ctx->info_dev;
   void* pinned0 = ctx->pinned;
-  double* out_h[GPBO_LML_BATCH_MAX];
-  int* info_h[GPBO_LML_BATCH_MAX];
-  rc = GPBO_OK;
+  ctx->stream = ctx->lml_stream[0];
+  ctx->red = base + o_scal; ctx->cap_red = (8 + GPBO_MAX_DIM) * 8;
+  ctx->info_dev = (int*)(base + o_info);
+  ctx->pinned = window;
+  ctx->lanes = n_theta; ctx->lane_stride = stride;
   ctx->no_timing = true;
-  for (int i = 0; i < n_theta && rc == GPBO_OK; ++i) {
-    LmlLane& lane = ctx->lml_lane[i];
-    Model& m = ctx->lml_model[i];
-    ctx->stream = ctx->lml_stream[i];
-    ctx->red = (char*)ctx->lml_scratch[i] + 64;
-    ctx->cap_red = 4096 - 64;
-    ctx->info_dev = (int*)ctx->lml_scratch[i];
-    ctx->pinned = (char*)pinned0 + (size_t)(i + 1) * 4096;
-    rc = prepare_model(ctx, m, "gpbo_lml_batch", true, N, d, kernel, length_scales + (size_t)i * n_ls, n_ls, noise, GPBO_F64);
-    if (rc) break;
-    out_h[i] = (double*)((char*)ctx->pinned + 2048);
-    info_h[i] = (int*)((char*)ctx->pinned + 1024);
-    const bool same = lane.seen && lane.N == N && lane.d == d && lane.kernel == kernel && lane.n_ls == n_ls &&
-                      lane.eval_gradient == eval_gradient && lane.noise == noise && lane.X == ctx->lml_X &&
-                      lane.y == ctx->lml_y && lane.K == m.K;
-    if (same && lane.exec) {
-      hipError_t e = hipGraphLaunch(lane.exec, ctx->stream);
-      if (e != hipSuccess) GPBO_HIP(ctx, e);
-      continue;
-    }
-    if (lane.exec) { (void)hipGraphExecDestroy(lane.exec); lane.exec = nullptr; }
+  auto restore = [&]() {
+    ctx->stream = stream0; ctx->red = red0; ctx->cap_red = cap_red0; ctx->info_dev = info0; ctx->pinned = pinned0;
+    ctx->lanes = 1; ctx->lane_stride = 0; ctx->no_timing = false;
+  };
+  auto enqueue = [&](double** oh, int** ih) {
+    int r = enqueue_factor(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, ih);
+    if (r == GPBO_OK) r = lml_tail(ctx, m, n_ls, eval_gradient, oh);
+    return r;
+  };
+  // An evaluation is ~60 short launches: the second time the same problem shape comes by, the sequence is captured
+  // into a hipGraph and from then on replayed with one launch.
+  LmlLane& key = ctx->lml_lane[n_theta - 1];     // one cached sequence per lane count (runs of a search retire one by one)
+  const bool same = key.seen && key.N == N && key.d == d && key.kernel == kernel && key.n_ls == n_ls &&
+                    key.eval_gradient == eval_gradient && key.noise == noise && key.lanes == n_theta &&
+                    key.X == ctx->lml_X && key.y == ctx->lml_y && key.K == base;
+  double* out_h = (double*)(window + (n_theta == 1 ? 2048 : PIN_LANE_OUT));      // where lml_tail / factor_resident
+  int* info_h = (int*)(window + (n_theta == 1 ? 1024 : PIN_LANE_INFO));          // put the results (single / lane mode)
+  rc = GPBO_OK;
+  bool launched = false;
+  if (same && key.exec) {
+    hipError_t e = hipGraphLaunch(key.exec, ctx->stream);
+    if (e != hipSuccess) { restore(); GPBO_HIP(ctx, e); }
+    launched = true;
+  } else {
+    if (key.exec) { (void)hipGraphExecDestroy(key.exec); key.exec = nullptr; }
     if (same && graphs_allowed && !ctx->lml_graph_off) {
-      // second sighting of this shape: capture, instantiate, launch
       hipGraph_t graph = nullptr;
       double* oh = nullptr; int* ih = nullptr;
       hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
       int crc = GPBO_ERR_HIP;
       if (e == hipSuccess) {
-        crc = enqueue_factor(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, &ih);
-        if (crc == GPBO_OK) crc = lml_tail(ctx, m, n_ls, eval_gradient, &oh);
+        crc = enqueue(&oh, &ih);
         e = hipStreamEndCapture(ctx->stream, &graph);
       }
       if (e == hipSuccess && crc == GPBO_OK && graph &&
-          hipGraphInstantiate(&lane.exec, graph, nullptr, nullptr, 0) == hipSuccess && lane.exec) {
+          hipGraphInstantiate(&key.exec, graph, nullptr, nullptr, 0) == hipSuccess && key.exec) {
         (void)hipGraphDestroy(graph);
-        e = hipGraphLaunch(lane.exec, ctx->stream);
-        if (e != hipSuccess) GPBO_HIP(ctx, e);
-        continue;
+        e = hipGraphLaunch(key.exec, ctx->stream);
+        if (e != hipSuccess) { restore(); GPBO_HIP(ctx, e); }
+        launched = true;
+      } else {   // capture is not available for this sequence on this runtime: direct launches from now on
+        if (graph) (void)hipGraphDestroy(graph);
+        if (key.exec) { (void)hipGraphExecDestroy(key.exec); key.exec = nullptr; }
+        (void)hipGetLastError();
+        ctx->lml_graph_off = true;
       }
-      // capture is not available for this sequence on this runtime: stay with direct launches from now on
-      if (graph) (void)hipGraphDestroy(graph);
-      if (lane.exec) { (void)hipGraphExecDestroy(lane.exec); lane.exec = nullptr; }
-      (void)hipGetLastError();
-      ctx->lml_graph_off = true;
     }
-    double* oh = nullptr; int* ih = nullptr;
-    rc = enqueue_factor(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, &ih);
-    if (rc == GPBO_OK) rc = lml_tail(ctx, m, n_ls, eval_gradient, &oh);
-    lane.seen = (rc == GPBO_OK);
-    lane.N = N; lane.d = d; lane.kernel = kernel; lane.n_ls = n_ls; lane.eval_gradient = eval_gradient; lane.noise = noise;
-    lane.X = ctx->lml_X; lane.y = ctx->lml_y; lane.K = m.K;
   }
-  ctx->stream = stream0; ctx->red = red0; ctx->cap_red = cap_red0; ctx->info_dev = info0; ctx->pinned = pinned0;
-  ctx->no_timing = false;
-  for (int i = 0; i < n_theta; ++i) {
-    hipError_t e = hipStreamSynchronize(ctx->lml_stream[i]);
+  if (!launched) {
+    double* oh = nullptr; int* ih = nullptr;
+    rc = enqueue(&oh, &ih);
+    key.seen = (rc == GPBO_OK);
+    key.N = N; key.d = d; key.kernel = kernel; key.n_ls = n_ls; key.eval_gradient = eval_gradient; key.noise = noise;
+    key.lanes = n_theta; key.X = ctx->lml_X; key.y = ctx->lml_y; key.K = base;
+  }
+  hipStream_t lane_stream = ctx->stream;
+  restore();
+  {
+    hipError_t e = hipStreamSynchronize(lane_stream);
     if (e != hipSuccess && rc == GPBO_OK) GPBO_HIP(ctx, e);
   }
   if (rc) return rc;
   for (int i = 0; i < n_theta; ++i) {
     if (info) info[i] = 0;
-    lml_finish(out_h[i], info_h[i], N, n_ls, eval_gradient, lml + i, eval_gradient ? grad + (size_t)i * n_ls : nullptr,
-               info ? info + i : nullptr);
+    lml_finish((const double*)((const char*)out_h + (size_t)i * PIN_OUT_PITCH),
+               (const int*)((const char*)info_h + (size_t)i * PIN_INFO_PITCH), N, n_ls, eval_gradient, lml + i,
+               eval_gradient ? grad + (size_t)i * n_ls : nullptr, info ? info + i : nullptr);
   }
   return GPBO_OK;
 }

@@ -50,12 +50,12 @@ struct Model {
   int64_t M_post = -1;     // number of candidates mu/sd are valid for (-1: none)
 };
 
-// One gpbo_lml_batch lane: the problem shape it last ran and, from the second run on, the captured launch sequence.
+// gpbo_lml_batch, per lane count: the problem shape it last ran and, from the second run on, the captured launch sequence.
 struct LmlLane {
   hipGraphExec_t exec = nullptr;
   bool seen = false;
   int64_t N = 0;
-  int d = 0, kernel = 0, n_ls = 0, eval_gradient = 0;
+  int d = 0, kernel = 0, n_ls = 0, eval_gradient = 0, lanes = 0;
   double noise = 0.0;
   const void* X = nullptr; const void* y = nullptr; const void* K = nullptr;
 };
@@ -72,11 +72,14 @@ struct gpbo_ctx {
   hipStream_t stream = nullptr;
   std::string err;
   gpbo::Model models[GPBO_MAX_MODELS];
-  // gpbo_lml_batch: scratch models, streams and scratch words (info word at +0, scalars at +64), one set per lane
-  gpbo::Model lml_model[GPBO_LML_BATCH_MAX];
+  // gpbo_lml_batch: its stream (lml_stream[0]); the lanes' buffers live in lml_slab
   hipStream_t lml_stream[GPBO_LML_BATCH_MAX] = {};
-  void* lml_scratch[GPBO_LML_BATCH_MAX] = {};
   bool no_timing = false;   // batch lanes do not touch the timing events
+  // Lane mode (gpbo_lml_batch): every fit/LML launcher runs its kernel for `lanes` models at once; model l's buffers
+  // sit l * lane_stride doubles behind the ones of the Model passed in (one slab, same layout per lane)
+  int lanes = 1;
+  int64_t lane_stride = 0;
+  double* lml_slab = nullptr; int64_t cap_lml_slab = 0;
   gpbo::LmlLane lml_lane[GPBO_LML_BATCH_MAX];
   double* lml_X = nullptr; int64_t cap_lml_X = 0;   // the batch's raw inputs, uploaded once per call
   double* lml_y = nullptr; int64_t cap_lml_y = 0;
@@ -196,6 +199,7 @@ struct GemmArgs {
   const double* A; int64_t lda; int64_t strideA;
   const double* B; int64_t ldb; int64_t strideB;
   double* C; int64_t ldc; int64_t strideC;
+  int lanes = 1; int64_t lane_stride = 0;   // filled in by launch_gemm from the context (lane mode)
   int batch;
   int b_trans;            // B given as (n,k) row-major
   int lower_only;         // skip output tiles strictly above the diagonal (m == n)

@@ -24,8 +24,12 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh) {
 // out[0] = y . alpha ; out[1] = sum_i log L_ii
 __global__ __launch_bounds__(256) void lml_terms_kernel(const double* __restrict__ y, const double* __restrict__ alpha,
                                                         const double* __restrict__ L, int64_t N, int64_t NP,
-                                                        double* __restrict__ out) {
+                                                        double* __restrict__ out, int64_t lane_stride) {
   __shared__ double sh[4];
+  y += (int64_t)blockIdx.x * lane_stride;
+  alpha += (int64_t)blockIdx.x * lane_stride;
+  L += (int64_t)blockIdx.x * lane_stride;
+  out += (int64_t)blockIdx.x * lane_stride;
   double a = 0.0, b = 0.0;
   for (int64_t i = threadIdx.x; i < N; i += 256) {
     a = fma(y[i], alpha[i], a);
@@ -43,9 +47,14 @@ __global__ __launch_bounds__(256) void lml_terms_kernel(const double* __restrict
 template <int KERNEL>
 __global__ __launch_bounds__(256) void lml_grad_kernel(const double* __restrict__ Xs, int DP, int n_ls, int64_t N,
                                                        int64_t NP, const double* __restrict__ alpha,
-                                                       const double* __restrict__ Kinv, double* __restrict__ partial) {
+                                                       const double* __restrict__ Kinv, double* __restrict__ partial,
+                                                       int64_t lane_stride) {
   const int bj = blockIdx.x, bi = blockIdx.y;
   if (bj > bi) return;
+  Xs += (int64_t)blockIdx.z * lane_stride;
+  alpha += (int64_t)blockIdx.z * lane_stride;
+  Kinv += (int64_t)blockIdx.z * lane_stride;
+  partial += (int64_t)blockIdx.z * lane_stride;
   extern __shared__ __attribute__((aligned(16))) double lg_smem[];
   double* XiT = lg_smem;             // [DP][64]
   double* XjT = lg_smem + DP * 64;   // [DP][64]
@@ -121,9 +130,11 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(const double* __restrict_
 
 // out[t] = 0.5 * sum over tiles (fixed order) of partial[tile][t]
 __global__ __launch_bounds__(256) void lml_grad_final_kernel(const double* __restrict__ partial, int64_t ntiles,
-                                                             int n_ls, double* __restrict__ out) {
+                                                             int n_ls, double* __restrict__ out, int64_t lane_stride) {
   __shared__ double sh[4];
   const int t = blockIdx.x;
+  partial += (int64_t)blockIdx.y * lane_stride;
+  out += (int64_t)blockIdx.y * lane_stride;
   double s = 0.0;
   for (int64_t k = threadIdx.x; k < ntiles; k += 256) s += partial[k * n_ls + t];
   const double tot = block_sum_256(s, sh);
@@ -131,7 +142,8 @@ __global__ __launch_bounds__(256) void lml_grad_final_kernel(const double* __res
 }
 
 int launch_lml_terms(gpbo_ctx* ctx, Model& m, double* out2_dev) {
-  lml_terms_kernel<<<dim3(1), dim3(256), 0, ctx->stream>>>(m.yn, m.alpha, m.L, m.N, m.NP, out2_dev);
+  lml_terms_kernel<<<dim3((unsigned)ctx->lanes), dim3(256), 0, ctx->stream>>>(m.yn, m.alpha, m.L, m.N, m.NP, out2_dev,
+                                                                                ctx->lane_stride);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
@@ -141,13 +153,14 @@ int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, doubl
   const unsigned nb = (unsigned)(m.NP / 64);
   const int64_t ntiles = (int64_t)nb * (nb + 1) / 2;
   const size_t lds = (size_t)(2 * m.DP * 64 + 8) * sizeof(double);
-  dim3 grid(nb, nb);
+  dim3 grid(nb, nb, (unsigned)ctx->lanes);
+  const int64_t ls = ctx->lane_stride;
   if (m.kernel == GPBO_KERNEL_MATERN25)
-    lml_grad_kernel<GPBO_KERNEL_MATERN25><<<grid, dim3(256), lds, ctx->stream>>>(m.Xs, m.DP, n_ls, m.N, m.NP, m.alpha, Kinv, partial);
+    lml_grad_kernel<GPBO_KERNEL_MATERN25><<<grid, dim3(256), lds, ctx->stream>>>(m.Xs, m.DP, n_ls, m.N, m.NP, m.alpha, Kinv, partial, ls);
   else
-    lml_grad_kernel<GPBO_KERNEL_RBF><<<grid, dim3(256), lds, ctx->stream>>>(m.Xs, m.DP, n_ls, m.N, m.NP, m.alpha, Kinv, partial);
+    lml_grad_kernel<GPBO_KERNEL_RBF><<<grid, dim3(256), lds, ctx->stream>>>(m.Xs, m.DP, n_ls, m.N, m.NP, m.alpha, Kinv, partial, ls);
   GPBO_HIP(ctx, hipGetLastError());
-  lml_grad_final_kernel<<<dim3((unsigned)n_ls), dim3(256), 0, ctx->stream>>>(partial, ntiles, n_ls, grad_dev);
+  lml_grad_final_kernel<<<dim3((unsigned)n_ls, (unsigned)ctx->lanes), dim3(256), 0, ctx->stream>>>(partial, ntiles, n_ls, grad_dev, ls);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
