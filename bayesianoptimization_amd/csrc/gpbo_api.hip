@@ -195,7 +195,7 @@ int gpbo_create(int device, gpbo_ctx** out) {
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->info_dev, sizeof(int));
-  if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, 64 * 1024, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, (1 + GPBO_LML_BATCH_MAX) * 16 * 1024, hipHostMallocDefault);
   if (e != hipSuccess) {
     set_global_error(std::string("gpbo_create: ") + hipGetErrorString(e));
     delete ctx;
@@ -531,8 +531,11 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
                    int* info) {
   if (!ctx) return GPBO_ERR_INVALID;
   if (n_theta < 1 || n_theta > GPBO_LML_BATCH_MAX) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: n_theta out of range [1, 8]");
-  if (!lml || !length_scales || !X || !y_norm || (eval_gradient && !grad))
+  if (!lml || !length_scales || (eval_gradient && !grad) || (!X) != (!y_norm))
     GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: NULL argument");
+  const bool reuse_inputs = !X;     // X == y_norm == NULL: the inputs of the previous call are still on the device
+  if (reuse_inputs && (ctx->lml_N != N || ctx->lml_d != d))
+    GPBO_FAIL(ctx, GPBO_ERR_STATE, "gpbo_lml_batch: no resident inputs of this shape (pass X and y_norm)");
   if (N < 1 || N > (1 << 16)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: N out of range [1, 65536]");
   if (d < 1 || d > GPBO_MAX_DIM) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "gpbo_lml_batch: d out of range [1, 64]");
   if (kernel != GPBO_KERNEL_RBF && kernel != GPBO_KERNEL_MATERN25)
@@ -543,7 +546,6 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
     if (!(length_scales[t] > 0.0) || !std::isfinite(length_scales[t]))
       GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: length_scale must be positive and finite");
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
-  if (!ctx->lml_stream[0]) GPBO_HIP(ctx, hipStreamCreateWithFlags(&ctx->lml_stream[0], hipStreamNonBlocking));
 
   // One slab, one layout per lane: every kernel of the evaluation runs ONCE for all lanes (lane = a grid dimension,
   // lane l's buffers l * stride doubles behind lane 0's) — the command processor sees ~60 dispatches per batch, not
@@ -567,102 +569,118 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
   const int64_t stride = off;
   int rc;
   if ((rc = ensure(ctx, &ctx->lml_slab, &ctx->cap_lml_slab, stride * n_theta))) return rc;
-  if ((rc = ensure(ctx, &ctx->lml_X, &ctx->cap_lml_X, N * d))) return rc;
-  if ((rc = ensure(ctx, &ctx->lml_y, &ctx->cap_lml_y, N))) return rc;
-  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  GPBO_HIP(ctx, hipMemcpy(ctx->lml_X, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice));
-  GPBO_HIP(ctx, hipMemcpy(ctx->lml_y, y_norm, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+  if (!reuse_inputs) {
+    ctx->lml_N = 0;
+    if ((rc = ensure(ctx, &ctx->lml_X, &ctx->cap_lml_X, N * d))) return rc;
+    if ((rc = ensure(ctx, &ctx->lml_y, &ctx->cap_lml_y, N))) return rc;
+    GPBO_HIP(ctx, hipMemcpy(ctx->lml_X, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice));
+    GPBO_HIP(ctx, hipMemcpy(ctx->lml_y, y_norm, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+    ctx->lml_N = N; ctx->lml_d = d;
+  }
   double* base = ctx->lml_slab;
-  Model m;     // a view of lane 0 (not owning)
-  m.N = N; m.NP = NP; m.d = d; m.DP = DP; m.kernel = kernel; m.precision = GPBO_F64; m.noise = noise;
-  m.ls = base + o_ls; m.Xs = base + o_Xs; m.K = base + o_K; m.L = base + o_L; m.W = base + o_W;
-  m.dinv = base + o_dinv; m.tmp = base + o_tmp; m.yn = base + o_yn; m.tvec = base + o_tvec; m.alpha = base + o_alpha;
-
-  // theta enters through the pinned length-scale words ([lane][64]) that the sequence's first copy reads
-  char* window = (char*)ctx->pinned + PIN_LANE_WINDOW;
-  double* ls_h = (double*)window;
-  for (int l = 0; l < n_theta; ++l)
-    for (int t = 0; t < GPBO_MAX_DIM; ++t)
-      ls_h[l * GPBO_MAX_DIM + t] = (t < d) ? (n_ls == 1 ? length_scales[l] : length_scales[(int64_t)l * n_ls + t]) : 1.0;
-
+  // Lanes are processed in groups: a group runs the launch sequence once for its lanes on its own stream.  Small
+  // problems are dispatch-bound (every kernel is tiny): ONE group of all lanes.  From NP = 2048 on the big GEMMs fill
+  // the chip by themselves and what is left to win is hiding one lane's latency-bound steps (the diagonal-block
+  // kernels) behind another lane's GEMMs: one lane per group, i.e. one stream per lane.
+  const int per_group = (NP >= 2048) ? 1 : n_theta;
+  const int n_groups = (n_theta + per_group - 1) / per_group;
+  for (int g = 0; g < n_groups; ++g)
+    if (!ctx->lml_stream[g]) GPBO_HIP(ctx, hipStreamCreateWithFlags(&ctx->lml_stream[g], hipStreamNonBlocking));
   static const bool graphs_allowed = !(getenv("GPBO_LML_GRAPH") && getenv("GPBO_LML_GRAPH")[0] == '0');
   hipStream_t stream0 = ctx->stream;
   void* red0 = ctx->red; int64_t cap_red0 = ctx->cap_red;
   int* info0 = ctx->info_dev;
   void* pinned0 = ctx->pinned;
-  ctx->stream = ctx->lml_stream[0];
-  ctx->red = base + o_scal; ctx->cap_red = (8 + GPBO_MAX_DIM) * 8;
-  ctx->info_dev = (int*)(base + o_info);
-  ctx->pinned = window;
-  ctx->lanes = n_theta; ctx->lane_stride = stride;
-  ctx->no_timing = true;
   auto restore = [&]() {
     ctx->stream = stream0; ctx->red = red0; ctx->cap_red = cap_red0; ctx->info_dev = info0; ctx->pinned = pinned0;
     ctx->lanes = 1; ctx->lane_stride = 0; ctx->no_timing = false;
   };
-  auto enqueue = [&](double** oh, int** ih) {
-    int r = enqueue_factor(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, ih);
-    if (r == GPBO_OK) r = lml_tail(ctx, m, n_ls, eval_gradient, oh);
-    return r;
-  };
-  // An evaluation is ~60 short launches: the second time the same problem shape comes by, the sequence is captured
-  // into a hipGraph and from then on replayed with one launch.
-  LmlLane& key = ctx->lml_lane[n_theta - 1];     // one cached sequence per lane count (runs of a search retire one by one)
-  const bool same = key.seen && key.N == N && key.d == d && key.kernel == kernel && key.n_ls == n_ls &&
-                    key.eval_gradient == eval_gradient && key.noise == noise && key.lanes == n_theta &&
-                    key.X == ctx->lml_X && key.y == ctx->lml_y && key.K == base;
-  double* out_h = (double*)(window + (n_theta == 1 ? 2048 : PIN_LANE_OUT));      // where lml_tail / factor_resident
-  int* info_h = (int*)(window + (n_theta == 1 ? 1024 : PIN_LANE_INFO));          // put the results (single / lane mode)
   rc = GPBO_OK;
-  bool launched = false;
-  if (same && key.exec) {
-    hipError_t e = hipGraphLaunch(key.exec, ctx->stream);
-    if (e != hipSuccess) { restore(); GPBO_HIP(ctx, e); }
-    launched = true;
-  } else {
-    if (key.exec) { (void)hipGraphExecDestroy(key.exec); key.exec = nullptr; }
-    if (same && graphs_allowed && !ctx->lml_graph_off) {
-      hipGraph_t graph = nullptr;
-      double* oh = nullptr; int* ih = nullptr;
-      hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
-      int crc = GPBO_ERR_HIP;
-      if (e == hipSuccess) {
-        crc = enqueue(&oh, &ih);
-        e = hipStreamEndCapture(ctx->stream, &graph);
-      }
-      if (e == hipSuccess && crc == GPBO_OK && graph &&
-          hipGraphInstantiate(&key.exec, graph, nullptr, nullptr, 0) == hipSuccess && key.exec) {
-        (void)hipGraphDestroy(graph);
-        e = hipGraphLaunch(key.exec, ctx->stream);
-        if (e != hipSuccess) { restore(); GPBO_HIP(ctx, e); }
-        launched = true;
-      } else {   // capture is not available for this sequence on this runtime: direct launches from now on
-        if (graph) (void)hipGraphDestroy(graph);
-        if (key.exec) { (void)hipGraphExecDestroy(key.exec); key.exec = nullptr; }
-        (void)hipGetLastError();
-        ctx->lml_graph_off = true;
+  for (int g = 0; g < n_groups && rc == GPBO_OK; ++g) {
+    const int l0 = g * per_group;
+    const int gl = std::min(per_group, n_theta - l0);             // lanes of this group
+    double* gbase = base + (int64_t)l0 * stride;
+    Model m;     // a view of the group's first lane (not owning)
+    m.N = N; m.NP = NP; m.d = d; m.DP = DP; m.kernel = kernel; m.precision = GPBO_F64; m.noise = noise;
+    m.ls = gbase + o_ls; m.Xs = gbase + o_Xs; m.K = gbase + o_K; m.L = gbase + o_L; m.W = gbase + o_W;
+    m.dinv = gbase + o_dinv; m.tmp = gbase + o_tmp; m.yn = gbase + o_yn; m.tvec = gbase + o_tvec; m.alpha = gbase + o_alpha;
+    // theta enters through the pinned length-scale words ([lane][64]) that the sequence's first copy reads
+    char* window = (char*)pinned0 + PIN_LANE_WINDOW * (size_t)(1 + g);
+    double* ls_h = (double*)window;
+    for (int l = 0; l < gl; ++l)
+      for (int t = 0; t < GPBO_MAX_DIM; ++t)
+        ls_h[l * GPBO_MAX_DIM + t] =
+            (t < d) ? (n_ls == 1 ? length_scales[l0 + l] : length_scales[(int64_t)(l0 + l) * n_ls + t]) : 1.0;
+    ctx->stream = ctx->lml_stream[g];
+    ctx->red = gbase + o_scal; ctx->cap_red = (8 + GPBO_MAX_DIM) * 8;
+    ctx->info_dev = (int*)(gbase + o_info);
+    ctx->pinned = window;
+    ctx->lanes = gl; ctx->lane_stride = stride;
+    ctx->no_timing = true;
+    auto enqueue = [&](double** oh, int** ih) {
+      int r = enqueue_factor(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, ih);
+      if (r == GPBO_OK) r = lml_tail(ctx, m, n_ls, eval_gradient, oh);
+      return r;
+    };
+    // An evaluation is ~60 short launches: the second time the same problem shape comes by, the group's sequence is
+    // captured into a hipGraph and from then on replayed with one launch.
+    LmlLane& key = ctx->lml_lane[g];
+    const bool same = key.seen && key.N == N && key.d == d && key.kernel == kernel && key.n_ls == n_ls &&
+                      key.eval_gradient == eval_gradient && key.noise == noise && key.lanes == gl &&
+                      key.X == ctx->lml_X && key.y == ctx->lml_y && key.K == gbase;
+    bool launched = false;
+    if (same && key.exec) {
+      hipError_t e = hipGraphLaunch(key.exec, ctx->stream);
+      if (e != hipSuccess) { restore(); GPBO_HIP(ctx, e); }
+      launched = true;
+    } else {
+      if (key.exec) { (void)hipGraphExecDestroy(key.exec); key.exec = nullptr; }
+      if (same && graphs_allowed && !ctx->lml_graph_off) {
+        hipGraph_t graph = nullptr;
+        double* oh = nullptr; int* ih = nullptr;
+        hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+        int crc = GPBO_ERR_HIP;
+        if (e == hipSuccess) {
+          crc = enqueue(&oh, &ih);
+          e = hipStreamEndCapture(ctx->stream, &graph);
+        }
+        if (e == hipSuccess && crc == GPBO_OK && graph &&
+            hipGraphInstantiate(&key.exec, graph, nullptr, nullptr, 0) == hipSuccess && key.exec) {
+          (void)hipGraphDestroy(graph);
+          e = hipGraphLaunch(key.exec, ctx->stream);
+          if (e != hipSuccess) { restore(); GPBO_HIP(ctx, e); }
+          launched = true;
+        } else {   // capture is not available for this sequence on this runtime: direct launches from now on
+          if (graph) (void)hipGraphDestroy(graph);
+          if (key.exec) { (void)hipGraphExecDestroy(key.exec); key.exec = nullptr; }
+          (void)hipGetLastError();
+          ctx->lml_graph_off = true;
+        }
       }
     }
+    if (!launched) {
+      double* oh = nullptr; int* ih = nullptr;
+      rc = enqueue(&oh, &ih);
+      key.seen = (rc == GPBO_OK);
+      key.N = N; key.d = d; key.kernel = kernel; key.n_ls = n_ls; key.eval_gradient = eval_gradient; key.noise = noise;
+      key.lanes = gl; key.X = ctx->lml_X; key.y = ctx->lml_y; key.K = gbase;
+    }
   }
-  if (!launched) {
-    double* oh = nullptr; int* ih = nullptr;
-    rc = enqueue(&oh, &ih);
-    key.seen = (rc == GPBO_OK);
-    key.N = N; key.d = d; key.kernel = kernel; key.n_ls = n_ls; key.eval_gradient = eval_gradient; key.noise = noise;
-    key.lanes = n_theta; key.X = ctx->lml_X; key.y = ctx->lml_y; key.K = base;
-  }
-  hipStream_t lane_stream = ctx->stream;
   restore();
-  {
-    hipError_t e = hipStreamSynchronize(lane_stream);
+  for (int g = 0; g < n_groups; ++g) {
+    hipError_t e = hipStreamSynchronize(ctx->lml_stream[g]);
     if (e != hipSuccess && rc == GPBO_OK) GPBO_HIP(ctx, e);
   }
   if (rc) return rc;
   for (int i = 0; i < n_theta; ++i) {
+    const int g = i / per_group, l = i - g * per_group;
+    const int gl = std::min(per_group, n_theta - g * per_group);
+    const char* window = (const char*)ctx->pinned + PIN_LANE_WINDOW * (size_t)(1 + g);
+    const char* out_h = window + (gl == 1 ? 2048 : PIN_LANE_OUT);      // where lml_tail / factor_resident put the
+    const char* info_h = window + (gl == 1 ? 1024 : PIN_LANE_INFO);    // results (single / lane mode)
     if (info) info[i] = 0;
-    lml_finish((const double*)((const char*)out_h + (size_t)i * PIN_OUT_PITCH),
-               (const int*)((const char*)info_h + (size_t)i * PIN_INFO_PITCH), N, n_ls, eval_gradient, lml + i,
-               eval_gradient ? grad + (size_t)i * n_ls : nullptr, info ? info + i : nullptr);
+    lml_finish((const double*)(out_h + (size_t)l * PIN_OUT_PITCH), (const int*)(info_h + (size_t)l * PIN_INFO_PITCH), N,
+               n_ls, eval_gradient, lml + i, eval_gradient ? grad + (size_t)i * n_ls : nullptr, info ? info + i : nullptr);
   }
   return GPBO_OK;
 }

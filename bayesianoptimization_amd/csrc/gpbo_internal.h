@@ -83,6 +83,7 @@ struct gpbo_ctx {
   gpbo::LmlLane lml_lane[GPBO_LML_BATCH_MAX];
   double* lml_X = nullptr; int64_t cap_lml_X = 0;   // the batch's raw inputs, uploaded once per call
   double* lml_y = nullptr; int64_t cap_lml_y = 0;
+  int64_t lml_N = 0; int lml_d = 0;                 // shape of the resident inputs (0: none)
   bool lml_graph_off = false;   // stream capture failed once: direct launches only
   // candidates
   double* Xc = nullptr;    // [M][d] raw

@@ -109,9 +109,10 @@ class GpEngine:
         self._check(rc, info.value)
         return self._touch(slot)
 
-    def lml_batch(self, X, y_norm, kernel: int, length_scales, noise: float, eval_gradient=True):
+    def lml_batch(self, X, y_norm, kernel: int, length_scales, noise: float, eval_gradient=True, reuse_inputs=False):
         """[(lml, grad)] for every row of `length_scales` (n_theta x n_ls), evaluated side by side on the device
-        (gpbo_lml_batch); each entry is bitwise what `lml()` returns for that row.  Model slots are not touched."""
+        (gpbo_lml_batch); each entry is bitwise what `lml()` returns for that row.  Model slots are not touched.
+        reuse_inputs=True: (X, y_norm) are the arrays of the previous call and are not uploaded again."""
         X = np.ascontiguousarray(X, dtype=np.float64)
         y_norm = np.ascontiguousarray(y_norm, dtype=np.float64).ravel()
         ls = np.ascontiguousarray(np.atleast_2d(np.asarray(length_scales, dtype=np.float64)))
@@ -119,7 +120,8 @@ class GpEngine:
         vals = np.zeros(n)
         grads = np.zeros((n, n_ls))
         infos = (C.c_int * n)()
-        rc = self._lib.gpbo_lml_batch(self._h, n, dptr(X), dptr(y_norm), X.shape[0], X.shape[1], int(kernel), dptr(ls),
+        rc = self._lib.gpbo_lml_batch(self._h, n, None if reuse_inputs else dptr(X), None if reuse_inputs else dptr(y_norm),
+                                      X.shape[0], X.shape[1], int(kernel), dptr(ls),
                                       n_ls, float(noise), int(bool(eval_gradient)), dptr(vals), dptr(grads), infos)
         self._check(rc)
         return [(float(vals[i]), grads[i].copy()) for i in range(n)]

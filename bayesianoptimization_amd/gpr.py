@@ -268,15 +268,19 @@ class HipGPR(GaussianProcessRegressor):
         X, y, noise = self._tx(self.X_train_), self.y_train_, float(self.alpha)
         n_dims = len(starts[0])
 
+        # theta = log(length scale(s)) for the kernels _device_lml_ok admits (one free length-scale hyper-parameter,
+        # kernels.py:Hyperparameter/theta); checked once here instead of cloning the kernel for every evaluation
+        kind, ls0 = describe_kernel(self.kernel_.clone_with_theta(starts[0]))
+        if not np.array_equal(ls0, np.exp(starts[0])):
+            raise RuntimeError("theta does not map to the length scale as expected")    # pragma: no cover
+        uploaded = [False]
+
         def evaluate(thetas):
             rows = np.empty((len(thetas), 1 + n_dims))
-            kinds, scales = [], []
-            for theta in thetas:
-                kind, ls = describe_kernel(self.kernel_.clone_with_theta(theta))
-                kinds.append(kind)
-                scales.append(ls)
+            scales = np.exp(np.asarray(thetas, dtype=np.float64))
             for lo in range(0, len(thetas), 8):
-                part = eng.lml_batch(X, y, kinds[0], np.vstack(scales[lo:lo + 8]), noise, eval_gradient=True)
+                part = eng.lml_batch(X, y, kind, scales[lo:lo + 8], noise, eval_gradient=True, reuse_inputs=uploaded[0])
+                uploaded[0] = True
                 for j, (val, grad) in enumerate(part):
                     rows[lo + j, 0] = val
                     rows[lo + j, 1:] = grad

@@ -85,7 +85,7 @@ class FakeEngine:
         self.models.pop(slot, None)   # like the device: the slot's fit is clobbered
         return O.log_marginal_likelihood(kernel, X, y_norm, length_scale, noise, eval_gradient)
 
-    def lml_batch(self, X, y_norm, kernel, length_scales, noise, eval_gradient=True):
+    def lml_batch(self, X, y_norm, kernel, length_scales, noise, eval_gradient=True, reuse_inputs=False):
         self.calls.append(("lml_batch", len(length_scales)))
         return [O.log_marginal_likelihood(kernel, X, y_norm, ls, noise, eval_gradient) for ls in np.atleast_2d(length_scales)]
 
