@@ -101,13 +101,13 @@ int gpbo_lml(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int
              double* lml, double* grad, int* info);
 
 /* n_theta evaluations of gpbo_lml on the SAME (X, y_norm) at different length scales (length_scales: n_theta x n_ls,
- * row-major), each on its own stream and scratch model so that the latency-bound factorisations overlap on the device.
+ * row-major), in scratch models of their own ("lanes") so that the latency-bound factorisations share the device.
  * This is what the theta search's independent L-BFGS-B runs (the initial theta + n_restarts_optimizer restarts,
  * _gpr.py:296-338) need when they advance together.  Results per theta as gpbo_lml (lml[i], grad[i * n_ls ...], info[i]);
  * every lane computes exactly what gpbo_lml computes, bit for bit.  Model slots and their fits are not touched.
  * X = y_norm = NULL re-uses the inputs the previous call uploaded (same N, d) — the rounds of one theta search.
- * All lanes run through the same ~60 launches (lane = a grid dimension); from the second call with the same shape and
- * lane count the sequence is replayed as one captured hipGraph. */
+ * Below N = 2048 all lanes run through ONE sequence of ~60 launches (lane = a grid dimension of every kernel); from there
+ * on each lane gets its own stream.  From the second call with the same shape a sequence is replayed as a captured hipGraph. */
 int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_norm, int64_t N, int d, int kernel,
                    const double* length_scales, int n_ls, double noise, int eval_gradient, double* lml, double* grad,
                    int* info);
