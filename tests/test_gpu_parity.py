@@ -460,7 +460,7 @@ def test_fit_append_long_run_stays_accurate():
 
 @pytest.mark.parametrize("N,d,kernel", [(300, 4, O.MATERN25), (1030, 9, O.RBF)])
 def test_lml_batch_lanes_are_bitwise_gpbo_lml(engine, N, d, kernel):
-    """gpbo_lml_batch: every lane (own stream, own scratch model) returns the bits gpbo_lml returns for that theta;
+    """gpbo_lml_batch: every lane (its own K, L, W in the shared slab) returns the bits gpbo_lml returns for that theta;
     anisotropic rows too; a non-PD lane reports -inf without disturbing its neighbours; the model slots keep their fits."""
     X, y = _data(N, d, seed=71)
     yn, ym, ys = O.normalize_targets(y)
