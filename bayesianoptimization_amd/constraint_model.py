@@ -59,6 +59,15 @@ class HipConstraintModel:
             prob = p if prob is None else prob * p
         return np.asarray(prob).reshape(lead_shape)
 
+    def _predict_trusted(self, pts):
+        """predict() for an (M, d) batch of points generated inside this package (see HipGPR._posterior_trusted)."""
+        prob = None
+        for gp, lo, hi in zip(self._model, self._lb, self._ub):
+            mean, std = gp._posterior_trusted(pts)
+            p = np.broadcast_to(_interval_probability(lo, hi, mean, std), mean.shape)
+            prob = p if prob is None else prob * p
+        return np.asarray(prob)
+
     def approx(self, X):
         lead_shape = X.shape[:-1]
         pts = X.reshape((-1, self._model[0].n_features_in_))

@@ -241,9 +241,17 @@ class AcquisitionFunction(abc.ABC):
     def _get_acq(self, gp, constraint=None):
         """Host objective x -> -acq(x) [* p_constraint(x)] for (M,d) or (d,) input (acquisition.py:171-219)."""
         ndim = gp.X_train_.shape[1]
+        # engine-backed models: finite float batches skip sklearn's per-call input validation and the warnings
+        # bookkeeping (the values are the same; anything else takes the reference-shaped path below and fails there)
+        trusted = isinstance(gp, HipGPR) and (constraint is None or hasattr(constraint, "_predict_trusted"))
 
         def objective(x):
             batch = x.reshape(-1, ndim)
+            if trusted and batch.dtype == np.float64 and np.isfinite(batch).all():
+                mean, std = gp._posterior_trusted(batch)
+                with np.errstate(all="ignore"):
+                    values = -1 * self.base_acq(mean, std)
+                    return values if constraint is None else values * constraint._predict_trusted(batch)
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 mean, std = gp.predict(batch, return_std=True)

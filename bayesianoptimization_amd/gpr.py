@@ -377,6 +377,13 @@ class HipGPR(GaussianProcessRegressor):
             return mean, std
         return mean
 
+    def _posterior_trusted(self, X):
+        """(mean, std) for points this package generated itself (finite, right shape): predict(return_std=True)
+        without sklearn's input validation and without the clipped-variance warning — the objective of the host
+        optimisers calls this hundreds of times per suggest()."""
+        return self._engine().predict(self._tx(X), slot=self.slot, y_mean=float(self._y_train_mean),
+                                      y_std=float(self._y_train_std))
+
     # engine-resident posterior for the fused acquisition path ----------------------------------
     def posterior_resident(self):
         """Run the posterior kernel over the engine's resident candidates, keeping mu/sd on the device."""
