@@ -3,7 +3,8 @@
 Seams B1 + B2: replaces `optimizer._gp` (bayes_opt/bayesian_optimization.py:124-130)
 and each constraint GP `optimizer._space._constraint._model[j]` (bayes_opt/constraint.py:72-81) by a
 `HipGPR` with the same hyper-parameters and the SAME RandomState object (so the stream is consumed
-exactly as before), and replaces a stock UCB/EI/POI acquisition function by its fused counterpart.
+exactly as before), and replaces a stock UCB/EI/POI acquisition function — also the ones a GPHedge or ConstantLiar
+meta-policy delegates to — by its fused counterpart.
 Everything else in the optimizer (space, queue, logging, state I/O) is untouched reference code.
 """
 from __future__ import annotations
@@ -34,8 +35,16 @@ def _convert_acquisition(fn):
         new = A.ProbabilityOfImprovement(xi=fn.xi, exploration_decay=fn.exploration_decay,
                                          exploration_decay_delay=fn.exploration_decay_delay)
         new.y_max = fn.y_max
+    elif name == "GPHedge" and hasattr(fn, "base_acquisitions"):
+        # the meta policy stays reference code (bayes_opt/acquisition.py:1181-1360); the policies it delegates the
+        # random + local searches to (`base.suggest(..., fit_gp=False)`, :1306-1316) become the fused ones
+        fn.base_acquisitions = [_convert_acquisition(b) for b in fn.base_acquisitions]
+        return fn
+    elif name == "ConstantLiar" and hasattr(fn, "base_acquisition"):
+        fn.base_acquisition = _convert_acquisition(fn.base_acquisition)    # acquisition.py:1135-1143
+        return fn
     else:
-        return fn  # meta / custom acquisitions keep running reference code over HipGPR.predict
+        return fn  # custom acquisitions keep running their own code over HipGPR.predict
     new.i = fn.i
     return new
 

@@ -176,28 +176,39 @@ def test_hipgpr_device_lml_override_semantics():
 
 
 def test_meta_acquisitions_run_through_the_seams():
-    """GPHedge and ConstantLiar (bayes_opt/acquisition.py:952-1360) stay reference code; after accelerate() they
-    reach the engine through the same seams (HipGPR.fit/predict), as SURVEY.md §2 scopes them."""
+    """GPHedge and ConstantLiar (bayes_opt/acquisition.py:952-1360) stay reference code; accelerate() swaps the GP and
+    the stock policies they delegate to, so every base `suggest(..., fit_gp=False)` runs the fused random stage — and the
+    optimisation visits exactly the points the un-accelerated reference visits (same RandomState consumption)."""
     import_reference()
     from bayes_opt import BayesianOptimization, acquisition
 
     from bayesianoptimization_amd import accelerate
+    from bayesianoptimization_amd import fused_acquisition as A
     from bayesianoptimization_amd.gpr import HipGPR
 
     for make in (lambda: acquisition.GPHedge([acquisition.UpperConfidenceBound(kappa=2.0),
                                                acquisition.ExpectedImprovement(xi=0.01)]),
                  lambda: acquisition.ConstantLiar(acquisition.UpperConfidenceBound(kappa=2.0))):
+        ref = BayesianOptimization(f=black_box, pbounds=PB, random_state=4, verbose=0, acquisition_function=make())
         opt = BayesianOptimization(f=black_box, pbounds=PB, random_state=4, verbose=0, acquisition_function=make())
         eng = FakeEngine()
         accelerate(opt, engine=eng)
         assert isinstance(opt._gp, HipGPR)
-        assert type(opt._acquisition_function).__module__.startswith("bayes_opt")   # meta policy untouched
+        meta = opt._acquisition_function
+        assert type(meta).__module__.startswith("bayes_opt")                         # meta policy untouched
+        bases = getattr(meta, "base_acquisitions", None) or [meta.base_acquisition]
+        assert all(isinstance(b, A.AcquisitionFunction) for b in bases)               # ... its delegates are fused
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            opt.maximize(init_points=2, n_iter=2)
-        assert len(opt.space) == 4
-        kinds = {c[0] for c in eng.calls}
-        assert "fit" in kinds and ("posterior" in kinds or "set_candidates" in kinds)
+            ref.maximize(init_points=2, n_iter=3)
+            opt.maximize(init_points=2, n_iter=3)
+        assert len(opt.space) == 5
+        # (the local searches end within optimiser precision of each other: the engine double and sklearn differ in the
+        # last bits of mu/sigma and L-BFGS-B amplifies that to ~1e-5 in x)
+        assert np.allclose(opt.space.params, ref.space.params, rtol=0, atol=1e-4)
+        assert ref._random_state.uniform() == opt._random_state.uniform()
+        kinds = [c[0] for c in eng.calls]
+        assert "fit" in kinds and "acq_argbest" in kinds                              # the device random stage ran
 
 
 def test_integer_parameters_use_the_host_transform():
