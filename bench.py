@@ -90,7 +90,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="C3")
+    ap.add_argument("--config", default=None,
+                    help="BASELINE.json config; default: C3 on one GPU, C4 (= C3's GP with EI, 2^20 candidates per GPU, "
+                         "8 x 2^20 at --gpus 8) when sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -107,7 +109,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    w = W.ALL[args.config]
+    w = W.ALL[args.config or ("C3" if world == 1 else "C4")]
     X, y, c = W.make_observations(w)
     y_mean, y_std = float(np.mean(y)), float(np.std(y))
     yn = (y - y_mean) / y_std
