@@ -88,3 +88,34 @@ def test_oracle_is_only_reachable_from_the_allowed_places():
     baseline = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "cpu_baseline")
     inside = {id(n) for n in ast.walk(baseline)}
     assert hits and all(id(h) in inside for h in hits)
+
+
+def test_header_is_plain_c_and_links_against_the_library(tmp_path):
+    """include/gpbo.h is the boundary a non-Python host would bind: it must be valid C99 on its own, and a C program
+    using only that header must link against libgpbo.so and run its GPU-free entry points (ABI version, device count —
+    which reports an error, not a crash, on a box without a GPU — and the NULL-context error string)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    from bayesianoptimization_amd import build
+
+    lib = build.build(verbose=False)
+    src = tmp_path / "probe.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "gpbo.h"\n'
+        "int main(void) {\n"
+        "  int n = -1;\n"
+        "  int rc = gpbo_device_count(&n);\n"
+        "  const char* msg = gpbo_last_error(NULL);\n"
+        '  printf("%d %d %d %s\\n", gpbo_abi_version() == GPBO_ABI_VERSION, rc, n, msg ? "msg" : "null");\n'
+        "  return (rc == GPBO_OK || rc == GPBO_ERR_HIP) ? 0 : 1;\n"
+        "}\n")
+    exe = tmp_path / "probe"
+    inc = os.path.join(ROOT, "include")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, str(src), "-o", str(exe),
+                    lib, "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out[0] == "1" and out[3] == "msg"
