@@ -85,6 +85,37 @@ def cpu_baseline(w, X, y, Xc, y_max, gpu_ys, n_chunks=3, chunk=8192):
     }
 
 
+def suggest_latency(w, X, y, eng, M, reps=3):
+    """Median wall time of AcquisitionFunction.suggest(gp, space, n_random=M, n_smart=0|10, fit_gp=True) through
+    FloatSpace + HipGPR + the fused acquisition classes (the seams bayes_opt itself calls)."""
+    import warnings
+
+    from sklearn.gaussian_process.kernels import Matern, RBF
+
+    from bayesianoptimization_amd import fused_acquisition as A
+    from bayesianoptimization_amd.float_space import FloatSpace
+    from bayesianoptimization_amd.gpr import HipGPR
+
+    sp = FloatSpace(w.pbounds())
+    sp.register_bulk(X, y)
+    kern = Matern(nu=2.5, length_scale=w.length_scale) if w.kernel == W.MATERN25 else RBF(length_scale=w.length_scale)
+    gp = HipGPR(kernel=kern, alpha=w.noise, normalize_y=True, optimizer=None, engine=eng, incremental=False)  # every call refits
+    fn = {W.UCB: lambda: A.UpperConfidenceBound(kappa=w.acq_param), W.EI: lambda: A.ExpectedImprovement(xi=w.acq_param),
+          W.POI: lambda: A.ProbabilityOfImprovement(xi=w.acq_param)}[w.acq]()
+    res = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for n_smart in (0, 10):
+            ts = []
+            for rep in range(reps + 1):
+                t0 = time.perf_counter()
+                fn.suggest(gp, sp, n_random=M, n_smart=n_smart, fit_gp=True, random_state=np.random.RandomState(7 + rep))
+                ts.append((time.perf_counter() - t0) * 1e3)
+            res[f"n_smart_{n_smart}"] = float(np.median(ts[1:]))      # first call: allocations
+    res["note"] = "median of 3 after one warm-up; fixed theta; candidates = the reference's RandomState stream, generated on the device"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,6 +295,14 @@ def main():
             except Exception as e:
                 log(f"[bench] cpu_baseline failed: {e!r}")
                 out["cpu_baseline"] = None
+        if n_gpus == 1 and not w.constrained:
+            # the other half of BASELINE.json's metric, ms/suggest: whole suggest() calls through the drop-in seams
+            # (refit at fixed theta, candidates drawn from the caller's RandomState on the device, posterior, acquisition,
+            # arg-best; with the reference's default 10 local searches and without) — outside the timed region above
+            try:
+                out["suggest_ms"] = suggest_latency(w, X, y, eng, M)
+            except Exception as e:  # noqa: BLE001
+                log(f"[bench] suggest latency failed: {e!r}")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
