@@ -61,6 +61,28 @@ SIGNATURES = {
     "gpbo_comm_allgather_best": (C.c_int, [C.c_void_p, _c_double_p, _c_int64_p, C.c_int, _c_double_p,
                                            _c_int64_p]),
     "gpbo_comm_destroy": (C.c_int, [C.c_void_p]),
+    "gpbo_comm_acq_argbest": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, _c_double_p,
+                                        _c_double_p, C.c_int, C.c_int64, _c_int64_p, _c_double_p, _c_int64_p,
+                                        _c_double_p, _c_double_p]),
+    "gpbo_comm_allreduce_max": (C.c_int, [C.c_void_p, _c_double_p]),
+    "gpbo_group_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]),
+    "gpbo_group_destroy": (C.c_int, [C.c_void_p]),
+    "gpbo_group_size": (C.c_int, [C.c_void_p]),
+    "gpbo_group_ctx": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "gpbo_group_collective": (C.c_char_p, [C.c_void_p]),
+    "gpbo_group_last_error": (C.c_char_p, [C.c_void_p]),
+    "gpbo_group_synchronize": (C.c_int, [C.c_void_p]),
+    "gpbo_group_fit": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, C.c_int64, C.c_int, C.c_int,
+                                 _c_double_p, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)]),
+    "gpbo_group_fit_append": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int64, C.c_int, _c_double_p, C.c_int64,
+                                        C.POINTER(C.c_int)]),
+    "gpbo_group_set_candidates": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, C.c_int]),
+    "gpbo_group_shard": (C.c_int, [C.c_void_p, C.c_int, _c_int64_p, _c_int64_p]),
+    "gpbo_group_posterior": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, _c_double_p, _c_double_p]),
+    "gpbo_group_acq_argbest": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, _c_double_p,
+                                         _c_double_p, C.c_int, _c_int64_p, _c_double_p, _c_int64_p, _c_double_p,
+                                         _c_double_p]),
+    "gpbo_group_get_candidate_rows": (C.c_int, [C.c_void_p, _c_int64_p, C.c_int, _c_double_p]),
     "gpbo_debug_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, _c_double_p, _c_double_p,
                                   C.c_int, C.c_double, _c_double_p]),
     "gpbo_mfma_f64_peak": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
@@ -126,10 +148,10 @@ def device_count() -> int:
     return n.value if rc == GPBO_OK else 0
 
 
-def raise_for_status(lib, handle, rc: int, info: int = 0):
+def raise_for_status(lib, handle, rc: int, info: int = 0, group=None):
     if rc == GPBO_OK:
         return
-    msg = lib.gpbo_last_error(handle)
+    msg = lib.gpbo_group_last_error(group) if group is not None else lib.gpbo_last_error(handle)
     msg = msg.decode(errors="replace") if msg else f"libgpbo error {rc}"
     if rc == ERR_NOT_PD:
         # same hint as sklearn (gaussian_process/_gpr.py:350-358)

@@ -15,6 +15,7 @@
 
 #include <cmath>
 #include <limits>
+#include <vector>
 
 namespace gpbo {
 
@@ -206,8 +207,9 @@ __global__ __launch_bounds__(SEL_BLOCK) void select_final_kernel(const Key* __re
   }
 }
 
-int launch_acq_argbest(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, int64_t offset,
-                       int64_t* best_idx, double* best_val, int64_t* seed_idx, double* seed_val) {
+// acq values + k selection passes enqueued on ctx->stream; SelState and picks[npass] stay in ctx->red
+static int enqueue_acq_select(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, SelState** st_out, Key** picks_out,
+                              int* npass_out) {
   int rc;
   if ((rc = ensure(ctx, &ctx->ys, &ctx->cap_ys, M))) return rc;
   const int nblocks = (int)((M + SEL_BLOCK * SEL_ITEMS - 1) / (SEL_BLOCK * SEL_ITEMS));
@@ -235,7 +237,8 @@ int launch_acq_argbest(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, 
 
   SelState init;
   init.prev.v = 0.0; init.prev.i = -1; init.first_nan = INT64_MAX;
-  SelState* hinit = (SelState*)ctx->pinned;
+  static_assert(sizeof(SelState) <= 32, "SelState outgrew its pinned window");
+  SelState* hinit = (SelState*)((char*)ctx->pinned_aux + PIN_AUX_SEL_INIT);
   *hinit = init;
   GPBO_HIP(ctx, hipMemcpyAsync(st, hinit, sizeof(SelState), hipMemcpyHostToDevice, ctx->stream));
   for (int pass = 0; pass < npass; ++pass) {
@@ -244,8 +247,18 @@ int launch_acq_argbest(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, 
     select_final_kernel<<<dim3(1), dim3(SEL_BLOCK), 0, ctx->stream>>>(partial, nan_partial, nblocks, st, picks, pass, want_nan);
   }
   GPBO_HIP(ctx, hipGetLastError());
+  *st_out = st; *picks_out = picks; *npass_out = npass;
+  return GPBO_OK;
+}
+
+int launch_acq_argbest(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, int64_t offset,
+                       int64_t* best_idx, double* best_val, int64_t* seed_idx, double* seed_val) {
+  SelState* st; Key* picks; int npass;
+  int rc = enqueue_acq_select(ctx, a, M, k_seeds, &st, &picks, &npass);
+  if (rc) return rc;
   // results -> pinned host staging
-  char* hp = (char*)ctx->pinned + 256;
+  static_assert(sizeof(SelState) + sizeof(Key) * (GPBO_MAX_SEEDS + 1) <= PIN_AUX_SEL_OUT_BYTES, "selection results outgrew their window");
+  char* hp = (char*)ctx->pinned_aux + PIN_AUX_SEL_OUT;
   GPBO_HIP(ctx, hipMemcpyAsync(hp, st, sizeof(SelState) + sizeof(Key) * npass, hipMemcpyDeviceToHost, ctx->stream));
   GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const SelState* hst = (const SelState*)hp;
@@ -263,6 +276,69 @@ int launch_acq_argbest(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, 
     seed_val[t] = hpicks[t].v;
   }
   return GPBO_OK;
+}
+
+// SelState + picks -> the 1 + k records a shard contributes to the exchange (global indices), still on the device
+__global__ void pack_records_kernel(const SelState* __restrict__ st, const Key* __restrict__ picks, int k_seeds,
+                                    int64_t offset, BestRecord* __restrict__ out) {
+  const int t = threadIdx.x;
+  if (t > k_seeds) return;
+  BestRecord r;
+  if (t == 0) {
+    if (st->first_nan != INT64_MAX) { r.v = std::numeric_limits<double>::quiet_NaN(); r.i = st->first_nan + offset; }
+    else { r.v = picks[0].v; r.i = picks[0].i + offset; }
+  } else {
+    const Key k = picks[t - 1];
+    r.v = k.v;
+    r.i = (k.i != INT64_MAX) ? k.i + offset : -1;
+  }
+  out[t] = r;
+}
+
+int launch_acq_records(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, int64_t offset, BestRecord* records_dev) {
+  SelState* st; Key* picks; int npass;
+  int rc = enqueue_acq_select(ctx, a, M, k_seeds, &st, &picks, &npass);
+  if (rc) return rc;
+  pack_records_kernel<<<dim3(1), dim3(128), 0, ctx->stream>>>(st, picks, k_seeds, offset, records_dev);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+// Host merge of the gathered records: first NaN overall wins the arg-best (numpy argmin), otherwise lexicographic
+// (value, index) with -0.0 == 0.0; the seeds are the k smallest by the same order with NaNs last and padding dropped.
+void merge_records(const BestRecord* all, int world, int k_seeds, int64_t* best_idx, double* best_val, int64_t* seed_idx,
+                   double* seed_val) {
+  const int stride = 1 + k_seeds;
+  auto less = [](const BestRecord& a, const BestRecord& b) {
+    const bool an = a.v != a.v, bn = b.v != b.v;
+    if (an != bn) return bn;
+    if (!an && a.v != b.v) return a.v < b.v;
+    return a.i < b.i;
+  };
+  bool any_nan = false;
+  int64_t nan_idx = INT64_MAX;
+  BestRecord best{0.0, -1};
+  for (int r = 0; r < world; ++r) {
+    const BestRecord& b = all[(size_t)r * stride];
+    if (b.v != b.v) { any_nan = true; if (b.i < nan_idx) nan_idx = b.i; }
+    else if (best.i < 0 || less(b, best)) best = b;
+  }
+  if (any_nan) { *best_idx = nan_idx; *best_val = std::numeric_limits<double>::quiet_NaN(); }
+  else { *best_idx = best.i; *best_val = best.v; }
+  // k smallest of the union of the per-rank sorted lists: selection by repeated minimum (k, world tiny)
+  std::vector<int> head((size_t)world, 0);   // cursor per rank
+  for (int t = 0; t < k_seeds; ++t) {
+    int pick = -1;
+    for (int r = 0; r < world; ++r) {
+      while (head[r] < k_seeds && all[(size_t)r * stride + 1 + head[r]].i < 0) ++head[r];   // padding
+      if (head[r] >= k_seeds) continue;
+      if (pick < 0 || less(all[(size_t)r * stride + 1 + head[r]], all[(size_t)pick * stride + 1 + head[pick]])) pick = r;
+    }
+    if (pick < 0) { seed_idx[t] = -1; seed_val[t] = std::numeric_limits<double>::quiet_NaN(); continue; }
+    const BestRecord& s = all[(size_t)pick * stride + 1 + head[pick]];
+    seed_idx[t] = s.i; seed_val[t] = s.v;
+    ++head[pick];
+  }
 }
 
 }  // namespace gpbo

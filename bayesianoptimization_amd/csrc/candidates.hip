@@ -70,7 +70,7 @@ extern "C" int gpbo_generate_candidates(gpbo_ctx* ctx, int64_t M, int d, const d
     ctx->red = p;
     ctx->cap_red = cap;
   }
-  double* h = (double*)ctx->pinned;
+  double* h = (double*)((char*)ctx->pinned_aux + PIN_AUX_CAND);
   for (int t = 0; t < d; ++t) { h[t] = lo[t]; h[GPBO_MAX_DIM + t] = hi[t]; }
   GPBO_HIP(ctx, hipMemcpyAsync(ctx->red, h, 2 * GPBO_MAX_DIM * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   const int64_t total = M * d, nq = (total + 1) / 2;

@@ -1,9 +1,27 @@
-// Multi-GPU arg-best exchange over RCCL (xGMI), one process per GPU.
-// The candidate shards are independent; the only exchange is an all-gather of each rank's
-// (value, global index) records — 16 bytes each — followed by an identical host-side merge on every
-// rank.  librccl is dlopen'ed on first use so that single-GPU users never load it.
+// Multi-GPU arg-best exchange over RCCL (xGMI) — SURVEY.md §8e / §8b-B3.
+//
+// The candidate shards are independent (sklearn _gpr.py:443-494 is row-wise; bayes_opt/acquisition.py:312-317 needs
+// only a global argmin and the k best), so the ONLY exchange is an all-gather of each shard's 1 + k (value, global
+// index) records — 16 bytes each — followed by an identical host merge on every rank.  The records are produced on
+// the device (pack_records_kernel) and go straight into ncclAllGather on the context's stream; nothing bounces
+// through the host before the collective.
+//
+// Two ways to own the GPUs, one exchange:
+//   * one process per GPU  : gpbo_comm_unique_id / gpbo_comm_init (ncclCommInitRank), then gpbo_comm_acq_argbest;
+//   * one process, G GPUs  : gpbo_group_create (ncclCommInitAll, one context + one host thread per device), then
+//                            gpbo_group_* — this is what sits behind BayesianOptimization.suggest(), which is one
+//                            Python process (bayes_opt/bayesian_optimization.py:323-333).
+// librccl is dlopen'ed on first use so that single-GPU users never load it.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <cstdlib>
+#include <functional>
+#include <limits>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 #include "gpbo_internal.h"
 
@@ -13,28 +31,42 @@ struct RcclApi {
   void* handle = nullptr;
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
 static RcclApi g_rccl;
+static std::mutex g_rccl_mu;
 
 static int load_rccl(gpbo_ctx* ctx) {
+  std::lock_guard<std::mutex> lk(g_rccl_mu);
   if (g_rccl.handle) return GPBO_OK;
+  // a copy that is already in the process (e.g. pulled in by another library) wins: two RCCL instances in one
+  // process must never talk to the same GPUs
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
   for (const char* n : names) {
-    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
     if (h) break;
   }
+  if (!h)
+    for (const char* n : names) {
+      h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
   if (!h) GPBO_FAIL(ctx, GPBO_ERR_COMM, std::string("dlopen(librccl) failed: ") + dlerror());
   g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
   g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+  g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll))dlsym(h, "ncclCommInitAll");
   g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
+  g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
-  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllGather || !g_rccl.CommDestroy)
+  if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommInitAll || !g_rccl.AllGather || !g_rccl.AllReduce ||
+      !g_rccl.CommDestroy)
     GPBO_FAIL(ctx, GPBO_ERR_COMM, "librccl is missing a required symbol");
   g_rccl.handle = h;
   return GPBO_OK;
@@ -49,6 +81,30 @@ static int load_rccl(gpbo_ctx* ctx) {
       GPBO_FAIL(ctx, GPBO_ERR_COMM, _m);                                                   \
     }                                                                                      \
   } while (0)
+
+// device [send | recv | 8-byte word] and pinned host [recv | word] buffers for n_records per rank
+static int comm_buffers(gpbo_ctx* ctx, int n_records, char** dsend, char** drecv, char** hrecv) {
+  const size_t send_bytes = sizeof(BestRecord) * (size_t)n_records, recv_bytes = send_bytes * (size_t)ctx->world;
+  int rc;
+  {
+    char* p = (char*)ctx->comm_buf;
+    int64_t cap = ctx->cap_comm_buf;
+    if ((rc = ensure(ctx, &p, &cap, (int64_t)(send_bytes + recv_bytes + 64)))) return rc;
+    ctx->comm_buf = p;
+    ctx->cap_comm_buf = cap;
+  }
+  if ((int64_t)(recv_bytes + 64) > ctx->cap_comm_host) {
+    if (ctx->comm_host) GPBO_HIP(ctx, hipHostFree(ctx->comm_host));
+    ctx->comm_host = nullptr;
+    ctx->cap_comm_host = 0;
+    GPBO_HIP(ctx, hipHostMalloc(&ctx->comm_host, recv_bytes + 64, hipHostMallocDefault));
+    ctx->cap_comm_host = (int64_t)(recv_bytes + 64);
+  }
+  *dsend = (char*)ctx->comm_buf;
+  *drecv = *dsend + send_bytes;
+  *hrecv = (char*)ctx->comm_host;
+  return GPBO_OK;
+}
 
 }  // namespace gpbo
 
@@ -84,31 +140,68 @@ extern "C" int gpbo_comm_allgather_best(gpbo_ctx* ctx, const double* vals, const
                                         int n_records, double* all_vals, int64_t* all_idxs) {
   if (!ctx || !ctx->comm) GPBO_FAIL(ctx, GPBO_ERR_STATE, "comm_allgather_best: communicator not initialised");
   if (n_records < 1 || n_records > 4096) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "comm_allgather_best: bad n_records");
+  if (!vals || !idxs || !all_vals || !all_idxs) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "comm_allgather_best: NULL argument");
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
-  const size_t rec = 16, send_bytes = rec * n_records, recv_bytes = send_bytes * ctx->world;
-  int rc;
-  {
-    char* p = (char*)ctx->comm_buf;
-    int64_t cap = ctx->cap_comm_buf;
-    if ((rc = ensure(ctx, &p, &cap, (int64_t)(send_bytes + recv_bytes)))) return rc;
-    ctx->comm_buf = p;
-    ctx->cap_comm_buf = cap;
-  }
-  std::string host(send_bytes + recv_bytes, '\0');
-  for (int t = 0; t < n_records; ++t) {
-    memcpy(&host[t * rec], &vals[t], 8);
-    memcpy(&host[t * rec + 8], &idxs[t], 8);
-  }
-  char* dsend = (char*)ctx->comm_buf;
-  char* drecv = dsend + send_bytes;
+  char *dsend, *drecv, *hrecv;
+  int rc = comm_buffers(ctx, n_records, &dsend, &drecv, &hrecv);
+  if (rc) return rc;
+  const size_t send_bytes = sizeof(BestRecord) * (size_t)n_records, recv_bytes = send_bytes * (size_t)ctx->world;
+  std::vector<BestRecord> host((size_t)n_records);
+  for (int t = 0; t < n_records; ++t) host[t] = BestRecord{vals[t], idxs[t]};
   GPBO_HIP(ctx, hipMemcpyAsync(dsend, host.data(), send_bytes, hipMemcpyHostToDevice, ctx->stream));
   GPBO_NCCL(ctx, g_rccl.AllGather(dsend, drecv, send_bytes, ncclChar, (ncclComm_t)ctx->comm, ctx->stream));
-  GPBO_HIP(ctx, hipMemcpyAsync(&host[send_bytes], drecv, recv_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  GPBO_HIP(ctx, hipMemcpyAsync(hrecv, drecv, recv_bytes, hipMemcpyDeviceToHost, ctx->stream));
   GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (int t = 0; t < n_records * ctx->world; ++t) {
-    memcpy(&all_vals[t], &host[send_bytes + t * rec], 8);
-    memcpy(&all_idxs[t], &host[send_bytes + t * rec + 8], 8);
+  const BestRecord* all = (const BestRecord*)hrecv;
+  for (int t = 0; t < n_records * ctx->world; ++t) { all_vals[t] = all[t].v; all_idxs[t] = all[t].i; }
+  return GPBO_OK;
+}
+
+extern "C" int gpbo_comm_acq_argbest(gpbo_ctx* ctx, int acq, double acq_param, double y_max, int n_constraints,
+                                     const double* lb, const double* ub, int k_seeds, int64_t index_offset,
+                                     int64_t* best_idx, double* best_val, int64_t* seed_idx, double* seed_val,
+                                     double* ys_out) {
+  AcqArgs a{};
+  int rc = build_acq_args(ctx, "comm_acq_argbest", acq, acq_param, y_max, n_constraints, lb, ub, k_seeds, best_idx,
+                          best_val, seed_idx, seed_val, &a);
+  if (rc) return rc;
+  if (ctx->world > 1 && !ctx->comm) GPBO_FAIL(ctx, GPBO_ERR_STATE, "comm_acq_argbest: communicator not initialised");
+  char *dsend, *drecv, *hrecv;
+  const int n_records = 1 + k_seeds;
+  if ((rc = comm_buffers(ctx, n_records, &dsend, &drecv, &hrecv))) return rc;
+  const size_t send_bytes = sizeof(BestRecord) * (size_t)n_records, recv_bytes = send_bytes * (size_t)ctx->world;
+  ev_begin(ctx, T_ACQ);
+  rc = launch_acq_records(ctx, a, ctx->M, k_seeds, index_offset, (BestRecord*)dsend);
+  if (rc) return rc;
+  const char* gathered = dsend;    // a single shard is its own union
+  if (ctx->comm) {
+    GPBO_NCCL(ctx, g_rccl.AllGather(dsend, drecv, send_bytes, ncclChar, (ncclComm_t)ctx->comm, ctx->stream));
+    gathered = drecv;
   }
+  ev_end(ctx, T_ACQ);
+  GPBO_HIP(ctx, hipMemcpyAsync(hrecv, gathered, ctx->comm ? recv_bytes : send_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (ys_out) GPBO_HIP(ctx, hipMemcpyAsync(ys_out, ctx->ys, (size_t)ctx->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  merge_records((const BestRecord*)hrecv, ctx->comm ? ctx->world : 1, k_seeds, best_idx, best_val, seed_idx, seed_val);
+  return GPBO_OK;
+}
+
+extern "C" int gpbo_comm_allreduce_max(gpbo_ctx* ctx, double* value) {
+  if (!ctx || !value) return GPBO_ERR_INVALID;
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (!ctx->comm) return GPBO_OK;    // one rank: the maximum is the value itself
+  char *dsend, *drecv, *hrecv;
+  int rc = comm_buffers(ctx, 1, &dsend, &drecv, &hrecv);
+  if (rc) return rc;
+  double* dword = (double*)(drecv + sizeof(BestRecord) * (size_t)ctx->world);
+  double* hword = (double*)(hrecv + sizeof(BestRecord) * (size_t)ctx->world);
+  *hword = *value;
+  GPBO_HIP(ctx, hipMemcpyAsync(dword, hword, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  GPBO_NCCL(ctx, g_rccl.AllReduce(dword, dword, 1, ncclDouble, ncclMax, (ncclComm_t)ctx->comm, ctx->stream));
+  GPBO_HIP(ctx, hipMemcpyAsync(hword, dword, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *value = *hword;
   return GPBO_OK;
 }
 
@@ -119,4 +212,268 @@ extern "C" int gpbo_comm_destroy(gpbo_ctx* ctx) {
   ctx->world = 1;
   ctx->rank = 0;
   return GPBO_OK;
+}
+
+// ================================================================================================================
+// Single-process device group
+// ================================================================================================================
+struct gpbo_group {
+  std::vector<gpbo_ctx*> ctx;
+  std::vector<int> devices;
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  std::function<int(int)> job;
+  uint64_t generation = 0;
+  int pending = 0;
+  bool stop = false;
+  std::vector<int> rcs;
+  bool virtual_ranks = false;      // duplicate devices (tests on one GPU): records merged on the host, no RCCL
+  std::string collective = "none";
+  std::string err;
+  int64_t M = 0;                   // candidates resident across the group
+  int d = 0;
+  std::vector<int64_t> row0;       // device r owns rows [row0[r], row0[r + 1])
+
+  int run(std::function<int(int)> f) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = std::move(f);
+      pending = (int)ctx.size();
+      ++generation;
+    }
+    cv_job.notify_all();
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return pending == 0; });
+    for (size_t r = 0; r < ctx.size(); ++r)
+      if (rcs[r] != GPBO_OK) {
+        err = "device " + std::to_string(devices[r]) + " (rank " + std::to_string(r) + "): " + ctx[r]->err;
+        set_global_error(err);
+        return rcs[r];
+      }
+    return GPBO_OK;
+  }
+};
+
+static void group_worker(gpbo_group* g, int rank) {
+  (void)hipSetDevice(g->devices[rank]);
+  uint64_t seen = 0;
+  for (;;) {
+    std::function<int(int)> f;
+    {
+      std::unique_lock<std::mutex> lk(g->mu);
+      g->cv_job.wait(lk, [&] { return g->stop || g->generation != seen; });
+      if (g->stop) return;
+      seen = g->generation;
+      f = g->job;
+    }
+    const int rc = f(rank);
+    {
+      std::lock_guard<std::mutex> lk(g->mu);
+      g->rcs[rank] = rc;
+      --g->pending;
+    }
+    g->cv_done.notify_all();
+  }
+}
+
+static int group_fail(gpbo_group* g, int code, const std::string& msg) {
+  if (g) g->err = msg;
+  set_global_error(msg);
+  return code;
+}
+
+extern "C" int gpbo_group_create(int n_dev, const int* devices, gpbo_group** out) {
+  if (!out) return GPBO_ERR_INVALID;
+  *out = nullptr;
+  if (n_dev < 1 || n_dev > 64 || !devices) return group_fail(nullptr, GPBO_ERR_INVALID, "group_create: bad arguments");
+  gpbo_group* g = new gpbo_group();
+  for (int r = 0; r < n_dev; ++r)
+    for (int q = 0; q < r; ++q)
+      if (devices[q] == devices[r]) g->virtual_ranks = true;
+  if (const char* e = getenv("GPBO_GROUP_HOST_MERGE"))
+    if (e[0] == '1') g->virtual_ranks = true;
+  g->devices.assign(devices, devices + n_dev);
+  g->rcs.assign((size_t)n_dev, GPBO_OK);
+  auto cleanup = [&](int rc) {
+    for (gpbo_ctx* c : g->ctx) gpbo_destroy(c);
+    delete g;
+    return rc;
+  };
+  for (int r = 0; r < n_dev; ++r) {
+    gpbo_ctx* c = nullptr;
+    int rc = gpbo_create(devices[r], &c);
+    if (rc) return cleanup(rc);
+    g->ctx.push_back(c);
+  }
+  if (g->virtual_ranks) {
+    g->collective = "host-merge(virtual ranks)";
+  } else {
+    int rc = load_rccl(nullptr);
+    if (rc) return cleanup(rc);
+    std::vector<ncclComm_t> comms((size_t)n_dev, nullptr);
+    ncclResult_t nr = g_rccl.CommInitAll(comms.data(), n_dev, devices);
+    if (nr != ncclSuccess) {
+      set_global_error(std::string("ncclCommInitAll failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(nr) : "?"));
+      return cleanup(GPBO_ERR_COMM);
+    }
+    for (int r = 0; r < n_dev; ++r) { g->ctx[r]->comm = comms[r]; g->ctx[r]->world = n_dev; g->ctx[r]->rank = r; }
+    g->collective = "rccl-allgather";
+  }
+  for (int r = 0; r < n_dev; ++r) g->workers.emplace_back(group_worker, g, r);
+  *out = g;
+  return GPBO_OK;
+}
+
+extern "C" int gpbo_group_destroy(gpbo_group* g) {
+  if (!g) return GPBO_OK;
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->stop = true;
+  }
+  g->cv_job.notify_all();
+  for (auto& t : g->workers) t.join();
+  for (gpbo_ctx* c : g->ctx) gpbo_destroy(c);
+  delete g;
+  return GPBO_OK;
+}
+
+extern "C" int gpbo_group_size(const gpbo_group* g) { return g ? (int)g->ctx.size() : 0; }
+extern "C" gpbo_ctx* gpbo_group_ctx(gpbo_group* g, int rank) {
+  return (g && rank >= 0 && rank < (int)g->ctx.size()) ? g->ctx[rank] : nullptr;
+}
+extern "C" const char* gpbo_group_collective(const gpbo_group* g) { return g ? g->collective.c_str() : "none"; }
+extern "C" const char* gpbo_group_last_error(const gpbo_group* g) { return g ? g->err.c_str() : gpbo_last_error(nullptr); }
+
+extern "C" int gpbo_group_synchronize(gpbo_group* g) {
+  if (!g) return GPBO_ERR_INVALID;
+  return g->run([g](int r) { return gpbo_synchronize(g->ctx[r]); });
+}
+
+extern "C" int gpbo_group_fit(gpbo_group* g, int slot, const double* X, const double* y_norm, int64_t N, int d, int kernel,
+                              const double* length_scale, int n_ls, double noise, int precision, int* info) {
+  if (!g) return GPBO_ERR_INVALID;
+  if (info) *info = 0;
+  std::vector<int> infos(g->ctx.size(), 0);
+  // replicated: every device factorises the same (deterministic) model — cheaper than shipping N^2 doubles
+  int rc = g->run([&](int r) {
+    return gpbo_fit(g->ctx[r], slot, X, y_norm, N, d, kernel, length_scale, n_ls, noise, precision, &infos[r]);
+  });
+  if (info) *info = infos[0];
+  return rc;
+}
+
+extern "C" int gpbo_group_fit_append(gpbo_group* g, int slot, const double* x_new, int64_t n_new, int d, const double* y_norm,
+                                     int64_t n_total, int* info) {
+  if (!g) return GPBO_ERR_INVALID;
+  if (info) *info = 0;
+  std::vector<int> infos(g->ctx.size(), 0);
+  int rc = g->run([&](int r) { return gpbo_fit_append(g->ctx[r], slot, x_new, n_new, d, y_norm, n_total, &infos[r]); });
+  if (info) *info = infos[0];
+  return rc;
+}
+
+// contiguous block partition in index order: rank r owns rows [r M / G, (r + 1) M / G), so that global index =
+// offset + local index keeps the reference's first-minimum tie-break
+static void group_partition(gpbo_group* g, int64_t M, int d) {
+  const int64_t G = (int64_t)g->ctx.size();
+  g->row0.assign((size_t)G + 1, 0);
+  for (int64_t r = 0; r <= G; ++r) g->row0[(size_t)r] = r * M / G;
+  g->M = M;
+  g->d = d;
+}
+
+extern "C" int gpbo_group_set_candidates(gpbo_group* g, const double* Xc, int64_t M, int d) {
+  if (!g) return GPBO_ERR_INVALID;
+  if (!Xc || d < 1 || d > GPBO_MAX_DIM || M < (int64_t)g->ctx.size())
+    return group_fail(g, GPBO_ERR_INVALID, "group_set_candidates: need at least one candidate per device");
+  group_partition(g, M, d);
+  return g->run([&](int r) {
+    const int64_t a = g->row0[r], b = g->row0[r + 1];
+    return gpbo_set_candidates(g->ctx[r], Xc + a * d, b - a, d);
+  });
+}
+
+extern "C" int gpbo_group_shard(const gpbo_group* g, int rank, int64_t* row_begin, int64_t* row_end) {
+  if (!g || rank < 0 || rank >= (int)g->ctx.size() || g->row0.empty()) return GPBO_ERR_INVALID;
+  if (row_begin) *row_begin = g->row0[rank];
+  if (row_end) *row_end = g->row0[rank + 1];
+  return GPBO_OK;
+}
+
+extern "C" int gpbo_group_posterior(gpbo_group* g, int slot, double y_mean, double y_std, double* mu, double* sd) {
+  if (!g) return GPBO_ERR_INVALID;
+  if (g->M < 1) return group_fail(g, GPBO_ERR_STATE, "group_posterior: no candidates resident (call gpbo_group_set_candidates)");
+  return g->run([&](int r) {
+    const int64_t a = g->row0[r];
+    return gpbo_posterior(g->ctx[r], slot, y_mean, y_std, mu ? mu + a : nullptr, sd ? sd + a : nullptr);
+  });
+}
+
+extern "C" int gpbo_group_acq_argbest(gpbo_group* g, int acq, double acq_param, double y_max, int n_constraints,
+                                      const double* lb, const double* ub, int k_seeds, int64_t* best_idx, double* best_val,
+                                      int64_t* seed_idx, double* seed_val, double* ys_out) {
+  if (!g) return GPBO_ERR_INVALID;
+  if (g->M < 1) return group_fail(g, GPBO_ERR_STATE, "group_acq_argbest: no candidates resident");
+  if (k_seeds < 0 || k_seeds > GPBO_MAX_SEEDS || !best_idx || !best_val || (k_seeds > 0 && (!seed_idx || !seed_val)))
+    return group_fail(g, GPBO_ERR_INVALID, "group_acq_argbest: bad arguments");
+  const int G = (int)g->ctx.size(), stride = 1 + k_seeds;
+  std::vector<BestRecord> rec((size_t)G * stride);     // per rank: [best, seeds...]
+  auto local = [&](int r, bool exchange) {
+    int64_t bi = -1; double bv = 0.0;
+    std::vector<int64_t> si((size_t)std::max(k_seeds, 1), -1);
+    std::vector<double> sv((size_t)std::max(k_seeds, 1), 0.0);
+    double* ys = ys_out ? ys_out + g->row0[r] : nullptr;
+    int rc = exchange
+      ? gpbo_comm_acq_argbest(g->ctx[r], acq, acq_param, y_max, n_constraints, lb, ub, k_seeds, g->row0[r], &bi, &bv,
+                              si.data(), sv.data(), ys)
+      : gpbo_acq_argbest(g->ctx[r], acq, acq_param, y_max, n_constraints, lb, ub, k_seeds, g->row0[r], &bi, &bv, si.data(),
+                         sv.data(), ys);
+    if (rc) return rc;
+    rec[(size_t)r * stride] = BestRecord{bv, bi};
+    for (int t = 0; t < k_seeds; ++t) rec[(size_t)r * stride + 1 + t] = BestRecord{sv[t], si[t]};
+    return (int)GPBO_OK;
+  };
+  if (g->virtual_ranks) {
+    // shards of one GPU (tests): every rank's local records, merged here exactly as the ranks merge the gathered ones
+    int rc = g->run([&](int r) { return local(r, false); });
+    if (rc) return rc;
+    merge_records(rec.data(), G, k_seeds, best_idx, best_val, seed_idx, seed_val);
+    return GPBO_OK;
+  }
+  // every device: records packed on the device -> ncclAllGather on its stream -> the same merge; all ranks must agree
+  int rc = g->run([&](int r) { return local(r, true); });
+  if (rc) return rc;
+  for (int r = 1; r < G; ++r)
+    for (int t = 0; t < stride; ++t) {
+      const BestRecord &a = rec[t], &b = rec[(size_t)r * stride + t];
+      const bool same_v = (a.v == b.v) || (a.v != a.v && b.v != b.v);
+      if (a.i != b.i || !same_v) return group_fail(g, GPBO_ERR_COMM, "group_acq_argbest: ranks disagree after the all-gather");
+    }
+  *best_idx = rec[0].i;
+  *best_val = rec[0].v;
+  for (int t = 0; t < k_seeds; ++t) { seed_idx[t] = rec[1 + t].i; seed_val[t] = rec[1 + t].v; }
+  return GPBO_OK;
+}
+
+extern "C" int gpbo_group_get_candidate_rows(gpbo_group* g, const int64_t* idx, int n, double* out) {
+  if (!g) return GPBO_ERR_INVALID;
+  if (!idx || !out || n < 1 || n > 4096) return group_fail(g, GPBO_ERR_INVALID, "group_get_candidate_rows: bad arguments");
+  if (g->M < 1) return group_fail(g, GPBO_ERR_STATE, "group_get_candidate_rows: no candidates resident");
+  const int d = g->d;
+  for (int t = 0; t < n; ++t)
+    if (idx[t] < 0 || idx[t] >= g->M)
+      for (int c = 0; c < d; ++c) out[(size_t)t * d + c] = std::numeric_limits<double>::quiet_NaN();
+  return g->run([&](int r) {
+    std::vector<int64_t> loc;
+    std::vector<int> pos;
+    for (int t = 0; t < n; ++t)
+      if (idx[t] >= g->row0[r] && idx[t] < g->row0[r + 1]) { loc.push_back(idx[t] - g->row0[r]); pos.push_back(t); }
+    if (loc.empty()) return (int)GPBO_OK;
+    std::vector<double> rows(loc.size() * (size_t)d);
+    int rc = gpbo_get_candidate_rows(g->ctx[r], loc.data(), (int)loc.size(), rows.data());
+    if (rc) return rc;
+    for (size_t q = 0; q < loc.size(); ++q) memcpy(out + (size_t)pos[q] * d, rows.data() + q * d, (size_t)d * sizeof(double));
+    return (int)GPBO_OK;
+  });
 }

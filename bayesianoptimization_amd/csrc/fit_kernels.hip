@@ -7,6 +7,8 @@
 //   potrf/gemm    cholesky(K, lower=True) -> LAPACK dpotrf  _gpr.py:349
 //   trtri         W = L^-1: turns the per-candidate solve_triangular (_gpr.py:454-456) into a GEMM
 //   trmv          alpha = cho_solve((L, True), y)           _gpr.py:360-364, as W^T (W y)
+#include <cstdlib>
+
 #include "gpbo_internal.h"
 
 namespace gpbo {
@@ -41,25 +43,27 @@ int launch_prescale(gpbo_ctx* ctx, const double* X, int64_t n, int d, int DP, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// Kernel value from a squared scaled distance.
+// Kernel value from a squared scaled distance: ONE arithmetic for both sides of the GP (gpbo_kernel_value in
+// gpbo_internal.h: v_rsq-seeded sqrt, K^2 * (1/3)) — the fit-side K and the posterior-side k* agree bit for bit
+// for equal distances, and both stay within ~1 ulp of sklearn's expression (kernels.py:1722-1724, 1559-1560).
 template <int KERNEL>
 __device__ __forceinline__ double kernel_value(double d2) {
-  if (KERNEL == GPBO_KERNEL_MATERN25) {
-    double k = sqrt(d2) * 2.23606797749978969641;  // dists * sqrt(5)
-    return (1.0 + k + k * k / 3.0) * exp(-k);
-  } else {
-    return exp(-0.5 * d2);
-  }
+  return gpbo_kernel_value<KERNEL>(d2);
 }
 
-// K (lower block triangle, 64x64 tiles): one workgroup per tile, 4x4 outputs per thread, the two
-// point tiles staged k-major in LDS.  HBM-write bound: N^2/2 * 8 B.
+// K (lower block triangle, 64x64 tiles): one workgroup per LOWER tile (linear block id -> (bi, bj), no idle
+// workgroups), 4x4 outputs per thread, the two point tiles staged k-major in LDS.  HBM-write bound: N^2/2 * 8 B.
+// `out` is K, or directly the buffer the Cholesky factorises in place (no K -> L copy on the fit path).
 template <int KERNEL>
 __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ Xs, int DP, int64_t N,
                                                    int64_t NP, double noise, double* __restrict__ K,
                                                    int64_t lane_stride) {
-  const int bj = blockIdx.x, bi = blockIdx.y;
-  if (bj > bi) return;
+  // blockIdx.x = bi (bi + 1) / 2 + bj, bj <= bi
+  const int b = blockIdx.x;
+  int bi = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
+  while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
+  while (bi * (bi + 1) / 2 > b) --bi;
+  const int bj = b - bi * (bi + 1) / 2;
   Xs += (int64_t)blockIdx.z * lane_stride;
   K += (int64_t)blockIdx.z * lane_stride;
   extern __shared__ __attribute__((aligned(16))) double kmat_smem[];
@@ -77,19 +81,19 @@ __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ Xs
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+    for (int b2 = 0; b2 < 4; ++b2) acc[a][b2] = 0.0;
   for (int t = 0; t < DP; ++t) {
     double xi[4], xj[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) xi[a] = XiT[t * 64 + ty * 4 + a];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) xj[b] = XjT[t * 64 + tx * 4 + b];
+    for (int b2 = 0; b2 < 4; ++b2) xj[b2] = XjT[t * 64 + tx * 4 + b2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        double df = xi[a] - xj[b];
-        acc[a][b] = fma(df, df, acc[a][b]);
+      for (int b2 = 0; b2 < 4; ++b2) {
+        double df = xi[a] - xj[b2];
+        acc[a][b2] = fma(df, df, acc[a][b2]);
       }
   }
 #pragma unroll
@@ -97,13 +101,13 @@ __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ Xs
     const int64_t i = (int64_t)bi * 64 + ty * 4 + a;
     double out[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int64_t j = (int64_t)bj * 64 + tx * 4 + b;
+    for (int b2 = 0; b2 < 4; ++b2) {
+      const int64_t j = (int64_t)bj * 64 + tx * 4 + b2;
       double v;
       if (i >= N || j >= N) v = (i == j) ? 1.0 : 0.0;       // identity padding
       else if (i == j) v = 1.0 + noise;                       // unit diagonal (+ alpha, _gpr.py:347)
-      else v = kernel_value<KERNEL>(acc[a][b]);
-      out[b] = v;
+      else v = kernel_value<KERNEL>(acc[a][b2]);
+      out[b2] = v;
     }
     double2* dst = reinterpret_cast<double2*>(K + i * NP + (int64_t)bj * 64 + tx * 4);
     dst[0] = make_double2(out[0], out[1]);
@@ -111,13 +115,14 @@ __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ Xs
   }
 }
 
-int launch_kmat(gpbo_ctx* ctx, Model& m, double noise) {
-  dim3 grid((unsigned)(m.NP / 64), (unsigned)(m.NP / 64), (unsigned)ctx->lanes);
+int launch_kmat(gpbo_ctx* ctx, Model& m, double noise, double* out) {
+  const int64_t nt = m.NP / 64;
+  dim3 grid((unsigned)(nt * (nt + 1) / 2), 1, (unsigned)ctx->lanes);
   const size_t lds = (size_t)2 * m.DP * 64 * sizeof(double);
   if (m.kernel == GPBO_KERNEL_MATERN25)
-    kmat_kernel<GPBO_KERNEL_MATERN25><<<grid, dim3(256), lds, ctx->stream>>>(m.Xs, m.DP, m.N, m.NP, noise, m.K, ctx->lane_stride);
+    kmat_kernel<GPBO_KERNEL_MATERN25><<<grid, dim3(256), lds, ctx->stream>>>(m.Xs, m.DP, m.N, m.NP, noise, out, ctx->lane_stride);
   else
-    kmat_kernel<GPBO_KERNEL_RBF><<<grid, dim3(256), lds, ctx->stream>>>(m.Xs, m.DP, m.N, m.NP, noise, m.K, ctx->lane_stride);
+    kmat_kernel<GPBO_KERNEL_RBF><<<grid, dim3(256), lds, ctx->stream>>>(m.Xs, m.DP, m.N, m.NP, noise, out, ctx->lane_stride);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
@@ -417,14 +422,193 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
       }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp64 MFMA GEMM for the big fit-side products (rank-512 trailing updates, W = L^-1 levels, W^T W):
+// 128x128 output tile per 512-thread workgroup — 8 waves as 4 (rows) x 2 (columns), wave tile 32 x 64 = 2 x 4
+// v_mfma_f64_16x16x4_f64 tiles = 64 accumulator VGPRs, two workgroups per CU (4 waves per SIMD, the occupancy the
+// matrix pipe needs: posterior_kernel_v2.hip) — BK = 16 per stage, DOUBLE-BUFFERED LDS with ONE barrier per stage:
+// the global loads of stage s+1 are issued before the MFMAs of stage s and stored to the other buffer after them.
+// Both operand tiles live k-major in LDS ([k][m], row stride 144 doubles = 128 + 16, so the two k-rows a 32-lane
+// ds_read_b64 group touches fall 32 banks apart): a fragment read is conflict-free whichever way the operand lies
+// in memory, and only the global->LDS copy differs between the layouts:
+//   row-type source (k contiguous: A, or B given transposed): thread = (row t & 127, k-quad t >> 7), one 32-byte
+//     load, four 8-byte LDS stores (a wave stores 64 consecutive rows of one k: conflict-free);
+//   col-type source (m contiguous: A given transposed, or B): thread = (k t >> 5, column quad t & 31), one 32-byte
+//     load, two 16-byte LDS stores.
+// Same flags as gemm_f64_kernel.  m, n multiples of 64 (a ragged last 128-block clamps its loads and drops the
+// stores), k multiple of 16.  With lower_only the diagonal blocks skip the wave tiles strictly above the diagonal.
+constexpr int G2_B = 128, G2_BK = 16, G2_LD = 144;
+constexpr int G2_TILE = G2_BK * G2_LD;   // doubles per operand tile
+
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+template <bool BT, bool AT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm128_f64_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double g2_smem[];   // [2 buffers][A | B][16][144]
+  const int bn = blockIdx.x, bm = blockIdx.y;
+  if (g.lower_only && bn > bm) return;
+  const int zl = blockIdx.z / g.batch, bz = blockIdx.z - zl * g.batch;   // lane mode: z = lane * batch + b
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t lo = (int64_t)zl * g.lane_stride;
+  const double* A = g.A + lo + (int64_t)bz * g.strideA;
+  const double* B = g.B + lo + (int64_t)bz * g.strideB;
+  double* C = g.C + lo + (int64_t)bz * g.strideC;
+  int kbeg = 0, kend = g.k;
+  if (g.a_lower) kend = min(kend, (bm + 1) * G2_B);
+  if (g.b_lower) kbeg = bn * G2_B;
+  if (g.k_from_tile) kbeg = max(bm, bn) * G2_B;   // both operands vanish above their diagonal tiles
+  const int nst = (kend - kbeg) / G2_BK;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
+  const bool idle = g.lower_only && bm == bn && wn >= wm + 32;   // wave tile strictly above the diagonal
+
+  // global -> register staging addresses
+  const double* asrc; const double* bsrc; int64_t astep, bstep;
+  int a_l0, b_l0;   // LDS offsets (doubles) inside a tile
+  if (AT) {   // A given as (k, m): col-type
+    const int kk = tid >> 5, c4 = (tid & 31) * 4;
+    int col = bm * G2_B + c4;
+    if (col >= g.m) col = g.m - 4;
+    asrc = A + (int64_t)(kbeg + kk) * g.lda + col;
+    astep = (int64_t)G2_BK * g.lda;
+    a_l0 = kk * G2_LD + c4;
+  } else {    // A (m, k): row-type
+    const int row = tid & 127, kq = (tid >> 7) * 4;
+    int r = bm * G2_B + row;
+    if (r >= g.m) r = g.m - 1;
+    asrc = A + (int64_t)r * g.lda + kbeg + kq;
+    astep = G2_BK;
+    a_l0 = kq * G2_LD + row;
+  }
+  if (BT) {   // B given as (n, k): row-type
+    const int row = tid & 127, kq = (tid >> 7) * 4;
+    int r = bn * G2_B + row;
+    if (r >= g.n) r = g.n - 1;
+    bsrc = B + (int64_t)r * g.ldb + kbeg + kq;
+    bstep = G2_BK;
+    b_l0 = kq * G2_LD + row;
+  } else {    // B (k, n): col-type
+    const int kk = tid >> 5, c4 = (tid & 31) * 4;
+    int col = bn * G2_B + c4;
+    if (col >= g.n) col = g.n - 4;
+    bsrc = B + (int64_t)(kbeg + kk) * g.ldb + col;
+    bstep = (int64_t)G2_BK * g.ldb;
+    b_l0 = kk * G2_LD + c4;
+  }
+  auto gload = [&](int st, d2v(&ra)[2], d2v(&rb)[2]) {
+    const d2v* ap = reinterpret_cast<const d2v*>(asrc + (int64_t)st * astep);
+    const d2v* bp = reinterpret_cast<const d2v*>(bsrc + (int64_t)st * bstep);
+    ra[0] = ap[0]; ra[1] = ap[1];
+    rb[0] = bp[0]; rb[1] = bp[1];
+  };
+  auto lstore = [&](int buf, const d2v(&ra)[2], const d2v(&rb)[2]) {
+    double* As = g2_smem + buf * 2 * G2_TILE;
+    double* Bs = As + G2_TILE;
+    if (AT) {
+      *reinterpret_cast<d2v*>(As + a_l0) = ra[0];
+      *reinterpret_cast<d2v*>(As + a_l0 + 2) = ra[1];
+    } else {
+      As[a_l0] = ra[0].x; As[a_l0 + G2_LD] = ra[0].y; As[a_l0 + 2 * G2_LD] = ra[1].x; As[a_l0 + 3 * G2_LD] = ra[1].y;
+    }
+    if (BT) {
+      Bs[b_l0] = rb[0].x; Bs[b_l0 + G2_LD] = rb[0].y; Bs[b_l0 + 2 * G2_LD] = rb[1].x; Bs[b_l0 + 3 * G2_LD] = rb[1].y;
+    } else {
+      *reinterpret_cast<d2v*>(Bs + b_l0) = rb[0];
+      *reinterpret_cast<d2v*>(Bs + b_l0 + 2) = rb[1];
+    }
+  };
+
+  d4 acc[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[t][u] = d4{0.0, 0.0, 0.0, 0.0};
+
+  if (nst > 0) {
+    d2v ra[2], rb[2];
+    gload(0, ra, rb);
+    lstore(0, ra, rb);
+    __syncthreads();
+    const int last = nst - 1;
+    const int fo = (lane >> 4) * G2_LD + (lane & 15);
+    for (int st = 0; st < nst; ++st) {
+      const int buf = st & 1;
+      gload(min(st + 1, last), ra, rb);            // clamped look-ahead keeps the body branch-free
+      __builtin_amdgcn_sched_barrier(0);           // keep the global loads at the top of the stage
+      if (!idle) {
+        const double* As = g2_smem + buf * 2 * G2_TILE + fo;
+        const double* Bs = As + G2_TILE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double a0 = As[q * 4 * G2_LD + wm];
+          const double a1 = As[q * 4 * G2_LD + wm + 16];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double b = Bs[q * 4 * G2_LD + wn + 16 * u];
+            acc[0][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][u], 0, 0, 0);
+            acc[1][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][u], 0, 0, 0);
+          }
+        }
+      }
+      lstore(buf ^ 1, ra, rb);    // the other buffer: everyone finished reading it before the previous barrier
+      __syncthreads();
+    }
+  }
+  if (idle) return;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = (int64_t)bm * G2_B + wm + 16 * t + (lane >> 4) + 4 * r;
+        const int64_t colx = (int64_t)bn * G2_B + wn + 16 * u + (lane & 15);
+        if (row < g.m && colx < g.n) {
+          double* cp = C + row * g.ldc + colx;
+          double v = g.alpha * acc[t][u][r];
+          if (g.beta != 0.0) v += g.beta * (*cp);
+          *cp = v;
+        }
+      }
+}
+
+static bool gemm128_enabled() {
+  static const bool on = !(getenv("GPBO_GEMM128") && getenv("GPBO_GEMM128")[0] == '0');
+  return on;
+}
+
 int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
   if (g_in.m <= 0 || g_in.n <= 0 || g_in.batch <= 0) return GPBO_OK;
   GemmArgs g = g_in;
   g.lanes = ctx->lanes;
   g.lane_stride = ctx->lane_stride;
   if (g.m % 64 || g.n % 64 || g.k % 16) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gemm: m,n must be multiples of 64 and k of 16");
-  dim3 grid((unsigned)(g.n / 64), (unsigned)(g.m / 64), (unsigned)(g.batch * g.lanes));
   if (g.a_trans && g.b_trans) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gemm: a_trans with b_trans is not instantiated");
+  // big products -> the 128x128 double-buffered kernel; panels and small blocks -> the 64x64 kernel
+  // (a triangular k-range must start/stop on a 128 boundary there, which the callers' block sizes guarantee from 128 on)
+  if (gemm128_enabled() && g.m >= 128 && g.n >= 128 && g.k >= 32) {
+    constexpr size_t lds = (size_t)4 * G2_TILE * sizeof(double);   // 73 728 B
+    static bool attr_set = false;
+    if (!attr_set) {
+      GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_f64_kernel<true, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_f64_kernel<false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_f64_kernel<false, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    dim3 grid((unsigned)((g.n + 127) / 128), (unsigned)((g.m + 127) / 128), (unsigned)(g.batch * g.lanes));
+    if (g.b_trans)
+      gemm128_f64_kernel<true, false><<<grid, dim3(512), lds, ctx->stream>>>(g);
+    else if (g.a_trans)
+      gemm128_f64_kernel<false, true><<<grid, dim3(512), lds, ctx->stream>>>(g);
+    else
+      gemm128_f64_kernel<false, false><<<grid, dim3(512), lds, ctx->stream>>>(g);
+    GPBO_HIP(ctx, hipGetLastError());
+    return GPBO_OK;
+  }
+  dim3 grid((unsigned)(g.n / 64), (unsigned)(g.m / 64), (unsigned)(g.batch * g.lanes));
   if (g.b_trans)
     gemm_f64_kernel<true, false><<<grid, dim3(256), 0, ctx->stream>>>(g);
   else if (g.a_trans)

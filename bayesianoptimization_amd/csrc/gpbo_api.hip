@@ -155,6 +155,31 @@ static int copy_square(gpbo_ctx* ctx, const Model& m, const double* dev, double*
   return GPBO_OK;
 }
 
+int build_acq_args(gpbo_ctx* ctx, const char* who, int acq, double acq_param, double y_max, int n_constraints,
+                   const double* lb, const double* ub, int k_seeds, const void* best_idx, const void* best_val,
+                   const void* seed_idx, const void* seed_val, AcqArgs* out) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  const std::string w(who);
+  if (acq < GPBO_ACQ_UCB || acq > GPBO_ACQ_POI) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": unknown acquisition");
+  if (n_constraints < 0 || n_constraints >= GPBO_MAX_MODELS) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": bad n_constraints");
+  if (n_constraints > 0 && (!lb || !ub)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": lb/ub required");
+  if (k_seeds < 0 || k_seeds > GPBO_MAX_SEEDS) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": k_seeds out of range [0, 64]");
+  if (!best_idx || !best_val || (k_seeds > 0 && (!seed_idx || !seed_val))) GPBO_FAIL(ctx, GPBO_ERR_INVALID, w + ": NULL output");
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  AcqArgs a{};
+  a.acq = acq; a.param = acq_param; a.y_max = y_max; a.n_constraints = n_constraints;
+  for (int j = 0; j <= n_constraints; ++j) {
+    Model& m = ctx->models[j];
+    if (!m.fitted || m.M_post != ctx->M || ctx->M < 1)
+      GPBO_FAIL(ctx, GPBO_ERR_STATE, w + ": run gpbo_posterior for slots 0..n_constraints first");
+    a.mu[j] = m.mu;
+    a.sd[j] = m.sd;
+  }
+  for (int j = 0; j < n_constraints; ++j) { a.lb[j] = lb[j]; a.ub[j] = ub[j]; }
+  *out = a;
+  return GPBO_OK;
+}
+
 }  // namespace gpbo
 
 using namespace gpbo;
@@ -195,7 +220,8 @@ int gpbo_create(int device, gpbo_ctx** out) {
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->info_dev, sizeof(int));
-  if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, (1 + GPBO_LML_BATCH_MAX) * 16 * 1024, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, PIN_WINDOWS * PIN_WINDOW, hipHostMallocDefault);
+  if (e == hipSuccess) ctx->pinned_aux = (char*)ctx->pinned + (PIN_WINDOWS - 1) * PIN_WINDOW;
   if (e != hipSuccess) {
     set_global_error(std::string("gpbo_create: ") + hipGetErrorString(e));
     delete ctx;
@@ -217,6 +243,7 @@ int gpbo_destroy(gpbo_ctx* ctx) {
   if (ctx->lml_X) (void)hipFree(ctx->lml_X);
   if (ctx->lml_y) (void)hipFree(ctx->lml_y);
   void* ptrs[] = {ctx->Xc, ctx->Xcs, ctx->part, ctx->mu_part, ctx->ys, ctx->red, ctx->info_dev, ctx->comm_buf, ctx->kst, ctx->stage};
+  if (ctx->comm_host) (void)hipHostFree(ctx->comm_host);
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -272,12 +299,16 @@ static hipError_t lane_d2h(gpbo_ctx* ctx, void* dst_host, size_t host_pitch, con
                           hipMemcpyDeviceToHost, ctx->stream);
 }
 
-// Host staging layout inside one 4 KiB pinned region (single lane) — lane mode uses per-lane pitches over several
-// regions: length scales [64] doubles at +0, potrf info word at +1024, LML scalars at +2048.
-constexpr size_t PIN_LS_PITCH = GPBO_MAX_DIM * sizeof(double);
+// Host staging: single lane = window 0 of the pinned allocation (PIN_LS / PIN_INFO / PIN_LML_OUT, gpbo_internal.h);
+// lane mode = one window per group with per-lane pitches: length scales at +0, info words at PIN_LANE_INFO, LML scalars
+// at PIN_LANE_OUT.
+constexpr size_t PIN_LS_PITCH = PIN_LS_BYTES;
 constexpr size_t PIN_INFO_PITCH = 8;
-constexpr size_t PIN_OUT_PITCH = (2 + GPBO_MAX_DIM) * sizeof(double);
-constexpr size_t PIN_LANE_WINDOW = 16384, PIN_LANE_INFO = 4096, PIN_LANE_OUT = 8192;   // lane-mode window inside ctx->pinned
+constexpr size_t PIN_OUT_PITCH = PIN_LML_OUT_BYTES;
+constexpr size_t PIN_LANE_WINDOW = PIN_WINDOW, PIN_LANE_INFO = 4096, PIN_LANE_OUT = 8192;   // lane-mode layout inside a group's window
+static_assert(GPBO_LML_BATCH_MAX * PIN_LS_PITCH <= PIN_LANE_INFO, "lane length scales overlap the lane info words");
+static_assert(PIN_LANE_INFO + GPBO_LML_BATCH_MAX * PIN_INFO_PITCH <= PIN_LANE_OUT, "lane info words overlap the lane LML scalars");
+static_assert(PIN_LANE_OUT + GPBO_LML_BATCH_MAX * PIN_OUT_PITCH <= PIN_WINDOW, "lane LML scalars leave the window");
 
 // K, L, W = L^-1 and alpha from the device-resident scaled inputs m.Xs / targets m.yn (m.N, m.NP, m.kernel set).
 static int factor_resident(gpbo_ctx* ctx, Model& m, double noise, int** info_host) {
@@ -286,13 +317,12 @@ static int factor_resident(gpbo_ctx* ctx, Model& m, double noise, int** info_hos
   m.noise = noise;
   GPBO_HIP(ctx, lane_memset(ctx, ctx->info_dev, sizeof(int)));
   ev_begin(ctx, T_KMAT);
-  if ((rc = launch_kmat(ctx, m, noise))) return rc;
+  if ((rc = launch_kmat(ctx, m, noise, m.L))) return rc;   // straight into the buffer the Cholesky factorises in place
   ev_end(ctx, T_KMAT);
-  GPBO_HIP(ctx, lane_copy_d2d(ctx, m.L, m.K, (size_t)NP * NP * sizeof(double)));
   ev_begin(ctx, T_CHOL);
   if ((rc = cholesky(ctx, m))) return rc;
   ev_end(ctx, T_CHOL);
-  int* info_h = (int*)((char*)ctx->pinned + (ctx->lanes == 1 ? 1024 : PIN_LANE_INFO));   // lane mode: one word per PIN_INFO_PITCH
+  int* info_h = (int*)((char*)ctx->pinned + (ctx->lanes == 1 ? PIN_INFO : PIN_LANE_INFO));   // lane mode: one word per PIN_INFO_PITCH
   GPBO_HIP(ctx, lane_d2h(ctx, info_h, PIN_INFO_PITCH, ctx->info_dev, sizeof(int)));
   // W and alpha are issued before the info check resolves (harmless on failure)
   ev_begin(ctx, T_TRTRI);
@@ -449,7 +479,7 @@ int gpbo_fit_append(gpbo_ctx* ctx, int slot, const double* x_new, int64_t n_new,
     for (int64_t j = N0; j < n_total; ++j)
       if ((rc = launch_append_row(ctx, m, j))) return rc;
     m.N = n_total;
-    info_h = (int*)((char*)ctx->pinned + 1024);
+    info_h = (int*)((char*)ctx->pinned + PIN_INFO);
     GPBO_HIP(ctx, hipMemcpyAsync(info_h, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = launch_trmv(ctx, m))) return rc;
   }
@@ -481,7 +511,7 @@ static int lml_tail(gpbo_ctx* ctx, Model& m, int n_ls, int eval_gradient, double
     if ((rc = launch_lml_grad(ctx, m, n_ls, m.K, m.tmp, scal + 2))) return rc;
   }
   ev_end(ctx, T_FIT);
-  double* out_h = (double*)((char*)ctx->pinned + (ctx->lanes == 1 ? 2048 : PIN_LANE_OUT));   // lane mode: PIN_OUT_PITCH bytes per lane
+  double* out_h = (double*)((char*)ctx->pinned + (ctx->lanes == 1 ? PIN_LML_OUT : PIN_LANE_OUT));   // lane mode: PIN_OUT_PITCH bytes per lane
   GPBO_HIP(ctx, lane_d2h(ctx, out_h, PIN_OUT_PITCH, scal, (size_t)(2 + (eval_gradient ? n_ls : 0)) * sizeof(double)));
   *out_host = out_h;
   return GPBO_OK;
@@ -676,8 +706,8 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
     const int g = i / per_group, l = i - g * per_group;
     const int gl = std::min(per_group, n_theta - g * per_group);
     const char* window = (const char*)ctx->pinned + PIN_LANE_WINDOW * (size_t)(1 + g);
-    const char* out_h = window + (gl == 1 ? 2048 : PIN_LANE_OUT);      // where lml_tail / factor_resident put the
-    const char* info_h = window + (gl == 1 ? 1024 : PIN_LANE_INFO);    // results (single / lane mode)
+    const char* out_h = window + (gl == 1 ? PIN_LML_OUT : PIN_LANE_OUT);      // where lml_tail / factor_resident put the
+    const char* info_h = window + (gl == 1 ? PIN_INFO : PIN_LANE_INFO);    // results (single / lane mode)
     if (info) info[i] = 0;
     lml_finish((const double*)(out_h + (size_t)l * PIN_OUT_PITCH), (const int*)(info_h + (size_t)l * PIN_INFO_PITCH), N,
                n_ls, eval_gradient, lml + i, eval_gradient ? grad + (size_t)i * n_ls : nullptr, info ? info + i : nullptr);
@@ -696,7 +726,11 @@ static int need_fitted(gpbo_ctx* ctx, int slot) {
 int gpbo_get_K(gpbo_ctx* ctx, int slot, double* out) {
   int rc = need_fitted(ctx, slot);
   if (rc) return rc;
-  return copy_square(ctx, ctx->models[slot], ctx->models[slot].K, out, 0);
+  // the fit assembles K directly into the buffer it factorises; the parity accessor re-assembles it from the
+  // device-resident scaled inputs (same kernel, same bits)
+  Model& m = ctx->models[slot];
+  if ((rc = launch_kmat(ctx, m, m.noise, m.K))) return rc;
+  return copy_square(ctx, m, m.K, out, 0);
 }
 int gpbo_get_L(gpbo_ctx* ctx, int slot, double* out) {
   int rc = need_fitted(ctx, slot);
@@ -755,26 +789,12 @@ int gpbo_acq_argbest(gpbo_ctx* ctx, int acq, double acq_param, double y_max, int
                      const double* lb, const double* ub, int k_seeds, int64_t index_offset,
                      int64_t* best_idx, double* best_val, int64_t* seed_idx, double* seed_val,
                      double* ys_out) {
-  if (!ctx) return GPBO_ERR_INVALID;
-  if (acq < GPBO_ACQ_UCB || acq > GPBO_ACQ_POI) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "acq_argbest: unknown acquisition");
-  if (n_constraints < 0 || n_constraints >= GPBO_MAX_MODELS) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "acq_argbest: bad n_constraints");
-  if (n_constraints > 0 && (!lb || !ub)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "acq_argbest: lb/ub required");
-  if (k_seeds < 0 || k_seeds > GPBO_MAX_SEEDS) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "acq_argbest: k_seeds out of range [0, 64]");
-  if (!best_idx || !best_val || (k_seeds > 0 && (!seed_idx || !seed_val)))
-    GPBO_FAIL(ctx, GPBO_ERR_INVALID, "acq_argbest: NULL output");
-  GPBO_HIP(ctx, hipSetDevice(ctx->device));
   AcqArgs a{};
-  a.acq = acq; a.param = acq_param; a.y_max = y_max; a.n_constraints = n_constraints;
-  for (int j = 0; j <= n_constraints; ++j) {
-    Model& m = ctx->models[j];
-    if (!m.fitted || m.M_post != ctx->M || ctx->M < 1)
-      GPBO_FAIL(ctx, GPBO_ERR_STATE, "acq_argbest: run gpbo_posterior for slots 0..n_constraints first");
-    a.mu[j] = m.mu;
-    a.sd[j] = m.sd;
-  }
-  for (int j = 0; j < n_constraints; ++j) { a.lb[j] = lb[j]; a.ub[j] = ub[j]; }
+  int rc = build_acq_args(ctx, "acq_argbest", acq, acq_param, y_max, n_constraints, lb, ub, k_seeds, best_idx, best_val,
+                          seed_idx, seed_val, &a);
+  if (rc) return rc;
   ev_begin(ctx, T_ACQ);
-  int rc = launch_acq_argbest(ctx, a, ctx->M, k_seeds, index_offset, best_idx, best_val, seed_idx, seed_val);
+  rc = launch_acq_argbest(ctx, a, ctx->M, k_seeds, index_offset, best_idx, best_val, seed_idx, seed_val);
   ev_end(ctx, T_ACQ);
   if (rc) return rc;
   if (ys_out) {

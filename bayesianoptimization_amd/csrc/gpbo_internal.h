@@ -105,16 +105,45 @@ struct gpbo_ctx {
   void* red = nullptr;     // reduction scratch
   int64_t cap_red = 0;
   int* info_dev = nullptr; // potrf info word
-  void* pinned = nullptr;  // small pinned host staging buffer
+  void* pinned = nullptr;  // pinned host staging: window 0 = fit/LML words (PIN_* below), windows 1..8 = gpbo_lml_batch groups
+  void* pinned_aux = nullptr;   // last window of the same allocation: selection / candidate staging (PIN_AUX_*); never re-pointed
   gpbo::EventPair ev[gpbo::T_COUNT];
   // RCCL
   void* comm = nullptr;
   int world = 1, rank = 0;
-  void* comm_buf = nullptr;
+  void* comm_buf = nullptr;      // device: [send records | gathered records | 8-byte reduction word]
   int64_t cap_comm_buf = 0;
+  void* comm_host = nullptr;     // pinned: gathered records / reduction word
+  int64_t cap_comm_host = 0;
 };
 
 namespace gpbo {
+
+// ---- pinned host staging layout -------------------------------------------------------------------------------
+// ONE allocation of PIN_WINDOWS windows of PIN_WINDOW bytes.  Window 0 (ctx->pinned) carries the words of a fit /
+// LML evaluation; gpbo_lml_batch re-points ctx->pinned at windows 1..GPBO_LML_BATCH_MAX for its groups (their own
+// sub-layout, PIN_LANE_* in gpbo_api.hip); the LAST window (ctx->pinned_aux) belongs to the selection and candidate
+// entry points, so that no two subsystems share a byte whatever stays in flight.
+constexpr size_t PIN_WINDOW = 16384;
+constexpr int PIN_WINDOWS = 2 + GPBO_LML_BATCH_MAX;
+// window 0
+constexpr size_t PIN_LS = 0;                                         // [GPBO_MAX_DIM] doubles: length scales
+constexpr size_t PIN_LS_BYTES = GPBO_MAX_DIM * sizeof(double);
+constexpr size_t PIN_INFO = 1024;                                    // potrf info word
+constexpr size_t PIN_LML_OUT = 2048;                                 // yT alpha, sum log L_ii, gradient[GPBO_MAX_DIM]
+constexpr size_t PIN_LML_OUT_BYTES = (2 + GPBO_MAX_DIM) * sizeof(double);
+static_assert(PIN_LS + PIN_LS_BYTES <= PIN_INFO, "length scales overlap the info word");
+static_assert(PIN_INFO + sizeof(int) <= PIN_LML_OUT, "info word overlaps the LML scalars");
+static_assert(PIN_LML_OUT + PIN_LML_OUT_BYTES <= PIN_WINDOW, "LML scalars leave the window");
+// aux window
+constexpr size_t PIN_AUX_SEL_INIT = 0;                               // SelState the selection passes start from (24 B)
+constexpr size_t PIN_AUX_SEL_OUT = 256;                              // SelState + picks[GPBO_MAX_SEEDS + 1] coming back
+constexpr size_t PIN_AUX_SEL_OUT_BYTES = 32 + 16 * (GPBO_MAX_SEEDS + 1);
+constexpr size_t PIN_AUX_CAND = 2048;                                // [lo | hi (or hi - lo)][GPBO_MAX_DIM] doubles | MT19937 key[624]
+constexpr size_t PIN_AUX_CAND_BYTES = 2 * GPBO_MAX_DIM * sizeof(double) + 624 * sizeof(uint32_t);
+static_assert(PIN_AUX_SEL_INIT + 32 <= PIN_AUX_SEL_OUT, "selection init overlaps its results");
+static_assert(PIN_AUX_SEL_OUT + PIN_AUX_SEL_OUT_BYTES <= PIN_AUX_CAND, "selection results overlap the candidate staging");
+static_assert(PIN_AUX_CAND + PIN_AUX_CAND_BYTES <= PIN_WINDOW, "candidate staging leaves the window");
 
 void set_global_error(const std::string& s);
 
@@ -141,7 +170,7 @@ void set_global_error(const std::string& s);
 // k(d2) for the posterior-side k* generation (device only).  Same formulas as sklearn (kernels.py:1722-1724,
 // 1559-1560) with two cost cuts that stay within ~1 ulp: sqrt via v_rsq_f64 + Goldschmidt/Newton without the
 // subnormal rescaling (d2 is a sum of squares of O(1) numbers; exact 0 handled), and K^2/3 as K^2 * (1/3).
-// The fit-side kernel matrix (kmat_kernel) keeps the literal sqrt and division.
+// The fit-side kernel matrix (kmat_kernel) uses the same function, so K and k* share one arithmetic.
 #ifdef __HIPCC__
 __device__ __forceinline__ double gpbo_sqrt_pos(double x) {
   const double y = __builtin_amdgcn_rsq(x);
@@ -188,7 +217,7 @@ int ensure(gpbo_ctx* ctx, T** p, int64_t* cap, int64_t need) {
 // fit_kernels.hip
 int launch_prescale(gpbo_ctx* ctx, const double* X, int64_t n, int d, int DP, const double* ls,
                     double* out, int64_t n_pad);
-int launch_kmat(gpbo_ctx* ctx, Model& m, double noise);
+int launch_kmat(gpbo_ctx* ctx, Model& m, double noise, double* out);   // out: m.K, or m.L (factorised in place)
 int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb);
 int launch_fill_w_diag(gpbo_ctx* ctx, Model& m);
 int launch_trmv(gpbo_ctx* ctx, Model& m);
@@ -226,6 +255,18 @@ struct AcqArgs {
 };
 int launch_acq_argbest(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, int64_t offset,
                        int64_t* best_idx, double* best_val, int64_t* seed_idx, double* seed_val);
+// (value, global index) records of one shard, as they travel between GPUs: record 0 = the arg-best (value NaN: "my
+// first NaN sits at this index"), records 1..k = argsort[:k] (index -1 = padding)
+struct BestRecord { double v; int64_t i; };
+// acq + selection enqueued on ctx->stream, the 1 + k_seeds records left ON THE DEVICE at `records_dev`
+int launch_acq_records(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, int64_t offset, BestRecord* records_dev);
+// the reference's argmin / min / argsort[:k] over the union of `world` shards from their records (host; identical on every rank)
+void merge_records(const BestRecord* all, int world, int k_seeds, int64_t* best_idx, double* best_val, int64_t* seed_idx,
+                   double* seed_val);
+// gpbo_api.hip: argument checks + posterior pointers of gpbo_acq_argbest, shared with the multi-GPU entry points
+int build_acq_args(gpbo_ctx* ctx, const char* who, int acq, double acq_param, double y_max, int n_constraints,
+                   const double* lb, const double* ub, int k_seeds, const void* best_idx, const void* best_val,
+                   const void* seed_idx, const void* seed_val, AcqArgs* out);
 // posterior_small.hip
 int launch_posterior_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double y_std);
 int small_batch_limit(int64_t NP);   // largest M the GEMV path takes (posterior_small.hip)

@@ -208,7 +208,7 @@ extern "C" int gpbo_generate_candidates_mt19937(gpbo_ctx* ctx, int64_t M, int d,
     ctx->red = p;
     ctx->cap_red = cap;
   }
-  double* h = (double*)ctx->pinned;                       // [lo | hi - lo | key]
+  double* h = (double*)((char*)ctx->pinned_aux + PIN_AUX_CAND);   // [lo | hi - lo | key]
   for (int t = 0; t < d; ++t) { h[t] = lo[t]; h[GPBO_MAX_DIM + t] = hi[t] - lo[t]; }
   unsigned* hkey = (unsigned*)(h + 2 * GPBO_MAX_DIM);
   for (int k = 0; k < MT_N; ++k) hkey[k] = key[k];

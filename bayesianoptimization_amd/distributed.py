@@ -52,16 +52,16 @@ def merge_best(best_vals, best_idxs, seed_vals, seed_idxs, k: int):
 class ShardedAcquisition:
     """Runs fit + posterior + acquisition on this rank's shard and merges the arg-best across ranks.
 
-    `allgather(vals, idxs) -> (all_vals, all_idxs)` is the transport: `engine.comm_allgather_best`
-    (RCCL) in production, any host collective in tests.
+    Transport: by default the engine's RCCL communicator — `engine.comm_acq_argbest` packs the shard's records on the
+    device, all-gathers them with ncclAllGather on the engine's stream and merges them in the library (the same merge
+    as `merge_best`).  `allgather(vals, idxs) -> (all_vals, all_idxs)` substitutes any host collective (the gloo tests).
     """
 
     def __init__(self, engine, world_size: int = 1, rank: int = 0, allgather=None):
         self.engine = engine
         self.world_size = int(world_size)
         self.rank = int(rank)
-        self.allgather = allgather if allgather is not None else (
-            engine.comm_allgather_best if world_size > 1 else (lambda v, i: (np.asarray(v), np.asarray(i))))
+        self.allgather = allgather
 
     def set_candidates_global(self, Xc_global: np.ndarray):
         """Keep this rank's block of a global candidate matrix resident."""
@@ -74,6 +74,10 @@ class ShardedAcquisition:
         self.engine.set_candidates(Xc_local)
 
     def argbest(self, acq, param, y_max=0.0, lb=None, ub=None, k_seeds: int = 0):
+        if self.world_size > 1 and self.allgather is None:       # device records -> RCCL all-gather -> merge
+            bi, bv, si, sv, _ = self.engine.comm_acq_argbest(acq, param, y_max, lb, ub, k_seeds=k_seeds,
+                                                             index_offset=self.offset)
+            return bi, bv, si, sv
         bi, bv, si, sv, _ = self.engine.acq_argbest(acq, param, y_max, lb, ub, k_seeds=k_seeds,
                                                     index_offset=self.offset)
         if self.world_size == 1:

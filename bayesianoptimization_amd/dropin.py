@@ -49,8 +49,13 @@ def _convert_acquisition(fn):
     return new
 
 
-def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=None, precision: str = "f64"):
+def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=None, precision: str = "f64",
+               devices=None):
     """Swap the GP(s) and the acquisition function of `optimizer` in place; returns `optimizer`.
+
+    `devices=[0, 1, ...]`: shard the random stage of every suggest() over these GPUs from this ONE process (GroupEngine:
+    replicated fit, contiguous candidate blocks, one RCCL all-gather of the per-device arg-best records); the suggestion
+    is bit for bit the single-GPU one.
 
     Raises NotImplementedError for kernels outside the HIP path (see gpr.describe_kernel) and
     RuntimeError/ImportError when no GPU or no built library is available: there is no CPU fallback.
@@ -58,7 +63,8 @@ def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=N
     `precision="f32"` keeps the fp64 factorisation but runs the posterior contraction in fp32 (2x matrix rate).
     `engine` lets several optimizers share (or tests inject) a GpEngine; default: one per device.
     """
-    engine = engine if engine is not None else shared_engine(device)
+    if engine is None:
+        engine = shared_engine(tuple(devices)) if devices is not None else shared_engine(device)
     space = optimizer._space
     transform = None if _identity_transform(space) else space.kernel_transform
     describe_kernel(optimizer._gp.kernel)

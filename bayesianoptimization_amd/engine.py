@@ -298,6 +298,32 @@ class GpEngine:
         self._check(self._lib.gpbo_comm_init(self._h, unique_id, int(world_size), int(rank)))
         self.world_size, self.rank = int(world_size), int(rank)
 
+    def comm_acq_argbest(self, acq: int, param: float, y_max: float = 0.0, lb=None, ub=None, k_seeds: int = 0,
+                         index_offset: int = 0, return_values: bool = False):
+        """`acq_argbest` over the union of every rank's shard (gpbo_comm_acq_argbest): the shard's records are packed on
+        the device, all-gathered over RCCL and merged identically on every rank.  Same return tuple; `ys` is this
+        rank's shard."""
+        lb = np.ascontiguousarray(np.atleast_1d(np.asarray(lb, dtype=np.float64))) if lb is not None else None
+        ub = np.ascontiguousarray(np.atleast_1d(np.asarray(ub, dtype=np.float64))) if ub is not None else None
+        n_c = 0 if lb is None else lb.shape[0]
+        if n_c and (ub is None or ub.shape[0] != n_c):
+            raise ValueError("lb and ub must have the same length")
+        best_idx, best_val = C.c_int64(0), C.c_double(0.0)
+        seed_idx = np.full(max(k_seeds, 1), -1, dtype=np.int64)
+        seed_val = np.full(max(k_seeds, 1), np.nan)
+        ys = np.empty(self.n_candidates) if return_values else None
+        rc = self._lib.gpbo_comm_acq_argbest(self._h, int(acq), float(param), float(y_max if y_max is not None else 0.0),
+                                             n_c, dptr(lb), dptr(ub), int(k_seeds), int(index_offset),
+                                             C.byref(best_idx), C.byref(best_val), iptr(seed_idx), dptr(seed_val), dptr(ys))
+        self._check(rc)
+        return best_idx.value, best_val.value, seed_idx[:k_seeds], seed_val[:k_seeds], ys
+
+    def comm_allreduce_max(self, value: float) -> float:
+        """Drain this rank's stream, then the maximum of `value` over all ranks (barrier + max-over-ranks timing)."""
+        v = np.array([float(value)])
+        self._check(self._lib.gpbo_comm_allreduce_max(self._h, dptr(v)))
+        return float(v[0])
+
     def comm_allgather_best(self, vals, idxs):
         vals = np.ascontiguousarray(vals, dtype=np.float64)
         idxs = np.ascontiguousarray(idxs, dtype=np.int64)
@@ -307,3 +333,188 @@ class GpEngine:
         self._check(self._lib.gpbo_comm_allgather_best(self._h, dptr(vals), iptr(idxs), n, dptr(all_vals),
                                                        iptr(all_idxs)))
         return all_vals, all_idxs
+
+
+class GroupEngine(GpEngine):
+    """G GPUs of one node behind the GpEngine interface, in ONE process (gpbo_group_*).
+
+    The model slots are replicated (every device factorises the same GP — deterministic, so the factors are identical),
+    the resident candidate matrix is block-partitioned in index order (device r keeps rows [r M / G, (r + 1) M / G)),
+    and `acq_argbest` ends in ONE exchange: each shard's 1 + k (value, global index) records, packed on the device,
+    all-gathered over RCCL and merged identically on every rank.  Everything that is not M-scaled — single-point and
+    finite-difference predicts of the host optimisers, the LML evaluations of the theta search, the parity accessors —
+    runs on the first device's context through the inherited methods.
+
+    `devices` listing a GPU more than once gives virtual ranks (several shards on one GPU, merged on the host): the
+    single-GPU rehearsal of the sharded path.  `collective` says which exchange the group uses.
+    """
+
+    def __init__(self, devices):
+        devices = [int(x) for x in devices]
+        if not devices:
+            raise ValueError("GroupEngine needs at least one device")
+        self._lib = _lib.load_library()
+        arr = (C.c_int * len(devices))(*devices)
+        g = C.c_void_p()
+        rc = self._lib.gpbo_group_create(len(devices), arr, C.byref(g))
+        if rc != _lib.GPBO_OK:
+            _lib.raise_for_status(self._lib, None, rc)
+        self._g = g
+        self._h = C.c_void_p(self._lib.gpbo_group_ctx(g, 0))     # borrowed: the first device's context
+        self.devices = devices
+        self.device = devices[0]
+        self.n_candidates = 0
+        self.world_size = len(devices)
+        self.rank = 0
+        self._serial = {}
+        self._resident = False      # the group's candidate shards are in place (a small predict on device 0 clobbers them)
+        self.collective = self._lib.gpbo_group_collective(g).decode()
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._lib.gpbo_group_destroy(self._g)
+            self._g = None
+            self._h = None
+
+    def _gcheck(self, rc, info=0):
+        if rc != _lib.GPBO_OK:
+            _lib.raise_for_status(self._lib, None, rc, info, group=self._g)
+
+    def synchronize(self):
+        self._gcheck(self._lib.gpbo_group_synchronize(self._g))
+
+    def member_timings(self, rank: int) -> dict:
+        ms = (C.c_float * 8)()
+        h = C.c_void_p(self._lib.gpbo_group_ctx(self._g, int(rank)))
+        self._check(self._lib.gpbo_last_timings(h, ms, 8))
+        return {n: float(ms[i]) for i, n in enumerate(TIMING_NAMES)}
+
+    def shard(self, rank: int) -> tuple[int, int]:
+        a, b = np.zeros(1, dtype=np.int64), np.zeros(1, dtype=np.int64)
+        self._gcheck(self._lib.gpbo_group_shard(self._g, int(rank), iptr(a), iptr(b)))
+        return int(a[0]), int(b[0])
+
+    # -- replicated model ----------------------------------------------------------------------
+    def fit(self, X, y_norm, kernel: int, length_scale, noise: float, slot: int = 0, precision: int = F64):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        if X.ndim != 2:
+            raise ValueError("X must be 2-D (n_samples, n_features)")
+        y_norm = np.ascontiguousarray(y_norm, dtype=np.float64).ravel()
+        if y_norm.shape[0] != X.shape[0]:
+            raise ValueError("X and y have inconsistent numbers of samples")
+        ls = np.ascontiguousarray(np.atleast_1d(np.asarray(length_scale, dtype=np.float64)))
+        info = C.c_int(0)
+        self._touch(slot)
+        rc = self._lib.gpbo_group_fit(self._g, int(slot), dptr(X), dptr(y_norm), X.shape[0], X.shape[1], int(kernel),
+                                      dptr(ls), int(ls.shape[0]), float(noise), int(precision), C.byref(info))
+        self._gcheck(rc, info.value)
+        return self._touch(slot)
+
+    def fit_append(self, x_new, y_norm, slot: int = 0):
+        y_norm = np.ascontiguousarray(y_norm, dtype=np.float64).ravel()
+        x_new = np.ascontiguousarray(x_new, dtype=np.float64)
+        if x_new.ndim != 2:
+            raise ValueError("x_new must be 2-D (n_new, n_features)")
+        info = C.c_int(0)
+        self._touch(slot)
+        rc = self._lib.gpbo_group_fit_append(self._g, int(slot), dptr(x_new) if x_new.shape[0] else None, x_new.shape[0],
+                                             x_new.shape[1], dptr(y_norm), y_norm.shape[0], C.byref(info))
+        self._gcheck(rc, info.value)
+        return self._touch(slot)
+
+    # -- sharded candidates ----------------------------------------------------------------------
+    def set_candidates(self, Xc):
+        Xc = np.ascontiguousarray(Xc, dtype=np.float64)
+        if Xc.ndim != 2:
+            raise ValueError("candidates must be 2-D (M, d)")
+        n_real = Xc.shape[0]
+        if n_real < self.world_size:
+            # fewer rows than devices: pad by repeating the last row (an equal value never beats the lower index, and
+            # the copies are dropped from every result)
+            pad = np.repeat(Xc[-1:], self.world_size - n_real, axis=0)
+            Xc = np.ascontiguousarray(np.vstack([Xc, pad]))
+        self._gcheck(self._lib.gpbo_group_set_candidates(self._g, dptr(Xc), Xc.shape[0], Xc.shape[1]))
+        self.n_candidates = n_real
+        self._M_pad = Xc.shape[0]
+        self._cand_dim = Xc.shape[1]
+        self._resident = True
+
+    def generate_candidates(self, M: int, lo, hi, seed: int):
+        raise NotImplementedError("the Philox throughput generator is per device; a device group draws the reference's "
+                                  "stream (device_sampling='auto' / False)")
+
+    def generate_candidates_like(self, M: int, lo, hi, random_state):
+        """The reference's candidate matrix from `random_state` (one uniform(lo_j, hi_j, M) per column, in order —
+        target_space.py:593-600, parameter.py:86-87), each device receiving its row block."""
+        lo = np.ascontiguousarray(lo, dtype=np.float64).ravel()
+        hi = np.ascontiguousarray(hi, dtype=np.float64).ravel()
+        if lo.shape != hi.shape:
+            raise ValueError("lo and hi must have the same length")
+        n = max(1, int(M))
+        Xc = np.empty((n, lo.shape[0]))
+        for j in range(lo.shape[0]):
+            Xc[:, j] = random_state.uniform(lo[j], hi[j], n)
+        self.set_candidates(Xc)
+
+    def get_candidate_rows(self, idx, d: int):
+        idx = np.ascontiguousarray(np.atleast_1d(idx), dtype=np.int64)
+        out = np.empty((idx.shape[0], d))
+        self._need_resident()
+        self._gcheck(self._lib.gpbo_group_get_candidate_rows(self._g, iptr(idx), idx.shape[0], dptr(out)))
+        return out
+
+    def _need_resident(self):
+        if not self._resident:
+            raise _lib.GpboError("the group's candidate shards are not resident (call set_candidates first; a small-batch "
+                                 "predict re-uses the first device's candidate buffer)")
+
+    def posterior(self, slot=0, y_mean=0.0, y_std=1.0, fetch=True):
+        self._need_resident()
+        M = self._M_pad
+        mu = np.empty(M) if fetch else None
+        sd = np.empty(M) if fetch else None
+        self._gcheck(self._lib.gpbo_group_posterior(self._g, int(slot), float(y_mean), float(y_std), dptr(mu), dptr(sd)))
+        return (mu[:self.n_candidates], sd[:self.n_candidates]) if fetch else (None, None)
+
+    def predict(self, Xc, slot=0, y_mean=0.0, y_std=1.0, sharded=None):
+        """Small batches (the host optimisers' points) run on the first device; from `world_size * 4096` rows on the
+        batch is sharded like the random stage."""
+        Xc = np.ascontiguousarray(Xc, dtype=np.float64)
+        if sharded is None:
+            sharded = Xc.shape[0] >= 4096 * self.world_size
+        if sharded:
+            self.set_candidates(Xc)
+            return self.posterior(slot, y_mean, y_std, fetch=True)
+        self._resident = False
+        M = Xc.shape[0]
+        mu, sd = np.empty(M), np.empty(M)
+        self._check(self._lib.gpbo_predict(self._h, int(slot), dptr(Xc), M, Xc.shape[1], float(y_mean), float(y_std),
+                                           dptr(mu), dptr(sd)))
+        return mu, sd
+
+    def acq_argbest(self, acq: int, param: float, y_max: float = 0.0, lb=None, ub=None, k_seeds: int = 0,
+                    index_offset: int = 0, return_values: bool = False):
+        if index_offset:
+            raise ValueError("a device group numbers its candidates globally; index_offset must be 0")
+        self._need_resident()
+        lb = np.ascontiguousarray(np.atleast_1d(np.asarray(lb, dtype=np.float64))) if lb is not None else None
+        ub = np.ascontiguousarray(np.atleast_1d(np.asarray(ub, dtype=np.float64))) if ub is not None else None
+        n_c = 0 if lb is None else lb.shape[0]
+        if n_c and (ub is None or ub.shape[0] != n_c):
+            raise ValueError("lb and ub must have the same length")
+        best_idx, best_val = np.zeros(1, dtype=np.int64), np.zeros(1)
+        seed_idx = np.full(max(k_seeds, 1), -1, dtype=np.int64)
+        seed_val = np.full(max(k_seeds, 1), np.nan)
+        ys = np.empty(self._M_pad) if return_values else None
+        rc = self._lib.gpbo_group_acq_argbest(self._g, int(acq), float(param), float(y_max if y_max is not None else 0.0),
+                                              n_c, dptr(lb), dptr(ub), int(k_seeds), iptr(best_idx), dptr(best_val),
+                                              iptr(seed_idx), dptr(seed_val), dptr(ys))
+        self._gcheck(rc)
+        seed_idx, seed_val = seed_idx[:k_seeds], seed_val[:k_seeds]
+        if self._M_pad != self.n_candidates:      # drop the padding copies of the last row
+            keep = seed_idx < self.n_candidates
+            n_keep = int(keep.sum())
+            seed_idx = np.concatenate([seed_idx[keep], np.full(k_seeds - n_keep, -1, dtype=np.int64)])
+            seed_val = np.concatenate([seed_val[keep], np.full(k_seeds - n_keep, np.nan)])
+            ys = ys[:self.n_candidates] if ys is not None else None
+        return int(best_idx[0]), float(best_val[0]), seed_idx, seed_val, ys

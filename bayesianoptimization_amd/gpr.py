@@ -32,14 +32,20 @@ from sklearn.utils.validation import validate_data
 from .engine import MATERN25, GpEngine
 from .engine import RBF as K_RBF
 
-_shared_engines: dict[int, GpEngine] = {}
+_shared_engines: dict = {}
 
 
-def shared_engine(device: int = 0) -> GpEngine:
-    """One context per device per process (created on first use; raises without a GPU)."""
-    if device not in _shared_engines:
-        _shared_engines[device] = GpEngine(device)
-    return _shared_engines[device]
+def shared_engine(device=0) -> GpEngine:
+    """One context per device — or one device group per tuple of devices — per process (created on first use; raises
+    without a GPU).  `device`: an int, or a sequence of ints for a single-process multi-GPU group (GroupEngine)."""
+    key = int(device) if np.isscalar(device) else tuple(int(x) for x in device)
+    if key not in _shared_engines:
+        if isinstance(key, tuple):
+            from .engine import GroupEngine
+            _shared_engines[key] = GroupEngine(key)
+        else:
+            _shared_engines[key] = GpEngine(key)
+    return _shared_engines[key]
 
 
 def describe_kernel(kernel):
@@ -155,6 +161,19 @@ class HipGPR(GaussianProcessRegressor):
             self._device_fit_tail()
         return out
 
+    def _ensure_resident(self):
+        """Make sure the engine slot holds THIS estimator's factorisation before reading it.  Slots are shared state:
+        another accelerated optimizer, a clone() of this estimator or an LML evaluation may have refitted the slot since
+        our last fit (the reference gives every estimator its own L_/alpha_).  The engine counts every rewrite of a
+        slot; a serial other than the one our fit got back means the slot is someone else's -> refit from X_train_."""
+        if getattr(self, "_in_fit", False) or not hasattr(self, "_kind"):
+            return
+        held = self.__dict__.get("_held")
+        eng = self._engine()
+        if held is None or held["engine"] is not eng or eng.fit_serial(self.slot) != held["serial"]:
+            self._held = None
+            self._device_fit_tail()
+
     # lazily fetched parity attributes -------------------------------------------------------------
     @property
     def L_(self):
@@ -162,6 +181,7 @@ class HipGPR(GaussianProcessRegressor):
         if "_L_cache" not in self.__dict__:
             if not hasattr(self, "X_train_"):
                 raise AttributeError("L_")
+            self._ensure_resident()
             self.__dict__["_L_cache"] = np.asfortranarray(self._engine().get_L(self.X_train_.shape[0], self.slot))
         return self.__dict__["_L_cache"]
 
@@ -174,12 +194,28 @@ class HipGPR(GaussianProcessRegressor):
         if "_alpha_cache" not in self.__dict__:
             if not hasattr(self, "X_train_"):
                 raise AttributeError("alpha_")
+            self._ensure_resident()
             self.__dict__["_alpha_cache"] = self._engine().get_alpha(self.X_train_.shape[0], self.slot)
         return self.__dict__["_alpha_cache"]
 
     @alpha_.setter
     def alpha_(self, v):
         self.__dict__["_alpha_cache"] = v
+
+    @property
+    def log_marginal_likelihood_value_(self):
+        """sklearn sets this in fit() also when no search runs (`log_marginal_likelihood(kernel_.theta)`, _gpr.py:339-342);
+        nothing on the suggest() path reads it, so on the fixed-theta path it is evaluated on first access."""
+        if "log_marginal_likelihood_value_" not in self.__dict__:
+            if not self.__dict__.get("_lml_lazy"):
+                raise AttributeError("log_marginal_likelihood_value_")
+            self.__dict__["log_marginal_likelihood_value_"] = GaussianProcessRegressor.log_marginal_likelihood(
+                self, self.kernel_.theta, clone_kernel=False)
+        return self.__dict__["log_marginal_likelihood_value_"]
+
+    @log_marginal_likelihood_value_.setter
+    def log_marginal_likelihood_value_(self, v):
+        self.__dict__["log_marginal_likelihood_value_"] = v
 
     # -- fit -------------------------------------------------------------------------------------
     def fit(self, X, y):
@@ -246,7 +282,8 @@ class HipGPR(GaussianProcessRegressor):
             self.kernel_._check_bounds_params()
             self.log_marginal_likelihood_value_ = -np.min(lml_values)
         else:
-            self.log_marginal_likelihood_value_ = None  # not evaluated on the fixed-theta path
+            self.__dict__.pop("log_marginal_likelihood_value_", None)   # evaluated lazily (property below): _gpr.py:339-342
+            self._lml_lazy = True
 
         self._in_fit = False
         kind, ls = describe_kernel(self.kernel_)
@@ -369,10 +406,14 @@ class HipGPR(GaussianProcessRegressor):
             # code handles them (for return_cov it reads the lazily fetched L_ / alpha_).
             return super().predict(X, return_std=return_std, return_cov=return_cov)
         X = np.asarray(validate_data(self, X, ensure_2d=True, dtype="numeric", reset=False), dtype=np.float64)  # _gpr.py:412
+        self._ensure_resident()
         mean, std = self._engine().predict(self._tx(X), slot=self.slot, y_mean=float(self._y_train_mean),
                                            y_std=float(self._y_train_std))
         if return_std:
-            if np.any(std == 0.0):  # _gpr.py:479-485: sklearn warns when it clips negative variances
+            # _gpr.py:479-485: sklearn warns when it clips NEGATIVE variances.  The device clips inside the finalize kernel,
+            # so the sign is gone by the time std arrives; a clipped variance comes back as exactly 0.0, which an
+            # unclipped one (1 - |W k*|^2 in fp64 at a point that is not a training point) practically never is
+            if np.any(std == 0.0):
                 warnings.warn("Predicted variances smaller than 0. Setting those variances to 0.", stacklevel=2)
             return mean, std
         return mean
@@ -381,10 +422,12 @@ class HipGPR(GaussianProcessRegressor):
         """(mean, std) for points this package generated itself (finite, right shape): predict(return_std=True)
         without sklearn's input validation and without the clipped-variance warning — the objective of the host
         optimisers calls this hundreds of times per suggest()."""
+        self._ensure_resident()
         return self._engine().predict(self._tx(X), slot=self.slot, y_mean=float(self._y_train_mean),
                                       y_std=float(self._y_train_std))
 
     # engine-resident posterior for the fused acquisition path ----------------------------------
     def posterior_resident(self):
         """Run the posterior kernel over the engine's resident candidates, keeping mu/sd on the device."""
+        self._ensure_resident()
         self._engine().posterior(self.slot, float(self._y_train_mean), float(self._y_train_std), fetch=False)

@@ -1,0 +1,59 @@
+"""File rendezvous for the one-process-per-GPU mode: ship rank 0's 128-byte RCCL unique id to its peers.
+
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py ...` starts N copies of the script with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment; nothing in this package needs torch for
+that — the only thing the ranks must share before `gpbo_comm_init` is the id `ncclGetUniqueId` returned on rank 0.
+All ranks of one node see the same filesystem and have the same parent (the launcher), so the id travels through one
+small file keyed by (MASTER_PORT, parent pid): written atomically by rank 0, polled by the others, removed by rank 0
+at the end.  Single node only (the multi-GPU target of this engine is the 8 GPUs of one node).
+"""
+from __future__ import annotations
+
+import os
+import tempfile
+import time
+
+
+def _path(key: str | None = None) -> str:
+    base = os.environ.get("GPBO_RDZV_DIR", tempfile.gettempdir())
+    if key is None:
+        key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    return os.path.join(base, f"gpbo_rdzv_{key}.id")
+
+
+def share_unique_id(rank: int, make_id, key: str | None = None, timeout: float = 180.0) -> bytes:
+    """Return the communicator id on every rank: rank 0 calls `make_id()` (-> 128 bytes) and publishes it."""
+    path = _path(key)
+    if rank == 0:
+        uid = bytes(make_id())
+        if len(uid) != 128:
+            raise ValueError("an RCCL unique id is 128 bytes")
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, path)          # atomic: a reader sees nothing or all 128 bytes
+        return uid
+    t_start = time.time()
+    deadline = t_start + timeout
+    while time.time() < deadline:
+        try:
+            # a file older than this launch is a leftover of a crashed run with the same key
+            if os.path.getmtime(path) >= t_start - 300.0:
+                with open(path, "rb") as f:
+                    uid = f.read()
+                if len(uid) == 128:
+                    return uid
+        except OSError:
+            pass
+        time.sleep(0.02)
+    raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout:.0f} s (is rank 0 alive?)")
+
+
+def cleanup(rank: int, key: str | None = None) -> None:
+    if rank == 0:
+        try:
+            os.unlink(_path(key))
+        except OSError:
+            pass

@@ -6,12 +6,18 @@
 A "step" is one pass of the hot path over one batch of synthetic input (BASELINE.json metric,
 configs[2] = C3 when it fits one GPU): fit the GP at fixed theta (K, Cholesky, W = L^-1, alpha), then
 posterior mu/sigma + acquisition + arg-best/top-10 over M = 2^20 candidates that are already
-resident in HBM.  N > 1 (launched by torch.distributed.run, one process per GPU): every rank fits
-redundantly and evaluates its own 2^20-candidate shard (weak scaling); the only exchange is an
-all-gather of 11 (value, index) records per rank over RCCL.  Rank 0 prints ONE JSON line.
+resident in HBM.  N > 1: every GPU fits redundantly and evaluates its own 2^20-candidate shard (weak
+scaling; BASELINE's sharded config C4); the only exchange is an all-gather of 11 (value, index) records
+per GPU over RCCL.  Two ways to own the GPUs, same kernels, same exchange:
 
-torch is used only as rendezvous plumbing (process group, barrier, max-over-ranks of the wall time)
-when N > 1; the product path is ctypes -> libgpbo.so (HIP).
+  * launched by `python -m torch.distributed.run --nproc-per-node N ...` (WORLD_SIZE = N in the environment): one
+    process per GPU, ncclCommInitRank; the 128-byte communicator id travels through a file (rendezvous.py), the
+    barrier and the max-over-ranks of the wall time are RCCL all-reduces;
+  * launched as plain `python bench.py --gpus N`: ONE process, one context + one host thread per GPU
+    (gpbo_group_*, ncclCommInitAll) — the shape that sits behind BayesianOptimization.suggest().
+
+No torch anywhere: the product path is ctypes -> libgpbo.so (HIP).  If RCCL cannot be brought up the line says
+`"collective": "FAILED"` and the exit status is non-zero — there is no fallback transport.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -19,6 +25,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -26,12 +33,16 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from bayesianoptimization_amd import rendezvous  # noqa: E402
 from bayesianoptimization_amd import workloads as W  # noqa: E402
 from bayesianoptimization_amd.distributed import ShardedAcquisition  # noqa: E402
-from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
+from bayesianoptimization_amd.engine import GpEngine, GroupEngine  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet (matrix FP64); the guide lists no fp64 row
-FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_*_f32 (f32 in / f32 accumulate)
+HBM_ACHIEVABLE_TBPS = 6.29     # MI355X_MICROARCH.md: float4 copy (8.0 spec)
+SHARDED = ("C4", "C5")         # quoted as 8-GPU jobs: one eighth of M per GPU
+METRIC = "acquisition candidates/sec (suggest step: GP fit at fixed theta + posterior + acquisition + arg-best)"
 
 
 def log(*a):
@@ -43,43 +54,76 @@ def flops_per_candidate(N, d, n_gp=1):
     return n_gp * (float(N) * N + (3.0 * d + 12.0) * N)
 
 
-def cpu_baseline(w, X, y, Xc, y_max, gpu_ys, n_chunks=3, chunk=8192):
+def cpu_baseline(w, X, y, c, Xc, y_max, gpu_ys, n_chunks=3):
     """The reference's CPU arithmetic on this box's host cores, on a bounded sample of the same workload.
 
-    scikit-learn's GaussianProcessRegressor (what bayes_opt delegates to: acquisition.py:84,205,216) at the
-    same fixed theta, plus the restated _get_acq closure from oracle/gp_oracle.py; parity is asserted on
-    the very chunks that are timed."""
+    kind "reference": /root/reference is mounted (build container) -> the real bayes_opt objects (`_fit_gp`, `_get_acq`
+    closure, acquisition.py:79-86, 198-217).  kind "port": the GPU box has no /root/reference -> scikit-learn's
+    GaussianProcessRegressor (what bayes_opt delegates to: acquisition.py:84,205,216; constraint.py:148-151,200-221) at the
+    same fixed theta + the restated closure from oracle/gp_oracle.py.  Parity is asserted on the very chunks that are timed."""
     from sklearn.gaussian_process import GaussianProcessRegressor
     from sklearn.gaussian_process.kernels import RBF, Matern
 
     from oracle import gp_oracle as O
+    from oracle.refenv import have_reference
 
-    k = RBF(length_scale=w.length_scale) if w.kernel == W.RBF else Matern(nu=2.5, length_scale=w.length_scale)
-    gp = GaussianProcessRegressor(kernel=k, alpha=w.noise, normalize_y=True, optimizer=None)
-    t0 = time.perf_counter()
-    gp.fit(X, y)
-    fit_s = time.perf_counter() - t0
-    times, worst = [], 0.0
-    for c in range(n_chunks):
-        xs = Xc[c * chunk:(c + 1) * chunk]
+    chunk = 8192 if w.N <= 4096 else 2048
+    kind = "port"
+    acq = None
+    if have_reference():
+        try:
+            from oracle.gen_golden import build_reference_objects
+            t0 = time.perf_counter()
+            opt, fn, _ = build_reference_objects(w)
+            fit_s = time.perf_counter() - t0
+            acq = fn._get_acq(gp=opt._gp, constraint=opt._space.constraint)
+            kind = "reference"
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] reference objects unavailable ({e!r}); timing the port")
+    if acq is None:
+        def mk(ls):
+            return RBF(length_scale=ls) if w.kernel == W.RBF else Matern(nu=2.5, length_scale=ls)
         t0 = time.perf_counter()
-        mean, std = gp.predict(xs, return_std=True)
-        ys = -1 * O.base_acq(w.acq, mean, std, w.acq_param, y_max if y_max is not None else 0.0)
-        times.append(time.perf_counter() - t0)
-        g = gpu_ys[c * chunk:(c + 1) * chunk]
-        worst = max(worst, float(np.max(np.abs(g - ys)) / np.max(np.abs(ys))))
+        gp = GaussianProcessRegressor(kernel=mk(w.length_scale), alpha=w.noise, normalize_y=True, optimizer=None).fit(X, y)
+        cgp = None
+        if w.constrained:
+            cgp = GaussianProcessRegressor(kernel=Matern(nu=2.5, length_scale=w.constraint_length_scale), alpha=w.noise,
+                                           normalize_y=True, optimizer=None).fit(X, c)
+        fit_s = time.perf_counter() - t0
+
+        def acq(xs):
+            mean, std = gp.predict(xs, return_std=True)
+            ys = -1 * O.base_acq(w.acq, mean, std, w.acq_param, y_max if y_max is not None else 0.0)
+            if cgp is not None:
+                cm, cs = cgp.predict(xs, return_std=True)
+                ys = ys * O.norm_cdf((w.constraint_ub - cm) / cs)      # lb = -inf -> 0 (constraint.py:202-207)
+            return ys
+    times, worst = [], 0.0
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for ci in range(n_chunks):
+            xs = Xc[ci * chunk:(ci + 1) * chunk]
+            t0 = time.perf_counter()
+            ys = acq(xs)
+            times.append(time.perf_counter() - t0)
+            g = gpu_ys[ci * chunk:(ci + 1) * chunk]
+            worst = max(worst, float(np.max(np.abs(g - ys)) / np.max(np.abs(ys))))
     med = float(np.median(times))
     try:
         from threadpoolctl import threadpool_info
         blas_threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
         blas_threads = os.cpu_count()
-    step_s = fit_s + med * (w.M / chunk)  # cost is linear in M: extrapolated to the full step
+    M = Xc.shape[0]
+    step_s = fit_s + med * (M / chunk)  # cost is linear in M: extrapolated to the full step
+    what = ("bayes_opt 3.3.0 _fit_gp + _get_acq closure" if kind == "reference"
+            else f"sklearn {__import__('sklearn').__version__} GaussianProcessRegressor.fit (fixed theta) + "
+                 "predict(return_std) + restated acquisition closure")
     return {
-        "value": w.M / step_s, "unit": "candidates/s", "cores": int(blas_threads), "kind": "port",
-        "sample": (f"sklearn {__import__('sklearn').__version__} GaussianProcessRegressor.fit (fixed theta) {fit_s:.2f}s + "
-                   f"predict(return_std)+acq on {n_chunks} chunks of {chunk} candidates (median {med:.2f}s/chunk), "
-                   f"extrapolated linearly to M={w.M}; host cpu_count={os.cpu_count()}"),
+        "value": M / step_s, "unit": "candidates/s", "cores": int(blas_threads), "kind": kind,
+        "sample": (f"{what}: fit {fit_s:.2f}s + {n_chunks} chunks of {chunk} candidates (median {med:.2f}s/chunk), "
+                   f"extrapolated linearly to M={M}; host cpu_count={os.cpu_count()}, BLAS threads={blas_threads}"),
         "acq_pass_value": chunk / med, "fit_s": fit_s,
         "parity_max_rel_vs_gpu_on_timed_chunks": worst,
     }
@@ -116,6 +160,59 @@ def suggest_latency(w, X, y, eng, M, reps=3):
     return res
 
 
+def reference_golden(name, n_shards, M_shard):
+    """The reference's answer for the job this run evaluates, from the committed goldens (tests/golden/, generated by
+    oracle/gen_golden*.py driving bayes_opt itself): C3 -> C3.npz; C4/C5 at n_shards GPUs -> shards 0..n-1 merged as the
+    reference would see the concatenated candidate matrix (argmin = first minimum, argsort = stable order)."""
+    gdir = os.path.join(ROOT, "tests", "golden")
+    if name not in SHARDED:
+        p = os.path.join(gdir, f"{name}.npz")
+        if n_shards != 1 or not os.path.exists(p):
+            return None
+        g = np.load(p)
+        if int(g["M_evaluated"]) != M_shard:
+            return None
+        return {"argmin": int(g["argmin"]), "min": float(g["min"]), "top_idx": g["topk_idx"].astype(np.int64),
+                "top_val": g["topk_val"], "source": f"tests/golden/{name}.npz"}
+    vals, idxs = [], []
+    for r in range(n_shards):
+        p = os.path.join(gdir, f"{name}_s{r}.npz")
+        if not os.path.exists(p):
+            return None
+        g = np.load(p)
+        if int(g["M_evaluated"]) != M_shard or int(g["n_nan"]) != 0:
+            return None
+        vals.append(g["topk_val"])
+        idxs.append(g["topk_idx"].astype(np.int64) + r * M_shard)
+    vals, idxs = np.concatenate(vals), np.concatenate(idxs)
+    o = np.lexsort((idxs, vals))
+    return {"argmin": int(idxs[o[0]]), "min": float(vals[o[0]]), "top_idx": idxs[o], "top_val": vals[o],
+            "source": f"tests/golden/{name}_s0..s{n_shards - 1}.npz (merged)"}
+
+
+def pmc_summary_for(w):
+    """HBM-side bytes per launch of the dominant kernels from the rocprofv3 --pmc passes of THIS command
+    (scripts/profile_pmc.sh -> scripts/pmc_summary.py), trusted only when the summary was taken from the very kernel
+    sources this run uses (the library's build fingerprint is stamped into the summary)."""
+    from bayesianoptimization_amd.build import _fingerprint
+    ppath = os.path.join(ROOT, "profiles", f"r02_pmc_{w.name}.json")
+    if not os.path.exists(ppath):
+        return None, "no PMC summary for this config under profiles/ (scripts/profile_pmc.sh)"
+    pm = json.load(open(ppath))
+    meta = pm.get("_meta", {})
+    if meta.get("source_fingerprint") != _fingerprint():
+        return None, (f"profiles/{os.path.basename(ppath)} was taken at another state of the kernel sources "
+                      f"(fingerprint {str(meta.get('source_fingerprint'))[:12]} != {_fingerprint()[:12]}): not reported")
+    return pm, f"profiles/{os.path.basename(ppath)} (same kernel sources: fingerprint {_fingerprint()[:12]})"
+
+
+def emit_failed(args, n_gpus, why):
+    print(json.dumps({"metric": METRIC, "value": None, "unit": "candidates/s", "n_gpus": n_gpus, "steps": args.steps,
+                      "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": None, "data": "synthetic",
+                      "config": {"workload": args.config or "C4", "collective": "FAILED"}, "error": why}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -125,28 +222,24 @@ def main():
                     help="BASELINE.json config; default: C3 on one GPU, C4 (= C3's GP with EI, 2^20 candidates per GPU, "
                          "8 x 2^20 at --gpus 8) when sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-suggest", action="store_true", help="skip the ms/suggest measurement after the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
+    if world > 1 and world != args.gpus:
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
-    n_gpus = world
+    mode = "ranks" if world > 1 else ("group" if args.gpus > 1 else "single")
+    n_gpus = world if mode == "ranks" else args.gpus
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # rendezvous plumbing only
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-
-    w = W.ALL[args.config or ("C3" if world == 1 else "C4")]
+    w = W.ALL[args.config or ("C3" if n_gpus == 1 else "C4")]
     X, y, c = W.make_observations(w)
     y_mean, y_std = float(np.mean(y)), float(np.std(y))
     yn = (y - y_mean) / y_std
     y_max = W.feasible_y_max(w, y, c)
     # per-GPU candidate count: C3 = its own M; C4/C5 are quoted as 8-GPU jobs -> one eighth per GPU (weak scaling)
-    M = w.M // 8 if w.name in ("C4", "C5") else w.M
+    M = w.M // 8 if w.name in SHARDED else w.M
     prec = 1 if w.dtype == "f32" else 0
     n_gp = 2 if w.constrained else 1
     if w.constrained:
@@ -155,52 +248,53 @@ def main():
         lb_c, ub_c = [-np.inf], [w.constraint_ub]
     else:
         lb_c = ub_c = None
-    Xc = W.make_candidates(w.bounds_array(), M, 7 + rank)  # rank r: shard r of a weak-scaled candidate set
 
-    # GPBO_BENCH_DEVICE pins every rank to one device (single-GPU rehearsal of the N > 1 flow; RCCL then
-    # refuses the duplicate GPU and the gloo fallback carries the 176-byte exchange)
-    dev = int(os.environ.get("GPBO_BENCH_DEVICE", local_rank))
-    eng = GpEngine(dev)
+    # ---- devices and the exchange ---------------------------------------------------------------------------------
     collective = "none"
-    allgather = None
-    if world > 1:
-        # RCCL bootstrap guarded by a watchdog: a hung ncclCommInitRank must not take the scaling run down.
-        import threading
+    if mode == "group":
+        # GPBO_BENCH_DEVICES=0,0 rehearses the sharded flow with virtual ranks on one GPU
+        devs = [int(t) for t in os.environ["GPBO_BENCH_DEVICES"].split(",")] if os.environ.get("GPBO_BENCH_DEVICES") \
+            else list(range(n_gpus))
+        try:
+            eng = GroupEngine(devs)
+        except Exception as e:  # noqa: BLE001
+            emit_failed(args, n_gpus, f"device group: {e!r}")
+            sys.exit(2)
+        collective = eng.collective
+        Xc = np.concatenate([W.make_candidates(w.bounds_array(), M, 7 + r) for r in range(n_gpus)])   # shard r -> device r
+        eng.set_candidates(Xc)
+        argbest = lambda: eng.acq_argbest(w.acq, w.acq_param, 0.0 if y_max is None else y_max, lb_c, ub_c, k_seeds=10)[:4]  # noqa: E731
+        barrier_max = lambda v: (eng.synchronize(), v)[1]  # noqa: E731
+    else:
+        dev = int(os.environ.get("GPBO_BENCH_DEVICE", local_rank))
+        eng = GpEngine(dev)
+        if mode == "ranks":
+            state = {"ok": False, "err": None}
 
-        ids = [GpEngine.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        state = {"ok": False, "err": None}
+            def _init():
+                try:
+                    uid = rendezvous.share_unique_id(rank, GpEngine.comm_unique_id)
+                    eng.comm_init(uid, world, rank)
+                    state["ok"] = True
+                except Exception as e:  # noqa: BLE001
+                    state["err"] = repr(e)
 
-        def _init():
-            try:
-                eng.comm_init(ids[0], world, rank)
-                state["ok"] = True
-            except Exception as e:  # noqa: BLE001
-                state["err"] = repr(e)
-
-        th = threading.Thread(target=_init, daemon=True)
-        th.start()
-        th.join(timeout=float(os.environ.get("GPBO_RCCL_INIT_TIMEOUT", "120")))
-        if state["ok"]:
+            th = threading.Thread(target=_init, daemon=True)
+            th.start()
+            th.join(timeout=float(os.environ.get("GPBO_RCCL_INIT_TIMEOUT", "300")))
+            if not state["ok"]:
+                why = f"RCCL bootstrap failed or hung on rank {rank}: {state['err']}"
+                log(f"[bench] {why}")
+                if rank == 0:
+                    emit_failed(args, n_gpus, why)
+                sys.stdout.flush()
+                os._exit(3)        # a hung ncclCommInitRank thread must not keep the process alive
             collective = "rccl-allgather"
-        else:
-            log(f"[bench] RCCL init failed/hung on rank {rank}: {state['err']}; using gloo for the 176-byte exchange")
-            collective = "gloo-allgather(fallback)"
-        flags = [None] * world
-        dist.all_gather_object(flags, collective)
-        if any(f != "rccl-allgather" for f in flags):
-            collective = "gloo-allgather(fallback)"
-            import torch
-
-            def allgather(vals, idxs):
-                tv = [torch.zeros(len(vals), dtype=torch.float64) for _ in range(world)]
-                ti = [torch.zeros(len(idxs), dtype=torch.int64) for _ in range(world)]
-                dist.all_gather(tv, torch.from_numpy(np.ascontiguousarray(vals)))
-                dist.all_gather(ti, torch.from_numpy(np.ascontiguousarray(idxs)))
-                return torch.cat(tv).numpy(), torch.cat(ti).numpy()
-
-    sh = ShardedAcquisition(eng, world, rank, allgather)
-    sh.set_candidates_local(Xc, offset=rank * M)
+        Xc = W.make_candidates(w.bounds_array(), M, 7 + rank)  # rank r: shard r of a weak-scaled candidate set
+        sh = ShardedAcquisition(eng, world, rank)
+        sh.set_candidates_local(Xc, offset=rank * M)
+        argbest = lambda: sh.argbest(w.acq, w.acq_param, 0.0 if y_max is None else y_max, lb_c, ub_c, k_seeds=10)  # noqa: E731
+        barrier_max = (lambda v: eng.comm_allreduce_max(v)) if mode == "ranks" else (lambda v: (eng.synchronize(), v)[1])
 
     post_ms = [0.0]
 
@@ -212,32 +306,22 @@ def main():
             eng.fit(X, cn, W.MATERN25, w.constraint_length_scale, w.noise, slot=1, precision=prec)
             eng.posterior(1, c_mean, c_std, fetch=False)
             post_ms[0] += eng.last_timings()["posterior_main"]
-        return sh.argbest(w.acq, w.acq_param, 0.0 if y_max is None else y_max, lb_c, ub_c, k_seeds=10)
-
-    def barrier():
-        eng.synchronize()
-        if dist is not None:
-            dist.barrier()
+        return argbest()
 
     for _ in range(args.warmup):
         step()
     kern_ms = {"fit": 0.0, "posterior_main": 0.0, "posterior_finalize": 0.0, "acq_argbest": 0.0, "kmat": 0.0,
                "cholesky": 0.0, "trtri": 0.0}
-    barrier()
+    barrier_max(0.0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         best = step()
-        tm = eng.last_timings()  # HIP events recorded on the engine's stream around each kernel group
+        tm = eng.last_timings()  # HIP events recorded on the (first) engine's own stream around each kernel group
         for k_ in kern_ms:
             kern_ms[k_] += tm[k_] * (n_gp if k_ in ("fit", "kmat", "cholesky", "trtri") else 1)
         kern_ms["posterior_main"] += post_ms[0] - tm["posterior_main"]   # both GPs' posterior launches
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    barrier_max(0.0)
+    elapsed = barrier_max(time.perf_counter() - t0)
 
     if rank == 0:
         steps = args.steps
@@ -247,55 +331,74 @@ def main():
         fl = flops_per_candidate(w.N, w.d, n_gp) * M
         achieved = fl / (main_ms * 1e-3) / 1e12
         peak = FP32_MFMA_PEAK_TFLOPS if prec else FP64_MFMA_PEAK_TFLOPS
+        kmat_ms, chol_ms = kern_ms["kmat"] / steps / n_gp, kern_ms["cholesky"] / steps / n_gp
+        NP = (w.N + 63) // 64 * 64
+        kmat_bytes = NP * (NP + 64) / 2 * 8          # lower block triangle written once
+        chol_flops = float(w.N) ** 3 / 3.0
         out = {
-            "metric": "acquisition candidates/sec (suggest step: GP fit at fixed theta + posterior + acquisition + arg-best)",
+            "metric": METRIC,
             "value": value, "unit": "candidates/s", "n_gpus": n_gpus, "steps": steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if prec else "f64", "data": "synthetic",
             "config": {"workload": f"{w.name}: d={w.d} N={w.N} {W.KERNEL_NAMES[w.kernel]} {W.ACQ_NAMES[w.acq]} "
                                    f"M={M} candidates per GPU, {n_gp} GP(s), fixed length_scale={w.length_scale}, "
                                    f"alpha={w.noise}, k_seeds=10; BASELINE.json config {w.name}",
-                       "N": w.N, "d": w.d, "M_per_gpu": M, "M_total": M * n_gpus, "collective": collective},
+                       "N": w.N, "d": w.d, "M_per_gpu": M, "M_total": M * n_gpus, "collective": collective,
+                       "processes": ("one per GPU (ncclCommInitRank, file rendezvous)" if mode == "ranks" else
+                                     "one for all GPUs (gpbo_group, ncclCommInitAll)" if mode == "group" else "one")},
             "roofline": {"bound": "mfma", "kernel": ("kstar_gen_f32_kernel + posterior_kernel_f32" if prec else
                                                      "kstar_gen_kernel + posterior_kernel_v2<GEN=2>") + " (k* slab + MFMA GEMM)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": None, "avg_launch_ms": main_ms, "flops_per_launch_algorithmic": fl},
+            # the fit path on its own rooflines (north_star: "achieved HBM GB/s on kernel assembly", "MFMA utilisation on
+            # the Cholesky"); HIP events on the engine's stream around each group, averaged over the timed steps
+            "roofline_fit": {"kmat_ms": kmat_ms, "kmat_GBps": kmat_bytes / (kmat_ms * 1e-3) / 1e9 if kmat_ms > 0 else None,
+                             "kmat_frac_of_achievable_hbm": (kmat_bytes / (kmat_ms * 1e-3) / 1e12 / HBM_ACHIEVABLE_TBPS)
+                             if kmat_ms > 0 else None,
+                             "kmat_bytes_algorithmic": kmat_bytes,
+                             "chol_ms": chol_ms, "chol_TFLOPs": chol_flops / (chol_ms * 1e-3) / 1e12 if chol_ms > 0 else None,
+                             "chol_frac": (chol_flops / (chol_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS) if chol_ms > 0 else None,
+                             "chol_flops_algorithmic": chol_flops, "fit_ms_per_gp": kern_ms["fit"] / steps / n_gp},
             "step_breakdown_ms": {k_: v / steps for k_, v in kern_ms.items()},
             "best": {"index": int(best[0]), "value": float(best[1])},
         }
-        # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this very command
-        # (scripts/profile_pmc.sh; FETCH_SIZE and WRITE_SIZE cannot share a pass), summarised in profiles/.
-        ppath = os.path.join(ROOT, "profiles", f"r01_pmc_{w.name}_final.json")
-        if os.path.exists(ppath):
+        # HBM traffic of the dominant kernels: separate rocprofv3 --pmc passes of this very command, summarised in profiles/
+        try:
+            pm, note = pmc_summary_for(w)
+            out["roofline"]["traffic_note"] = note
+            if pm is not None:
+                keys = [k_ for k_ in pm if "posterior_kernel" in k_ or "kstar_gen" in k_]
+                out["roofline"]["traffic"] = sum(pm[k_].get("fetch_bytes_corrected_x2", 0.0) * pm[k_].get("launches_per_step", 1)
+                                                 + pm[k_].get("write_bytes", 0.0) * pm[k_].get("launches_per_step", 1) for k_ in keys)
+                out["roofline"]["traffic_algorithmic"] = (w.d + 1) * 8 * M * n_gp + n_gp * w.N * w.N * 4
+                busy = [pm[k_].get("mfma_pipe_busy_frac") for k_ in keys if "posterior_kernel" in k_ and pm[k_].get("mfma_pipe_busy_frac")]
+                out["roofline"]["mfma_pipe_busy_frac_pmc"] = max(busy) if busy else None
+                for k_ in pm:
+                    if k_.startswith("_"):
+                        continue
+                    if "gemm128" in k_ and pm[k_].get("mfma_pipe_busy_frac") is not None:
+                        out["roofline_fit"].setdefault("trailing_update_mfma_busy", {})[k_[:60]] = pm[k_]["mfma_pipe_busy_frac"]
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] PMC summary not usable: {e!r}")
+        # parity with the reference's answer for exactly this job (any n_gpus)
+        g = reference_golden(w.name, n_gpus, M)
+        if g is not None:
+            top10 = np.asarray(best[2], dtype=np.int64)
+            out["parity"] = {"argmin_equals_reference": bool(int(best[0]) == g["argmin"]),
+                             "top10_equals_reference": bool(np.array_equal(top10, g["top_idx"][:10])),
+                             "argmin_in_reference_top16": bool(int(best[0]) in set(g["top_idx"][:16].tolist())),
+                             "min_rel_err": float(abs(best[1] - g["min"]) / abs(g["min"])),
+                             "reference": g["source"],
+                             "arithmetic": "fp32 posterior vs the fp64 reference" if prec else "fp64"}
+        if mode == "single" and not args.no_cpu_baseline:
             try:
-                pm = json.load(open(ppath))
-                keys = [k_ for k_ in pm if "posterior_kernel_v2" in k_ or "kstar_gen_kernel" in k_]
-                key = [k_ for k_ in keys if "posterior_kernel_v2" in k_][0]
-                out["roofline"]["traffic"] = sum(pm[k_]["fetch_bytes_corrected_x2"] + pm[k_]["write_bytes"] for k_ in keys)
-                out["roofline"]["traffic_note"] = (
-                    "HBM-side bytes per launch = 2*FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE from "
-                    f"profiles/{os.path.basename(ppath)}; algorithmic compulsory bytes = "
-                    f"{(w.d + 1) * 8 * M + w.N * w.N * 4:.3g}; the excess is the k* slab (written once, N*M*8 B, and "
-                    "re-read by every row chunk that needs it) plus W re-streamed per candidate tile from L2/Infinity "
-                    "Cache — ~1.3 TB/s, a fraction of HBM bandwidth: the path stays MFMA-bound")
-                out["roofline"]["mfma_pipe_busy_frac_pmc"] = pm[key].get("mfma_pipe_busy_frac")
-            except Exception as e:  # noqa: BLE001
-                log(f"[bench] could not read {ppath}: {e!r}")
-        gpath = os.path.join(ROOT, "tests", "golden", f"{w.name}.npz")
-        if n_gpus == 1 and os.path.exists(gpath) and int(np.load(gpath)["M_evaluated"]) == M and not prec:
-            g = np.load(gpath)
-            out["parity"] = {"argmin_equals_reference": bool(int(best[0]) == int(g["argmin"])),
-                             "top10_equals_reference": bool(np.array_equal(best[2], g["topk_idx"][:10])),
-                             "min_rel_err": float(abs(best[1] - float(g["min"])) / abs(float(g["min"])))}
-        if n_gpus == 1 and not args.no_cpu_baseline and not w.constrained:
-            try:
-                _, _, _, _, gpu_ys = eng.acq_argbest(w.acq, w.acq_param, 0.0 if y_max is None else y_max,
+                _, _, _, _, gpu_ys = eng.acq_argbest(w.acq, w.acq_param, 0.0 if y_max is None else y_max, lb_c, ub_c,
                                                      k_seeds=0, return_values=True)
-                out["cpu_baseline"] = cpu_baseline(w, X, y, Xc, y_max, gpu_ys)
+                out["cpu_baseline"] = cpu_baseline(w, X, y, c, Xc, y_max, gpu_ys)
             except Exception as e:
                 log(f"[bench] cpu_baseline failed: {e!r}")
                 out["cpu_baseline"] = None
-        if n_gpus == 1 and not w.constrained:
+        if mode == "single" and not w.constrained and not args.no_suggest:
             # the other half of BASELINE.json's metric, ms/suggest: whole suggest() calls through the drop-in seams
             # (refit at fixed theta, candidates drawn from the caller's RandomState on the device, posterior, acquisition,
             # arg-best; with the reference's default 10 local searches and without) — outside the timed region above
@@ -304,12 +407,9 @@ def main():
             except Exception as e:  # noqa: BLE001
                 log(f"[bench] suggest latency failed: {e!r}")
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-        if th.is_alive():  # a hung RCCL bootstrap thread: leave without running its destructors
-            sys.stdout.flush()
-            os._exit(0)
+    if mode == "ranks":
+        barrier_max(0.0)
+        rendezvous.cleanup(rank)
     eng.close()
 
 

@@ -171,15 +171,59 @@ int gpbo_acq_argbest(gpbo_ctx* ctx, int acq, double acq_param, double y_max, int
  * [2] posterior finalize, [3] acquisition + arg-best, [4] kmat assembly, [5] cholesky, [6] trtri. */
 int gpbo_last_timings(gpbo_ctx* ctx, float* ms, int n);
 
-/* ---- multi-GPU arg-best exchange (RCCL over xGMI; one process per GPU) ------------------- */
-/* rank 0 calls gpbo_comm_unique_id and ships the 128 bytes to its peers through any host channel;
- * then every rank calls gpbo_comm_init.  gpbo_comm_allgather_best gathers (val,idx) records of
- * every rank (n_records each) with ncclAllGather on the context stream. */
+/* ---- multi-GPU (RCCL over xGMI) --------------------------------------------------------- */
+/* The candidate rows are independent (sklearn _gpr.py:443-494 is row-wise; bayes_opt/acquisition.py:312-317 needs only
+ * the global argmin and the k best), so the candidate matrix is block-partitioned in index order, every GPU fits the
+ * same GP redundantly (deterministic -> identical L) and evaluates its block, and ONE exchange — ncclAllGather of each
+ * shard's 1 + k (value, global index) records, 16 bytes each, produced on the device — precedes an identical merge
+ * on every rank: first NaN wins the arg-best, otherwise lexicographic (value, index); seeds = the k smallest.
+ *
+ * (a) one process per GPU.  rank 0 calls gpbo_comm_unique_id and ships the 128 bytes to its peers through any host
+ * channel; every rank calls gpbo_comm_init; gpbo_comm_acq_argbest is gpbo_acq_argbest over the union of all shards
+ * (index_offset = first global row of this rank's shard); outputs are identical on every rank. */
 int gpbo_comm_unique_id(char id[128]);
 int gpbo_comm_init(gpbo_ctx* ctx, const char id[128], int world_size, int rank);
+int gpbo_comm_acq_argbest(gpbo_ctx* ctx, int acq, double acq_param, double y_max, int n_constraints,
+                          const double* lb, const double* ub, int k_seeds, int64_t index_offset,
+                          int64_t* best_idx, double* best_val, int64_t* seed_idx, double* seed_val,
+                          double* ys_out /* this rank's shard, (M_local,) or NULL */);
+/* Host records in, gathered host records out (n_records per rank, rank-major): the bare exchange, for callers that
+ * select on the host. */
 int gpbo_comm_allgather_best(gpbo_ctx* ctx, const double* vals, const int64_t* idxs, int n_records,
                              double* all_vals, int64_t* all_idxs);
+/* Drain this rank's stream, then *value = max over ranks (ncclAllReduce): barrier + max-over-ranks timing. */
+int gpbo_comm_allreduce_max(gpbo_ctx* ctx, double* value);
 int gpbo_comm_destroy(gpbo_ctx* ctx);
+
+/* (b) one process, G GPUs — what sits behind BayesianOptimization.suggest(), which is a single Python process
+ * (bayes_opt/bayesian_optimization.py:323-333).  gpbo_group_create opens one context per entry of `devices`
+ * (ncclCommInitAll) and one host thread per context; every gpbo_group_* call runs its per-device part on all devices
+ * concurrently and returns when all are done.  Listing a device more than once gives VIRTUAL ranks (several shards on
+ * one GPU, records merged on the host without RCCL): the single-GPU rehearsal of the sharded path.
+ * gpbo_group_collective: "rccl-allgather" or "host-merge(virtual ranks)". */
+typedef struct gpbo_group gpbo_group;
+int gpbo_group_create(int n_dev, const int* devices, gpbo_group** out);
+int gpbo_group_destroy(gpbo_group* grp);
+int gpbo_group_size(const gpbo_group* grp);
+gpbo_ctx* gpbo_group_ctx(gpbo_group* grp, int rank);          /* borrowed: parity accessors, timings, small predicts */
+const char* gpbo_group_collective(const gpbo_group* grp);
+const char* gpbo_group_last_error(const gpbo_group* grp);
+int gpbo_group_synchronize(gpbo_group* grp);
+/* gpbo_fit / gpbo_fit_append on every device (replicated model). */
+int gpbo_group_fit(gpbo_group* grp, int slot, const double* X, const double* y_norm, int64_t N, int d, int kernel,
+                   const double* length_scale, int n_ls, double noise, int precision, int* info);
+int gpbo_group_fit_append(gpbo_group* grp, int slot, const double* x_new, int64_t n_new, int d, const double* y_norm,
+                          int64_t n_total, int* info);
+/* x_tries (M,d): device r keeps rows [r M / G, (r + 1) M / G) resident (gpbo_group_shard reports the range). */
+int gpbo_group_set_candidates(gpbo_group* grp, const double* Xc, int64_t M, int d);
+int gpbo_group_shard(const gpbo_group* grp, int rank, int64_t* row_begin, int64_t* row_end);
+/* gpbo_posterior on every shard; mu / sd (M,) in global row order, or NULL to keep them on the devices. */
+int gpbo_group_posterior(gpbo_group* grp, int slot, double y_mean, double y_std, double* mu, double* sd);
+/* gpbo_acq_argbest over all M candidates: global indices, same tie/NaN rules; ys_out (M,) optional. */
+int gpbo_group_acq_argbest(gpbo_group* grp, int acq, double acq_param, double y_max, int n_constraints,
+                           const double* lb, const double* ub, int k_seeds, int64_t* best_idx, double* best_val,
+                           int64_t* seed_idx, double* seed_val, double* ys_out);
+int gpbo_group_get_candidate_rows(gpbo_group* grp, const int64_t* idx, int n, double* out);
 
 /* ---- device self-tests / micro-benchmarks (used by tests and bench headers) -------------- */
 /* C = alpha * A(m,k) * op(B) + beta * C on the fit GEMM kernel; b_trans: B given as (n,k). */
