@@ -85,6 +85,8 @@ SIGNATURES = {
     "gpbo_group_get_candidate_rows": (C.c_int, [C.c_void_p, _c_int64_p, C.c_int, _c_double_p]),
     "gpbo_debug_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, _c_double_p, _c_double_p,
                                   C.c_int, C.c_double, _c_double_p]),
+    "gpbo_debug_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        _c_double_p]),
     "gpbo_mfma_f64_peak": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
     "gpbo_mfma_f64_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _c_double_p]),
     "gpbo_hybrid_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_double_p]),

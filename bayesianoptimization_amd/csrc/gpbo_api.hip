@@ -841,6 +841,47 @@ int gpbo_debug_gemm(gpbo_ctx* ctx, int m, int n, int k, double alpha, const doub
   return rc;
 }
 
+int gpbo_debug_gemm_bench(gpbo_ctx* ctx, int m, int n, int k, int b_trans, int a_trans, int lower_only, int iters,
+                          double* out) {
+  if (!ctx || !out || m < 64 || n < 64 || k < 16 || iters < 1 || (a_trans && b_trans)) return GPBO_ERR_INVALID;
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+  const size_t na = (size_t)m * k, nb = (size_t)n * k, nc = (size_t)m * n;
+  GPBO_HIP(ctx, hipMalloc((void**)&dA, na * 8));
+  GPBO_HIP(ctx, hipMalloc((void**)&dB, nb * 8));
+  GPBO_HIP(ctx, hipMalloc((void**)&dC, nc * 8));
+  {
+    // random (not zero) operands: the clock a kernel sustains depends on the data (MI355X_MICROARCH.md, DVFS)
+    std::vector<double> h(std::max(na, nb));
+    uint64_t sx = 0x9E3779B97F4A7C15ull;
+    for (auto& v : h) { sx ^= sx << 13; sx ^= sx >> 7; sx ^= sx << 17; v = (double)(sx >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
+    GPBO_HIP(ctx, hipMemcpy(dA, h.data(), na * 8, hipMemcpyHostToDevice));
+    GPBO_HIP(ctx, hipMemcpy(dB, h.data(), nb * 8, hipMemcpyHostToDevice));
+    GPBO_HIP(ctx, hipMemset(dC, 0, nc * 8));
+  }
+  GemmArgs g{};
+  g.m = m; g.n = n; g.k = k; g.alpha = 1.0; g.beta = 0.0;
+  g.A = dA; g.lda = a_trans ? m : k; g.a_trans = a_trans;
+  g.B = dB; g.ldb = b_trans ? k : n; g.b_trans = b_trans;
+  g.C = dC; g.ldc = n; g.batch = 1; g.lower_only = lower_only;
+  int rc = launch_gemm(ctx, g);    // warm-up
+  hipEvent_t e0, e1;
+  GPBO_HIP(ctx, hipEventCreate(&e0));
+  GPBO_HIP(ctx, hipEventCreate(&e1));
+  GPBO_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  for (int it = 0; it < iters && rc == GPBO_OK; ++it) rc = launch_gemm(ctx, g);
+  GPBO_HIP(ctx, hipEventRecord(e1, ctx->stream));
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  float ms = 0.f;
+  GPBO_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+  const double flops = 2.0 * m * (double)n * k * (lower_only ? 0.5 : 1.0);
+  out[0] = ms / iters;
+  out[1] = flops / (ms / iters * 1e-3) / 1e12;
+  return rc;
+}
+
 int gpbo_mfma_f64_peak(gpbo_ctx* ctx, int iters, double* tflops) {
   if (!ctx || !tflops || iters < 1) return GPBO_ERR_INVALID;
   GPBO_HIP(ctx, hipSetDevice(ctx->device));

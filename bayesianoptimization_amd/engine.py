@@ -263,6 +263,12 @@ class GpEngine:
                                               float(beta), dptr(Cm)))
         return Cm
 
+    def gemm_bench(self, m, n, k, b_trans=True, a_trans=False, lower_only=False, iters=10) -> dict:
+        out = np.zeros(2)
+        self._check(self._lib.gpbo_debug_gemm_bench(self._h, int(m), int(n), int(k), int(b_trans), int(a_trans),
+                                                    int(lower_only), int(iters), dptr(out)))
+        return {"ms": float(out[0]), "tflops": float(out[1])}
+
     def mfma_f64_peak(self, iters=20000) -> float:
         out = C.c_double(0.0)
         self._check(self._lib.gpbo_mfma_f64_peak(self._h, int(iters), C.byref(out)))

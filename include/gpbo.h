@@ -229,6 +229,10 @@ int gpbo_group_get_candidate_rows(gpbo_group* grp, const int64_t* idx, int n, do
 /* C = alpha * A(m,k) * op(B) + beta * C on the fit GEMM kernel; b_trans: B given as (n,k). */
 int gpbo_debug_gemm(gpbo_ctx* ctx, int m, int n, int k, double alpha, const double* A,
                     const double* B, int b_trans, double beta, double* C);
+/* The same kernel timed on device-resident random operands: out[2] = { ms per launch, TFLOP/s } (lower_only counts half
+ * the flops); a_trans: A given as (k,m). */
+int gpbo_debug_gemm_bench(gpbo_ctx* ctx, int m, int n, int k, int b_trans, int a_trans, int lower_only, int iters,
+                          double* out);
 /* Sustained v_mfma_f64_16x16x4_f64 rate in TFLOP/s over `iters` dependent-chain-free MFMAs. */
 int gpbo_mfma_f64_peak(gpbo_ctx* ctx, int iters, double* tflops);
 /* The same MFMA stream with in-kernel clocks. out[4] = { TFLOP/s, shader cycles per MFMA per SIMD,

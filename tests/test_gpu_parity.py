@@ -22,7 +22,10 @@ def _data(N, d, seed=0):
     return X, y
 
 
-@pytest.mark.parametrize("m,n,k,bt", [(64, 64, 16, False), (128, 192, 64, False), (192, 64, 48, True), (64, 128, 32, True)])
+@pytest.mark.parametrize("m,n,k,bt", [(64, 64, 16, False), (128, 192, 64, False), (192, 64, 48, True), (64, 128, 32, True),
+                                      # the 128x128 double-buffered kernel (m, n >= 128, k >= 32), incl. ragged last blocks
+                                      (128, 128, 32, True), (256, 384, 512, True), (320, 192, 80, False),
+                                      (448, 704, 144, True), (192, 192, 48, False)])
 def test_mfma_gemm_layout(engine, m, n, k, bt):
     """Transpose-detecting check of the f64 MFMA fragment maps (asymmetric random operands)."""
     rng = np.random.RandomState(1)
