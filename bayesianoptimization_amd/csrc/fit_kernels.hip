@@ -305,7 +305,232 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// potrf_diag2: the same job (Cholesky + inverse of one 64x64 diagonal block, one 256-thread workgroup) restructured for the
+// critical path of the blocked factorisation — at N = 4096 the 64 serial diagonal-block kernels were 53 % of the Cholesky.
+//
+// Factorisation: INTERLEAVED column ownership — thread (row i = tid & 63, wave q = tid >> 6) keeps A[i][4 cc + q], cc < 16,
+// in registers, so that the rank-1 update of every finished column is shared by all four waves (<= 16 FMAs each) instead of
+// trailing inside the owner wave (in-wave v_readlane, ~45 instructions per column on the critical path).  A finished column
+// is published to a column-major LDS image + release/acquire counter.  The wave that owns column j + 1 applies column j to
+// that ONE column first, factors and publishes it, and only then catches up on its other columns: the chain per column is
+// LDS hand-off -> 1 FMA -> pivot (v_rsq_f64 + 2 Newton steps) -> publish.  Every element still receives its updates in
+// column order, so the result is independent of timing.  Spins are bounded (a broken hand-off reports instead of hanging).
+//
+// Inverse: 16x16 diagonal sub-blocks by forward substitution (thread = column), then the two doubling levels
+// W21 = -W22 (L21 W11) as v_mfma_f64_16x16x4_f64 products out of LDS (the scalar LDS matmuls of v1 took ~4 of its 7 us).
+constexpr int PD_S = 80;   // LDS row stride (doubles): the two k-rows of a 32-lane ds_read_b64 group fall 32 banks apart
+
+__global__ __launch_bounds__(256) void potrf_diag2_kernel(double* L, int64_t ld, int kb, double* __restrict__ dinv, int* info,
+                                                          int64_t lane_stride) {
+  L += (int64_t)blockIdx.x * lane_stride;
+  dinv += (int64_t)blockIdx.x * lane_stride;
+  info += (int64_t)blockIdx.x * lane_stride * 2;
+  extern __shared__ __attribute__((aligned(16))) double pd2_smem[];
+  double* Lc = pd2_smem;                 // [64][PD_S] column-major image of L: Lc[j * PD_S + i] = L[i][j]
+  double* Wr = Lc + 64 * PD_S;           // [64][PD_S] row-major W = L^-1 (first: staging of the input tile, stride 65)
+  double* Tb = Wr + 64 * PD_S;           // [32][PD_S] product temporaries
+  double* rdiag = Tb + 32 * PD_S;        // [64] 1 / L[j][j]
+  int* flags = reinterpret_cast<int*>(rdiag + 64);   // [0] bad pivot (1-based), [1] columns published, [2] hand-off broken
+  const int tid = threadIdx.x;
+  const int i = tid & 63;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double* A = L + (int64_t)kb * 64 * ld + (int64_t)kb * 64;
+  if (tid < 3) flags[tid] = 0;
+  {   // tile -> LDS (row-major, stride 65: the strided register fill below is conflict-free) -> registers
+    const int row = tid >> 2, seg = (tid & 3) * 16;
+    const double2* src = reinterpret_cast<const double2*>(A + (int64_t)row * ld + seg);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      const double2 v = src[h];
+      Wr[row * 65 + seg + 2 * h] = v.x;
+      Wr[row * 65 + seg + 2 * h + 1] = v.y;
+    }
+  }
+  __syncthreads();
+  double a[16];
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) a[cc] = Wr[i * 65 + 4 * cc + q];
+  __syncthreads();
+
+  int have = 0;   // columns this wave has seen published
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) {
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+      const int j = 4 * jj + j4;
+      if (q == j4) {
+        // ---- owner of column j: it has received every update (the last one in the previous step) ----
+        const unsigned long long pv = __double_as_longlong(a[jj]);
+        const unsigned plo = __builtin_amdgcn_readlane((int)(unsigned)pv, j);
+        const unsigned phi = __builtin_amdgcn_readlane((int)(unsigned)(pv >> 32), j);
+        double piv = __longlong_as_double(((unsigned long long)phi << 32) | plo);
+        if (!(piv > 0.0)) {
+          if (i == 0 && flags[0] == 0) flags[0] = j + 1;
+          piv = 1.0;
+        }
+        double rs = __builtin_amdgcn_rsq(piv);
+        double e = fma(-piv * rs, rs, 1.0);
+        rs = fma(0.5 * rs, e, rs);
+        e = fma(-piv * rs, rs, 1.0);
+        rs = fma(0.5 * rs, e, rs);
+        double dg = piv * rs;
+        dg = fma(fma(-dg, dg, piv), 0.5 * rs, dg);
+        double l = (i == j) ? dg : a[jj] * rs;
+        l = (i >= j) ? l : 0.0;
+        a[jj] = l;
+        Lc[j * PD_S + i] = l;
+        if (i == 0) {
+          rdiag[j] = rs;
+          __hip_atomic_store(&flags[1], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        have = j + 1;
+        if (j > 0) {   // catch up: column j - 1 on my columns right of j (column j itself got it in the previous step)
+          const double lp = Lc[(j - 1) * PD_S + i];
+#pragma unroll
+          for (int cc = jj + 1; cc < 16; ++cc) a[cc] = fma(-lp, Lc[(j - 1) * PD_S + 4 * cc + q], a[cc]);
+        }
+#pragma unroll
+        for (int cc = jj + 1; cc < 16; ++cc) a[cc] = fma(-l, Lc[j * PD_S + 4 * cc + q], a[cc]);
+      } else {
+        if (have <= j) {
+          int spins = 0;
+          for (;;) {
+            have = __hip_atomic_load(&flags[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (have > j) break;
+            if (++spins > (1 << 22)) {   // cannot happen while the owner wave runs; never hang the GPU on a bug
+              if (i == 0) flags[2] = 1;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        const double li = Lc[j * PD_S + i];
+        if (q == ((j4 + 1) & 3)) {
+          // next owner: column j + 1 only, the rest after it has published (above)
+          constexpr int dummy = 0; (void)dummy;
+          const int cc1 = (j4 < 3) ? jj : jj + 1;
+          if (cc1 < 16) a[cc1] = fma(-li, Lc[j * PD_S + 4 * cc1 + q], a[cc1]);
+        } else {
+#pragma unroll
+          for (int cc = jj; cc < 16; ++cc)
+            if (cc > jj || q > j4) a[cc] = fma(-li, Lc[j * PD_S + 4 * cc + q], a[cc]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (flags[2] && *info == 0) *info = -1 - kb;                    // broken hand-off (never seen): surfaces as an error
+    else if (flags[0] && *info == 0) *info = kb * 64 + flags[0];
+  }
+  // L -> global (row-major, upper part zero); clear W
+  {
+    const int row = tid >> 2, seg = (tid & 3) * 16;
+    double2* dst = reinterpret_cast<double2*>(A + (int64_t)row * ld + seg);
+#pragma unroll
+    for (int h = 0; h < 8; ++h)
+      dst[h] = make_double2(Lc[(seg + 2 * h) * PD_S + row], Lc[(seg + 2 * h + 1) * PD_S + row]);
+    for (int e = tid; e < 64 * PD_S; e += 256) Wr[e] = 0.0;
+  }
+  __syncthreads();
+  // --- inverse, step A: 16x16 diagonal sub-blocks (thread = sub-block b, column c)
+  if (tid < 64) {
+    const int b = tid >> 4, c = tid & 15;
+    double w[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[r] = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const double wk = w[k] * rdiag[16 * b + k];
+      w[k] = wk;
+#pragma unroll
+      for (int r = k + 1; r < 16; ++r) w[r] = fma(-Lc[(16 * b + k) * PD_S + 16 * b + r], wk, w[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Wr[(16 * b + r) * PD_S + 16 * b + c] = w[r];
+  }
+  __syncthreads();
+  const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+  // --- step B: 16 -> 32 for the two 32x32 diagonal blocks (wave 0: o = 0, wave 1: o = 32)
+  {
+    const int o = 32 * q;
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+    if (q < 2) {   // T = L21 W11
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const double av = Lc[(o + 4 * ks + lk) * PD_S + o + 16 + lr];
+        const double bv = Wr[(o + 4 * ks + lk) * PD_S + o + lr];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Tb[(16 * q + lk + 4 * r) * PD_S + lr] = acc[r];
+    }
+    __syncthreads();
+    if (q < 2) {   // W21 = -W22 T
+      d4 acc2 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const double av = Wr[(o + 16 + lr) * PD_S + o + 16 + 4 * ks + lk];
+        const double bv = Tb[(16 * q + 4 * ks + lk) * PD_S + lr];
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wr[(o + 16 + lk + 4 * r) * PD_S + o + lr] = -acc2[r];
+    }
+    __syncthreads();
+  }
+  // --- step C: 32 -> 64, four 16x16 output tiles, one per wave (ti = q >> 1, tj = q & 1)
+  {
+    const int ti = q >> 1, tj = q & 1;
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {   // T = L21 W11 over k = 0..31
+      const double av = Lc[(4 * ks + lk) * PD_S + 32 + 16 * ti + lr];
+      const double bv = Wr[(4 * ks + lk) * PD_S + 16 * tj + lr];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Tb[(16 * ti + lk + 4 * r) * PD_S + 16 * tj + lr] = acc[r];
+    __syncthreads();
+    d4 acc2 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {   // W21 = -W22 T over k = 0..31
+      const double av = Wr[(32 + 16 * ti + lr) * PD_S + 32 + 4 * ks + lk];
+      const double bv = Tb[(4 * ks + lk) * PD_S + 16 * tj + lr];
+      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc2, 0, 0, 0);
+    }
+    __syncthreads();   // every wave has read W22 / T before the lower-left quadrant is written (it is disjoint, but keep the phases apart)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wr[(32 + 16 * ti + lk + 4 * r) * PD_S + 16 * tj + lr] = -acc2[r];
+  }
+  __syncthreads();
+  double* D = dinv + (int64_t)kb * 64 * 64;
+  for (int e = tid; e < 4096; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    D[e] = (c <= r) ? Wr[r * PD_S + c] : 0.0;
+  }
+}
+
+static bool potrf_diag2_enabled() {
+  static const bool on = !(getenv("GPBO_POTRF_DIAG") && getenv("GPBO_POTRF_DIAG")[0] == '1');
+  return on;
+}
+
 int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb) {
+  if (potrf_diag2_enabled()) {
+    constexpr size_t lds2 = (size_t)(64 * PD_S * 2 + 32 * PD_S + 64 + 8) * sizeof(double);
+    static bool attr2_set = false;
+    if (!attr2_set) {
+      GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_diag2_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      attr2_set = true;
+    }
+    potrf_diag2_kernel<<<dim3((unsigned)ctx->lanes), dim3(256), lds2, ctx->stream>>>(m.L, m.NP, kb, m.dinv, ctx->info_dev,
+                                                                                      ctx->lane_stride);
+    GPBO_HIP(ctx, hipGetLastError());
+    return GPBO_OK;
+  }
   constexpr size_t lds = (size_t)(2 * 64 * 65 + 128 + 2) * sizeof(double);   // Ls, Wl (= colbuf), spare, flags
   static bool attr_set = false;
   if (!attr_set) {
@@ -586,7 +811,11 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
   if (g.a_trans && g.b_trans) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gemm: a_trans with b_trans is not instantiated");
   // big products -> the 128x128 double-buffered kernel; panels and small blocks -> the 64x64 kernel
   // (a triangular k-range must start/stop on a 128 boundary there, which the callers' block sizes guarantee from 128 on)
-  if (gemm128_enabled() && g.m >= 128 && g.n >= 128 && g.k >= 32) {
+  // Measured (scripts/r02_fit_probe.py, MI355X): 4096^3 60 vs 50 TFLOP/s, rank-512 SYRK at 3584 / 7680 rows 44 / 47 vs 38 / 41 —
+  // but the 64x64 kernel wins where there are too few 128-blocks to fill 256 CUs (1024^3: 15 vs 28) and on rank-64 panel
+  // updates (8 vs 15), so: deep k and at least ~a chip's worth of 128x128 blocks.
+  const int64_t blocks128 = (int64_t)((g.m + 127) / 128) * ((g.n + 127) / 128) * g.batch * g.lanes / (g.lower_only ? 2 : 1);
+  if (gemm128_enabled() && g.m >= 128 && g.n >= 128 && g.k >= 256 && blocks128 >= 192) {
     constexpr size_t lds = (size_t)4 * G2_TILE * sizeof(double);   // 73 728 B
     static bool attr_set = false;
     if (!attr_set) {

@@ -785,6 +785,26 @@ int gpbo_predict(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d, do
   return gpbo_posterior(ctx, slot, y_mean, y_std, mu, sd);
 }
 
+int gpbo_predict_grad(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d, double y_mean, double y_std,
+                      double* mu, double* sd, double* dmu, double* dsd) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  if (!mu || !sd || !dmu || !dsd) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "predict_grad: NULL output");
+  if (M < 1 || M > 4 * GPBO_MAX_SEEDS) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "predict_grad: M out of range [1, 256]");
+  int rc = gpbo_set_candidates(ctx, Xc, M, d);
+  if (rc) return rc;
+  if ((rc = need_fitted(ctx, slot))) return rc;
+  Model& m = ctx->models[slot];
+  if (d != m.d) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "predict_grad: candidate dimension differs from the fitted model");
+  double *dmu_dev = nullptr, *dsd_dev = nullptr;
+  if ((rc = launch_posterior_grad(ctx, m, M, y_mean, y_std, &dmu_dev, &dsd_dev))) return rc;
+  GPBO_HIP(ctx, hipMemcpyAsync(mu, m.mu, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  GPBO_HIP(ctx, hipMemcpyAsync(sd, m.sd, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  GPBO_HIP(ctx, hipMemcpyAsync(dmu, dmu_dev, (size_t)M * d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  GPBO_HIP(ctx, hipMemcpyAsync(dsd, dsd_dev, (size_t)M * d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GPBO_OK;
+}
+
 int gpbo_acq_argbest(gpbo_ctx* ctx, int acq, double acq_param, double y_max, int n_constraints,
                      const double* lb, const double* ub, int k_seeds, int64_t index_offset,
                      int64_t* best_idx, double* best_val, int64_t* seed_idx, double* seed_val,

@@ -241,6 +241,7 @@ struct GemmArgs {
 int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g);
 // posterior_kernel.hip
 int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std);
+int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std, double** dmu_dev, double** dsd_dev);
 // posterior_kernel_v2.hip
 int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
 int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
@@ -270,6 +271,7 @@ int build_acq_args(gpbo_ctx* ctx, const char* who, int acq, double acq_param, do
 // posterior_small.hip
 int launch_posterior_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double y_std);
 int small_batch_limit(int64_t NP);   // largest M the GEMV path takes (posterior_small.hip)
+int launch_posterior_grad_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double y_std, double* dmu_dev, double* dsd_dev);
 // lml_kernels.hip
 int launch_lml_terms(gpbo_ctx* ctx, Model& m, double* out2_dev);
 int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, double* partial, double* grad_dev);

@@ -13,11 +13,10 @@
 // The row-chunk partial sums every path writes are combined in a fixed order by posterior_finalize_kernel,
 // so results are run-to-run deterministic.  (The first version of the fused kernel — 128 candidates x 256
 // rows per workgroup, 2 waves/SIMD, 403 ms per C3 launch — is in the git history)
+#include <algorithm>
 #include <cstdlib>
 
 #include "gpbo_internal.h"
-
-#include <cstdlib>
 
 namespace gpbo {
 
@@ -43,13 +42,7 @@ __global__ __launch_bounds__(256) void posterior_finalize_kernel(const double* _
   mu[m] = y_std * mun + y_mean;
 }
 
-int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std) {
-  const int64_t Mp = round_up(M, POST_CANDS);
-  const int nchunks = (int)((m.NP + POST_ROWS - 1) / POST_ROWS);
-  int rc;
-  if ((rc = ensure(ctx, &ctx->Xcs, &ctx->cap_Xcs, Mp * m.DP))) return rc;
-  if ((rc = ensure(ctx, &ctx->part, &ctx->cap_part, (int64_t)nchunks * Mp))) return rc;
-  if ((rc = ensure(ctx, &ctx->mu_part, &ctx->cap_mu_part, (int64_t)nchunks * Mp))) return rc;
+static int ensure_posterior_outputs(gpbo_ctx* ctx, Model& m, int64_t Mp) {
   if (Mp > m.cap_M) {
     if (m.mu) { GPBO_HIP(ctx, hipFree(m.mu)); m.mu = nullptr; }
     if (m.sd) { GPBO_HIP(ctx, hipFree(m.sd)); m.sd = nullptr; }
@@ -58,6 +51,35 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
     GPBO_HIP(ctx, hipMalloc((void**)&m.sd, (size_t)Mp * sizeof(double)));
     m.cap_M = Mp;
   }
+  return GPBO_OK;
+}
+
+// mu, sd and their gradients in the (raw) inputs for the M resident candidates (M <= 256): posterior_small.hip
+int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std, double** dmu_dev, double** dsd_dev) {
+  const int64_t Mp = round_up(M, POST_CANDS);
+  int rc;
+  if ((rc = ensure(ctx, &ctx->Xcs, &ctx->cap_Xcs, Mp * m.DP))) return rc;
+  if ((rc = ensure(ctx, &ctx->mu_part, &ctx->cap_mu_part, std::max<int64_t>((int64_t)2 * M * m.d, Mp)))) return rc;
+  if ((rc = ensure_posterior_outputs(ctx, m, Mp))) return rc;
+  if ((rc = launch_prescale(ctx, ctx->Xc, M, m.d, m.DP, m.ls, ctx->Xcs, Mp))) return rc;
+  *dmu_dev = ctx->mu_part;
+  *dsd_dev = ctx->mu_part + M * m.d;
+  ev_begin(ctx, T_POST_MAIN);
+  rc = launch_posterior_grad_small(ctx, m, (int)M, y_mean, y_std, *dmu_dev, *dsd_dev);
+  ev_end(ctx, T_POST_MAIN);
+  if (rc) return rc;
+  m.M_post = M;
+  return GPBO_OK;
+}
+
+int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std) {
+  const int64_t Mp = round_up(M, POST_CANDS);
+  const int nchunks = (int)((m.NP + POST_ROWS - 1) / POST_ROWS);
+  int rc;
+  if ((rc = ensure(ctx, &ctx->Xcs, &ctx->cap_Xcs, Mp * m.DP))) return rc;
+  if ((rc = ensure(ctx, &ctx->part, &ctx->cap_part, (int64_t)nchunks * Mp))) return rc;
+  if ((rc = ensure(ctx, &ctx->mu_part, &ctx->cap_mu_part, (int64_t)nchunks * Mp))) return rc;
+  if ((rc = ensure_posterior_outputs(ctx, m, Mp))) return rc;
   if ((rc = launch_prescale(ctx, ctx->Xc, M, m.d, m.DP, m.ls, ctx->Xcs, Mp))) return rc;
   {
     // latency path: a handful of candidates (HipGPR.predict from the host optimiser) -> batched GEMV

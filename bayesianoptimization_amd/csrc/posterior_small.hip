@@ -5,6 +5,9 @@
 //   kstar_small_kernel : k*[c][k] for all train points (N x M values)
 //   gemv_small_kernel  : v[c][i] = sum_k W[i][k] k*[c][k], one wave per 4 rows, fixed shuffle tree
 //   finalize_small     : mu = y_std * (k* . alpha) + y_mean ; sd = sqrt(max(1 - sum_i v^2, 0)) * y_std
+#include <algorithm>
+#include <cstdlib>
+
 #include "gpbo_internal.h"
 
 namespace gpbo {
@@ -153,6 +156,222 @@ int launch_posterior_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double
   }
   GPBO_HIP(ctx, hipGetLastError());
   finalize_small_kernel<<<dim3((unsigned)M), dim3(256), 0, ctx->stream>>>(vsq, ks, m.alpha, m.NP, y_mean, y_std, m.mu, m.sd);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+
+// ================================================================================================================
+// Posterior WITH its gradient in the inputs: what one L-BFGS-B evaluation of the reference's local
+// search (bayes_opt/acquisition.py:365-374, `minimize(acq, x0, method="L-BFGS-B")` with finite differences: d + 1
+// predicts) needs, from ONE point instead of d + 1.  With xs = x / l, k_k = k(xs, Xs_k), v = W k, u = W^T v:
+//   mu      = y_std * sum_k alpha_k k_k + y_mean          d mu    / d x_t = y_std * sum_k alpha_k dk_k/dxs_t / l_t
+//   var_n   = 1 - v.v                                     d var_n / d x_t = -2 * sum_k u_k dk_k/dxs_t / l_t
+//   sd      = y_std * sqrt(max(var_n, 0))                 d sd    / d x_t = y_std * (d var_n / d x_t) / (2 sqrt(var_n))
+//   dk_k/dxs_t = f_k * (xs_t - Xs_kt),  f_k = -(5/3) (1 + sqrt5 r) exp(-sqrt5 r)  (Matern-2.5, no 1/r singularity)
+//                                       f_k = -k_k                                 (RBF)
+// (sklearn has no analytic input gradient; the formulas are the derivatives of kernels.py:1722-1724 / 1559-1560 and of
+// _gpr.py:443-494.)  Kernels: kstar_grad_small (k and f), gemv_small<STORE_V> (v), gemvt_small + reduce (u = W^T v in
+// two deterministic passes), grad_small (the two k-sums per dimension, fixed reduction order), finalize_small.
+template <int KERNEL>
+__global__ __launch_bounds__(256) void kstar_grad_small_kernel(const double* __restrict__ Xs, const double* __restrict__ Xcs,
+                                                               int DP, int64_t NP, int64_t N, int M, double* __restrict__ ks,
+                                                               double* __restrict__ fs) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= NP) return;
+  const double* xr = Xs + k * DP;
+  const int c_end = min(M, ((int)blockIdx.y + 1) * 16);
+  for (int c = (int)blockIdx.y * 16; c < c_end; ++c) {
+    const double* xc = Xcs + (int64_t)c * DP;
+    double d2 = 0.0;
+    for (int t = 0; t < DP; ++t) {
+      const double df = xc[t] - xr[t];
+      d2 = fma(df, df, d2);
+    }
+    const double kv = gpbo_kernel_value<KERNEL>(d2);
+    double f;
+    if (KERNEL == GPBO_KERNEL_MATERN25) {
+      const double s = gpbo_sqrt_pos(d2) * 2.23606797749978969641;      // sqrt(5) r
+      f = -1.66666666666666666667 * (1.0 + s) * exp(-s);
+    } else {
+      f = -kv;
+    }
+    ks[(int64_t)c * NP + k] = kv;
+    fs[(int64_t)c * NP + k] = (k < N) ? f : 0.0;      // padding rows carry no gradient
+  }
+}
+
+// v[c][i] = sum_k W[i][k] ks[c][k] (rows >= N: 0) — the arithmetic of gemv_small_kernel, storing v instead of v^2
+template <int MS, int R>
+__global__ __launch_bounds__(256) void gemv_small_v_kernel(const double* __restrict__ W, const double* __restrict__ ks,
+                                                           int64_t N, int64_t NP, double* __restrict__ vout) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i0 = ((int64_t)blockIdx.x * 4 + wave) * R;
+  if (i0 >= NP) return;
+  ks += (int64_t)blockIdx.y * MS * NP;
+  vout += (int64_t)blockIdx.y * MS * NP;
+  double acc[R][MS];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < MS; ++c) acc[r][c] = 0.0;
+  const int64_t kmax = min(NP, i0 + R);
+  for (int64_t k = lane; k < kmax; k += 64) {
+    double w[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) w[r] = W[(i0 + r) * NP + k];
+#pragma unroll
+    for (int c = 0; c < MS; ++c) {
+      const double kv = ks[(int64_t)c * NP + k];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r][c] = fma(w[r], kv, acc[r][c]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < MS; ++c) {
+      double v = acc[r][c];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) vout[(int64_t)c * NP + i0 + r] = (i0 + r < N) ? v : 0.0;
+    }
+}
+
+// partial[split][c][j] = sum over the split's rows i >= j of W[i][j] v[c][i]: 64 columns per workgroup, 4 row lanes,
+// GS candidates per pass (blockIdx.z), fixed summation order
+constexpr int GRAD_SPLITS = 16;
+constexpr int GRAD_MS = 8;
+
+__global__ __launch_bounds__(256) void gemvt_small_kernel(const double* __restrict__ W, const double* __restrict__ v,
+                                                          int64_t NP, int M, double* __restrict__ partial) {
+  __shared__ double red[4][GRAD_MS][64];
+  const int ig = threadIdx.x >> 6, jl = threadIdx.x & 63;
+  const int64_t j0 = (int64_t)blockIdx.x * 64;
+  const int c0 = (int)blockIdx.z * GRAD_MS;
+  const int64_t rows = NP - j0;
+  const int64_t chunk = (rows + GRAD_SPLITS - 1) / GRAD_SPLITS;
+  const int64_t r0 = j0 + (int64_t)blockIdx.y * chunk;
+  const int64_t r1 = min(NP, r0 + chunk);
+  double acc[GRAD_MS];
+#pragma unroll
+  for (int c = 0; c < GRAD_MS; ++c) acc[c] = 0.0;
+  for (int64_t i = r0 + ig; i < r1; i += 4) {
+    const double w = W[i * NP + j0 + jl];
+#pragma unroll
+    for (int c = 0; c < GRAD_MS; ++c)
+      if (c0 + c < M) acc[c] = fma(w, v[(int64_t)(c0 + c) * NP + i], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < GRAD_MS; ++c) red[ig][c][jl] = acc[c];
+  __syncthreads();
+  if (ig == 0) {
+#pragma unroll
+    for (int c = 0; c < GRAD_MS; ++c)
+      if (c0 + c < M)
+        partial[((int64_t)blockIdx.y * M + c0 + c) * NP + j0 + jl] = ((red[0][c][jl] + red[1][c][jl]) + red[2][c][jl]) + red[3][c][jl];
+  }
+}
+
+// One workgroup per candidate.  Threads = DP dimensions x (256 / DP) k-lanes; u_k = sum over the splits (fixed order);
+// the two sums over k per dimension are reduced over the k-lanes in a fixed order.
+__global__ __launch_bounds__(256) void grad_small_kernel(const double* __restrict__ Xs, const double* __restrict__ Xcs,
+                                                         const double* __restrict__ fs, const double* __restrict__ vbuf,
+                                                         const double* __restrict__ ks, const double* __restrict__ partial,
+                                                         const double* __restrict__ alpha, const double* __restrict__ ls,
+                                                         int DP, int d, int64_t NP, int M, double y_mean, double y_std,
+                                                         double* __restrict__ mu, double* __restrict__ sd,
+                                                         double* __restrict__ dmu, double* __restrict__ dsd) {
+  extern __shared__ __attribute__((aligned(16))) double gs_smem[];   // [2][256] partial sums | [8] scalars
+  const int c = blockIdx.x;
+  const int t = threadIdx.x % DP, kl = threadIdx.x / DP, nkl = 256 / DP;
+  const double xt = Xcs[(int64_t)c * DP + t];
+  double gm = 0.0, gv = 0.0;
+  for (int64_t k = kl; k < NP; k += nkl) {
+    double u = 0.0;
+#pragma unroll
+    for (int s = 0; s < GRAD_SPLITS; ++s) u += partial[((int64_t)s * M + c) * NP + k];
+    const double f = fs[(int64_t)c * NP + k];
+    const double df = (xt - Xs[k * DP + t]) * f;
+    gm = fma(alpha[k], df, gm);
+    gv = fma(u, df, gv);
+  }
+  gs_smem[threadIdx.x] = gm;
+  gs_smem[256 + threadIdx.x] = gv;
+  // mean and sum of squares (the finalize_small arithmetic), one value per thread over i
+  double s2 = 0.0, mm = 0.0;
+  for (int64_t i = threadIdx.x; i < NP; i += 256) {
+    const double vi = vbuf[(int64_t)c * NP + i];
+    s2 = fma(vi, vi, s2);
+    mm = fma(ks[(int64_t)c * NP + i], alpha[i], mm);
+  }
+  double* sh = gs_smem + 512;
+  double tot[2] = {s2, mm};
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    double v = tot[q];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    tot[q] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+  }
+  __syncthreads();
+  double var = 1.0 - tot[0];
+  if (var < 0.0) var = 0.0;
+  const double sdn = sqrt(var);
+  if (threadIdx.x == 0) {
+    sd[c] = sqrt(var * (y_std * y_std));
+    mu[c] = y_std * tot[1] + y_mean;
+  }
+  if (threadIdx.x < d) {
+    double a = 0.0, b = 0.0;
+    for (int q = 0; q < nkl; ++q) {
+      a += gs_smem[q * DP + threadIdx.x];
+      b += gs_smem[256 + q * DP + threadIdx.x];
+    }
+    const double inv_l = 1.0 / ls[threadIdx.x];
+    dmu[(int64_t)c * d + threadIdx.x] = y_std * a * inv_l;
+    // d sd / d x = y_std * (-2 b / l) / (2 sqrt(var_n)); a clipped (zero) variance has no slope
+    dsd[(int64_t)c * d + threadIdx.x] = (sdn > 0.0) ? -(y_std * b * inv_l) / sdn : 0.0;
+  }
+}
+
+// Requires ctx->Xcs to hold the scaled candidates; scratch in ctx->part.  Outputs on the device: m.mu, m.sd (M) and
+// dmu_dev, dsd_dev (M x d).
+int launch_posterior_grad_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double y_std, double* dmu_dev,
+                                double* dsd_dev) {
+  if (M < 1 || M > GPBO_MAX_SEEDS * 4) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "posterior_grad: M out of range [1, 256]");
+  int rc;
+  const int64_t rows = (int64_t)M + 16;
+  // ks | fs | v | partial[GRAD_SPLITS][M]
+  if ((rc = ensure(ctx, &ctx->part, &ctx->cap_part, std::max<int64_t>((int64_t)2 * (SMALL_MAX + 16) * m.NP,
+                                                                       (3 * rows + (int64_t)GRAD_SPLITS * M) * m.NP))))
+    return rc;
+  double* ks = ctx->part;
+  double* fs = ks + rows * m.NP;
+  double* vb = fs + rows * m.NP;
+  double* partial = vb + rows * m.NP;
+  const dim3 kgrid((unsigned)((m.NP + 255) / 256), (unsigned)((M + 15) / 16));
+  if (m.kernel == GPBO_KERNEL_MATERN25)
+    kstar_grad_small_kernel<GPBO_KERNEL_MATERN25><<<kgrid, dim3(256), 0, ctx->stream>>>(m.Xs, ctx->Xcs, m.DP, m.NP, m.N, M, ks, fs);
+  else
+    kstar_grad_small_kernel<GPBO_KERNEL_RBF><<<kgrid, dim3(256), 0, ctx->stream>>>(m.Xs, ctx->Xcs, m.DP, m.NP, m.N, M, ks, fs);
+  GPBO_HIP(ctx, hipGetLastError());
+  // v = W k*: passes of 8 candidates (a padded last pass reads/writes scratch rows that exist: rows = M + 16)
+  {
+    const unsigned gb = (unsigned)((m.NP / 2 + 3) / 4);
+    gemv_small_v_kernel<8, 2><<<dim3(gb, (unsigned)((M + 7) / 8)), dim3(256), 0, ctx->stream>>>(m.W, ks, m.N, m.NP, vb);
+    GPBO_HIP(ctx, hipGetLastError());
+  }
+  gemvt_small_kernel<<<dim3((unsigned)(m.NP / 64), GRAD_SPLITS, (unsigned)((M + GRAD_MS - 1) / GRAD_MS)), dim3(256), 0,
+                       ctx->stream>>>(m.W, vb, m.NP, M, partial);
+  GPBO_HIP(ctx, hipGetLastError());
+  const size_t lds = (size_t)(512 + 8) * sizeof(double);
+  grad_small_kernel<<<dim3((unsigned)M), dim3(256), lds, ctx->stream>>>(m.Xs, ctx->Xcs, fs, vb, ks, partial, m.alpha, m.ls,
+                                                                         m.DP, m.d, m.NP, M, y_mean, y_std, m.mu, m.sd,
+                                                                         dmu_dev, dsd_dev);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }

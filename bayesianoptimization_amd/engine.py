@@ -227,6 +227,18 @@ class GpEngine:
         self.set_candidates(Xc)
         return self.posterior(slot, y_mean, y_std, fetch=True)
 
+    def predict_grad(self, Xc, slot=0, y_mean=0.0, y_std=1.0):
+        """(mu (M,), sd (M,), dmu (M,d), dsd (M,d)) for a small host batch (M <= 256): gpbo_predict_grad."""
+        Xc = np.ascontiguousarray(Xc, dtype=np.float64)
+        M, d = Xc.shape
+        mu, sd = np.empty(M), np.empty(M)
+        dmu, dsd = np.empty((M, d)), np.empty((M, d))
+        self._check(self._lib.gpbo_predict_grad(self._h, int(slot), dptr(Xc), M, d, float(y_mean), float(y_std),
+                                                dptr(mu), dptr(sd), dptr(dmu), dptr(dsd)))
+        self.n_candidates = M
+        self._resident = False       # (device groups: the first device's candidate buffer was re-used)
+        return mu, sd, dmu, dsd
+
     # -- acquisition -----------------------------------------------------------------------------
     def acq_argbest(self, acq: int, param: float, y_max: float = 0.0, lb=None, ub=None, k_seeds: int = 0,
                     index_offset: int = 0, return_values: bool = False):

@@ -181,6 +181,13 @@ class AcquisitionFunction(abc.ABC):
     #:   True      THROUGHPUT MODE: a Philox generator on the device; NOT the reference's stream (two 31-bit integers
     #:             are drawn from it as the seed), so suggestions differ
     device_sampling = "auto"
+    #: local-search gradient.  False (default): the reference's finite differences (d + 1 predicts
+    #: per evaluation, batched) — L-BFGS-B sees the same (f, g) as under bayes_opt and walks the same iterates.
+    #: True: the exact gradient from ONE point per evaluation (gpbo_predict_grad: u = W^T W k*, chain rule through the
+    #: acquisition and the constraint probabilities) — d + 1 times fewer posterior points per evaluation; the iterates
+    #: are no longer SciPy's finite-difference ones, so parity with the reference is statistical (equal or better
+    #: acquisition value), not bit-wise.  Needs engine-backed GPs without input transform and a stock policy.
+    analytic_gradient = False
     _acq_kind: int | None = None     # engine acquisition id of the stock policies; None = host formula only
 
     def __init__(self, random_state=None) -> None:
@@ -232,11 +239,13 @@ class AcquisitionFunction(abc.ABC):
             self._fit_gp(gp=gp, target_space=target_space)
         objective = self._get_acq(gp=gp, constraint=target_space.constraint)
         self._fused = None if self._acq_kind is None else _fused_models(gp, target_space.constraint)
+        self._fused_constraint = target_space.constraint if self._fused is not None and len(self._fused) > 1 else None
         try:
             return self._acq_min(objective, target_space, n_smart=n_smart, random_state=rng,
                                  n_random=self.default_n_random if n_random is None else n_random)
         finally:
             self._fused = None
+            self._fused_constraint = None
 
     def _get_acq(self, gp, constraint=None):
         """Host objective x -> -acq(x) [* p_constraint(x)] for (M,d) or (d,) input (acquisition.py:171-219)."""
@@ -261,6 +270,50 @@ class AcquisitionFunction(abc.ABC):
             return -1 * self.base_acq(mean, std) * feasible
 
         return objective
+
+    def base_acq_grad(self, mean, std, dmean, dstd):
+        """(acq, d acq / d x) from the posterior and its input gradient; stock policies override."""
+        raise NotImplementedError
+
+    def _value_and_grad(self, models, constraint):
+        """Batch objective X (S, d) -> (-acq(x) [* p_c(x)], its gradient (S, d)) on the engine, one point per
+        evaluation (the analytic counterpart of `_get_acq`, acquisition.py:171-219)."""
+        target = models[0]
+
+        def fun(X):
+            X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, target.X_train_.shape[1])
+            mean, std, dmean, dstd = target._posterior_grad_trusted(X)
+            with np.errstate(all="ignore"):
+                a, da = self.base_acq_grad(mean, std, dmean, dstd)
+                f, g = -a, -da
+                if constraint is not None:
+                    p = np.ones_like(mean)
+                    dlogs = []                      # (p_j, d p_j / d x) per constraint
+                    for gp, lo, hi in zip(models[1:], constraint._lb, constraint._ub):
+                        cm, cs, dcm, dcs = gp._posterior_grad_trusted(X)
+                        pj = np.zeros_like(cm)
+                        dpj = np.zeros_like(dcm)
+                        for bound, sign in ((hi, 1.0), (lo, -1.0)):
+                            if not np.isfinite(bound):
+                                pj = pj + (1.0 if (sign > 0 and bound == np.inf) else 0.0)
+                                continue
+                            z = (bound - cm) / cs
+                            pj = pj + sign * ndtr(z)
+                            dpj = dpj + sign * (_norm_pdf(z) / cs)[:, None] * (-dcm - z[:, None] * dcs)
+                        dlogs.append((pj, dpj))
+                        p = p * pj
+                    gp_sum = np.zeros_like(g)
+                    for j, (pj, dpj) in enumerate(dlogs):
+                        others = np.ones_like(pj)
+                        for i, (pi, _) in enumerate(dlogs):
+                            if i != j:
+                                others = others * pi
+                        gp_sum = gp_sum + dpj * others[:, None]
+                    g = g * p[:, None] + f[:, None] * gp_sum
+                    f = f * p
+            return f, np.where(np.isfinite(g), g, 0.0)
+
+        return fun
 
     def _acq_min(self, acq, space, random_state, n_random: int = 10_000, n_smart: int = 10):
         """Random stage, then local searches from its best points; the better of the two (acquisition.py:221-272)."""
@@ -333,6 +386,21 @@ class AcquisitionFunction(abc.ABC):
         return np.clip(x_best, space.bounds[:, 0], space.bounds[:, 1]), f_best
 
     def _polish_seeds(self, acq, x_seeds, box):
+        chain = getattr(self, "_fused", None)
+        if (self.analytic_gradient and chain is not None and len(x_seeds) > 0 and chain[0].transform is None
+                and not np.any(box[:, 0] == box[:, 1])):
+            cons = getattr(self, "_fused_constraint", None)
+            fg = self._value_and_grad(chain, cons)
+            winner = None
+            if lbfgsb_lockstep.driver_available():
+                outcomes = lbfgsb_lockstep.minimize_many_with_grad(fg, x_seeds, box)       # one device call per round
+            else:
+                outcomes = (minimize(lambda x: tuple(v[0] for v in fg(x[None])), s0, jac=True, bounds=box, method="L-BFGS-B")
+                            for s0 in x_seeds)
+            for res in outcomes:
+                if res.success and (winner is None or np.squeeze(res.fun) < winner[1]):
+                    winner = (res.x, np.squeeze(res.fun))
+            return winner
         batched = self.batched_fd and getattr(self, "_fused", None) is not None
         value_and_grad = _fd_value_and_grad(acq, box) if batched else None
         winner = None
@@ -431,6 +499,9 @@ class UpperConfidenceBound(_DecayingParameter, AcquisitionFunction):
     def base_acq(self, mean, std):
         return mean + self.kappa * std
 
+    def base_acq_grad(self, mean, std, dmean, dstd):
+        return mean + self.kappa * std, dmean + self.kappa * dstd
+
     def suggest(self, gp, target_space, n_random=None, n_smart: int = 10, fit_gp: bool = True, random_state=None):
         if target_space.constraint is not None:
             raise ConstraintNotSupportedError(
@@ -482,6 +553,11 @@ class ProbabilityOfImprovement(_ImprovementBased):
         with np.errstate(divide="ignore", invalid="ignore"):
             return ndtr((mean - self.y_max - self.xi) / std)
 
+    def base_acq_grad(self, mean, std, dmean, dstd):
+        self._need_y_max()
+        z = (mean - self.y_max - self.xi) / std
+        return ndtr(z), (_norm_pdf(z) / std)[:, None] * (dmean - z[:, None] * dstd)
+
 
 class ExpectedImprovement(_ImprovementBased):
     """EI(x) = a Phi(z) + sigma phi(z), a = mu - y_max - xi, z = a/sigma  (bayes_opt/acquisition.py:779-949)."""
@@ -494,3 +570,11 @@ class ExpectedImprovement(_ImprovementBased):
             a = mean - self.y_max - self.xi
             z = a / std
             return a * ndtr(z) + std * _norm_pdf(z)
+
+    def base_acq_grad(self, mean, std, dmean, dstd):
+        # d/dx [a Phi(z) + s phi(z)] = Phi(z) da + phi(z) ds   (the z-terms cancel)
+        self._need_y_max()
+        a = mean - self.y_max - self.xi
+        z = a / std
+        cdf, pdf = ndtr(z), _norm_pdf(z)
+        return a * cdf + std * pdf, cdf[:, None] * dmean + pdf[:, None] * dstd

@@ -426,6 +426,15 @@ class HipGPR(GaussianProcessRegressor):
         return self._engine().predict(self._tx(X), slot=self.slot, y_mean=float(self._y_train_mean),
                                       y_std=float(self._y_train_std))
 
+    def _posterior_grad_trusted(self, X):
+        """(mean, std, d mean / d x, d std / d x) for a small batch of points this package generated itself
+        (gpbo_predict_grad; identity input transform only — the chain rule through a host transform is not formed)."""
+        if self.transform is not None:
+            raise NotImplementedError("input gradients need the identity input transform")
+        self._ensure_resident()
+        return self._engine().predict_grad(np.ascontiguousarray(X, dtype=np.float64), slot=self.slot,
+                                           y_mean=float(self._y_train_mean), y_std=float(self._y_train_std))
+
     # engine-resident posterior for the fused acquisition path ----------------------------------
     def posterior_resident(self):
         """Run the posterior kernel over the engine's resident candidates, keeping mu/sd on the device."""

@@ -150,6 +150,15 @@ int gpbo_posterior(gpbo_ctx* ctx, int slot, double y_mean, double y_std, double*
 int gpbo_predict(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d, double y_mean,
                  double y_std, double* mu, double* sd);
 
+/* Posterior AND its gradient in the inputs for a small host batch (M <= 256): mu, sd (M,) as gpbo_predict, and
+ * dmu, dsd (M,d) = d mu / d x, d sd / d x.  One evaluation gives the local search of the reference
+ * (bayes_opt/acquisition.py:365-374: scipy L-BFGS-B, which forms its gradient from d + 1 predicts by finite differences)
+ * value and gradient from ONE point: u = W^T (W k*), d sd^2 / d x = -2 y_std^2 u . dk* / dx.
+ * A clipped (zero) variance has zero slope.  sklearn has no counterpart; parity is against finite differences of
+ * gpbo_predict / the oracle. */
+int gpbo_predict_grad(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d, double y_mean, double y_std,
+                      double* mu, double* sd, double* dmu, double* dsd);
+
 /* ---- acquisition + arg-best ------------------------------------------------------------- */
 /* Replaces the _get_acq closure + base_acq + argmin/min/argsort[:k]
  * (bayes_opt/acquisition.py:198-217, 485, 660-661, 847-849, 312-317) and, when n_constraints > 0,

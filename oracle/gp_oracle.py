@@ -109,6 +109,31 @@ def predict(gp: GPState, Xc: np.ndarray):
     return mean, np.sqrt(var)
 
 
+def predict_grad(gp: GPState, Xc: np.ndarray):
+    """(mean, std, d mean / d x, d std / d x): the analytic input gradient of `predict` — the checker of
+    gpbo_predict_grad.  sklearn has no such routine; the formulas differentiate _gpr.py:443-494 with the kernels of
+    kernels.py:1722-1724 / 1559-1560:  dk/dx_t = f(r) (x_t - X_kt) / l_t^2 with f = -(5/3)(1 + sqrt5 r) exp(-sqrt5 r)
+    (Matern-2.5) or -k (RBF);  d var_n / d x = -2 (K^-1 k*)^T dk*/dx."""
+    Xc = np.asarray(Xc, dtype=np.float64).reshape(-1, gp.X.shape[1])
+    ls = np.broadcast_to(gp.length_scale, (gp.X.shape[1],))
+    mean, std = predict(gp, Xc)
+    Kt = kernel_matrix(gp.kind, Xc, gp.X, gp.length_scale)                    # (M, N)
+    diff = (Xc[:, None, :] - gp.X[None, :, :]) / ls**2                        # (M, N, d)
+    if gp.kind == MATERN25:
+        r = cdist(Xc / ls, gp.X / ls, metric="euclidean")
+        f = -(5.0 / 3.0) * (1.0 + _SQRT5 * r) * np.exp(-_SQRT5 * r)
+    else:
+        f = -Kt
+    dK = f[:, :, None] * diff                                                   # (M, N, d)
+    dmean = gp.y_std * np.einsum("mnd,n->md", dK, gp.alpha)
+    u = cho_solve((gp.L, True), Kt.T, check_finite=False).T                     # (M, N) = K^-1 k*
+    dvar_n = -2.0 * np.einsum("mnd,mn->md", dK, u)
+    sd_n = std / gp.y_std
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dstd = np.where(sd_n[:, None] > 0, gp.y_std * dvar_n / (2.0 * sd_n[:, None]), 0.0)
+    return mean, std, dmean, dstd
+
+
 def norm_cdf(x):
     return ndtr(x)
 

@@ -124,6 +124,11 @@ class FakeEngine:
         self.set_candidates(Xc)
         return self.posterior(slot, y_mean, y_std, True)
 
+    def predict_grad(self, Xc, slot=0, y_mean=0.0, y_std=1.0):
+        self.calls.append(("predict_grad", slot, np.shape(Xc)))
+        mu, sd, dmu, dsd = O.predict_grad(self.models[slot], np.asarray(Xc, dtype=np.float64))
+        return y_std * mu + y_mean, sd * y_std, y_std * dmu, y_std * dsd
+
     def acq_argbest(self, acq, param, y_max=0.0, lb=None, ub=None, k_seeds=0, index_offset=0, return_values=False):
         self.calls.append(("acq_argbest", acq, k_seeds))
         mu, sd = self.post[0]

@@ -499,3 +499,23 @@ def test_lml_batch_lanes_are_bitwise_gpbo_lml(engine, N, d, kernel):
     assert all(v == -np.inf and np.all(g == 0) for v, g in mixed)
     with pytest.raises(ValueError):
         engine.lml_batch(X, yn, kernel, np.ones((9, 1)), 1e-6)
+
+
+@pytest.mark.parametrize("N,d,kernel,ls,M", [(60, 3, O.MATERN25, 0.7, 1), (200, 5, O.RBF, 0.6, 7), (513, 8, O.MATERN25, 1.0, 10),
+                                             (130, 4, O.MATERN25, [0.4, 0.7, 1.0, 1.3], 33), (1000, 16, O.MATERN25, 1.5, 64),
+                                             (300, 40, O.RBF, 2.5, 256)])
+def test_predict_grad_equals_the_oracle_gradient(engine, N, d, kernel, ls, M):
+    """gpbo_predict_grad: mu, sd bitwise-or-rounding the small-batch predict, d mu / d x and d sd / d x
+    against the oracle's analytic gradient (itself pinned to central differences on CPU)."""
+    X, y = _data(N, d)
+    gp = O.fit_fixed_theta(kernel, X, y, ls, 1e-6)
+    yn, ym, ys_ = O.normalize_targets(y)
+    engine.fit(X, yn, kernel, ls, 1e-6)
+    Xq = np.random.RandomState(5).uniform(size=(M, d))
+    mu, sd, dmu, dsd = engine.predict_grad(Xq, 0, ym, ys_)
+    mu_o, sd_o, dmu_o, dsd_o = O.predict_grad(gp, Xq)
+    assert rel_err(mu, mu_o) < 1e-8 and rel_err(sd, sd_o) < 1e-7
+    assert rel_err(dmu, dmu_o) < 1e-7 and rel_err(dsd, dsd_o) < 1e-6
+    # a training point: the clipped variance has zero slope, nothing is NaN
+    mu1, sd1, dmu1, dsd1 = engine.predict_grad(X[:3], 0, ym, ys_)
+    assert np.all(np.isfinite(dmu1)) and np.all(np.isfinite(dsd1))
