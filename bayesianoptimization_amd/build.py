@@ -29,6 +29,7 @@ SOURCES = {
     "posterior_kernel_v2.hip": [],
     "posterior_small.hip": [],
     "posterior_kernel_f32.hip": [],
+    "posterior_cov.hip": [],
     "lml_kernels.hip": [],
     "acq_kernels.hip": ["-ffp-contract=off"],  # elementwise formulas follow NumPy op by op
     "candidates.hip": [],

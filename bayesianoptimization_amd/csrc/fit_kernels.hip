@@ -353,15 +353,21 @@ __global__ __launch_bounds__(256) void potrf_diag2_kernel(double* L, int64_t ld,
   for (int cc = 0; cc < 16; ++cc) a[cc] = Wr[i * 65 + 4 * cc + q];
   __syncthreads();
 
+  // The 16 column groups are walked by a REAL loop (not unrolled: fully unrolled this kernel was 63 KB of straight-line
+  // code and ran at instruction-fetch speed, 2x slower than v1).  The register array is rotated once per group so that
+  // slot 0 always holds the group's column and every register index below is a compile-time constant; slots past the
+  // last column hold dead values whose updates are harmless.
   int have = 0;   // columns this wave has seen published
-#pragma unroll
+#pragma unroll 1
   for (int jj = 0; jj < 16; ++jj) {
 #pragma unroll
     for (int j4 = 0; j4 < 4; ++j4) {
       const int j = 4 * jj + j4;
+      const double* colj = Lc + j * PD_S;
+      const double* mine = colj + 4 * jj + q;      // L[4 (jj + k) + q][j] sits at mine[4 k]
       if (q == j4) {
-        // ---- owner of column j: it has received every update (the last one in the previous step) ----
-        const unsigned long long pv = __double_as_longlong(a[jj]);
+        // ---- owner of column j (slot 0): it has received every update (the last one in the previous step) ----
+        const unsigned long long pv = __double_as_longlong(a[0]);
         const unsigned plo = __builtin_amdgcn_readlane((int)(unsigned)pv, j);
         const unsigned phi = __builtin_amdgcn_readlane((int)(unsigned)(pv >> 32), j);
         double piv = __longlong_as_double(((unsigned long long)phi << 32) | plo);
@@ -376,9 +382,9 @@ __global__ __launch_bounds__(256) void potrf_diag2_kernel(double* L, int64_t ld,
         rs = fma(0.5 * rs, e, rs);
         double dg = piv * rs;
         dg = fma(fma(-dg, dg, piv), 0.5 * rs, dg);
-        double l = (i == j) ? dg : a[jj] * rs;
+        double l = (i == j) ? dg : a[0] * rs;
         l = (i >= j) ? l : 0.0;
-        a[jj] = l;
+        a[0] = l;
         Lc[j * PD_S + i] = l;
         if (i == 0) {
           rdiag[j] = rs;
@@ -386,12 +392,12 @@ __global__ __launch_bounds__(256) void potrf_diag2_kernel(double* L, int64_t ld,
         }
         have = j + 1;
         if (j > 0) {   // catch up: column j - 1 on my columns right of j (column j itself got it in the previous step)
-          const double lp = Lc[(j - 1) * PD_S + i];
+          const double lp = colj[i - PD_S];
 #pragma unroll
-          for (int cc = jj + 1; cc < 16; ++cc) a[cc] = fma(-lp, Lc[(j - 1) * PD_S + 4 * cc + q], a[cc]);
+          for (int k = 1; k < 16; ++k) a[k] = fma(-lp, mine[4 * k - PD_S], a[k]);
         }
 #pragma unroll
-        for (int cc = jj + 1; cc < 16; ++cc) a[cc] = fma(-l, Lc[j * PD_S + 4 * cc + q], a[cc]);
+        for (int k = 1; k < 16; ++k) a[k] = fma(-l, mine[4 * k], a[k]);
       } else {
         if (have <= j) {
           int spins = 0;
@@ -405,19 +411,21 @@ __global__ __launch_bounds__(256) void potrf_diag2_kernel(double* L, int64_t ld,
             __builtin_amdgcn_s_sleep(1);
           }
         }
-        const double li = Lc[j * PD_S + i];
+        const double li = colj[i];
         if (q == ((j4 + 1) & 3)) {
-          // next owner: column j + 1 only, the rest after it has published (above)
-          constexpr int dummy = 0; (void)dummy;
-          const int cc1 = (j4 < 3) ? jj : jj + 1;
-          if (cc1 < 16) a[cc1] = fma(-li, Lc[j * PD_S + 4 * cc1 + q], a[cc1]);
+          // next owner: column j + 1 only (slot 0, or slot 1 when it opens the next group); the rest after it has published
+          if (j4 < 3) a[0] = fma(-li, mine[0], a[0]);
+          else a[1] = fma(-li, mine[4], a[1]);
         } else {
+          if (q > j4) a[0] = fma(-li, mine[0], a[0]);
 #pragma unroll
-          for (int cc = jj; cc < 16; ++cc)
-            if (cc > jj || q > j4) a[cc] = fma(-li, Lc[j * PD_S + 4 * cc + q], a[cc]);
+          for (int k = 1; k < 16; ++k) a[k] = fma(-li, mine[4 * k], a[k]);
         }
       }
     }
+#pragma unroll
+    for (int k = 0; k < 15; ++k) a[k] = a[k + 1];
+    a[15] = 0.0;
   }
   __syncthreads();
   if (tid == 0) {

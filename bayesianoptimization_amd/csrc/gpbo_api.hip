@@ -785,6 +785,29 @@ int gpbo_predict(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d, do
   return gpbo_posterior(ctx, slot, y_mean, y_std, mu, sd);
 }
 
+int gpbo_predict_cov(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d, double y_mean, double y_std,
+                     double* mu, double* cov) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  if (!cov) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "predict_cov: NULL output");
+  if (M < 1 || M > 16384) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "predict_cov: M out of range [1, 16384]");
+  int rc = gpbo_set_candidates(ctx, Xc, M, d);
+  if (rc) return rc;
+  if ((rc = need_fitted(ctx, slot))) return rc;
+  Model& m = ctx->models[slot];
+  if (d != m.d) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "predict_cov: candidate dimension differs from the fitted model");
+  if (mu) {   // the mean through the usual posterior path (_gpr.py:443-447)
+    if ((rc = launch_posterior(ctx, m, M, y_mean, y_std))) return rc;
+    GPBO_HIP(ctx, hipMemcpyAsync(mu, m.mu, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  double* cov_dev = nullptr;
+  int64_t ldc = 0;
+  if ((rc = launch_posterior_cov(ctx, m, M, y_std, &cov_dev, &ldc))) return rc;
+  GPBO_HIP(ctx, hipMemcpy2DAsync(cov, (size_t)M * sizeof(double), cov_dev, (size_t)ldc * sizeof(double), (size_t)M * sizeof(double),
+                                 (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GPBO_OK;
+}
+
 int gpbo_predict_grad(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d, double y_mean, double y_std,
                       double* mu, double* sd, double* dmu, double* dsd) {
   if (!ctx) return GPBO_ERR_INVALID;

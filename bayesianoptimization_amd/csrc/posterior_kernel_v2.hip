@@ -46,11 +46,17 @@ struct PostArgs2 {
 // kstar_gen_kernel (the fp64 VALU work of the generation shares the FP64 datapath with the MFMAs — measured:
 // 31 % of the fused kernel's time at C3 — so paying it once per candidate instead of once per row chunk wins).
 // GEN = 0 is a timing-only ablation (k* replaced by a constant; results are wrong): GPBO_POST_ABLATE_GEN=1.
-template <int DP, int KERNEL, int GEN>
+// BK = train points per LDS stage (one s_barrier per stage): 16, or 32 for the slab kernel (half the barriers; the
+// triangular cut-off of a 16-row tile then rounds up to 32 columns — zeros of the packed W, a few per cent more MFMAs
+// in the diagonal chunk only).
+template <int DP, int KERNEL, int GEN, int BK = POST_BK>
 __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
+  static_assert(BK == 16 || (BK == 32 && GEN == 2), "32-point stages are built for the slab kernel only");
+  constexpr int E = BK / 8;                        // stage elements per thread (lane = candidate, wave = E train points)
+  constexpr int KP = BK / 8;                       // k-pairs (8 columns of W) per stage
   extern __shared__ __attribute__((aligned(16))) double smem2[];
-  double* Ks = smem2;                              // [2][POST_BK][V2_STRIDE]
-  double* Xl = smem2 + 2 * POST_BK * V2_STRIDE;    // [DP][64] candidate coordinates, dimension-major
+  double* Ks = smem2;                              // [2][BK][V2_STRIDE]
+  double* Xl = smem2 + 2 * BK * V2_STRIDE;         // [DP][64] candidate coordinates, dimension-major
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   const bool last = (r == p.nchunks - 1);
   const int NP = p.NP;
   const int k_end = min(NP, (r + 1) * POST_ROWS);
-  const int n_stages = k_end / POST_BK;
+  const int n_stages = k_end / BK;
 
   // candidate tile -> LDS (thread t loads candidate t>>3, dims (t&7)*DP/8 ...)
   if constexpr (GEN != 2) {
@@ -92,9 +98,9 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
     for (int j = 0; j < 4; ++j) acc[t][j] = d4{0.0, 0.0, 0.0, 0.0};
   double mu_acc = 0.0;
 
-  // generation role: candidate = lane, train points 2*wave, 2*wave+1 of the stage
-  auto gen_compute = [&](int stage, double (&kv)[2], double mu_weight) {
-    const int j0 = stage * POST_BK + wave * 2;
+  // generation role: candidate = lane, train points E*wave .. E*wave + E - 1 of the stage
+  auto gen_compute = [&](int stage, double (&kv)[E], double mu_weight) {
+    const int j0 = stage * BK + wave * E;
     if constexpr (GEN == 0) {
       kv[0] = 1e-3 * lane;
       kv[1] = 2e-3 * lane + stage;
@@ -102,8 +108,8 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
     }
     if constexpr (GEN == 2) {
       const double* src = p.Kst + (int64_t)j0 * p.ldk + (int64_t)ct * V2_CANDS + lane;
-      kv[0] = src[0];
-      kv[1] = src[p.ldk];
+#pragma unroll
+      for (int e = 0; e < E; ++e) kv[e] = src[(int64_t)e * p.ldk];
       return;
     }
     const double* xr = p.Xs + (int64_t)j0 * DP;  // wave-uniform -> scalar loads
@@ -134,9 +140,9 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
     mu_acc = fma(kv[0] * mu_weight, p.alpha[j0], mu_acc);
     mu_acc = fma(kv[1] * mu_weight, p.alpha[j0 + 1], mu_acc);
   };
-  auto gen_store = [&](const double (&kv)[2], int buf) {
-    Ks[(buf * POST_BK + wave * 2) * V2_STRIDE + lane] = kv[0];
-    Ks[(buf * POST_BK + wave * 2 + 1) * V2_STRIDE + lane] = kv[1];
+  auto gen_store = [&](const double (&kv)[E], int buf) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) Ks[(buf * BK + wave * E + e) * V2_STRIDE + lane] = kv[e];
   };
 
   // A fragments for one k-pair (8 columns): [tile] double2 = 8 VGPRs
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
       const int q = pp * 2 + e;
       const double a0 = e ? a[0].y : a[0].x;
       const double a1 = e ? a[1].y : a[1].x;
-      const double* kb = Ks + (buf * POST_BK + q * 4 + (lane >> 4)) * V2_STRIDE + (lane & 15);
+      const double* kb = Ks + (buf * BK + q * 4 + (lane >> 4)) * V2_STRIDE + (lane & 15);
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
         const double b = kb[jt * 16];
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
 
   __syncthreads();   // Xl visible
   {
-    double kv0[2];
+    double kv0[E];
     gen_compute(0, kv0, 1.0);
     gen_store(kv0, 0);
   }
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   loadA(0, aA);
   __syncthreads();
 
-  // One stage = 16 train points.  MODE 2: both tiles multiply, 1: only the later tile, 0: none (the wave only
+  // One stage = BK train points.  MODE 2: both tiles multiply, 1: only the later tile, 0: none (the wave only
   // feeds the stage tile).  The body is branch-free (the look-ahead indices are clamped instead of tested) so that
   // loads, MFMAs and the LDS store of a stage stay in one basic block.
   const int last_stage = n_stages - 1;
@@ -182,21 +188,31 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   auto stage = [&](int st, auto mode) {
     constexpr int MODE = decltype(mode)::value;
     const int buf = st & 1;
-    double kv[2];
-    if constexpr (MODE > 0) loadA(min(2 * st + 1, last_pair), aB);
+    double kv[E];
+    if constexpr (MODE > 0) loadA(min(KP * st + 1, last_pair), aB);
     gen_compute(min(st + 1, last_stage), kv, st < last_stage ? 1.0 : 0.0);
     // slab mode: these are plain global loads — keep them at the top of the stage (a full stage of MFMAs hides
     // their latency); without the fence hipcc sinks them next to their first use
     if constexpr (GEN == 2) __builtin_amdgcn_sched_barrier(0);
-    if constexpr (MODE > 0) mma_pair(buf, 0, aA, mode);
-    if constexpr (MODE > 0) loadA(min(2 * st + 2, last_pair), aA);
-    if constexpr (MODE > 0) mma_pair(buf, 1, aB, mode);
+    // k-pairs alternate between the two fragment registers; each is refilled (two pairs ahead) right after its use —
+    // the last one of the stage at the top of the next stage
+    if constexpr (MODE > 0) {
+#pragma unroll
+      for (int pp = 0; pp < KP; ++pp) {
+        if (pp & 1) mma_pair(buf, pp, aB, mode);
+        else mma_pair(buf, pp, aA, mode);
+        if (pp + 1 < KP || (pp & 1) == 0) {
+          if (pp & 1) loadA(min(KP * st + pp + 2, last_pair), aB);
+          else loadA(min(KP * st + pp + 2, last_pair), aA);
+        }
+      }
+    }
     gen_store(kv, buf ^ 1);   // after the last LDS read of this stage (for st == last_stage nobody reads it)
     __syncthreads();
   };
   // stages 0 .. sA: both tiles; sA+1 .. sB: the later tile only; beyond: none (W is lower triangular)
-  const int sA = min(last_stage, (rowA0 + 15) / POST_BK);
-  const int sB = min(last_stage, (rowB0 + 15) / POST_BK);
+  const int sA = min(last_stage, (rowA0 + 15) / BK);
+  const int sB = min(last_stage, (rowB0 + 15) / BK);
   int s = 0;
   for (; s <= sA; ++s) stage(s, both_t{});
   for (; s <= sB; ++s) stage(s, later_t{});
@@ -294,12 +310,23 @@ static int launch_gen_k(gpbo_ctx* ctx, Model& m, double* Kst, int64_t ldk, int64
   GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: unsupported padded dimension");
 }
 
+// k* slab [NP][ldk] (+ partial means) for candidates [m0, m0 + ldk) of the scaled set ctx->Xcs — also used by the
+// covariance path (posterior_cov.hip)
+int launch_kstar_slab(gpbo_ctx* ctx, Model& m, double* Kst, int64_t ldk, int64_t Mp, int64_t m0, int nchunks) {
+  if (m.kernel == GPBO_KERNEL_MATERN25) return launch_gen_k<GPBO_KERNEL_MATERN25>(ctx, m, Kst, ldk, Mp, m0, nchunks);
+  return launch_gen_k<GPBO_KERNEL_RBF>(ctx, m, Kst, ldk, Mp, m0, nchunks);
+}
+
 // Two-kernel pipeline per candidate slab: kstar_gen_kernel -> posterior_kernel_v2<.., GEN = 2>.
 // The slab width is bounded by a workspace budget (default 40 GB, GPBO_KSTAR_GB to override); mu partials
 // need nchunks x Mp doubles in ctx->mu_part (allocated by the caller).
 int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
-  double budget_gb = 40.0;
+  // k* workspace: the candidate set is walked slab by slab; a slab only has to be wide enough to fill the chip
+  // (4 GB = 131 072 candidates at N = 4096 = 2048 candidate tiles x 16 row chunks per launch); measured at C3: one 34 GB
+  // slab 263.7 ms, eight 4 GB slabs 264.4 ms (round 1 A/B) — the big workspace bought nothing.  GPBO_KSTAR_GB overrides.
+  double budget_gb = 4.0;
   if (const char* e = getenv("GPBO_KSTAR_GB")) budget_gb = atof(e) > 0.0 ? atof(e) : budget_gb;
+  static const int post_bk = (getenv("GPBO_POST_BK") && atoi(getenv("GPBO_POST_BK")) == 32) ? 32 : 16;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
     const double avail = ((double)free_b + (double)ctx->cap_kst * 8.0) * 0.8 / 1e9;
@@ -322,8 +349,13 @@ int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
     a.n_ctiles = (int)(ldk / V2_CANDS); a.Kst = ctx->kst; a.ldk = ldk; a.m0 = m0;
     const int64_t nblocks = (int64_t)a.n_ctiles * nchunks;
     if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
-    const size_t lds = (size_t)(2 * POST_BK * V2_STRIDE) * sizeof(double);
-    posterior_kernel_v2<4, 0, 2><<<dim3((unsigned)nblocks), dim3(512), lds, ctx->stream>>>(a);
+    if (post_bk == 32) {
+      const size_t lds = (size_t)(2 * 32 * V2_STRIDE) * sizeof(double);
+      posterior_kernel_v2<4, 0, 2, 32><<<dim3((unsigned)nblocks), dim3(512), lds, ctx->stream>>>(a);
+    } else {
+      const size_t lds = (size_t)(2 * POST_BK * V2_STRIDE) * sizeof(double);
+      posterior_kernel_v2<4, 0, 2><<<dim3((unsigned)nblocks), dim3(512), lds, ctx->stream>>>(a);
+    }
     GPBO_HIP(ctx, hipGetLastError());
   }
   return GPBO_OK;

@@ -227,6 +227,17 @@ class GpEngine:
         self.set_candidates(Xc)
         return self.posterior(slot, y_mean, y_std, fetch=True)
 
+    def predict_cov(self, Xc, slot=0, y_mean=0.0, y_std=1.0):
+        """(mu (M,), cov (M,M)) as GaussianProcessRegressor.predict(return_cov=True) (gpbo_predict_cov)."""
+        Xc = np.ascontiguousarray(Xc, dtype=np.float64)
+        M, d = Xc.shape
+        mu, cov = np.empty(M), np.empty((M, M))
+        self._check(self._lib.gpbo_predict_cov(self._h, int(slot), dptr(Xc), M, d, float(y_mean), float(y_std),
+                                               dptr(mu), dptr(cov)))
+        self.n_candidates = M
+        self._resident = False
+        return mu, cov
+
     def predict_grad(self, Xc, slot=0, y_mean=0.0, y_std=1.0):
         """(mu (M,), sd (M,), dmu (M,d), dsd (M,d)) for a small host batch (M <= 256): gpbo_predict_grad."""
         Xc = np.ascontiguousarray(Xc, dtype=np.float64)

@@ -578,3 +578,136 @@ class ExpectedImprovement(_ImprovementBased):
         z = a / std
         cdf, pdf = ndtr(z), _norm_pdf(z)
         return a * cdf + std * pdf, cdf[:, None] * dmean + pdf[:, None] * dstd
+
+
+class GPHedge(AcquisitionFunction):
+    """Portfolio of acquisition policies (bayes_opt/acquisition.py:1181-1360; Brochu et al., arXiv:1009.5419): every
+    base policy nominates a point, one nominee is drawn with probability softmax(gains), and at the next step the gains
+    grow by the new posterior mean at the previous nominees.  Same interface, state (`gains`, `previous_candidates`),
+    parameter dict and RandomState consumption as the reference class.
+
+    `share_candidates`:
+      False (default)  the reference's arithmetic: base policy i draws its own `n_random // n_acq` candidates and runs
+                       its own random + local stages through `base.suggest(..., fit_gp=False)` (:1306-1316) — with
+                       engine-backed GPs each of those is the fused device stage; nominees and RandomState position are
+                       the reference's.
+      True             ONE candidate set of `n_random` points and ONE posterior pass (`gpbo_posterior` per model) serve
+                       all base policies; each policy then costs only its acquisition + arg-best pass
+                       (`gpbo_acq_argbest`, HBM-bound, ~0.1 ms per 2^20 candidates) and its local search.  n_acq times
+                       fewer posterior flops for n_acq times MORE candidates per policy; the candidate stream differs
+                       from the reference's (one draw of n_random instead of n_acq draws of n_random // n_acq), so this
+                       mode is labelled non-parity.  Needs engine-backed GPs and stock base policies; otherwise the
+                       per-policy path runs.
+    """
+
+    def __init__(self, base_acquisitions, random_state=None, share_candidates: bool = False) -> None:
+        super().__init__(random_state)
+        self.base_acquisitions = list(base_acquisitions)
+        self.n_acq = len(self.base_acquisitions)
+        self.gains = np.zeros(self.n_acq)
+        self.previous_candidates = None
+        self.share_candidates = share_candidates
+
+    def base_acq(self, *args, **kwargs):
+        raise TypeError("GPHedge base acquisition function is ambiguous."
+                        " You may use self.base_acquisitions[i].base_acq(mean, std)"
+                        " to get the base acquisition function for the i-th acquisition.")
+
+    @staticmethod
+    def _softmax_cumsum(g):
+        z = np.exp(g - np.max(g))          # scipy.special.softmax
+        return np.cumsum(z / z.sum())
+
+    def _sample_idx_from_softmax_gains(self, random_state) -> int:
+        return int(np.argmax(random_state.rand() <= self._softmax_cumsum(self.gains)))    # first True
+
+    def _update_gains(self, gp) -> None:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            self.gains += gp.predict(self.previous_candidates)
+        self.previous_candidates = None
+
+    def _nominate_shared(self, chain, gp, target_space, n_random, n_smart, rng):
+        """All base policies over ONE resident candidate set and ONE posterior pass."""
+        eng = chain[0]._engine()
+        k = n_smart // self.n_acq
+        n = max(n_random, k, 1)
+        if _reference_stream_on_device(chain, target_space, rng, n):
+            eng.generate_candidates_like(n, target_space.bounds[:, 0], target_space.bounds[:, 1], rng)
+        else:
+            eng.set_candidates(chain[0]._tx(target_space.random_sample(n, random_state=rng)))
+        for model in chain:
+            model.posterior_resident()                       # ONE pass per GP, shared by every policy below
+        lb, ub = (target_space.constraint._lb, target_space.constraint._ub) if len(chain) > 1 else (None, None)
+        d = target_space.bounds.shape[0]
+        picks_all = []
+        for base in self.base_acquisitions:                  # selection only: mu / sd stay on the device
+            if isinstance(base, _ImprovementBased):
+                base.y_max = target_space._target_max()
+                if base.y_max is None and not target_space.empty:
+                    raise NoValidPointRegisteredError("Cannot suggest a point without an allowed point.")
+            y_max = getattr(base, "y_max", None)
+            best, best_val, picks, _v, _ = eng.acq_argbest(base._acq_kind, base._acq_param(), 0.0 if y_max is None else y_max,
+                                                           lb, ub, k_seeds=min(k, _MAX_DEVICE_SEEDS))
+            picks = picks[picks >= 0]
+            rows = eng.get_candidate_rows(np.concatenate([[int(best)], picks]), d)   # now: a local search re-uses the buffer
+            picks_all.append((float(best_val), rows))
+        nominees = []
+        for base, (best_val, rows) in zip(self.base_acquisitions, picks_all):
+            x_rand, seeds = rows[0], rows[1:]
+            base.i += 1
+            x = x_rand
+            if k:
+                base._fused, base._fused_constraint = chain, (target_space.constraint if len(chain) > 1 else None)
+                try:
+                    acq = base._get_acq(gp=gp, constraint=target_space.constraint)
+                    x_loc, f_loc = base._smart_minimize(acq, target_space, x_seeds=seeds, random_state=rng)
+                finally:
+                    base._fused = base._fused_constraint = None
+                if best_val > f_loc:
+                    x = x_loc
+            base.decay_exploration()
+            nominees.append(x)
+        return nominees
+
+    def suggest(self, gp, target_space, n_random: int = 10_000, n_smart: int = 10, fit_gp: bool = True, random_state=None):
+        if len(target_space) == 0:
+            raise TargetSpaceEmptyError(
+                "Cannot suggest a point without previous samples. Use "
+                " target_space.random_sample() to generate a point and "
+                " target_space.probe(*) to evaluate it.")
+        self.i += 1
+        rng = ensure_rng(random_state)
+        if fit_gp:
+            self._fit_gp(gp=gp, target_space=target_space)
+        if self.previous_candidates is not None:
+            self._update_gains(gp)
+        chain = _fused_models(gp, target_space.constraint) if self.share_candidates else None
+        shared = (chain is not None and all(getattr(b, "_acq_kind", None) is not None for b in self.base_acquisitions)
+                  and not (target_space.constraint is not None
+                           and any(isinstance(b, UpperConfidenceBound) for b in self.base_acquisitions)))
+        if shared:
+            x_max = self._nominate_shared(chain, gp, target_space, n_random, n_smart, rng)
+        else:
+            x_max = [base.suggest(gp=gp, target_space=target_space, n_random=n_random // self.n_acq,
+                                  n_smart=n_smart // self.n_acq, fit_gp=False, random_state=rng)
+                     for base in self.base_acquisitions]
+        self.previous_candidates = np.array(x_max)
+        idx = self._sample_idx_from_softmax_gains(random_state=rng)
+        if not getattr(target_space, "_allow_duplicate_points", True) and x_max[idx] in target_space:
+            fresh = [t for t, x in enumerate(x_max) if x not in target_space]
+            if fresh:      # every nominee a duplicate: keep the draw (the caller decides what a duplicate means)
+                idx = fresh[int(np.argmax(rng.rand() <= self._softmax_cumsum(self.gains[fresh])))]
+        return x_max[idx]
+
+    def get_acquisition_params(self):
+        return {"base_acquisitions_params": [b.get_acquisition_params() for b in self.base_acquisitions],
+                "gains": self.gains.tolist(),
+                "previous_candidates": None if self.previous_candidates is None else self.previous_candidates.tolist()}
+
+    def set_acquisition_params(self, params):
+        for base, p in zip(self.base_acquisitions, params["base_acquisitions_params"]):
+            base.set_acquisition_params(p)
+        self.gains = np.array(params["gains"])
+        pc = params["previous_candidates"]
+        self.previous_candidates = None if pc is None else np.array(pc)

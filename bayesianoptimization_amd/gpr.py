@@ -401,12 +401,17 @@ class HipGPR(GaussianProcessRegressor):
     def predict(self, X, return_std=False, return_cov=False):
         if return_std and return_cov:
             raise RuntimeError("At most one of return_std or return_cov can be requested.")
-        if not hasattr(self, "X_train_") or return_cov:
-            # prior (unfitted) predictions and full covariances are not on the hot path: sklearn's own
-            # code handles them (for return_cov it reads the lazily fetched L_ / alpha_).
+        if not hasattr(self, "X_train_"):
+            # prior (unfitted) predictions are not on the hot path: sklearn's own code handles them
             return super().predict(X, return_std=return_std, return_cov=return_cov)
         X = np.asarray(validate_data(self, X, ensure_2d=True, dtype="numeric", reset=False), dtype=np.float64)  # _gpr.py:412
         self._ensure_resident()
+        if return_cov:   # _gpr.py:458-469 on the device: V = W K*^T and V^T V as MFMA GEMMs; only M x M comes back
+            if X.shape[0] > 16384:
+                return super().predict(X, return_cov=True)      # (host path over the fetched L_: beyond the device buffers)
+            mean, cov = self._engine().predict_cov(self._tx(X), slot=self.slot, y_mean=float(self._y_train_mean),
+                                                   y_std=float(self._y_train_std))
+            return mean, cov
         mean, std = self._engine().predict(self._tx(X), slot=self.slot, y_mean=float(self._y_train_mean),
                                            y_std=float(self._y_train_std))
         if return_std:

@@ -150,6 +150,13 @@ int gpbo_posterior(gpbo_ctx* ctx, int slot, double y_mean, double y_std, double*
 int gpbo_predict(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d, double y_mean,
                  double y_std, double* mu, double* sd);
 
+/* Replaces GaussianProcessRegressor.predict(X, return_cov=True) (_gpr.py:443-447, 458-469; reached from
+ * BayesianOptimization.predict(..., return_cov=True), bayes_opt/bayesian_optimization.py:238) for a host batch:
+ * cov (M,M) row-major = (k(X, X) - V^T V) * y_std^2 with V = L^-1 K*^T formed as two MFMA GEMMs on the device (no clipping,
+ * as sklearn on this branch); mu (M,) optional.  M <= 16384. */
+int gpbo_predict_cov(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d, double y_mean, double y_std,
+                     double* mu, double* cov);
+
 /* Posterior AND its gradient in the inputs for a small host batch (M <= 256): mu, sd (M,) as gpbo_predict, and
  * dmu, dsd (M,d) = d mu / d x, d sd / d x.  One evaluation gives the local search of the reference
  * (bayes_opt/acquisition.py:365-374: scipy L-BFGS-B, which forms its gradient from d + 1 predicts by finite differences)

@@ -109,6 +109,16 @@ def predict(gp: GPState, Xc: np.ndarray):
     return mean, np.sqrt(var)
 
 
+def predict_cov(gp: GPState, Xc: np.ndarray):
+    """(mean, covariance) as GaussianProcessRegressor.predict(return_cov=True) (_gpr.py:443-469)."""
+    Xc = np.asarray(Xc, dtype=np.float64).reshape(-1, gp.X.shape[1])
+    Kt = kernel_matrix(gp.kind, Xc, gp.X, gp.length_scale)
+    mean = gp.y_std * (Kt @ gp.alpha) + gp.y_mean
+    V = solve_triangular(gp.L, Kt.T, lower=True, check_finite=False)
+    cov = kernel_matrix(gp.kind, Xc, None, gp.length_scale) - V.T @ V
+    return mean, cov * gp.y_std**2
+
+
 def predict_grad(gp: GPState, Xc: np.ndarray):
     """(mean, std, d mean / d x, d std / d x): the analytic input gradient of `predict` — the checker of
     gpbo_predict_grad.  sklearn has no such routine; the formulas differentiate _gpr.py:443-494 with the kernels of

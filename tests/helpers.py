@@ -124,6 +124,11 @@ class FakeEngine:
         self.set_candidates(Xc)
         return self.posterior(slot, y_mean, y_std, True)
 
+    def predict_cov(self, Xc, slot=0, y_mean=0.0, y_std=1.0):
+        self.calls.append(("predict_cov", slot, np.shape(Xc)))
+        mu, cov = O.predict_cov(self.models[slot], np.asarray(Xc, dtype=np.float64))
+        return y_std * mu + y_mean, cov * y_std**2
+
     def predict_grad(self, Xc, slot=0, y_mean=0.0, y_std=1.0):
         self.calls.append(("predict_grad", slot, np.shape(Xc)))
         mu, sd, dmu, dsd = O.predict_grad(self.models[slot], np.asarray(Xc, dtype=np.float64))

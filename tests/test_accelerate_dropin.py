@@ -313,3 +313,58 @@ def test_theta_search_runs_in_lockstep_equal_the_sequential_runs(monkeypatch):
     singles = [c for c in fits[False][3] if c[0] == "lml"]
     assert batches and batches[0] == 6 and sum(batches) == len(singles) and len(batches) * 2 < len(singles)
     assert not [c for c in fits[True][3] if c[0] == "lml"]
+
+
+def test_fused_gphedge_is_the_reference_gphedge_and_can_share_one_posterior_pass():
+    """fused_acquisition.GPHedge: in its default mode it IS bayes_opt's GPHedge (acquisition.py:1181-1360)
+    — same nominees, gains, RandomState position through a maximize() loop, same parameter dict; with
+    share_candidates=True all base policies are served by ONE candidate set and ONE posterior pass per suggest()."""
+    import_reference()
+    from bayes_opt import BayesianOptimization, acquisition
+
+    from bayesianoptimization_amd import accelerate
+    from bayesianoptimization_amd import fused_acquisition as A
+
+    ref = BayesianOptimization(f=black_box, pbounds=PB, random_state=6, verbose=0, acquisition_function=acquisition.GPHedge(
+        [acquisition.UpperConfidenceBound(kappa=2.0), acquisition.ExpectedImprovement(xi=0.01),
+         acquisition.ProbabilityOfImprovement(xi=0.02)]))
+    fused = A.GPHedge([A.UpperConfidenceBound(kappa=2.0), A.ExpectedImprovement(xi=0.01), A.ProbabilityOfImprovement(xi=0.02)])
+    opt = BayesianOptimization(f=black_box, pbounds=PB, random_state=6, verbose=0, acquisition_function=fused)
+    eng = FakeEngine()
+    accelerate(opt, engine=eng)
+    assert opt._acquisition_function is fused
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref.maximize(init_points=2, n_iter=4)
+        opt.maximize(init_points=2, n_iter=4)
+    assert np.allclose(opt.space.params, ref.space.params, rtol=0, atol=1e-4)
+    assert np.allclose(fused.gains, ref._acquisition_function.gains, rtol=0, atol=1e-4)
+    assert ref._random_state.uniform() == opt._random_state.uniform()
+    pr, pf = ref._acquisition_function.get_acquisition_params(), fused.get_acquisition_params()
+    assert sorted(pr) == sorted(pf) and len(pf["base_acquisitions_params"]) == 3
+    clone = A.GPHedge([A.UpperConfidenceBound(), A.ExpectedImprovement(xi=0.5), A.ProbabilityOfImprovement(xi=0.5)])
+    clone.set_acquisition_params(pf)
+    assert np.array_equal(clone.gains, fused.gains) and clone.base_acquisitions[1].xi == 0.01
+    with pytest.raises(TypeError, match="ambiguous"):
+        fused.base_acq(0.0, 1.0)
+
+    # shared mode: one candidate draw, one posterior pass per GP, one arg-best pass per policy
+    shared = A.GPHedge([A.UpperConfidenceBound(kappa=2.0), A.ExpectedImprovement(xi=0.01), A.ProbabilityOfImprovement(xi=0.02)],
+                       share_candidates=True)
+    opt2 = BayesianOptimization(f=black_box, pbounds=PB, random_state=6, verbose=0, acquisition_function=shared)
+    eng2 = FakeEngine()
+    accelerate(opt2, engine=eng2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        opt2.maximize(init_points=2, n_iter=1)
+        eng2.calls.clear()
+        x = opt2.suggest()
+    kinds = [c[0] for c in eng2.calls]
+    start = kinds.index("generate_candidates_like")           # (before it: the gains update, a 3-point predict)
+    rest = kinds[start + 1:]
+    stop = rest.index("set_candidates") if "set_candidates" in rest else len(rest)      # first local-search predict
+    stage = rest[:stop]
+    assert kinds.count("generate_candidates_like") == 1
+    assert stage.count("posterior") == 1 and stage.count("acq_argbest") == 3      # ONE pass, three selections
+    assert all(PB[k][0] <= v <= PB[k][1] for k, v in x.items())
+    assert shared.previous_candidates.shape == (3, 2) and [b.i for b in shared.base_acquisitions] == [2, 2, 2]

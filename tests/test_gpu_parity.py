@@ -519,3 +519,28 @@ def test_predict_grad_equals_the_oracle_gradient(engine, N, d, kernel, ls, M):
     # a training point: the clipped variance has zero slope, nothing is NaN
     mu1, sd1, dmu1, dsd1 = engine.predict_grad(X[:3], 0, ym, ys_)
     assert np.all(np.isfinite(dmu1)) and np.all(np.isfinite(dsd1))
+
+
+@pytest.mark.parametrize("N,d,kernel,ls,M", [(60, 3, O.MATERN25, 0.7, 5), (200, 5, O.RBF, 0.6, 130), (513, 8, O.MATERN25, 1.0, 300),
+                                             (1100, 16, O.MATERN25, 1.5, 257)])
+def test_predict_cov_equals_sklearn_return_cov(engine, N, d, kernel, ls, M):
+    """gpbo_predict_cov against GaussianProcessRegressor.predict(return_cov=True) (_gpr.py:458-469), and
+    HipGPR.predict(return_cov=True) — the call BayesianOptimization.predict(return_cov=True) makes."""
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF, Matern
+
+    from bayesianoptimization_amd.gpr import HipGPR
+
+    X, y = _data(N, d)
+    k = Matern(nu=2.5, length_scale=ls) if kernel == O.MATERN25 else RBF(length_scale=ls)
+    sk = GaussianProcessRegressor(kernel=k, alpha=1e-6, normalize_y=True, optimizer=None).fit(X, y)
+    Xq = np.random.RandomState(6).uniform(size=(M, d))
+    mu_s, cov_s = sk.predict(Xq, return_cov=True)
+    gp = HipGPR(kernel=k, alpha=1e-6, normalize_y=True, optimizer=None, engine=engine).fit(X, y)
+    mu, cov = gp.predict(Xq, return_cov=True)
+    assert cov.shape == (M, M)
+    assert rel_err(mu, mu_s) < 1e-8
+    assert np.max(np.abs(cov - cov_s)) < 1e-8 * np.max(np.abs(cov_s))
+    assert np.max(np.abs(cov - cov.T)) < 1e-12 * np.max(np.abs(cov_s))
+    _, sd = gp.predict(Xq, return_std=True)
+    assert np.max(np.abs(np.sqrt(np.clip(np.diag(cov), 0, None)) - sd)) < 1e-6 * np.max(sd)
