@@ -128,44 +128,41 @@ int launch_kmat(gpbo_ctx* ctx, Model& m, double noise, double* out) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Cholesky + inverse of one 64x64 diagonal block by one 256-thread workgroup.
+// Cholesky + inverse of one 64x64 diagonal block by one 256-thread workgroup — the serial link of the blocked
+// factorisation (N / 64 of these run one after another; at N = 4096 they are about half of the Cholesky's time).
 //
 // Factorisation (right-looking, one column per step, NO workgroup barrier): thread (row i = tid & 63, quarter
 // q = tid >> 6) keeps A[i][16q .. 16q+15] in registers, so wave q owns 16 whole columns.  A wave first applies the
 // columns left of its own as the owning waves publish them (column-major LDS image + a release/acquire counter it
 // polls), then factors its 16 columns inside the wave — pivot and pivot-row entries by v_readlane — publishing
 // each column the moment it is final.  Every element still receives its rank-1 updates in column order, so the
-// result does not depend on the timing.  All indices are compile-time (the 16 steps are unrolled).
+// result does not depend on the timing.  All register indices are compile-time (the 16 steps are unrolled).
+// (Measured alternative, round 2: interleaved column ownership — every wave takes a quarter of each rank-1 update,
+// columns handed over through LDS one by one — is SLOWER, 33 vs 25 us per block: the chain is the pivot arithmetic
+// (v_rsq_f64 + two Newton steps, ~12 dependent fp64 operations) plus one LDS hand-off per column instead of one per 16.)
 //
-// Inverse: the four 16x16 diagonal sub-blocks by forward substitution in registers (thread = column),
-// then two doubling levels  W21 = -W22 (L21 W11)  as LDS-resident matrix products; the temporaries live
-// in the (zero) upper-right quadrants of the W image.
+// Inverse: the four 16x16 diagonal sub-blocks by forward substitution in registers (thread = column), then the two
+// doubling levels  W21 = -W22 (L21 W11)  as v_mfma_f64_16x16x4_f64 products out of LDS (round 1 used scalar LDS matrix
+// products: ~4 of the kernel's 25 us).
 // Writes L_kk in place (upper part zeroed) and L_kk^-1 to dinv[kb].
-__device__ __forceinline__ void lds_matmul(double* __restrict__ Cm, int ldc, const double* __restrict__ Am, int lda,
-                                           const double* __restrict__ Bm, int ldb, int m, int n, int k,
-                                           double alpha) {
-  for (int e = threadIdx.x; e < m * n; e += 256) {
-    const int i = e / n, c = e - i * n;
-    double s = 0.0;
-    for (int t = 0; t < k; ++t) s = fma(Am[i * lda + t], Bm[t * ldb + c], s);
-    Cm[i * ldc + c] = alpha * s;
-  }
-}
+constexpr int PD_S = 80;   // LDS row stride (doubles): the two k-rows of a 32-lane ds_read_b64 group fall 32 banks apart
 
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, int kb,
-                                                         double* __restrict__ dinv, int* info, int64_t lane_stride) {
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, int kb, double* __restrict__ dinv, int* info,
+                                                          int64_t lane_stride) {
   L += (int64_t)blockIdx.x * lane_stride;
   dinv += (int64_t)blockIdx.x * lane_stride;
-  info += (int64_t)blockIdx.x * lane_stride * 2;      // the info word lives in the lane's slab too (ints: 2 per double)
-  extern __shared__ __attribute__((aligned(16))) double pd_smem[];
-  double* Ls = pd_smem;              // [64][65]
-  double* Wl = pd_smem + 64 * 65;    // [64][65]
-  double* col = Wl + 64 * 65;        // [64] reciprocals of the diagonal of L (+ 64 spare)
-  int* bad_sh = reinterpret_cast<int*>(col + 128);
+  info += (int64_t)blockIdx.x * lane_stride * 2;
+  extern __shared__ __attribute__((aligned(16))) double pd2_smem[];
+  double* Lc = pd2_smem;                 // [64][PD_S] column-major image of L: Lc[j * PD_S + i] = L[i][j]
+  double* Wr = Lc + 64 * PD_S;           // [64][PD_S] row-major W = L^-1
+  double* Tb = Wr + 64 * PD_S;           // [32][PD_S] product temporaries
+  double* rdiag = Tb + 32 * PD_S;        // [64] 1 / L[j][j]
+  int* flags = reinterpret_cast<int*>(rdiag + 64);   // [0] bad pivot (1-based), [1] columns published, [2] hand-off broken
   const int tid = threadIdx.x;
   const int i = tid & 63;
   const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
   double* A = L + (int64_t)kb * 64 * ld + (int64_t)kb * 64;
+  if (tid < 3) flags[tid] = 0;
   double a[16];
   {
     const double2* src = reinterpret_cast<const double2*>(A + (int64_t)i * ld + 16 * q);
@@ -176,28 +173,25 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
       a[2 * h + 1] = v.y;
     }
   }
-  // Column-major image of the finished columns (colbuf[j][i] = L[i][j]) in the LDS the inverse uses later, and the
-  // number of columns published so far.  No workgroup barrier inside the factorisation: a wave first CONSUMES the
-  // columns left of its own 16 as they appear (polling `ready`), then factors its own 16 columns entirely inside the
-  // wave (pivot and the entries of the pivot row by v_readlane), publishing each column as soon as it is final — so
-  // the critical path is the 64 pivots themselves, and the rank-1 updates of the other waves trail one column behind.
-  double* colbuf = Wl;
-  int* ready = bad_sh + 1;
-  if (tid == 0) { *bad_sh = 0; *ready = 0; }
   __syncthreads();
   {
+    // consume the columns left of this wave's 16 as they appear, then factor the own 16 inside the wave
     const int need = 16 * q;
-    int applied = 0;
+    int applied = 0, spins = 0;
     while (applied < need) {
-      int avail = __hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      int avail = __hip_atomic_load(&flags[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (avail <= applied) {
+        if (++spins > (1 << 22)) {   // cannot happen while the owner wave runs; never hang the GPU on a bug
+          if (i == 0) flags[2] = 1;
+          break;
+        }
         __builtin_amdgcn_s_sleep(1);
         continue;
       }
       if (avail > need) avail = need;
       for (int k = applied; k < avail; ++k) {
-        const double li = colbuf[k * 64 + i];
-        const double* prow = colbuf + k * 64 + 16 * q;      // L[16q + cc][k]: the same address for every lane
+        const double li = Lc[k * PD_S + i];
+        const double* prow = Lc + k * PD_S + 16 * q;      // L[16q + cc][k]: the same address for every lane
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) a[cc] = fma(-li, prow[cc], a[cc]);
       }
@@ -211,7 +205,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
       const unsigned phi = __builtin_amdgcn_readlane((int)(unsigned)(pv >> 32), j);
       double piv = __longlong_as_double(((unsigned long long)phi << 32) | plo);
       if (!(piv > 0.0)) {
-        if (i == 0 && *bad_sh == 0) *bad_sh = j + 1;
+        if (i == 0 && flags[0] == 0) flags[0] = j + 1;
         piv = 1.0;
       }
       // 1/sqrt(piv): v_rsq_f64 seed (2^-23) + two Newton steps, then sqrt = piv * rs with one correction;
@@ -226,10 +220,10 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
       double l = (i == j) ? dg : a[jj] * rs;
       l = (i >= j) ? l : 0.0;
       a[jj] = l;
-      colbuf[j * 64 + i] = l;
+      Lc[j * PD_S + i] = l;
       if (i == 0) {
-        col[j] = rs;    // 1 / L[j][j] for the inverse below (saves its 16 dependent fp64 divisions per thread)
-        __hip_atomic_store(ready, j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        rdiag[j] = rs;    // 1 / L[j][j] for the inverse below (saves its 16 dependent fp64 divisions per thread)
+        __hip_atomic_store(&flags[1], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       // this wave's remaining columns: L[16q + cc][j] sits in lane 16q + cc of `l`
       const unsigned long long lv = __double_as_longlong(l);
@@ -240,192 +234,6 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
         a[cc] = fma(-l, __longlong_as_double(((unsigned long long)lhi << 32) | llo), a[cc]);
       }
     }
-  }
-  __syncthreads();
-  // L -> global (upper part zero) and -> LDS for the inverse
-  {
-    double2* dst = reinterpret_cast<double2*>(A + (int64_t)i * ld + 16 * q);
-#pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      const int c0 = 16 * q + 2 * h;
-      const double v0 = (c0 <= i) ? a[2 * h] : 0.0;
-      const double v1 = (c0 + 1 <= i) ? a[2 * h + 1] : 0.0;
-      dst[h] = make_double2(v0, v1);
-      Ls[i * 65 + c0] = v0;
-      Ls[i * 65 + c0 + 1] = v1;
-      Wl[i * 65 + c0] = 0.0;
-      Wl[i * 65 + c0 + 1] = 0.0;
-    }
-  }
-  __syncthreads();
-  if (tid == 0 && *bad_sh && *info == 0) *info = kb * 64 + *bad_sh;
-  // --- inverse, step A: 16x16 diagonal sub-blocks (thread = sub-block b, column c)
-  if (tid < 64) {
-    const int b = tid >> 4, c = tid & 15;
-    const double* Lb = Ls + (16 * b) * 65 + 16 * b;
-    double w[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) w[r] = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const double wk = w[k] * col[16 * b + k];
-      w[k] = wk;
-#pragma unroll
-      for (int r = k + 1; r < 16; ++r) w[r] = fma(-Lb[r * 65 + k], wk, w[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Wl[(16 * b + r) * 65 + 16 * b + c] = w[r];
-  }
-  __syncthreads();
-  // --- step B: 16 -> 32 (two pairs).  T (16x16) sits in the upper-right 16x16 of each 32x32 diagonal block.
-  for (int p2 = 0; p2 < 2; ++p2) {
-    const int o = 32 * p2;
-    lds_matmul(Wl + o * 65 + o + 16, 65, Ls + (o + 16) * 65 + o, 65, Wl + o * 65 + o, 65, 16, 16, 16, 1.0);
-  }
-  __syncthreads();
-  for (int p2 = 0; p2 < 2; ++p2) {
-    const int o = 32 * p2;
-    lds_matmul(Wl + (o + 16) * 65 + o, 65, Wl + (o + 16) * 65 + o + 16, 65, Wl + o * 65 + o + 16, 65, 16, 16, 16, -1.0);
-  }
-  __syncthreads();
-  // --- step C: 32 -> 64.  T (32x32) sits in the upper-right quadrant; first clear step B's temporaries there.
-  for (int e = tid; e < 512; e += 256) {
-    const int p2 = e >> 8, r = (e >> 4) & 15, c = e & 15;
-    Wl[(32 * p2 + r) * 65 + 32 * p2 + 16 + c] = 0.0;
-  }
-  __syncthreads();
-  lds_matmul(Wl + 32, 65, Ls + 32 * 65, 65, Wl, 65, 32, 32, 32, 1.0);
-  __syncthreads();
-  lds_matmul(Wl + 32 * 65, 65, Wl + 32 * 65 + 32, 65, Wl + 32, 65, 32, 32, 32, -1.0);
-  __syncthreads();
-  double* D = dinv + (int64_t)kb * 64 * 64;
-  for (int e = tid; e < 4096; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    D[e] = (c <= r) ? Wl[r * 65 + c] : 0.0;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// potrf_diag2: the same job (Cholesky + inverse of one 64x64 diagonal block, one 256-thread workgroup) restructured for the
-// critical path of the blocked factorisation — at N = 4096 the 64 serial diagonal-block kernels were 53 % of the Cholesky.
-//
-// Factorisation: INTERLEAVED column ownership — thread (row i = tid & 63, wave q = tid >> 6) keeps A[i][4 cc + q], cc < 16,
-// in registers, so that the rank-1 update of every finished column is shared by all four waves (<= 16 FMAs each) instead of
-// trailing inside the owner wave (in-wave v_readlane, ~45 instructions per column on the critical path).  A finished column
-// is published to a column-major LDS image + release/acquire counter.  The wave that owns column j + 1 applies column j to
-// that ONE column first, factors and publishes it, and only then catches up on its other columns: the chain per column is
-// LDS hand-off -> 1 FMA -> pivot (v_rsq_f64 + 2 Newton steps) -> publish.  Every element still receives its updates in
-// column order, so the result is independent of timing.  Spins are bounded (a broken hand-off reports instead of hanging).
-//
-// Inverse: 16x16 diagonal sub-blocks by forward substitution (thread = column), then the two doubling levels
-// W21 = -W22 (L21 W11) as v_mfma_f64_16x16x4_f64 products out of LDS (the scalar LDS matmuls of v1 took ~4 of its 7 us).
-constexpr int PD_S = 80;   // LDS row stride (doubles): the two k-rows of a 32-lane ds_read_b64 group fall 32 banks apart
-
-__global__ __launch_bounds__(256) void potrf_diag2_kernel(double* L, int64_t ld, int kb, double* __restrict__ dinv, int* info,
-                                                          int64_t lane_stride) {
-  L += (int64_t)blockIdx.x * lane_stride;
-  dinv += (int64_t)blockIdx.x * lane_stride;
-  info += (int64_t)blockIdx.x * lane_stride * 2;
-  extern __shared__ __attribute__((aligned(16))) double pd2_smem[];
-  double* Lc = pd2_smem;                 // [64][PD_S] column-major image of L: Lc[j * PD_S + i] = L[i][j]
-  double* Wr = Lc + 64 * PD_S;           // [64][PD_S] row-major W = L^-1 (first: staging of the input tile, stride 65)
-  double* Tb = Wr + 64 * PD_S;           // [32][PD_S] product temporaries
-  double* rdiag = Tb + 32 * PD_S;        // [64] 1 / L[j][j]
-  int* flags = reinterpret_cast<int*>(rdiag + 64);   // [0] bad pivot (1-based), [1] columns published, [2] hand-off broken
-  const int tid = threadIdx.x;
-  const int i = tid & 63;
-  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
-  double* A = L + (int64_t)kb * 64 * ld + (int64_t)kb * 64;
-  if (tid < 3) flags[tid] = 0;
-  {   // tile -> LDS (row-major, stride 65: the strided register fill below is conflict-free) -> registers
-    const int row = tid >> 2, seg = (tid & 3) * 16;
-    const double2* src = reinterpret_cast<const double2*>(A + (int64_t)row * ld + seg);
-#pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      const double2 v = src[h];
-      Wr[row * 65 + seg + 2 * h] = v.x;
-      Wr[row * 65 + seg + 2 * h + 1] = v.y;
-    }
-  }
-  __syncthreads();
-  double a[16];
-#pragma unroll
-  for (int cc = 0; cc < 16; ++cc) a[cc] = Wr[i * 65 + 4 * cc + q];
-  __syncthreads();
-
-  // The 16 column groups are walked by a REAL loop (not unrolled: fully unrolled this kernel was 63 KB of straight-line
-  // code and ran at instruction-fetch speed, 2x slower than v1).  The register array is rotated once per group so that
-  // slot 0 always holds the group's column and every register index below is a compile-time constant; slots past the
-  // last column hold dead values whose updates are harmless.
-  int have = 0;   // columns this wave has seen published
-#pragma unroll 1
-  for (int jj = 0; jj < 16; ++jj) {
-#pragma unroll
-    for (int j4 = 0; j4 < 4; ++j4) {
-      const int j = 4 * jj + j4;
-      const double* colj = Lc + j * PD_S;
-      const double* mine = colj + 4 * jj + q;      // L[4 (jj + k) + q][j] sits at mine[4 k]
-      if (q == j4) {
-        // ---- owner of column j (slot 0): it has received every update (the last one in the previous step) ----
-        const unsigned long long pv = __double_as_longlong(a[0]);
-        const unsigned plo = __builtin_amdgcn_readlane((int)(unsigned)pv, j);
-        const unsigned phi = __builtin_amdgcn_readlane((int)(unsigned)(pv >> 32), j);
-        double piv = __longlong_as_double(((unsigned long long)phi << 32) | plo);
-        if (!(piv > 0.0)) {
-          if (i == 0 && flags[0] == 0) flags[0] = j + 1;
-          piv = 1.0;
-        }
-        double rs = __builtin_amdgcn_rsq(piv);
-        double e = fma(-piv * rs, rs, 1.0);
-        rs = fma(0.5 * rs, e, rs);
-        e = fma(-piv * rs, rs, 1.0);
-        rs = fma(0.5 * rs, e, rs);
-        double dg = piv * rs;
-        dg = fma(fma(-dg, dg, piv), 0.5 * rs, dg);
-        double l = (i == j) ? dg : a[0] * rs;
-        l = (i >= j) ? l : 0.0;
-        a[0] = l;
-        Lc[j * PD_S + i] = l;
-        if (i == 0) {
-          rdiag[j] = rs;
-          __hip_atomic_store(&flags[1], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        have = j + 1;
-        if (j > 0) {   // catch up: column j - 1 on my columns right of j (column j itself got it in the previous step)
-          const double lp = colj[i - PD_S];
-#pragma unroll
-          for (int k = 1; k < 16; ++k) a[k] = fma(-lp, mine[4 * k - PD_S], a[k]);
-        }
-#pragma unroll
-        for (int k = 1; k < 16; ++k) a[k] = fma(-l, mine[4 * k], a[k]);
-      } else {
-        if (have <= j) {
-          int spins = 0;
-          for (;;) {
-            have = __hip_atomic_load(&flags[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (have > j) break;
-            if (++spins > (1 << 22)) {   // cannot happen while the owner wave runs; never hang the GPU on a bug
-              if (i == 0) flags[2] = 1;
-              break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-          }
-        }
-        const double li = colj[i];
-        if (q == ((j4 + 1) & 3)) {
-          // next owner: column j + 1 only (slot 0, or slot 1 when it opens the next group); the rest after it has published
-          if (j4 < 3) a[0] = fma(-li, mine[0], a[0]);
-          else a[1] = fma(-li, mine[4], a[1]);
-        } else {
-          if (q > j4) a[0] = fma(-li, mine[0], a[0]);
-#pragma unroll
-          for (int k = 1; k < 16; ++k) a[k] = fma(-li, mine[4 * k], a[k]);
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 15; ++k) a[k] = a[k + 1];
-    a[15] = 0.0;
   }
   __syncthreads();
   if (tid == 0) {
@@ -520,26 +328,8 @@ __global__ __launch_bounds__(256) void potrf_diag2_kernel(double* L, int64_t ld,
   }
 }
 
-static bool potrf_diag2_enabled() {
-  static const bool on = !(getenv("GPBO_POTRF_DIAG") && getenv("GPBO_POTRF_DIAG")[0] == '1');
-  return on;
-}
-
 int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb) {
-  if (potrf_diag2_enabled()) {
-    constexpr size_t lds2 = (size_t)(64 * PD_S * 2 + 32 * PD_S + 64 + 8) * sizeof(double);
-    static bool attr2_set = false;
-    if (!attr2_set) {
-      GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_diag2_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-      attr2_set = true;
-    }
-    potrf_diag2_kernel<<<dim3((unsigned)ctx->lanes), dim3(256), lds2, ctx->stream>>>(m.L, m.NP, kb, m.dinv, ctx->info_dev,
-                                                                                      ctx->lane_stride);
-    GPBO_HIP(ctx, hipGetLastError());
-    return GPBO_OK;
-  }
-  constexpr size_t lds = (size_t)(2 * 64 * 65 + 128 + 2) * sizeof(double);   // Ls, Wl (= colbuf), spare, flags
+  constexpr size_t lds = (size_t)(64 * PD_S * 2 + 32 * PD_S + 64 + 8) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
     GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_diag_kernel),

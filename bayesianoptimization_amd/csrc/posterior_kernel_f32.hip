@@ -19,6 +19,17 @@
 namespace gpbo {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// Which f32 MFMA the big chunks (NP >= 512) run on: v_mfma_f32_32x32x2_f32 (default) or v_mfma_f32_16x16x4_f32
+// (GPBO_F32_MFMA=16; NP < 512 always).  Same rate, same operand bytes per flop — the 32x32 form is HALF the MFMA
+// instructions (64 cycles each instead of 32), which leaves the issue slots the LDS reads, the slab / W loads and the
+// barrier need: the 16x16 kernel ran its matrix pipe 81 % busy.  The two forms want W packed differently.
+static bool f32_use_mfma32(int64_t NP) {
+  static const bool off = getenv("GPBO_F32_MFMA") && atoi(getenv("GPBO_F32_MFMA")) == 16;
+  static const bool rt2 = getenv("GPBO_F32_RT") && getenv("GPBO_F32_RT")[0] == '2';
+  return !off && !rt2 && NP >= 512;
+}
 
 constexpr int F32_CANDS = 64;
 constexpr int F32_BK = 32;
@@ -55,8 +66,33 @@ __global__ __launch_bounds__(256) void pack_w32_kernel(const double* __restrict_
   Wp[idx] = v;
 }
 
+// W -> fp32 A fragments of v_mfma_f32_32x32x2_f32: for slab s (64 rows), k-quad q (16 columns), tile t (32 rows), half h
+// (8 columns): 64 lanes x 4 floats contiguous; lane l, element e holds W[64 s + 32 t + (l & 31)][16 q + 8 h + 2 e + (l >> 5)].
+__global__ __launch_bounds__(256) void pack_w32x_kernel(const double* __restrict__ W, float* __restrict__ Wp,
+                                                        int64_t N, int64_t NP) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= NP * NP) return;
+  const int e = (int)(idx & 3);
+  const int lane = (int)((idx >> 2) & 63);
+  const int h = (int)((idx >> 8) & 1);
+  const int t = (int)((idx >> 9) & 1);
+  const int64_t sq = idx >> 10;
+  const int64_t quads = NP / 16;
+  const int64_t s = sq / quads, q = sq - s * quads;
+  const int64_t row = 64 * s + 32 * t + (lane & 31);
+  const int64_t colx = 16 * q + 8 * h + 2 * e + (lane >> 5);
+  float v = 0.f;
+  if (row < N && colx < N && colx <= row) v = (float)W[row * NP + colx];
+  Wp[idx] = v;
+}
+
 int launch_pack_w32(gpbo_ctx* ctx, Model& m) {
   const int64_t total = m.NP * m.NP;
+  if (f32_use_mfma32(m.NP)) {
+    pack_w32x_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream>>>(m.W, m.Wp32, m.N, m.NP);
+    GPBO_HIP(ctx, hipGetLastError());
+    return GPBO_OK;
+  }
   pack_w32_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream>>>(m.W, m.Wp32, m.N, m.NP);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
@@ -223,6 +259,130 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32(PostArgsF32 p) {
   }
 }
 
+// The same pipeline on v_mfma_f32_32x32x2_f32: wave = 64 rows x 64 candidates = 2 x 2 tiles of 32 x 32 (64 accumulator
+// VGPRs, as the 4 x 4 tiles of 16 x 16), workgroup chunk = 512 rows, 32 train points per stage.  A fragment: lane l holds
+// W[row l & 31][k l >> 5]; B fragment: k*[k l >> 5][candidate l & 31]; C/D: column l & 31, rows (reg & 3) + 8 (reg >> 2) +
+// 4 (l >> 5) (cdna_hip_programming.md §3) — so a lane already holds 16 rows of ONE candidate and the sum of squares
+// needs a single cross-lane add (lane ^ 32).
+__global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
+  __shared__ __attribute__((aligned(16))) float Ks[2 * F32_BK * F32_STRIDE];   // 20 KiB
+  constexpr int WROWS = 64, CROWS = 512;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int bid = blockIdx.x;
+  const int r = p.nchunks - 1 - bid / p.n_ctiles;
+  const int ct = bid - (bid / p.n_ctiles) * p.n_ctiles;
+  const int NP = p.NP;
+  const int k_end = min(NP, (r + 1) * CROWS);
+  const int n_stages = (k_end + F32_BK - 1) / F32_BK;
+  const int wrow0 = r * CROWS + wave * WROWS;
+  const bool active = wrow0 < NP;
+  const int64_t quads = NP / 16;
+  const int wrow_ld = active ? wrow0 : (NP - WROWS);
+  // packed: [slab64][quad][tile2][half2][lane] float4
+  const f4* wp = reinterpret_cast<const f4*>(p.Wp) + (int64_t)(wrow_ld / 64) * quads * 256 + lane;
+
+  f16v acc[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
+
+  auto ld_stage = [&](int stage, float (&kv)[4]) {
+    const float* src = p.Kst + (int64_t)(stage * F32_BK + wave * 4) * p.ldk + (int64_t)ct * F32_CANDS + lane;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) kv[e] = src[(int64_t)e * p.ldk];
+  };
+  auto st_stage = [&](const float (&kv)[4], int buf) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Ks[(buf * F32_BK + wave * 4 + e) * F32_STRIDE + lane] = kv[e];
+  };
+  auto loadA = [&](int kquad, f4(&a)[2][2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) a[t][h] = wp[(((int64_t)kquad * 2 + t) * 2 + h) * 64];
+  };
+  auto mma_quad = [&](int buf, int qq, const f4(&a)[2][2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* kb = Ks + (buf * F32_BK + qq * 16 + h * 8 + 2 * e + (lane >> 5)) * F32_STRIDE + (lane & 31);
+        const float b0 = kb[0], b1 = kb[32];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][h][e], b0, acc[t][0], 0, 0, 0);
+          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][h][e], b1, acc[t][1], 0, 0, 0);
+        }
+      }
+  };
+
+  {
+    float kv0[4];
+    ld_stage(0, kv0);
+    st_stage(kv0, 0);
+  }
+  f4 aA[2][2], aB[2][2];
+  loadA(0, aA);
+  __syncthreads();
+
+  const int n_full = r * (CROWS / F32_BK);
+  int s = 0;
+  for (; s < n_full; ++s) {
+    const int buf = s & 1;
+    float kv[4];
+    loadA(2 * s + 1, aB);
+    ld_stage(s + 1, kv);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_quad(buf, 0, aA);
+    loadA(2 * s + 2, aA);
+    mma_quad(buf, 1, aB);
+    st_stage(kv, buf ^ 1);
+    __syncthreads();
+  }
+  for (; s < n_stages; ++s) {
+    const int buf = s & 1;
+    const bool has_next = (s + 1 < n_stages);
+    const bool domma = (s * F32_BK <= wrow0 + WROWS - 1);
+    const bool domma_next = has_next && ((s + 1) * F32_BK <= wrow0 + WROWS - 1);
+    if (domma) loadA(2 * s + 1, aB);
+    float kv[4];
+    if (has_next) ld_stage(s + 1, kv);
+    if (domma) {
+      mma_quad(buf, 0, aA);
+      mma_quad(buf, 1, aB);
+    }
+    if (has_next) st_stage(kv, buf ^ 1);
+    if (domma_next) loadA(2 * s + 2, aA);
+    __syncthreads();
+  }
+
+  // epilogue: squares in fp32 per lane (32 rows of one candidate), everything beyond that in fp64, fixed order
+  double* red = reinterpret_cast<double*>(Ks);   // [8][64] doubles = 4 KiB
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    float vs = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) vs = fmaf(acc[t][u][e], acc[t][u][e], vs);
+    double v = (double)vs;
+    v += __shfl_xor(v, 32);
+    if (lane < 32) red[wave * F32_CANDS + u * 32 + lane] = active ? v : 0.0;
+  }
+  __syncthreads();
+  if (tid < F32_CANDS) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v += red[w * F32_CANDS + tid];
+    p.part[(int64_t)r * p.Mp + p.m0 + (int64_t)ct * F32_CANDS + tid] = v;
+  }
+}
+
 template <int DP, int KERNEL>
 static int launch_gen32_t(gpbo_ctx* ctx, Model& m, float* Kst, int64_t ldk, int64_t Mp, int64_t m0, int nchunks) {
   dim3 grid((unsigned)((ldk + 255) / 256), (unsigned)nchunks);
@@ -247,7 +407,7 @@ static int launch_gen32_k(gpbo_ctx* ctx, Model& m, float* Kst, int64_t ldk, int6
 // fp32 pipeline per candidate slab; the slab buffer (ctx->kst, sized in doubles) is shared with the fp64 path.
 int launch_posterior_f32(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, int* part_chunks) {
   *part_chunks = nchunks;
-  double budget_gb = 40.0;
+  double budget_gb = 4.0;     // as the fp64 path: a slab only has to fill the chip (posterior_kernel_v2.hip)
   if (const char* e = getenv("GPBO_KSTAR_GB")) budget_gb = atof(e) > 0.0 ? atof(e) : budget_gb;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -272,10 +432,12 @@ int launch_posterior_f32(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, int* 
     // wave tile: 64 rows (chunks of 512 rows) by default; GPBO_F32_RT=2 selects 32 rows (chunks of 256)
     const char* e = getenv("GPBO_F32_RT");
     const bool rt2 = (e && e[0] == '2') || m.NP < 512;
+    const bool mf32 = f32_use_mfma32(m.NP);     // (the packed W of this fit was laid out for the same choice)
     a.nchunks = rt2 ? nchunks : (int)((m.NP + 511) / 512);
     const int64_t nblocks = (int64_t)a.n_ctiles * a.nchunks;
     if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
-    if (rt2) posterior_kernel_f32<2><<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
+    if (mf32) posterior_kernel_f32x<<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
+    else if (rt2) posterior_kernel_f32<2><<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
     else posterior_kernel_f32<4><<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
     GPBO_HIP(ctx, hipGetLastError());
     *part_chunks = a.nchunks;

@@ -326,7 +326,8 @@ int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
   // slab 263.7 ms, eight 4 GB slabs 264.4 ms (round 1 A/B) — the big workspace bought nothing.  GPBO_KSTAR_GB overrides.
   double budget_gb = 4.0;
   if (const char* e = getenv("GPBO_KSTAR_GB")) budget_gb = atof(e) > 0.0 ? atof(e) : budget_gb;
-  static const int post_bk = (getenv("GPBO_POST_BK") && atoi(getenv("GPBO_POST_BK")) == 32) ? 32 : 16;
+  // 32 train points per stage: 262.9 vs 264.0 ms per C3 launch (round-2 A/B, same box, same run); GPBO_POST_BK=16 restores 16
+  static const int post_bk = (getenv("GPBO_POST_BK") && atoi(getenv("GPBO_POST_BK")) == 16) ? 16 : 32;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
     const double avail = ((double)free_b + (double)ctx->cap_kst * 8.0) * 0.8 / 1e9;
