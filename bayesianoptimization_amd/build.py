@@ -34,6 +34,7 @@ SOURCES = {
     "acq_kernels.hip": ["-ffp-contract=off"],  # elementwise formulas follow NumPy op by op
     "candidates.hip": [],
     "mt19937.hip": ["-ffp-contract=off"],      # lo + (hi - lo) * u as NumPy computes it
+    "mt_jump.hip": [],                         # jump-ahead polynomials (host) + sub-stream start states (device)
     "probe.hip": [],
     "comm.hip": [],
 }

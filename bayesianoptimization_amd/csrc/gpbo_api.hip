@@ -244,6 +244,9 @@ int gpbo_destroy(gpbo_ctx* ctx) {
   if (ctx->lml_y) (void)hipFree(ctx->lml_y);
   void* ptrs[] = {ctx->Xc, ctx->Xcs, ctx->part, ctx->mu_part, ctx->ys, ctx->red, ctx->info_dev, ctx->comm_buf, ctx->kst, ctx->stage};
   if (ctx->comm_host) (void)hipHostFree(ctx->comm_host);
+  if (ctx->mt_work) (void)hipFree(ctx->mt_work);
+  if (ctx->mt_bits) (void)hipFree(ctx->mt_bits);
+  if (ctx->mt_offset) (void)hipFree(ctx->mt_offset);
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);

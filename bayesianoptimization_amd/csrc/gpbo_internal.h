@@ -92,6 +92,11 @@ struct gpbo_ctx {
   int d_c = 0;
   double* stage = nullptr; // [d][M] stream-order image of device-generated candidates (mt19937.hip)
   int64_t cap_stage = 0;
+  unsigned* mt_work = nullptr;   // MT19937 jump-ahead work area: returned state | 34-block stretch | sub-stream states
+  int64_t cap_mt_work = 0;
+  uint16_t* mt_bits = nullptr;   // jump polynomial table on the device (set-bit lists), its offsets and its (stride, count) key
+  int* mt_offset = nullptr;
+  int64_t mt_table_key = -1;
   double* Xcs = nullptr;   // [Mp][DP] scaled/padded workspace
   int64_t cap_Xcs = 0;
   double* part = nullptr;  // [nchunks][Mp] partial |W k*|^2
@@ -278,6 +283,9 @@ int launch_posterior_grad_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, d
 // lml_kernels.hip
 int launch_lml_terms(gpbo_ctx* ctx, Model& m, double* out2_dev);
 int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, double* partial, double* grad_dev);
+// mt_jump.hip: states_dev[s] (s = 0 .. count) = block 1 + s * stride_blocks of the MT19937 sequence whose block 0 is key_dev
+int mt_jump_states(gpbo_ctx* ctx, const unsigned* key_dev, int64_t stride_blocks, int count, unsigned* seq_dev,
+                   unsigned* states_dev, uint16_t** bits_dev_io, int** offset_dev_io, int64_t* table_key_io);
 // probe.hip
 int run_mfma_peak(gpbo_ctx* ctx, int iters, double* tflops);
 int run_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);

@@ -95,42 +95,56 @@ __device__ __forceinline__ void mt_regenerate(const unsigned* __restrict__ cur, 
   if (2 * LAG + lane + 128 < MT_N) nxt[2 * LAG + lane + 128] = vC[2];
 }
 
-// key_io: 624 state words (in: the caller's state, out: the last block touched); pos0: words of key_io already
+// key_io: 624 state words (in: the caller's state = block 0, out: the last block touched); pos0: words of key_io already
 // consumed (0..624); T = M * d doubles written in STREAM order (out[t], i.e. the column-major [d][M] image of the
 // candidate matrix: coalesced stores; transpose_stream_kernel turns it into the row-major matrix afterwards);
-// n_blocks = regenerations needed.  Block b lives in ring slot b % 16; per step wave 0 regenerates the next group of
-// four blocks while waves 1..7 temper and store the doubles of the previous group; one workgroup barrier per step.
+// n_blocks = regenerations needed.
+// SUB-STREAMS (mt_jump.hip): workgroup s walks blocks (bs, be] with bs = 0 for s = 0 and 1 + s * stride otherwise,
+// be = min(n_blocks, 1 + (s + 1) * stride); its start block comes from states[s] (jump-ahead), the caller's key for s = 0.
+// A workgroup emits the doubles whose SECOND word lies in its blocks (s = 0 also those of block 0), so a double that
+// straddles two sub-streams belongs to the later one — whose start block holds the first word.  gridDim.x = 1 is the
+// sequential walk.  Block b lives in ring slot b % 16; per step wave 0 regenerates the next group of four blocks while
+// waves 1..7 temper and store the doubles of the previous group; one workgroup barrier per step.
 __global__ __launch_bounds__(512) void mt19937_uniform_kernel(unsigned* __restrict__ key_io, int pos0, int64_t T,
                                                               int64_t M, int d, int64_t n_blocks,
                                                               const double* __restrict__ lohi, double* __restrict__ out,
-                                                              int skip) {   // skip: 1 = no emission, 2 = no regeneration (timing probes)
+                                                              int skip,   // 1 = no emission, 2 = no regeneration (timing probes)
+                                                              const unsigned* __restrict__ states, int64_t stride,
+                                                              unsigned* __restrict__ key_out) {
   __shared__ unsigned ring[MT_RING][MT_N];
   __shared__ double lohi_s[2 * GPBO_MAX_DIM];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const bool generator = tid < 64;
   const int etid = tid - 64;            // 0..447 for the emitting waves: one double each per block (<= 312)
-  for (int k = tid; k < MT_N; k += 512) ring[0][k] = key_io[k];
+  const int64_t sidx = blockIdx.x;
+  const int64_t bs = (sidx == 0) ? 0 : 1 + sidx * stride;                      // start block (given)
+  int64_t be = (gridDim.x == 1) ? n_blocks : 1 + (sidx + 1) * stride;         // last block this workgroup produces
+  if (be > n_blocks || sidx == (int64_t)gridDim.x - 1) be = n_blocks;
+  if (bs > n_blocks) return;                                                   // nothing left for this sub-stream
+  const unsigned* src = (sidx == 0) ? key_io : states + sidx * MT_N;
+  for (int k = tid; k < MT_N; k += 512) ring[bs & (MT_RING - 1)][k] = src[k];
   if (tid < 2 * GPBO_MAX_DIM) lohi_s[tid] = lohi[tid];
   __syncthreads();
-  int64_t col = 0, row = 0;        // position of the first double of the next block to emit (uniform across lanes)
-  const int64_t n_steps = (n_blocks + MT_GROUP - 1) / MT_GROUP;
+  const int64_t my_blocks = be - bs;
+  const int64_t n_steps = (my_blocks + MT_GROUP - 1) / MT_GROUP;
   for (int64_t step = 0; step <= n_steps; ++step) {
     if (generator) {
       if (!(skip & 2)) {
         for (int j = 1; j <= MT_GROUP; ++j) {
-          const int64_t b = step * MT_GROUP + j;          // block to produce, from block b - 1
-          if (b > n_blocks) break;
-          mt_regenerate(ring[(b - 1) % MT_RING], ring[b % MT_RING], lane);
+          const int64_t b = bs + step * MT_GROUP + j;          // block to produce, from block b - 1
+          if (b > be) break;
+          mt_regenerate(ring[(b - 1) & (MT_RING - 1)], ring[b & (MT_RING - 1)], lane);
           GPBO_WAVE_SYNC();
         }
       }
-    } else if (!(skip & 1)) {
+    } else if (!(skip & 1) && !(step == 0 && sidx > 0)) {
       // Doubles whose SECOND word lies in the previous group of blocks (block 0, the caller's state, in the first
-      // step).  Their stream indices t are contiguous, so the emitting lanes simply split [t_lo, t_hi); a double's
-      // two words sit at virtual positions v1 = pos0 + 2t and v1 + 1, located in the ring relative to b_first.
-      const int64_t b_first = (step == 0) ? 0 : (step - 1) * MT_GROUP + 1;
-      const int64_t b_last = (step == 0) ? 0 : min(n_blocks, (step - 1) * MT_GROUP + MT_GROUP);
+      // step of the first sub-stream).  Their stream indices t are contiguous, so the emitting lanes simply split
+      // [t_lo, t_hi); a double's two words sit at virtual positions v1 = pos0 + 2t and v1 + 1, located in the ring
+      // relative to b_first.
+      const int64_t b_first = (step == 0) ? bs : bs + (step - 1) * MT_GROUP + 1;
+      const int64_t b_last = (step == 0) ? bs : min(be, bs + (step - 1) * MT_GROUP + MT_GROUP);
       const int64_t v_lo = (int64_t)MT_N * b_first, v_hi = (int64_t)MT_N * (b_last + 1);   // [v_lo, v_hi)
       const int64_t t_lo = (v_lo - pos0 - 1 >= 0) ? (v_lo - pos0) / 2 : 0;                 // ceil((v_lo - pos0 - 1) / 2)
       int64_t t_hi = (v_hi - pos0 - 2 >= 0) ? (v_hi - pos0 - 2) / 2 + 1 : 0;               // exclusive
@@ -138,8 +152,10 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(unsigned* __restri
       const int cnt = (t_hi > t_lo) ? (int)(t_hi - t_lo) : 0;                              // <= 4 * 312 + 1
       const int rel0 = (int)(pos0 + 2 * t_lo - v_lo);                                      // first word of double t_lo: >= -1
       const int slot0 = (int)(b_first & (MT_RING - 1));
-      const int cn = (col + 1 < d) ? (int)col + 1 : (int)col;      // a group spans at most two columns when M >= 1280
-      const double lo0 = lohi_s[col], rg0 = lohi_s[GPBO_MAX_DIM + col];
+      const int64_t col = t_lo / M, row = t_lo - col * M;          // position of double t_lo in the [d][M] image
+      const int c0 = (int)min(col, (int64_t)d - 1);
+      const int cn = (c0 + 1 < d) ? c0 + 1 : c0;                   // a group spans at most two columns when M >= 1280
+      const double lo0 = lohi_s[c0], rg0 = lohi_s[GPBO_MAX_DIM + c0];
       const double lo1 = lohi_s[cn], rg1 = lohi_s[GPBO_MAX_DIM + cn];
       for (int o = etid; o < cnt; o += 448) {
         const int rel1 = rel0 + 2 * o, rel2 = rel1 + 1;
@@ -166,18 +182,15 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(unsigned* __restri
         }
         out[t_lo + o] = lo_c + rg_c * u;                                      // lo + (hi - lo) * u
       }
-      row += cnt;
-      if (M >= 1280) {
-        if (row >= M) { row -= M; ++col; }
-      } else {
-        col += row / M;
-        row = row % M;
-      }
     }
     __syncthreads();
   }
-  const unsigned* last = ring[n_blocks % MT_RING];
-  for (int k = tid; k < MT_N; k += 512) key_io[k] = last[k];
+  // the workgroup that produced the last block hands the state back (exactly one: the one with bs < n_blocks <= be,
+  // or the first when nothing had to be regenerated); key_out is not key_io — other workgroups may still be reading that
+  if (be == n_blocks && (bs < n_blocks || sidx == 0)) {
+    const unsigned* last = ring[n_blocks & (MT_RING - 1)];
+    for (int k = tid; k < MT_N; k += 512) key_out[k] = last[k];
+  }
 }
 
 // stream image S[c][r] (d x M) -> candidate matrix Xc[r][c] (M x d)
@@ -217,13 +230,37 @@ extern "C" int gpbo_generate_candidates_mt19937(gpbo_ctx* ctx, int64_t M, int d,
   unsigned* dkey = (unsigned*)((char*)ctx->red + head);
   const int64_t T = M * d, words = 2 * T, avail = MT_N - *pos;
   const int64_t n_blocks = (words > avail) ? (words - avail + MT_N - 1) / MT_N : 0;
-  mt19937_uniform_kernel<<<dim3(1), dim3(512), 0, ctx->stream>>>(dkey, *pos, T, M, d, n_blocks,
-                                                                  (const double*)ctx->red, ctx->stage,
-                                                                  getenv("GPBO_MT_PROBE") ? atoi(getenv("GPBO_MT_PROBE")) : 0);
+  // Sub-streams by jump-ahead (mt_jump.hip): the block chain is sequential, so a long stream is cut into S pieces whose
+  // start states are computed side by side from the polynomial table of (stride, S - 1) — cached per process, hence a
+  // stride that depends on (M, d) only, not on the caller's position in its block.  Short streams keep the single walk.
+  int S = 1;
+  int64_t stride = 0;
+  {
+    const char* e = getenv("GPBO_MT_STREAMS");               // 64 sub-streams by default; 1 = the sequential walk
+    const int want = e ? atoi(e) : 64;
+    const int64_t upper = words / MT_N + 2;                  // >= n_blocks for any pos
+    if (want > 1 && upper >= (int64_t)want * (e ? 4 : 16)) {  // (short streams are not worth the jump kernels)
+      S = want > 256 ? 256 : want;
+      stride = (upper + S - 1) / S;
+    }
+  }
+  // device work area: [key_out 624 | seq 34 x 624 | states S x 624] words
+  if ((rc = ensure(ctx, &ctx->mt_work, &ctx->cap_mt_work, (int64_t)MT_N * (1 + 34 + (S > 1 ? S : 1))))) return rc;
+  unsigned* key_out = ctx->mt_work;
+  unsigned* seq_dev = key_out + MT_N;
+  unsigned* states_dev = seq_dev + 34 * MT_N;
+  if (S > 1) {
+    if ((rc = mt_jump_states(ctx, dkey, stride, S - 1, seq_dev, states_dev, &ctx->mt_bits, &ctx->mt_offset, &ctx->mt_table_key)))
+      return rc;
+  }
+  mt19937_uniform_kernel<<<dim3((unsigned)S), dim3(512), 0, ctx->stream>>>(dkey, *pos, T, M, d, n_blocks,
+                                                                          (const double*)ctx->red, ctx->stage,
+                                                                          getenv("GPBO_MT_PROBE") ? atoi(getenv("GPBO_MT_PROBE")) : 0,
+                                                                          states_dev, stride, key_out);
   GPBO_HIP(ctx, hipGetLastError());
   transpose_stream_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->stage, M, d, ctx->Xc);
   GPBO_HIP(ctx, hipGetLastError());
-  GPBO_HIP(ctx, hipMemcpyAsync(hkey, dkey, MT_N * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  GPBO_HIP(ctx, hipMemcpyAsync(hkey, key_out, MT_N * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int k = 0; k < MT_N; ++k) key[k] = hkey[k];
   *pos = (words <= avail) ? (int)(*pos + words) : (int)((words - avail - 1) % MT_N + 1);

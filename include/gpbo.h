@@ -135,6 +135,11 @@ int gpbo_generate_candidates(gpbo_ctx* ctx, int64_t M, int d, const double* lo, 
  * stream.  Removes the host sampling and the upload without changing a single candidate. */
 int gpbo_generate_candidates_mt19937(gpbo_ctx* ctx, int64_t M, int d, const double* lo, const double* hi,
                                      uint32_t* key, int* pos);
+/* MT19937 jump-ahead on the host: key_out = the 624-word block n_blocks (>= 1) after key_in, computed as
+ * (x^(624 (n_blocks - 1)) mod phi)(F) applied to the state — the same polynomial route by which
+ * gpbo_generate_candidates_mt19937 starts its sub-streams on the device (csrc/mt_jump.hip).  Equivalent to drawing
+ * 624 * n_blocks outputs from numpy.random.RandomState and reading get_state()[1], in O(log n_blocks) polynomial products. */
+int gpbo_mt19937_jump_blocks(const uint32_t key_in[624], int64_t n_blocks, uint32_t key_out[624]);
 /* Copy n rows (by index) of the resident candidate matrix back to the host (x_min and the seeds,
  * bayes_opt/acquisition.py:313-317); out is (n, d) row-major; out-of-range indices give NaN rows. */
 int gpbo_get_candidate_rows(gpbo_ctx* ctx, const int64_t* idx, int n, double* out);

@@ -281,7 +281,28 @@ def test_incremental_refit_in_a_maximize_loop(engine):
     assert np.array_equal(picks[True], picks[False])
 
 
-@pytest.mark.parametrize("M,d,burn", [(1, 1, 0), (311, 2, 1), (313, 3, 623), (5000, 7, 0), (70000, 16, 12345), (100, 64, 7)])
+@pytest.mark.parametrize("streams", [2, 7, 64, 256])
+def test_device_candidate_substreams_by_jump_ahead_are_the_sequential_stream(engine, streams, monkeypatch):
+    """The sub-stream generator (csrc/mt_jump.hip: S start states by polynomial jump-ahead, S workgroups) against the
+    reference stream, EVERY value, for sub-stream counts that do and do not divide the block count, an odd stream
+    position, doubles that straddle sub-stream boundaries, and the state handed back."""
+    monkeypatch.setenv("GPBO_MT_STREAMS", str(streams))
+    M, d = 150001, 5
+    lo = np.linspace(-1.0, 2.0, d)
+    hi = lo + np.linspace(0.5, 3.0, d)
+    ref, dev = np.random.RandomState(99), np.random.RandomState(99)
+    for r in (ref, dev):
+        r.randint(0, 2**31 - 1, size=1001)
+    want = np.column_stack([ref.uniform(lo[t], hi[t], M) for t in range(d)])
+    engine.generate_candidates_like(M, lo, hi, dev)
+    got = np.vstack([engine.get_candidate_rows(np.arange(s0, min(M, s0 + 4096)), d) for s0 in range(0, M, 4096)])
+    assert np.array_equal(got, want)
+    assert np.array_equal(dev.get_state()[1], ref.get_state()[1]) and dev.get_state()[2] == ref.get_state()[2]
+    assert np.array_equal(dev.uniform(size=700), ref.uniform(size=700))
+
+
+@pytest.mark.parametrize("M,d,burn", [(1, 1, 0), (311, 2, 1), (313, 3, 623), (5000, 7, 0), (70000, 16, 12345), (100, 64, 7),
+                                      (1 << 17, 8, 3)])
 def test_device_candidates_are_the_reference_stream(engine, M, d, burn):
     """gpbo_generate_candidates_mt19937: the resident candidate matrix equals, bit for bit, the per-column
     RandomState.uniform draws of TargetSpace.random_sample (target_space.py:593-600) from any stream position, and the
