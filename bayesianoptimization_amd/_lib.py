@@ -48,6 +48,9 @@ SIGNATURES = {
     "gpbo_generate_candidates": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, _c_double_p, _c_double_p, C.c_uint64]),
     "gpbo_generate_candidates_mt19937": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, _c_double_p, _c_double_p,
                                                    C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "gpbo_generate_candidate_rows_mt19937": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int64, C.c_int64, _c_double_p,
+                                                       _c_double_p, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32),
+                                                       C.POINTER(C.c_int)]),
     "gpbo_mt19937_jump_blocks": (C.c_int, [C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_uint32)]),
     "gpbo_get_candidate_rows": (C.c_int, [C.c_void_p, _c_int64_p, C.c_int, _c_double_p]),
     "gpbo_posterior": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, _c_double_p, _c_double_p]),
@@ -82,6 +85,8 @@ SIGNATURES = {
     "gpbo_group_fit_append": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int64, C.c_int, _c_double_p, C.c_int64,
                                         C.POINTER(C.c_int)]),
     "gpbo_group_set_candidates": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, C.c_int]),
+    "gpbo_group_generate_candidates_mt19937": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, _c_double_p, _c_double_p,
+                                                         C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "gpbo_group_shard": (C.c_int, [C.c_void_p, C.c_int, _c_int64_p, _c_int64_p]),
     "gpbo_group_posterior": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, _c_double_p, _c_double_p]),
     "gpbo_group_acq_argbest": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, _c_double_p,

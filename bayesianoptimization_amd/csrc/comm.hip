@@ -394,6 +394,31 @@ extern "C" int gpbo_group_set_candidates(gpbo_group* g, const double* Xc, int64_
   });
 }
 
+extern "C" int gpbo_generate_candidate_rows_mt19937(gpbo_ctx* ctx, int64_t M, int d, int64_t row_begin, int64_t row_end,
+                                                    const double* lo, const double* hi, const uint32_t* key, int pos,
+                                                    uint32_t* key_out, int* pos_out);
+
+extern "C" int gpbo_group_generate_candidates_mt19937(gpbo_group* g, int64_t M, int d, const double* lo, const double* hi,
+                                                      uint32_t* key, int* pos) {
+  if (!g) return GPBO_ERR_INVALID;
+  if (!lo || !hi || !key || !pos || d < 1 || d > GPBO_MAX_DIM || M < (int64_t)g->ctx.size() || *pos < 0 || *pos > 624)
+    return group_fail(g, GPBO_ERR_INVALID, "group_generate_candidates_mt19937: bad arguments (need >= one candidate per device)");
+  group_partition(g, M, d);
+  uint32_t key_new[624];
+  int pos_new = *pos;
+  // every device draws ITS rows of every column straight from the caller's stream (jump-ahead sub-streams): no host
+  // sampling, no upload; the device that owns the last row hands the advanced state back
+  int rc = g->run([&](int r) {
+    const bool last = (r + 1 == (int)g->ctx.size());
+    return gpbo_generate_candidate_rows_mt19937(g->ctx[r], M, d, g->row0[r], g->row0[r + 1], lo, hi, key, *pos,
+                                                last ? key_new : nullptr, last ? &pos_new : nullptr);
+  });
+  if (rc) return rc;
+  memcpy(key, key_new, sizeof(key_new));
+  *pos = pos_new;
+  return GPBO_OK;
+}
+
 extern "C" int gpbo_group_shard(const gpbo_group* g, int rank, int64_t* row_begin, int64_t* row_end) {
   if (!g || rank < 0 || rank >= (int)g->ctx.size() || g->row0.empty()) return GPBO_ERR_INVALID;
   if (row_begin) *row_begin = g->row0[rank];

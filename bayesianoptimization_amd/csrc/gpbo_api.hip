@@ -247,6 +247,7 @@ int gpbo_destroy(gpbo_ctx* ctx) {
   if (ctx->mt_work) (void)hipFree(ctx->mt_work);
   if (ctx->mt_bits) (void)hipFree(ctx->mt_bits);
   if (ctx->mt_offset) (void)hipFree(ctx->mt_offset);
+  if (ctx->mt_desc) (void)hipFree(ctx->mt_desc);
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -94,9 +94,12 @@ struct gpbo_ctx {
   int64_t cap_stage = 0;
   unsigned* mt_work = nullptr;   // MT19937 jump-ahead work area: returned state | 34-block stretch | sub-stream states
   int64_t cap_mt_work = 0;
-  uint16_t* mt_bits = nullptr;   // jump polynomial table on the device (set-bit lists), its offsets and its (stride, count) key
+  uint16_t* mt_bits = nullptr;   // jump polynomial table on the device (set-bit lists), its offsets, its stride and size
   int* mt_offset = nullptr;
-  int64_t mt_table_key = -1;
+  int64_t mt_table_stride = -1;
+  int mt_table_count = 0;
+  void* mt_desc = nullptr;       // sub-stream descriptors + polynomial indices of the current call (device)
+  int64_t cap_mt_desc = 0;
   double* Xcs = nullptr;   // [Mp][DP] scaled/padded workspace
   int64_t cap_Xcs = 0;
   double* part = nullptr;  // [nchunks][Mp] partial |W k*|^2
@@ -283,9 +286,9 @@ int launch_posterior_grad_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, d
 // lml_kernels.hip
 int launch_lml_terms(gpbo_ctx* ctx, Model& m, double* out2_dev);
 int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, double* partial, double* grad_dev);
-// mt_jump.hip: states_dev[s] (s = 0 .. count) = block 1 + s * stride_blocks of the MT19937 sequence whose block 0 is key_dev
-int mt_jump_states(gpbo_ctx* ctx, const unsigned* key_dev, int64_t stride_blocks, int count, unsigned* seq_dev,
-                   unsigned* states_dev, uint16_t** bits_dev_io, int** offset_dev_io, int64_t* table_key_io);
+// mt_jump.hip: states_dev[w] = block 1 + poly_idx[w] * stride_blocks of the MT19937 sequence whose block 0 is key_dev
+int mt_jump_states(gpbo_ctx* ctx, const unsigned* key_dev, int64_t stride_blocks, int max_k, const int* poly_idx_dev,
+                   int n_states, unsigned* seq_dev, unsigned* states_dev);
 // probe.hip
 int run_mfma_peak(gpbo_ctx* ctx, int iters, double* tflops);
 int run_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);

@@ -18,7 +18,11 @@
 // later ones are written): wave 0 regenerates (the three phases chained through registers, see mt_regenerate), waves
 // 1..7 meanwhile temper the previous group's words into doubles and store them (312 per block); one workgroup
 // barrier per group of four blocks.  The kernel is latency-bound by construction (53 k dependent blocks for 2^20 x 16 candidates).
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
 
 #include "gpbo_internal.h"
 
@@ -95,36 +99,45 @@ __device__ __forceinline__ void mt_regenerate(const unsigned* __restrict__ cur, 
   if (2 * LAG + lane + 128 < MT_N) nxt[2 * LAG + lane + 128] = vC[2];
 }
 
-// key_io: 624 state words (in: the caller's state = block 0, out: the last block touched); pos0: words of key_io already
-// consumed (0..624); T = M * d doubles written in STREAM order (out[t], i.e. the column-major [d][M] image of the
-// candidate matrix: coalesced stores; transpose_stream_kernel turns it into the row-major matrix afterwards);
-// n_blocks = regenerations needed.
-// SUB-STREAMS (mt_jump.hip): workgroup s walks blocks (bs, be] with bs = 0 for s = 0 and 1 + s * stride otherwise,
-// be = min(n_blocks, 1 + (s + 1) * stride); its start block comes from states[s] (jump-ahead), the caller's key for s = 0.
-// A workgroup emits the doubles whose SECOND word lies in its blocks (s = 0 also those of block 0), so a double that
-// straddles two sub-streams belongs to the later one — whose start block holds the first word.  gridDim.x = 1 is the
-// sequential walk.  Block b lives in ring slot b % 16; per step wave 0 regenerates the next group of four blocks while
-// waves 1..7 temper and store the doubles of the previous group; one workgroup barrier per step.
-__global__ __launch_bounds__(512) void mt19937_uniform_kernel(unsigned* __restrict__ key_io, int pos0, int64_t T,
-                                                              int64_t M, int d, int64_t n_blocks,
+// One sub-stream = one workgroup = one descriptor: a run of doubles [t_begin, t_end) of ONE column of the reference's
+// candidate matrix (stream index t = column * M + row; double t is made of the 32-bit outputs pos0 + 2t and pos0 + 2t + 1,
+// counted from the start of the caller's current 624-word block).  The workgroup starts from block `bs` — the caller's
+// state (state_idx < 0, bs = 0) or a jump-ahead state (mt_jump.hip) at or before the block that holds the first word —
+// walks the chain to the block that holds its last word, and stores lo + (hi - lo) * u at out[t + out_base], i.e. into the
+// column-major image of the rows this context keeps (transpose_stream_kernel makes the row-major matrix of it).  Block b
+// lives in ring slot b % 16; per step wave 0 regenerates the next group of four blocks while waves 1..7 temper and store the
+// doubles whose second word lies in the previous group; one workgroup barrier per step.  The descriptor flagged `is_last`
+// (it ends at the last double of the whole matrix) also returns the last block: the state the caller's RandomState must
+// continue from.
+struct MtChunk {
+  int64_t bs;          // block the walk starts from
+  int64_t t_begin, t_end;
+  int64_t out_base;    // out index = t + out_base
+  int state_idx;       // < 0: the caller's state (block 0); else index into states[]
+  int col;
+  int is_last;
+  int pad;
+};
+
+__global__ __launch_bounds__(512) void mt19937_uniform_kernel(const unsigned* __restrict__ key_in, int pos0,
+                                                              const MtChunk* __restrict__ chunks,
+                                                              const unsigned* __restrict__ states,
                                                               const double* __restrict__ lohi, double* __restrict__ out,
-                                                              int skip,   // 1 = no emission, 2 = no regeneration (timing probes)
-                                                              const unsigned* __restrict__ states, int64_t stride,
-                                                              unsigned* __restrict__ key_out) {
+                                                              unsigned* __restrict__ key_out,
+                                                              int skip) {   // 1 = no emission, 2 = no regeneration (timing probes)
   __shared__ unsigned ring[MT_RING][MT_N];
-  __shared__ double lohi_s[2 * GPBO_MAX_DIM];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const bool generator = tid < 64;
   const int etid = tid - 64;            // 0..447 for the emitting waves: one double each per block (<= 312)
-  const int64_t sidx = blockIdx.x;
-  const int64_t bs = (sidx == 0) ? 0 : 1 + sidx * stride;                      // start block (given)
-  int64_t be = (gridDim.x == 1) ? n_blocks : 1 + (sidx + 1) * stride;         // last block this workgroup produces
-  if (be > n_blocks || sidx == (int64_t)gridDim.x - 1) be = n_blocks;
-  if (bs > n_blocks) return;                                                   // nothing left for this sub-stream
-  const unsigned* src = (sidx == 0) ? key_io : states + sidx * MT_N;
+  const MtChunk c = chunks[blockIdx.x];
+  const int64_t bs = c.bs;
+  // block that holds the last word of the last double (>= bs by construction); an empty run still returns the state
+  const int64_t v_last = (c.t_end > c.t_begin) ? (int64_t)pos0 + 2 * c.t_end - 1 : (int64_t)MT_N * bs;
+  const int64_t be = max(bs, v_last / MT_N);
+  const unsigned* src = (c.state_idx < 0) ? key_in : states + (int64_t)c.state_idx * MT_N;
   for (int k = tid; k < MT_N; k += 512) ring[bs & (MT_RING - 1)][k] = src[k];
-  if (tid < 2 * GPBO_MAX_DIM) lohi_s[tid] = lohi[tid];
+  const double lo_c = lohi[c.col], rg_c = lohi[GPBO_MAX_DIM + c.col];
   __syncthreads();
   const int64_t my_blocks = be - bs;
   const int64_t n_steps = (my_blocks + MT_GROUP - 1) / MT_GROUP;
@@ -138,25 +151,21 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(unsigned* __restri
           GPBO_WAVE_SYNC();
         }
       }
-    } else if (!(skip & 1) && !(step == 0 && sidx > 0)) {
-      // Doubles whose SECOND word lies in the previous group of blocks (block 0, the caller's state, in the first
-      // step of the first sub-stream).  Their stream indices t are contiguous, so the emitting lanes simply split
-      // [t_lo, t_hi); a double's two words sit at virtual positions v1 = pos0 + 2t and v1 + 1, located in the ring
-      // relative to b_first.
+    } else if (!(skip & 1)) {
+      // Doubles whose SECOND word lies in the previous group of blocks (the start block itself in the first step), cut to
+      // [t_begin, t_end).  Their stream indices are contiguous, so the emitting lanes simply split [t_lo, t_hi); the two
+      // words of double t sit at virtual positions v1 = pos0 + 2t and v1 + 1, located in the ring relative to b_first.
+      // (t >= t_begin has its first word at or after block bs, so every word read here has been produced.)
       const int64_t b_first = (step == 0) ? bs : bs + (step - 1) * MT_GROUP + 1;
       const int64_t b_last = (step == 0) ? bs : min(be, bs + (step - 1) * MT_GROUP + MT_GROUP);
       const int64_t v_lo = (int64_t)MT_N * b_first, v_hi = (int64_t)MT_N * (b_last + 1);   // [v_lo, v_hi)
-      const int64_t t_lo = (v_lo - pos0 - 1 >= 0) ? (v_lo - pos0) / 2 : 0;                 // ceil((v_lo - pos0 - 1) / 2)
+      int64_t t_lo = (v_lo - pos0 - 1 >= 0) ? (v_lo - pos0) / 2 : 0;                       // ceil((v_lo - pos0 - 1) / 2)
       int64_t t_hi = (v_hi - pos0 - 2 >= 0) ? (v_hi - pos0 - 2) / 2 + 1 : 0;               // exclusive
-      if (t_hi > T) t_hi = T;
+      if (t_lo < c.t_begin) t_lo = c.t_begin;
+      if (t_hi > c.t_end) t_hi = c.t_end;
       const int cnt = (t_hi > t_lo) ? (int)(t_hi - t_lo) : 0;                              // <= 4 * 312 + 1
       const int rel0 = (int)(pos0 + 2 * t_lo - v_lo);                                      // first word of double t_lo: >= -1
       const int slot0 = (int)(b_first & (MT_RING - 1));
-      const int64_t col = t_lo / M, row = t_lo - col * M;          // position of double t_lo in the [d][M] image
-      const int c0 = (int)min(col, (int64_t)d - 1);
-      const int cn = (c0 + 1 < d) ? c0 + 1 : c0;                   // a group spans at most two columns when M >= 1280
-      const double lo0 = lohi_s[c0], rg0 = lohi_s[GPBO_MAX_DIM + c0];
-      const double lo1 = lohi_s[cn], rg1 = lohi_s[GPBO_MAX_DIM + cn];
       for (int o = etid; o < cnt; o += 448) {
         const int rel1 = rel0 + 2 * o, rel2 = rel1 + 1;
         const int q2 = rel2 / MT_N;
@@ -170,25 +179,13 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(unsigned* __restri
         }
         const unsigned a = mt_temper(w1) >> 5, bb = mt_temper(w2) >> 6;
         const double u = ((double)a * 67108864.0 + (double)bb) / 9007199254740992.0;
-        double lo_c, rg_c;
-        if (M >= 1280) {
-          const bool nextcol = row + o >= M;
-          lo_c = nextcol ? lo1 : lo0;
-          rg_c = nextcol ? rg1 : rg0;
-        } else {
-          const int64_t c = col + (row + o) / M;
-          lo_c = lohi_s[c];
-          rg_c = lohi_s[GPBO_MAX_DIM + c];
-        }
-        out[t_lo + o] = lo_c + rg_c * u;                                      // lo + (hi - lo) * u
+        out[t_lo + o + c.out_base] = lo_c + rg_c * u;                                     // lo + (hi - lo) * u
       }
     }
     __syncthreads();
   }
-  // the workgroup that produced the last block hands the state back (exactly one: the one with bs < n_blocks <= be,
-  // or the first when nothing had to be regenerated); key_out is not key_io — other workgroups may still be reading that
-  if (be == n_blocks && (bs < n_blocks || sidx == 0)) {
-    const unsigned* last = ring[n_blocks & (MT_RING - 1)];
+  if (c.is_last) {
+    const unsigned* last = ring[be & (MT_RING - 1)];
     for (int k = tid; k < MT_N; k += 512) key_out[k] = last[k];
   }
 }
@@ -205,15 +202,19 @@ __global__ __launch_bounds__(256) void transpose_stream_kernel(const double* __r
 
 using namespace gpbo;
 
-extern "C" int gpbo_generate_candidates_mt19937(gpbo_ctx* ctx, int64_t M, int d, const double* lo, const double* hi,
-                                                uint32_t* key, int* pos) {
-  if (!ctx) return GPBO_ERR_INVALID;
-  if (!lo || !hi || !key || !pos || M < 1 || d < 1 || d > GPBO_MAX_DIM || *pos < 0 || *pos > MT_N)
-    GPBO_FAIL(ctx, GPBO_ERR_INVALID, "generate_candidates_mt19937: bad arguments");
+// Rows [r0, r1) of the (M, d) candidate matrix TargetSpace.random_sample(M, random_state) would return, generated from the
+// state (key, pos) and left resident as this context's candidate matrix ((r1 - r0) x d).  Sub-streams: every column's run
+// of rows is cut into pieces; each piece starts from a jump-ahead state on a uniform grid of block offsets (stride chosen
+// from (M, d, pieces) only, so the polynomial table is built once per process) and walks at most `stride` blocks before
+// its first word.  key_out / pos_out (may be NULL): the state after the WHOLE matrix — available only when the last row
+// is generated here (r1 == M); *has_state says so.
+static int mt_generate_rows(gpbo_ctx* ctx, int64_t M, int d, int64_t r0, int64_t r1, const double* lo, const double* hi,
+                            const uint32_t* key, int pos, uint32_t* key_out, int* pos_out, int* has_state) {
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t Mloc = r1 - r0;
   int rc;
-  if ((rc = ensure(ctx, &ctx->Xc, &ctx->cap_Xc, M * d))) return rc;
-  if ((rc = ensure(ctx, &ctx->stage, &ctx->cap_stage, M * d))) return rc;
+  if ((rc = ensure(ctx, &ctx->Xc, &ctx->cap_Xc, Mloc * d))) return rc;
+  if ((rc = ensure(ctx, &ctx->stage, &ctx->cap_stage, Mloc * d))) return rc;
   {
     char* p = (char*)ctx->red;
     int64_t cap = ctx->cap_red;
@@ -228,44 +229,113 @@ extern "C" int gpbo_generate_candidates_mt19937(gpbo_ctx* ctx, int64_t M, int d,
   const size_t head = 2 * GPBO_MAX_DIM * sizeof(double);
   GPBO_HIP(ctx, hipMemcpyAsync(ctx->red, h, head + MT_N * sizeof(unsigned), hipMemcpyHostToDevice, ctx->stream));
   unsigned* dkey = (unsigned*)((char*)ctx->red + head);
-  const int64_t T = M * d, words = 2 * T, avail = MT_N - *pos;
-  const int64_t n_blocks = (words > avail) ? (words - avail + MT_N - 1) / MT_N : 0;
-  // Sub-streams by jump-ahead (mt_jump.hip): the block chain is sequential, so a long stream is cut into S pieces whose
-  // start states are computed side by side from the polynomial table of (stride, S - 1) — cached per process, hence a
-  // stride that depends on (M, d) only, not on the caller's position in its block.  Short streams keep the single walk.
-  int S = 1;
-  int64_t stride = 0;
-  {
-    const char* e = getenv("GPBO_MT_STREAMS");               // 64 sub-streams by default; 1 = the sequential walk
-    const int want = e ? atoi(e) : 64;
-    const int64_t upper = words / MT_N + 2;                  // >= n_blocks for any pos
-    if (want > 1 && upper >= (int64_t)want * (e ? 4 : 16)) {  // (short streams are not worth the jump kernels)
-      S = want > 256 ? 256 : want;
-      stride = (upper + S - 1) / S;
+  const int64_t T = M * d, words = 2 * T, avail = MT_N - pos;
+  const int64_t n_blocks = (words > avail) ? (words - avail + MT_N - 1) / MT_N : 0;   // block that holds the last word
+
+  // ---- plan: d columns x P pieces --------------------------------------------------------------------------------------
+  int want = 64;                                            // sub-streams aimed at (GPBO_MT_STREAMS); at least one per column
+  if (const char* e = getenv("GPBO_MT_STREAMS")) want = atoi(e) > 0 ? atoi(e) : 1;
+  if (want > 1024) want = 1024;
+  const int64_t my_blocks = 2 * Mloc * d / MT_N + 1;        // blocks' worth of words generated here
+  // a tiny stream: one run per column, each walking from the caller's block (the prefix it re-walks is tiny by definition)
+  const bool tiny = 2 * M * d / MT_N < 64;
+  int P = 1;                                                // pieces per column
+  if (!tiny && want > d && my_blocks >= (int64_t)want * 4) P = (int)((want + d - 1) / d);
+  // uniform grid of jump targets: block 1 + k * stride.  A quarter of a piece: a piece walks < stride idle blocks.
+  const int64_t piece_blocks = std::max<int64_t>(1, 2 * ((Mloc + P - 1) / P) / MT_N);
+  const int64_t stride = std::max<int64_t>(1, piece_blocks / 4);
+  std::vector<MtChunk> chunks;
+  std::vector<int> polys;        // polynomial index per state slot
+  int max_k = 0;
+  for (int col = 0; col < d; ++col) {
+    for (int p = 0; p < P; ++p) {
+      MtChunk c{};
+      const int64_t ra = r0 + Mloc * p / P, rb = r0 + Mloc * (p + 1) / P;
+      c.t_begin = (int64_t)col * M + ra;
+      c.t_end = (int64_t)col * M + rb;
+      c.out_base = (int64_t)col * Mloc - ((int64_t)col * M + r0);
+      c.col = col;
+      c.is_last = (c.t_end == T) ? 1 : 0;
+      const int64_t bneed = ((int64_t)pos + 2 * c.t_begin) / MT_N;       // block of the first word
+      if (bneed == 0 || tiny) {
+        c.bs = 0;
+        c.state_idx = -1;
+      } else {
+        const int64_t k = (bneed - 1) / stride;
+        c.bs = 1 + k * stride;
+        c.state_idx = (int)polys.size();
+        polys.push_back((int)k);
+        if (k > max_k) max_k = (int)k;
+      }
+      chunks.push_back(c);
     }
   }
-  // device work area: [key_out 624 | seq 34 x 624 | states S x 624] words
-  if ((rc = ensure(ctx, &ctx->mt_work, &ctx->cap_mt_work, (int64_t)MT_N * (1 + 34 + (S > 1 ? S : 1))))) return rc;
-  unsigned* key_out = ctx->mt_work;
-  unsigned* seq_dev = key_out + MT_N;
+  if (M * (int64_t)d >= 1 && chunks.empty()) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "generate_candidates_mt19937: empty plan");
+  // when the last double is not generated here, nobody returns the state
+  const bool owns_end = (r1 == M);
+  // device work area: [key_out 624 | seq 34 x 624 | states n x 624] words ; descriptors + polynomial indices
+  const int n_states = (int)polys.size();
+  if ((rc = ensure(ctx, &ctx->mt_work, &ctx->cap_mt_work, (int64_t)MT_N * (1 + 34 + std::max(1, n_states))))) return rc;
+  unsigned* key_out_dev = ctx->mt_work;
+  unsigned* seq_dev = key_out_dev + MT_N;
   unsigned* states_dev = seq_dev + 34 * MT_N;
-  if (S > 1) {
-    if ((rc = mt_jump_states(ctx, dkey, stride, S - 1, seq_dev, states_dev, &ctx->mt_bits, &ctx->mt_offset, &ctx->mt_table_key)))
-      return rc;
+  const size_t desc_bytes = chunks.size() * sizeof(MtChunk), idx_bytes = (size_t)std::max(1, n_states) * sizeof(int);
+  {
+    char* p = (char*)ctx->mt_desc;
+    int64_t cap = ctx->cap_mt_desc;
+    if ((rc = ensure(ctx, &p, &cap, (int64_t)(desc_bytes + idx_bytes + 64)))) return rc;
+    ctx->mt_desc = p;
+    ctx->cap_mt_desc = cap;
   }
-  mt19937_uniform_kernel<<<dim3((unsigned)S), dim3(512), 0, ctx->stream>>>(dkey, *pos, T, M, d, n_blocks,
-                                                                          (const double*)ctx->red, ctx->stage,
-                                                                          getenv("GPBO_MT_PROBE") ? atoi(getenv("GPBO_MT_PROBE")) : 0,
-                                                                          states_dev, stride, key_out);
+  MtChunk* chunks_dev = (MtChunk*)ctx->mt_desc;
+  int* polys_dev = (int*)((char*)ctx->mt_desc + ((desc_bytes + 63) / 64) * 64);
+  GPBO_HIP(ctx, hipMemcpyAsync(chunks_dev, chunks.data(), desc_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (n_states > 0) {
+    GPBO_HIP(ctx, hipMemcpyAsync(polys_dev, polys.data(), (size_t)n_states * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = mt_jump_states(ctx, dkey, stride, max_k, polys_dev, n_states, seq_dev, states_dev))) return rc;
+  }
+  mt19937_uniform_kernel<<<dim3((unsigned)chunks.size()), dim3(512), 0, ctx->stream>>>(
+      dkey, pos, chunks_dev, states_dev, (const double*)ctx->red, ctx->stage, key_out_dev,
+      getenv("GPBO_MT_PROBE") ? atoi(getenv("GPBO_MT_PROBE")) : 0);
   GPBO_HIP(ctx, hipGetLastError());
-  transpose_stream_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->stage, M, d, ctx->Xc);
+  transpose_stream_kernel<<<dim3((unsigned)((Mloc + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->stage, Mloc, d, ctx->Xc);
   GPBO_HIP(ctx, hipGetLastError());
-  GPBO_HIP(ctx, hipMemcpyAsync(hkey, key_out, MT_N * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  if (owns_end) GPBO_HIP(ctx, hipMemcpyAsync(hkey, key_out_dev, MT_N * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (int k = 0; k < MT_N; ++k) key[k] = hkey[k];
-  *pos = (words <= avail) ? (int)(*pos + words) : (int)((words - avail - 1) % MT_N + 1);
-  ctx->M = M;
+  // (the pageable vectors `chunks` / `polys` were consumed by the synchronisation above)
+  if (has_state) *has_state = owns_end ? 1 : 0;
+  if (owns_end && key_out && pos_out) {
+    for (int k = 0; k < MT_N; ++k) key_out[k] = hkey[k];
+    *pos_out = (words <= avail) ? (int)(pos + words) : (int)((words - avail - 1) % MT_N + 1);
+  }
+  (void)n_blocks;
+  ctx->M = Mloc;
   ctx->d_c = d;
   for (auto& m : ctx->models) m.M_post = -1;
   return GPBO_OK;
+}
+
+extern "C" int gpbo_generate_candidates_mt19937(gpbo_ctx* ctx, int64_t M, int d, const double* lo, const double* hi,
+                                                uint32_t* key, int* pos) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  if (!lo || !hi || !key || !pos || M < 1 || d < 1 || d > GPBO_MAX_DIM || *pos < 0 || *pos > MT_N)
+    GPBO_FAIL(ctx, GPBO_ERR_INVALID, "generate_candidates_mt19937: bad arguments");
+  uint32_t key_new[MT_N];
+  int pos_new = 0, has = 0;
+  int rc = mt_generate_rows(ctx, M, d, 0, M, lo, hi, key, *pos, key_new, &pos_new, &has);
+  if (rc) return rc;
+  memcpy(key, key_new, sizeof(key_new));
+  *pos = pos_new;
+  return GPBO_OK;
+}
+
+extern "C" int gpbo_generate_candidate_rows_mt19937(gpbo_ctx* ctx, int64_t M, int d, int64_t row_begin, int64_t row_end,
+                                                    const double* lo, const double* hi, const uint32_t* key, int pos,
+                                                    uint32_t* key_out, int* pos_out) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  if (!lo || !hi || !key || M < 1 || d < 1 || d > GPBO_MAX_DIM || pos < 0 || pos > MT_N || row_begin < 0 ||
+      row_end <= row_begin || row_end > M)
+    GPBO_FAIL(ctx, GPBO_ERR_INVALID, "generate_candidate_rows_mt19937: bad arguments");
+  int has = 0;
+  return mt_generate_rows(ctx, M, d, row_begin, row_end, lo, hi, key, pos, key_out, pos_out, &has);
 }

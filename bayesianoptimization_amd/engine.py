@@ -474,16 +474,33 @@ class GroupEngine(GpEngine):
 
     def generate_candidates_like(self, M: int, lo, hi, random_state):
         """The reference's candidate matrix from `random_state` (one uniform(lo_j, hi_j, M) per column, in order —
-        target_space.py:593-600, parameter.py:86-87), each device receiving its row block."""
+        target_space.py:593-600, parameter.py:86-87): every device generates ITS row block from the caller's MT19937
+        state by jump-ahead (gpbo_group_generate_candidates_mt19937); fewer rows than devices: host draw + upload."""
         lo = np.ascontiguousarray(lo, dtype=np.float64).ravel()
         hi = np.ascontiguousarray(hi, dtype=np.float64).ravel()
         if lo.shape != hi.shape:
             raise ValueError("lo and hi must have the same length")
+        if not np.all(np.isfinite(hi - lo)):
+            raise OverflowError("Range exceeds valid bounds")        # as RandomState.uniform
         n = max(1, int(M))
-        Xc = np.empty((n, lo.shape[0]))
-        for j in range(lo.shape[0]):
-            Xc[:, j] = random_state.uniform(lo[j], hi[j], n)
-        self.set_candidates(Xc)
+        if n < self.world_size:
+            Xc = np.empty((n, lo.shape[0]))
+            for j in range(lo.shape[0]):
+                Xc[:, j] = random_state.uniform(lo[j], hi[j], n)
+            self.set_candidates(Xc)
+            return
+        name, key, pos, has_gauss, cached = random_state.get_state(legacy=True)
+        if name != "MT19937":
+            raise TypeError("generate_candidates_like needs an MT19937 RandomState")
+        key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+        cpos = C.c_int(int(pos))
+        self._gcheck(self._lib.gpbo_group_generate_candidates_mt19937(
+            self._g, n, lo.shape[0], dptr(lo), dptr(hi), key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cpos)))
+        random_state.set_state((name, key, cpos.value, has_gauss, cached))
+        self.n_candidates = n
+        self._M_pad = n
+        self._cand_dim = lo.shape[0]
+        self._resident = True
 
     def get_candidate_rows(self, idx, d: int):
         idx = np.ascontiguousarray(np.atleast_1d(idx), dtype=np.int64)

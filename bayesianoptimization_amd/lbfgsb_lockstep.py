@@ -41,8 +41,47 @@ def _setulb():
     return fn
 
 
+_SELF_CHECK: bool | None = None
+
+
+def _self_check() -> bool:
+    """`setulb` is private SciPy API driven with hand-built work arrays: before the first real use, run the driver on a
+    small bound-constrained problem and require the result of the public `scipy.optimize.minimize` — iterates, counts
+    and status — bit for bit.  A SciPy patch release that changed array sizes or task codes fails here (and the callers
+    fall back to the thread-based lockstep over the public API) instead of corrupting memory or diverging silently."""
+    try:
+        from scipy.optimize import minimize
+
+        def fg(x):
+            x = np.asarray(x, dtype=np.float64)
+            r = x - np.array([0.3, -1.7, 2.5])
+            return float(r @ r + 0.1 * np.sum(x**4)), 2 * r + 0.4 * x**3
+
+        box = np.array([[-1.0, 1.0], [-1.0, 2.0], [0.0, 2.0]])
+        starts = [np.array([0.9, 1.5, 0.1]), np.array([-0.5, -0.5, 1.0])]
+
+        def batch(X):
+            vals = [fg(x) for x in X]
+            return np.array([v[0] for v in vals]), np.array([v[1] for v in vals])
+
+        mine = _drive(batch, 1, starts, box, 10, 2.2204460492503131e-09, 1e-5, 15000, 15000, 20)
+        for r, s0 in zip(mine, starts):
+            ref = minimize(fg, s0, jac=True, bounds=box, method="L-BFGS-B")
+            if not (np.array_equal(r.x, ref.x) and r.fun == ref.fun and r.nit == ref.nit and r.nfev == ref.nfev
+                    and r.status == ref.status):
+                return False
+        return True
+    except Exception:   # noqa: BLE001  (any surprise from a private API = not available)
+        return False
+
+
 def driver_available() -> bool:
-    return _setulb() is not None
+    global _SELF_CHECK
+    if _setulb() is None:
+        return False
+    if _SELF_CHECK is None:
+        _SELF_CHECK = _self_check()
+    return _SELF_CHECK
 
 
 def forward_difference_points(X0, lb, ub):

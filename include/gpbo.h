@@ -135,6 +135,12 @@ int gpbo_generate_candidates(gpbo_ctx* ctx, int64_t M, int d, const double* lo, 
  * stream.  Removes the host sampling and the upload without changing a single candidate. */
 int gpbo_generate_candidates_mt19937(gpbo_ctx* ctx, int64_t M, int d, const double* lo, const double* hi,
                                      uint32_t* key, int* pos);
+/* The same for rows [row_begin, row_end) only (one shard of a candidate set drawn by several GPUs from ONE stream): this
+ * context keeps (row_end - row_begin) x d candidates resident.  key / pos are read only; key_out / pos_out (may be NULL)
+ * receive the state after the WHOLE (M, d) draw and are written only when row_end == M. */
+int gpbo_generate_candidate_rows_mt19937(gpbo_ctx* ctx, int64_t M, int d, int64_t row_begin, int64_t row_end,
+                                         const double* lo, const double* hi, const uint32_t* key, int pos,
+                                         uint32_t* key_out, int* pos_out);
 /* MT19937 jump-ahead on the host: key_out = the 624-word block n_blocks (>= 1) after key_in, computed as
  * (x^(624 (n_blocks - 1)) mod phi)(F) applied to the state — the same polynomial route by which
  * gpbo_generate_candidates_mt19937 starts its sub-streams on the device (csrc/mt_jump.hip).  Equivalent to drawing
@@ -238,6 +244,10 @@ int gpbo_group_fit_append(gpbo_group* grp, int slot, const double* x_new, int64_
 /* x_tries (M,d): device r keeps rows [r M / G, (r + 1) M / G) resident (gpbo_group_shard reports the range). */
 int gpbo_group_set_candidates(gpbo_group* grp, const double* Xc, int64_t M, int d);
 int gpbo_group_shard(const gpbo_group* grp, int rank, int64_t* row_begin, int64_t* row_end);
+/* gpbo_generate_candidates_mt19937 across the group: every device generates ITS row block of the reference's candidate
+ * matrix from the caller's MT19937 state by jump-ahead — no host sampling, no upload; key / pos come back advanced. */
+int gpbo_group_generate_candidates_mt19937(gpbo_group* grp, int64_t M, int d, const double* lo, const double* hi,
+                                           uint32_t* key, int* pos);
 /* gpbo_posterior on every shard; mu / sd (M,) in global row order, or NULL to keep them on the devices. */
 int gpbo_group_posterior(gpbo_group* grp, int slot, double y_mean, double y_std, double* mu, double* sd);
 /* gpbo_acq_argbest over all M candidates: global indices, same tie/NaN rules; ys_out (M,) optional. */

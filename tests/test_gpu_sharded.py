@@ -252,3 +252,26 @@ def test_two_estimators_sharing_a_slot_do_not_read_each_others_factorisation(eng
         assert rel_err(mu, mr) < 1e-8 and rel_err(sd, sr) < 1e-7
     assert rel_err(b.alpha_, rb.alpha_) < 1e-8 and rel_err(a.L_, ra.L_) < 1e-10
     assert a.log_marginal_likelihood_value_ == pytest.approx(ra.log_marginal_likelihood_value_, rel=1e-9)
+
+
+@pytest.mark.parametrize("devices,M,d", [([0, 0], 40001, 3), ([0, 0, 0], 300007, 6), ([0], 5, 2), ([0, 0, 0, 0], 3, 2)])
+def test_device_group_draws_the_reference_candidate_stream_shard_by_shard(devices, M, d):
+    """gpbo_group_generate_candidates_mt19937: every device generates ITS row block of TargetSpace.random_sample(M, rs)
+    (one RandomState.uniform(lo_j, hi_j, M) per column, target_space.py:593-600) from the caller's MT19937 state by
+    jump-ahead — the union of the shards is the reference matrix bit for bit and the RandomState comes back where the
+    reference leaves it."""
+    lo = np.linspace(-2.0, 1.0, d)
+    hi = lo + np.linspace(0.7, 4.0, d)
+    ref, dev = np.random.RandomState(2024), np.random.RandomState(2024)
+    for r in (ref, dev):
+        r.randint(0, 2**31 - 1, size=777)
+    want = np.column_stack([ref.uniform(lo[t], hi[t], M) for t in range(d)])
+    grp = GroupEngine(devices)
+    try:
+        grp.generate_candidates_like(M, lo, hi, dev)
+        got = np.vstack([grp.get_candidate_rows(np.arange(s0, min(M, s0 + 4096)), d) for s0 in range(0, M, 4096)])
+        assert np.array_equal(got, want)
+        assert np.array_equal(dev.get_state()[1], ref.get_state()[1]) and dev.get_state()[2] == ref.get_state()[2]
+        assert dev.uniform() == ref.uniform()
+    finally:
+        grp.close()
