@@ -147,8 +147,14 @@ int launch_kmat(gpbo_ctx* ctx, Model& m, double noise, double* out) {
 // Writes L_kk in place (upper part zeroed) and L_kk^-1 to dinv[kb].
 constexpr int PD_S = 80;   // LDS row stride (doubles): the two k-rows of a 32-lane ds_read_b64 group fall 32 banks apart
 
+// FUSE (look-ahead, see cholesky() in gpbo_api.hip): the block has received the rank-64 updates of every block column but
+// the previous one, whose panel solve and update are still running on the second stream.  The kernel applies that last
+// update to ITS block itself: X = Q dprev^T (Q = a copy of block (kb, kb-1) taken before the panel solve overwrites it,
+// dprev = the inverse of the previous diagonal block), A_kk -= X X^T — two 64^3 MFMA products out of LDS — and then
+// factors.  The concurrent update kernel leaves block (kb, kb) alone.
+template <bool FUSE>
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, int kb, double* __restrict__ dinv, int* info,
-                                                          int64_t lane_stride) {
+                                                          int64_t lane_stride, const double* __restrict__ Q) {
   L += (int64_t)blockIdx.x * lane_stride;
   dinv += (int64_t)blockIdx.x * lane_stride;
   info += (int64_t)blockIdx.x * lane_stride * 2;
@@ -172,6 +178,58 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
       a[2 * h] = v.x;
       a[2 * h + 1] = v.y;
     }
+  }
+  if constexpr (FUSE) {
+    const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
+    double* At = Lc;     // [k][i] stride PD_S: Q^T, then X^T
+    double* Dt = Wr;     // [k][j] stride PD_S: dprev^T
+    {
+      const int row = tid >> 2, seg = (tid & 3) * 16;
+      const double2* qs = reinterpret_cast<const double2*>(Q + (int64_t)row * 64 + seg);
+      const double2* ds = reinterpret_cast<const double2*>(dinv + (int64_t)(kb - 1) * 4096 + (int64_t)row * 64 + seg);
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const double2 qv = qs[h], dv = ds[h];
+        At[(seg + 2 * h) * PD_S + row] = qv.x;
+        At[(seg + 2 * h + 1) * PD_S + row] = qv.y;
+        Dt[(seg + 2 * h) * PD_S + row] = dv.x;
+        Dt[(seg + 2 * h + 1) * PD_S + row] = dv.y;
+      }
+    }
+    __syncthreads();
+    d4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {     // X[i][j] = sum_k Q[i][k] dprev[j][k], wave q: rows 16q .. 16q+15
+      const double av = At[(4 * ks + lk) * PD_S + 16 * q + lr];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Dt[(4 * ks + lk) * PD_S + 16 * u + lr], acc[u], 0, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) At[(16 * u + lr) * PD_S + 16 * q + lk + 4 * r] = acc[u][r];     // X^T
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {     // (X X^T)[i][c] = sum_k X[i][k] X[c][k]
+      const double av = At[(4 * ks + lk) * PD_S + 16 * q + lr];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, At[(4 * ks + lk) * PD_S + 16 * u + lr], acc[u], 0, 0, 0);
+    }
+    double* Ur = Wr;     // [i][c] stride 81 (odd: a thread walks its own row conflict-free); runs over into Tb
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ur[(16 * q + lk + 4 * r) * 81 + 16 * u + lr] = acc[u][r];
+    __syncthreads();
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) a[cc] -= Ur[i * 81 + 16 * q + cc];
   }
   __syncthreads();
   {
@@ -328,16 +386,37 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
   }
 }
 
-int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb) {
+int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb, const double* fuse_q) {
   constexpr size_t lds = (size_t)(64 * PD_S * 2 + 32 * PD_S + 64 + 8) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
-    GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_diag_kernel),
+    GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_diag_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_diag_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  potrf_diag_kernel<<<dim3((unsigned)ctx->lanes), dim3(256), lds, ctx->stream>>>(m.L, m.NP, kb, m.dinv, ctx->info_dev,
-                                                                                   ctx->lane_stride);
+  if (fuse_q)
+    potrf_diag_kernel<true><<<dim3((unsigned)ctx->lanes), dim3(256), lds, ctx->stream>>>(m.L, m.NP, kb, m.dinv, ctx->info_dev,
+                                                                                           ctx->lane_stride, fuse_q);
+  else
+    potrf_diag_kernel<false><<<dim3((unsigned)ctx->lanes), dim3(256), lds, ctx->stream>>>(m.L, m.NP, kb, m.dinv, ctx->info_dev,
+                                                                                            ctx->lane_stride, nullptr);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+
+// 64x64 block of the row-major matrix -> contiguous side buffer (the copy of block (kb, kb-1) the fused diagonal kernel reads)
+__global__ __launch_bounds__(256) void copy_block_kernel(const double* __restrict__ src, int64_t ld, double* __restrict__ dst) {
+  const int row = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
+  const double2* s2 = reinterpret_cast<const double2*>(src + (int64_t)row * ld + seg);
+  double2* d2 = reinterpret_cast<double2*>(dst + row * 64 + seg);
+#pragma unroll
+  for (int h = 0; h < 8; ++h) d2[h] = s2[h];
+}
+
+int launch_copy_block(gpbo_ctx* ctx, const double* src, int64_t ld, double* dst, hipStream_t stream) {
+  copy_block_kernel<<<dim3(1), dim3(256), 0, stream>>>(src, ld, dst);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
@@ -353,6 +432,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   const int bn = blockIdx.x, bm = blockIdx.y;
   const int zl = blockIdx.z / g.batch, bz = blockIdx.z - zl * g.batch;   // lane mode: z = lane * batch + b
   if (g.lower_only && bn > bm) return;
+  if (g.skip00 && bn == 0 && bm == 0) return;      // block (0, 0) belongs to a concurrently running diagonal-block kernel
   __shared__ double As[16][68];
   __shared__ double Bs[16][68];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
