@@ -147,17 +147,12 @@ int launch_kmat(gpbo_ctx* ctx, Model& m, double noise, double* out) {
 // Writes L_kk in place (upper part zeroed) and L_kk^-1 to dinv[kb].
 constexpr int PD_S = 80;   // LDS row stride (doubles): the two k-rows of a 32-lane ds_read_b64 group fall 32 banks apart
 
-// FUSE (look-ahead, see cholesky() in gpbo_api.hip): the block has received the rank-64 updates of every block column but
-// the previous one, whose panel solve and update are still running on the second stream.  The kernel applies that last
-// update to ITS block itself: X = Q dprev^T (Q = a copy of block (kb, kb-1) taken before the panel solve overwrites it,
-// dprev = the inverse of the previous diagonal block), A_kk -= X X^T — two 64^3 MFMA products out of LDS — and then
-// factors.  The concurrent update kernel leaves block (kb, kb) alone.
+// FUSE (chol_step_kernel below): the block has received the rank-64 updates of every block column but the previous one,
+// whose in-panel update runs in the OTHER workgroups of the same launch.  The workgroup applies that last update to its
+// own block itself: A_kk -= X X^T with X = L[kb][kb-1] (already solved by the panel kernel) — one 64^3 MFMA product out
+// of LDS — and then factors; the update tiles of the launch leave block (kb, kb) alone.
 template <bool FUSE>
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, int kb, double* __restrict__ dinv, int* info,
-                                                          int64_t lane_stride, const double* __restrict__ Q) {
-  L += (int64_t)blockIdx.x * lane_stride;
-  dinv += (int64_t)blockIdx.x * lane_stride;
-  info += (int64_t)blockIdx.x * lane_stride * 2;
+__device__ __forceinline__ void potrf_diag_body(double* L, int64_t ld, int kb, double* __restrict__ dinv, int* info) {
   extern __shared__ __attribute__((aligned(16))) double pd2_smem[];
   double* Lc = pd2_smem;                 // [64][PD_S] column-major image of L: Lc[j * PD_S + i] = L[i][j]
   double* Wr = Lc + 64 * PD_S;           // [64][PD_S] row-major W = L^-1
@@ -181,19 +176,15 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
   }
   if constexpr (FUSE) {
     const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
-    double* At = Lc;     // [k][i] stride PD_S: Q^T, then X^T
-    double* Dt = Wr;     // [k][j] stride PD_S: dprev^T
+    double* At = Lc;     // [k][i] stride PD_S: X^T
     {
       const int row = tid >> 2, seg = (tid & 3) * 16;
-      const double2* qs = reinterpret_cast<const double2*>(Q + (int64_t)row * 64 + seg);
-      const double2* ds = reinterpret_cast<const double2*>(dinv + (int64_t)(kb - 1) * 4096 + (int64_t)row * 64 + seg);
+      const double2* xs = reinterpret_cast<const double2*>(A - 64 + (int64_t)row * ld + seg);    // block (kb, kb - 1)
 #pragma unroll
       for (int h = 0; h < 8; ++h) {
-        const double2 qv = qs[h], dv = ds[h];
-        At[(seg + 2 * h) * PD_S + row] = qv.x;
-        At[(seg + 2 * h + 1) * PD_S + row] = qv.y;
-        Dt[(seg + 2 * h) * PD_S + row] = dv.x;
-        Dt[(seg + 2 * h + 1) * PD_S + row] = dv.y;
+        const double2 xv = xs[h];
+        At[(seg + 2 * h) * PD_S + row] = xv.x;
+        At[(seg + 2 * h + 1) * PD_S + row] = xv.y;
       }
     }
     __syncthreads();
@@ -201,22 +192,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {     // X[i][j] = sum_k Q[i][k] dprev[j][k], wave q: rows 16q .. 16q+15
-      const double av = At[(4 * ks + lk) * PD_S + 16 * q + lr];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Dt[(4 * ks + lk) * PD_S + 16 * u + lr], acc[u], 0, 0, 0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) At[(16 * u + lr) * PD_S + 16 * q + lk + 4 * r] = acc[u][r];     // X^T
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {     // (X X^T)[i][c] = sum_k X[i][k] X[c][k]
+    for (int ks = 0; ks < 16; ++ks) {     // (X X^T)[i][c] = sum_k X[i][k] X[c][k], wave q: rows 16q .. 16q+15
       const double av = At[(4 * ks + lk) * PD_S + 16 * q + lr];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -386,37 +362,24 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
   }
 }
 
-int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb, const double* fuse_q) {
-  constexpr size_t lds = (size_t)(64 * PD_S * 2 + 32 * PD_S + 64 + 8) * sizeof(double);
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, int kb, double* __restrict__ dinv, int* info,
+                                                          int64_t lane_stride) {
+  // lane mode: one workgroup per lane; the info word lives in the lane's slab too (ints: 2 per double)
+  potrf_diag_body<false>(L + (int64_t)blockIdx.x * lane_stride, ld, kb, dinv + (int64_t)blockIdx.x * lane_stride,
+                         info + (int64_t)blockIdx.x * lane_stride * 2);
+}
+
+constexpr size_t PD_LDS_BYTES = (size_t)(64 * PD_S * 2 + 32 * PD_S + 64 + 8) * sizeof(double);
+
+int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb) {
   static bool attr_set = false;
   if (!attr_set) {
-    GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_diag_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_diag_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_diag_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)PD_LDS_BYTES));
     attr_set = true;
   }
-  if (fuse_q)
-    potrf_diag_kernel<true><<<dim3((unsigned)ctx->lanes), dim3(256), lds, ctx->stream>>>(m.L, m.NP, kb, m.dinv, ctx->info_dev,
-                                                                                           ctx->lane_stride, fuse_q);
-  else
-    potrf_diag_kernel<false><<<dim3((unsigned)ctx->lanes), dim3(256), lds, ctx->stream>>>(m.L, m.NP, kb, m.dinv, ctx->info_dev,
-                                                                                            ctx->lane_stride, nullptr);
-  GPBO_HIP(ctx, hipGetLastError());
-  return GPBO_OK;
-}
-
-// 64x64 block of the row-major matrix -> contiguous side buffer (the copy of block (kb, kb-1) the fused diagonal kernel reads)
-__global__ __launch_bounds__(256) void copy_block_kernel(const double* __restrict__ src, int64_t ld, double* __restrict__ dst) {
-  const int row = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
-  const double2* s2 = reinterpret_cast<const double2*>(src + (int64_t)row * ld + seg);
-  double2* d2 = reinterpret_cast<double2*>(dst + row * 64 + seg);
-#pragma unroll
-  for (int h = 0; h < 8; ++h) d2[h] = s2[h];
-}
-
-int launch_copy_block(gpbo_ctx* ctx, const double* src, int64_t ld, double* dst, hipStream_t stream) {
-  copy_block_kernel<<<dim3(1), dim3(256), 0, stream>>>(src, ld, dst);
+  potrf_diag_kernel<<<dim3((unsigned)ctx->lanes), dim3(256), PD_LDS_BYTES, ctx->stream>>>(m.L, m.NP, kb, m.dinv, ctx->info_dev,
+                                                                                            ctx->lane_stride);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
@@ -428,11 +391,9 @@ int launch_copy_block(gpbo_ctx* ctx, const double* src, int64_t ld, double* dst,
 // Fragment layout (cdna_hip_programming.md §3): A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15],
 // D lane l, reg r = D[(l>>4) + 4r][l&15].
 template <bool BT, bool AT>
-__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
-  const int bn = blockIdx.x, bm = blockIdx.y;
-  const int zl = blockIdx.z / g.batch, bz = blockIdx.z - zl * g.batch;   // lane mode: z = lane * batch + b
+__device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn, int zl, int bz) {
   if (g.lower_only && bn > bm) return;
-  if (g.skip00 && bn == 0 && bm == 0) return;      // block (0, 0) belongs to a concurrently running diagonal-block kernel
+  if (g.skip00 && bn == 0 && bm == 0) return;      // tile (0, 0) belongs to the diagonal-block workgroup of the same launch
   __shared__ double As[16][68];
   __shared__ double Bs[16][68];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -523,6 +484,46 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
         if (g.beta != 0.0) v += g.beta * (*cp);
         *cp = v;
       }
+}
+
+template <bool BT, bool AT>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
+  const int zl = blockIdx.z / g.batch, bz = blockIdx.z - zl * g.batch;   // lane mode: z = lane * batch + b
+  gemm_tile_body<BT, AT>(g, (int)blockIdx.y, (int)blockIdx.x, zl, bz);
+}
+
+// One step of the blocked Cholesky inside an outer panel, as ONE launch: workgroup 0 factors (and inverts) diagonal
+// block kb after applying the previous block column's update to it itself (potrf_diag_body<FUSE>), the other workgroups
+// are the 64x64 tiles of that previous column's rank-64 update of the rest of the panel (tile (0, 0) = block (kb, kb)
+// excluded).  The two are independent, so the ~10 us update disappears behind the ~25 us diagonal block instead of
+// standing in front of it — per 64 columns the chain is panel solve -> this launch, two launches instead of three.
+// (A two-stream schedule of the same dependency graph was measured first: correct, but the cross-stream event waits
+// cost more than the kernels they hid — 3.51 vs 3.33 ms at N = 4096.)
+__global__ __launch_bounds__(256) void chol_step_kernel(double* L, int64_t ld, int kb, double* __restrict__ dinv, int* info,
+                                                         GemmArgs g, int tiles_n) {
+  if (blockIdx.x == 0) {
+    potrf_diag_body<true>(L, ld, kb, dinv, info);
+    return;
+  }
+  const int b = (int)blockIdx.x - 1;
+  const int bm = b / tiles_n, bn = b - bm * tiles_n;
+  gemm_tile_body<true, false>(g, bm, bn, 0, 0);
+}
+
+int launch_chol_step(gpbo_ctx* ctx, Model& m, int kb, const GemmArgs& g_in) {
+  GemmArgs g = g_in;
+  g.lanes = 1; g.lane_stride = 0; g.batch = 1; g.skip00 = 1;
+  static bool attr_set = false;
+  if (!attr_set) {
+    GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(chol_step_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)PD_LDS_BYTES));
+    attr_set = true;
+  }
+  const int tiles_m = g.m / 64, tiles_n = g.n / 64;
+  chol_step_kernel<<<dim3((unsigned)(1 + tiles_m * tiles_n)), dim3(256), PD_LDS_BYTES, ctx->stream>>>(
+      m.L, m.NP, kb, m.dinv, ctx->info_dev, g, tiles_n);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

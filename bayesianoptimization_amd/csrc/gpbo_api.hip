@@ -57,11 +57,8 @@ static int alloc_model(gpbo_ctx* ctx, Model& m, int64_t NP, int DP) {
   return GPBO_OK;
 }
 
-// Blocked Cholesky of m.L (lower), two levels: 64-wide inner blocks (diagonal block factored and inverted by one
-// workgroup, panel solve = GEMM with the inverted block) inside CHOL_OUTER-wide outer panels.  Inside an outer panel the
-// rank-64 updates touch only the panel's own remaining columns; the rest of the matrix gets ONE rank-CHOL_OUTER update
-// per outer panel, so the trailing matrix is read and written N / CHOL_OUTER times instead of N / 64 times (the rank-64
-// update is HBM-bound on exactly that traffic).  GPBO_CHOL_OUTER=64 restores the one-level algorithm (A/B runs); default 512 (measured: N = 8192 13.2 -> 10.6 ms, N <= 4096 unchanged — there the chain of diagonal blocks is the critical path).
+// The three-launch schedule of the blocked Cholesky (see cholesky() below): per 64 columns diagonal block -> panel solve ->
+// in-panel update, one after the other.
 static int cholesky_serial(gpbo_ctx* ctx, Model& m, int outer) {
   const int nblk = (int)(m.NP / NB);
   const int per_outer = outer / NB;
@@ -106,88 +103,37 @@ static int cholesky_serial(gpbo_ctx* ctx, Model& m, int outer) {
   return GPBO_OK;
 }
 
-// The same factorisation with ONE-STEP LOOK-AHEAD inside an outer panel.  The serial version runs, per 64-column step,
-// diagonal block (one workgroup, ~23 us) -> panel solve -> in-panel rank-64 update, one after the other: the next
-// diagonal block waits for two small launches it barely depends on.  Here the chain of diagonal-block kernels runs
-// back to back on the context's stream while panel solve + update of step k run on a second stream:
-//   stream A:  D(ob)  D'(ob+1)  D'(ob+2) ...                     D' = potrf_diag_kernel<FUSE>: applies step k's update to
-//   stream B:        P(ob) U(ob) Q   P(ob+1) U(ob+1) Q  ...       ITS block itself from Q, a side copy of block (k+1, k)
-// Dependencies: P(k) after D(k) [needs its inverse]; U(k) leaves block (k+1, k+1) to D'(k+1); after U(k) the block
-// (k+2, k+1) is final for step k+1 and is copied aside (Q) BEFORE P(k+1) overwrites it in place; D'(k+2) waits for that
-// copy (hence for U(k)).  Two Q buffers and two events of each kind alternate by step parity — an event/buffer of step
-// k is re-recorded/re-written only after the kernel that consumed it (step k) is complete, which the stream order and
-// the opposite-parity event guarantee.  At the end of an outer panel both streams join and the rank-512 update runs as
-// before.  Same arithmetic as the serial version up to the order in which block (k+1, k+1) receives step k's update
-// (privately, from an MFMA product of the same operands).
-static int cholesky_lookahead(gpbo_ctx* ctx, Model& m, int outer) {
+// The same factorisation with the in-panel update of step k and the diagonal block of step k + 1 in ONE launch
+// (chol_step_kernel, fit_kernels.hip): per 64 columns the dependent chain is  panel solve -> [diagonal block k+1 || update k]
+// instead of  diagonal block -> panel solve -> update.  The diagonal-block workgroup applies step k's update to its own
+// block itself (one extra 64^3 MFMA product), the update tiles skip that block.
+static int cholesky_fused(gpbo_ctx* ctx, Model& m, int outer) {
   const int nblk = (int)(m.NP / NB);
   const int per_outer = outer / NB;
   int rc;
-  if (!ctx->aux_stream) {
-    GPBO_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-    GPBO_HIP(ctx, hipMalloc((void**)&ctx->chol_q, 2 * NB * NB * sizeof(double)));
-    for (int p = 0; p < 2; ++p) {
-      GPBO_HIP(ctx, hipEventCreateWithFlags(&ctx->chol_ev_diag[p], hipEventDisableTiming));
-      GPBO_HIP(ctx, hipEventCreateWithFlags(&ctx->chol_ev_q[p], hipEventDisableTiming));
-    }
-    GPBO_HIP(ctx, hipEventCreateWithFlags(&ctx->chol_ev_join, hipEventDisableTiming));
-  }
-  hipStream_t sa = ctx->stream, sb = ctx->aux_stream;
-  auto on_b = [&](auto&& fn) { ctx->stream = sb; int r = fn(); ctx->stream = sa; return r; };
   for (int ob = 0; ob < nblk; ob += per_outer) {
     const int oe = (ob + per_outer < nblk) ? ob + per_outer : nblk;
-    // fork: stream B sees everything enqueued on A so far (previous rank-512 update, the kernel-matrix assembly)
-    GPBO_HIP(ctx, hipEventRecord(ctx->chol_ev_join, sa));
-    GPBO_HIP(ctx, hipStreamWaitEvent(sb, ctx->chol_ev_join, 0));
+    if ((rc = launch_potrf_diag(ctx, m, ob))) return rc;          // first block of the panel: everything before it is applied
     for (int kb = ob; kb < oe; ++kb) {
-      double* qbuf = ctx->chol_q + (size_t)(kb & 1) * NB * NB;
-      // ---- stream A: diagonal block kb
-      if (kb == ob) {
-        if ((rc = launch_potrf_diag(ctx, m, kb))) return rc;
-      } else {
-        GPBO_HIP(ctx, hipStreamWaitEvent(sa, ctx->chol_ev_q[kb & 1], 0));      // Q(kb) ready => U(kb - 2) done
-        if ((rc = launch_potrf_diag(ctx, m, kb, qbuf))) return rc;
-      }
-      GPBO_HIP(ctx, hipEventRecord(ctx->chol_ev_diag[kb & 1], sa));
       const int rem = (int)(m.NP - (int64_t)(kb + 1) * NB);
       if (rem == 0) break;
-      // ---- stream B: panel solve + in-panel update of step kb, then the side copy for step kb + 2
       double* panel = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)kb * NB;
-      if (kb == ob && kb + 1 < oe) {
-        // first step of the panel: block (kb + 1, kb) is final already (the fork above); copy it aside — concurrently with
-        // D(kb) — before the panel solve overwrites it
-        double* q1 = ctx->chol_q + (size_t)((kb + 1) & 1) * NB * NB;
-        if ((rc = launch_copy_block(ctx, panel, m.NP, q1, sb))) return rc;
-        GPBO_HIP(ctx, hipEventRecord(ctx->chol_ev_q[(kb + 1) & 1], sb));
-      }
-      GPBO_HIP(ctx, hipStreamWaitEvent(sb, ctx->chol_ev_diag[kb & 1], 0));
-      GemmArgs g{};
+      GemmArgs g{};      // panel: L21 = A21 * L11^-T  (in place)
       g.m = rem; g.n = NB; g.k = NB; g.alpha = 1.0; g.beta = 0.0;
       g.A = panel; g.lda = m.NP; g.strideA = 0;
       g.B = m.dinv + (int64_t)kb * NB * NB; g.ldb = NB; g.strideB = 0; g.b_trans = 1;
       g.C = panel; g.ldc = m.NP; g.strideC = 0; g.batch = 1;
-      if ((rc = on_b([&] { return launch_gemm(ctx, g); }))) return rc;
+      if ((rc = launch_gemm(ctx, g))) return rc;
       const int wi = (oe - (kb + 1)) * NB;
       if (wi > 0) {
-        GemmArgs s{};
+        GemmArgs s{};    // rank-64 update of the panel's remaining columns, tile (0, 0) left to the diagonal-block workgroup
         s.m = rem; s.n = wi; s.k = NB; s.alpha = -1.0; s.beta = 1.0;
         s.A = panel; s.lda = m.NP; s.B = panel; s.ldb = m.NP; s.b_trans = 1;
         s.C = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)(kb + 1) * NB; s.ldc = m.NP;
         s.batch = 1; s.lower_only = 1;
-        s.skip00 = 1;      // block (kb + 1, kb + 1) gets this update inside D'(kb + 1)
-        if ((rc = on_b([&] { return launch_gemm(ctx, s); }))) return rc;
-        if (kb + 2 < oe) {
-          // block (kb + 2, kb + 1) now carries every update up to step kb: the copy D'(kb + 2) will read
-          double* q2 = ctx->chol_q + (size_t)((kb + 2) & 1) * NB * NB;
-          const double* src = m.L + (int64_t)(kb + 2) * NB * m.NP + (int64_t)(kb + 1) * NB;
-          if ((rc = launch_copy_block(ctx, src, m.NP, q2, sb))) return rc;
-          GPBO_HIP(ctx, hipEventRecord(ctx->chol_ev_q[(kb + 2) & 1], sb));
-        }
+        if ((rc = launch_chol_step(ctx, m, kb + 1, s))) return rc;
       }
     }
-    // join: the rank-(outer) update needs every panel column
-    GPBO_HIP(ctx, hipEventRecord(ctx->chol_ev_join, sb));
-    GPBO_HIP(ctx, hipStreamWaitEvent(sa, ctx->chol_ev_join, 0));
     const int rem2 = (int)(m.NP - (int64_t)oe * NB);
     if (rem2 > 0) {
       const double* P = m.L + (int64_t)oe * NB * m.NP + (int64_t)ob * NB;
@@ -207,15 +153,15 @@ static int cholesky_lookahead(gpbo_ctx* ctx, Model& m, int outer) {
 // rank-64 updates touch only the panel's own remaining columns; the rest of the matrix gets ONE rank-CHOL_OUTER update
 // per outer panel, so the trailing matrix is read and written N / CHOL_OUTER times instead of N / 64 times (the rank-64
 // update is HBM-bound on exactly that traffic).  GPBO_CHOL_OUTER=64 restores the one-level algorithm (A/B runs); default
-// 512.  GPBO_CHOL_LOOKAHEAD=0 selects the serial schedule (also used in lane mode / inside gpbo_lml_batch, where the
-// launch sequence of a lane is captured into a hipGraph on one stream).
+// 512.  GPBO_CHOL_FUSED=0 selects the three-launch schedule (A/B runs; lane mode — several models per launch, inside
+// gpbo_lml_batch — always uses it).
 static int cholesky(gpbo_ctx* ctx, Model& m) {
   int outer = 512;
   if (const char* e = getenv("GPBO_CHOL_OUTER")) outer = atoi(e);
   if (outer < NB || outer % NB) outer = NB;
-  static const bool la_off = getenv("GPBO_CHOL_LOOKAHEAD") && getenv("GPBO_CHOL_LOOKAHEAD")[0] == '0';
-  if (la_off || ctx->lanes != 1 || ctx->no_timing || outer < 2 * NB) return cholesky_serial(ctx, m, outer);
-  return cholesky_lookahead(ctx, m, outer);
+  static const bool fused_off = getenv("GPBO_CHOL_FUSED") && getenv("GPBO_CHOL_FUSED")[0] == '0';
+  if (fused_off || ctx->lanes != 1 || outer < 2 * NB) return cholesky_serial(ctx, m, outer);
+  return cholesky_fused(ctx, m, outer);
 }
 
 // W = L^-1 by recursive doubling from the inverted 64x64 diagonal blocks:
@@ -357,13 +303,7 @@ int gpbo_destroy(gpbo_ctx* ctx) {
   if (ctx->mt_bits) (void)hipFree(ctx->mt_bits);
   if (ctx->mt_offset) (void)hipFree(ctx->mt_offset);
   if (ctx->mt_desc) (void)hipFree(ctx->mt_desc);
-  if (ctx->chol_q) (void)hipFree(ctx->chol_q);
-  for (int p = 0; p < 2; ++p) {
-    if (ctx->chol_ev_diag[p]) (void)hipEventDestroy(ctx->chol_ev_diag[p]);
-    if (ctx->chol_ev_q[p]) (void)hipEventDestroy(ctx->chol_ev_q[p]);
-  }
-  if (ctx->chol_ev_join) (void)hipEventDestroy(ctx->chol_ev_join);
-  if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -112,12 +112,6 @@ struct gpbo_ctx {
   int64_t cap_ys = 0;
   void* red = nullptr;     // reduction scratch
   int64_t cap_red = 0;
-  // look-ahead Cholesky (cholesky() in gpbo_api.hip): second stream, the two side buffers for block (k, k-1), events
-  hipStream_t aux_stream = nullptr;
-  double* chol_q = nullptr;          // [2][64][64]
-  hipEvent_t chol_ev_diag[2] = {nullptr, nullptr};   // diagonal block of step k finished (parity k & 1)
-  hipEvent_t chol_ev_q[2] = {nullptr, nullptr};      // side copy of block (k, k-1) ready (parity k & 1)
-  hipEvent_t chol_ev_join = nullptr;
   int* info_dev = nullptr; // potrf info word
   void* pinned = nullptr;  // pinned host staging: window 0 = fit/LML words (PIN_* below), windows 1..8 = gpbo_lml_batch groups
   void* pinned_aux = nullptr;   // last window of the same allocation: selection / candidate staging (PIN_AUX_*); never re-pointed
@@ -232,8 +226,7 @@ int ensure(gpbo_ctx* ctx, T** p, int64_t* cap, int64_t need) {
 int launch_prescale(gpbo_ctx* ctx, const double* X, int64_t n, int d, int DP, const double* ls,
                     double* out, int64_t n_pad);
 int launch_kmat(gpbo_ctx* ctx, Model& m, double noise, double* out);   // out: m.K, or m.L (factorised in place)
-int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb, const double* fuse_q = nullptr);   // fuse_q: see potrf_diag_kernel<FUSE>
-int launch_copy_block(gpbo_ctx* ctx, const double* src, int64_t ld, double* dst, hipStream_t stream);
+int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb);
 int launch_fill_w_diag(gpbo_ctx* ctx, Model& m);
 int launch_trmv(gpbo_ctx* ctx, Model& m);
 int launch_append_row(gpbo_ctx* ctx, Model& m, int64_t j);   // row j (== current m.N) from the prescaled m.Xs[j]
@@ -255,6 +248,8 @@ struct GemmArgs {
   int skip00;             // leave output tile (0, 0) alone (64x64-tile kernel only): a concurrent diagonal-block kernel owns it
 };
 int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g);
+// diagonal block kb (with the previous block column's update applied by the workgroup itself) || the 64x64 tiles of update g
+int launch_chol_step(gpbo_ctx* ctx, Model& m, int kb, const GemmArgs& g);
 // posterior_kernel.hip
 int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std);
 int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std, double** dmu_dev, double** dsd_dev);
