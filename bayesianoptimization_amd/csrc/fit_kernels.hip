@@ -390,10 +390,8 @@ int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb) {
 //   C = alpha * A(m,k) * op(B) + beta * C ;  A row-major; B row-major (k,n), or (n,k) if b_trans.
 // Fragment layout (cdna_hip_programming.md §3): A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15],
 // D lane l, reg r = D[(l>>4) + 4r][l&15].
-// STASH: the finished tile goes TRANSPOSED into LDS (stash[col * PD_S + row]) instead of to memory — chol_step_kernel
-// solves it against the diagonal block's inverse right away.
-template <bool BT, bool AT, bool STASH = false>
-__device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn, int zl, int bz, double* stash = nullptr) {
+template <bool BT, bool AT>
+__device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn, int zl, int bz) {
   if (g.lower_only && bn > bm) return;
   if (g.skip00 && bn == 0 && bm == 0) return;      // tile (0, 0) belongs to the diagonal-block workgroup of the same launch
   __shared__ double As[16][68];
@@ -484,8 +482,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn
         double* cp = C + row * g.ldc + colx;
         double v = g.alpha * acc[t][u][r];
         if (g.beta != 0.0) v += g.beta * (*cp);
-        if constexpr (STASH) stash[(wn + 16 * u + (lane & 15)) * PD_S + wm + 16 * t + (lane >> 4) + 4 * r] = v;
-        else *cp = v;
+        *cp = v;
       }
 }
 
@@ -495,88 +492,28 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   gemm_tile_body<BT, AT>(g, (int)blockIdx.y, (int)blockIdx.x, zl, bz);
 }
 
-// One step of the blocked Cholesky inside an outer panel, as ONE launch — three roles:
-//   workgroup 0        factors (and inverts) diagonal block kb after applying the previous block column's update to it
-//                      itself (potrf_diag_body<FUSE>), then publishes "inverse ready" (agent-scope release + flag);
-//   tiles (bm, bn > 0) the 64x64 tiles of that previous column's rank-64 update of the rest of the panel;
-//   tiles (bm >= 1, 0) the same for block column kb itself — and, since that finishes the column, its PANEL SOLVE too:
-//                      the tile stays in LDS, the workgroup waits for workgroup 0's flag (one relaxed poll loop, one
-//                      agent-scope acquire, __syncthreads — cdna_hip_programming.md Guideline 16) and multiplies by the
-//                      inverse:  L[kb + bm][kb] = tile * inv(L_kk)^T.
-// Update and diagonal block are independent, so the ~10 us update disappears behind the ~25 us diagonal block; the panel
-// solve follows inside the launch.  Per 64 columns the dependent chain is ONE launch instead of three.  Workgroup 0 is
-// dispatched first and waits for nobody, so the waiters always make progress; their spin is bounded anyway (a broken
-// hand-off reports through `info` instead of hanging the GPU).  `flags` is zeroed before every factorisation.
-// (A two-stream schedule of the same dependency graph was measured first: correct, but the cross-stream event waits
-// cost more than the kernels they hid — 3.51 vs 3.33 ms at N = 4096.)
-__global__ __launch_bounds__(256) void chol_step_kernel(double* L, int64_t ld, int kb, double* dinv, int* info, int* flags,
+// One step of the blocked Cholesky inside an outer panel, as ONE launch: workgroup 0 factors (and inverts) diagonal
+// block kb after applying the previous block column's update to it itself (potrf_diag_body<FUSE>), the other workgroups
+// are the 64x64 tiles of that previous column's rank-64 update of the rest of the panel (tile (0, 0) = block (kb, kb)
+// excluded).  The two are independent, so the ~10 us update disappears behind the ~25 us diagonal block instead of
+// standing in front of it — per 64 columns the chain is panel solve -> this launch, two launches instead of three.
+// Measured at N = 4096 (scripts/r02_fit_probe.py): three launches per step 3.34 ms, this 2.84 ms.  Two variants were built,
+// validated and dropped: a two-stream schedule of the same dependency graph (the cross-stream event waits cost more than
+// the kernels they hid: 3.51 ms), and folding the panel solve into this launch as well (column-0 tiles waiting for the
+// diagonal workgroup's inverse through an agent-scope release/acquire flag: 2.80 ms — the in-launch hand-off costs what
+// the launch boundary costs, so the simpler form stays).
+__global__ __launch_bounds__(256) void chol_step_kernel(double* L, int64_t ld, int kb, double* __restrict__ dinv, int* info,
                                                          GemmArgs g, int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) double cs_smem[];
-  const int tid = threadIdx.x;
   if (blockIdx.x == 0) {
     potrf_diag_body<true>(L, ld, kb, dinv, info);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its stores of L_kk and the inverse have landed
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(flags + kb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
     return;
   }
   const int b = (int)blockIdx.x - 1;
   const int bm = b / tiles_n, bn = b - bm * tiles_n;
-  if (bn != 0 || bm == 0) {
-    gemm_tile_body<true, false>(g, bm, bn, 0, 0);
-    return;
-  }
-  double* Tt = cs_smem;                   // [k][row] stride PD_S: the updated tile, transposed
-  double* Dt = cs_smem + 64 * PD_S;       // [k][j]   stride PD_S: inv(L_kk)^T
-  gemm_tile_body<true, false, true>(g, bm, 0, 0, 0, Tt);
-  __syncthreads();
-  if (tid == 0) {
-    int spins = 0;
-    while (__hip_atomic_load(flags + kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-      if (++spins > (1 << 24)) {          // ~seconds; cannot happen while workgroup 0 runs
-        if (*info == 0) *info = -1 - kb;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-  {
-    const int row = tid >> 2, seg = (tid & 3) * 16;
-    const double2* ds = reinterpret_cast<const double2*>(dinv + (int64_t)kb * 4096 + (int64_t)row * 64 + seg);
-#pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      const double2 dv = ds[h];
-      Dt[(seg + 2 * h) * PD_S + row] = dv.x;
-      Dt[(seg + 2 * h + 1) * PD_S + row] = dv.y;
-    }
-  }
-  __syncthreads();
-  const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
-  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
-  d4 acc[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {       // X[i][j] = sum_k T[i][k] inv[j][k], wave q: rows 16q .. 16q + 15
-    const double av = Tt[(4 * ks + lk) * PD_S + 16 * q + lr];
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Dt[(4 * ks + lk) * PD_S + 16 * u + lr], acc[u], 0, 0, 0);
-  }
-  double* Cb = g.C + (int64_t)bm * 64 * g.ldc;      // tile (bm, 0) of the update region = block (kb + bm, kb) of the matrix
-#pragma unroll
-  for (int u = 0; u < 4; ++u)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Cb[(int64_t)(16 * q + lk + 4 * r) * g.ldc + 16 * u + lr] = acc[u][r];
+  gemm_tile_body<true, false>(g, bm, bn, 0, 0);
 }
 
-int launch_chol_step(gpbo_ctx* ctx, Model& m, int kb, const GemmArgs& g_in, int* flags) {
+int launch_chol_step(gpbo_ctx* ctx, Model& m, int kb, const GemmArgs& g_in) {
   GemmArgs g = g_in;
   g.lanes = 1; g.lane_stride = 0; g.batch = 1; g.skip00 = 1;
   static bool attr_set = false;
@@ -587,7 +524,7 @@ int launch_chol_step(gpbo_ctx* ctx, Model& m, int kb, const GemmArgs& g_in, int*
   }
   const int tiles_m = g.m / 64, tiles_n = g.n / 64;
   chol_step_kernel<<<dim3((unsigned)(1 + tiles_m * tiles_n)), dim3(256), PD_LDS_BYTES, ctx->stream>>>(
-      m.L, m.NP, kb, m.dinv, ctx->info_dev, flags, g, tiles_n);
+      m.L, m.NP, kb, m.dinv, ctx->info_dev, g, tiles_n);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }

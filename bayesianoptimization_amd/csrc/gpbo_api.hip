@@ -103,41 +103,36 @@ static int cholesky_serial(gpbo_ctx* ctx, Model& m, int outer) {
   return GPBO_OK;
 }
 
-// The same factorisation with ONE launch per 64 columns inside an outer panel (chol_step_kernel, fit_kernels.hip):
-// [diagonal block k+1 || rank-64 update of step k -> panel solve of column k+1].  Only the first column of an outer panel
-// (whose diagonal block needs the previous panel's rank-512 update, not a rank-64 one) takes the separate diagonal-block
-// and panel-solve launches.
+// The same factorisation with the in-panel update of step k and the diagonal block of step k + 1 in ONE launch
+// (chol_step_kernel, fit_kernels.hip): per 64 columns the dependent chain is  panel solve -> [diagonal block k+1 || update k]
+// instead of  diagonal block -> panel solve -> update.  The diagonal-block workgroup applies step k's update to its own
+// block itself (one extra 64^3 MFMA product), the update tiles skip that block.
 static int cholesky_fused(gpbo_ctx* ctx, Model& m, int outer) {
   const int nblk = (int)(m.NP / NB);
   const int per_outer = outer / NB;
   int rc;
-  if ((rc = ensure(ctx, &ctx->chol_flags, &ctx->cap_chol_flags, (int64_t)nblk + 8))) return rc;
-  GPBO_HIP(ctx, hipMemsetAsync(ctx->chol_flags, 0, (size_t)nblk * sizeof(int), ctx->stream));
   for (int ob = 0; ob < nblk; ob += per_outer) {
     const int oe = (ob + per_outer < nblk) ? ob + per_outer : nblk;
-    if ((rc = launch_potrf_diag(ctx, m, ob))) return rc;
-    {
-      const int rem = (int)(m.NP - (int64_t)(ob + 1) * NB);
-      if (rem > 0) {
-        double* panel = m.L + (int64_t)(ob + 1) * NB * m.NP + (int64_t)ob * NB;
-        GemmArgs g{};      // panel solve of the first column: L21 = A21 * L11^-T  (in place)
-        g.m = rem; g.n = NB; g.k = NB; g.alpha = 1.0; g.beta = 0.0;
-        g.A = panel; g.lda = m.NP; g.strideA = 0;
-        g.B = m.dinv + (int64_t)ob * NB * NB; g.ldb = NB; g.strideB = 0; g.b_trans = 1;
-        g.C = panel; g.ldc = m.NP; g.strideC = 0; g.batch = 1;
-        if ((rc = launch_gemm(ctx, g))) return rc;
-      }
-    }
-    for (int kb = ob; kb + 1 < oe; ++kb) {
+    if ((rc = launch_potrf_diag(ctx, m, ob))) return rc;          // first block of the panel: everything before it is applied
+    for (int kb = ob; kb < oe; ++kb) {
       const int rem = (int)(m.NP - (int64_t)(kb + 1) * NB);
-      if (rem <= 0) break;
-      const double* panel = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)kb * NB;
-      GemmArgs s{};    // rank-64 update of the panel's remaining columns by column kb
-      s.m = rem; s.n = (oe - (kb + 1)) * NB; s.k = NB; s.alpha = -1.0; s.beta = 1.0;
-      s.A = panel; s.lda = m.NP; s.B = panel; s.ldb = m.NP; s.b_trans = 1;
-      s.C = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)(kb + 1) * NB; s.ldc = m.NP;
-      s.batch = 1; s.lower_only = 1;
-      if ((rc = launch_chol_step(ctx, m, kb + 1, s, ctx->chol_flags))) return rc;
+      if (rem == 0) break;
+      double* panel = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)kb * NB;
+      GemmArgs g{};      // panel: L21 = A21 * L11^-T  (in place)
+      g.m = rem; g.n = NB; g.k = NB; g.alpha = 1.0; g.beta = 0.0;
+      g.A = panel; g.lda = m.NP; g.strideA = 0;
+      g.B = m.dinv + (int64_t)kb * NB * NB; g.ldb = NB; g.strideB = 0; g.b_trans = 1;
+      g.C = panel; g.ldc = m.NP; g.strideC = 0; g.batch = 1;
+      if ((rc = launch_gemm(ctx, g))) return rc;
+      const int wi = (oe - (kb + 1)) * NB;
+      if (wi > 0) {
+        GemmArgs s{};    // rank-64 update of the panel's remaining columns, tile (0, 0) left to the diagonal-block workgroup
+        s.m = rem; s.n = wi; s.k = NB; s.alpha = -1.0; s.beta = 1.0;
+        s.A = panel; s.lda = m.NP; s.B = panel; s.ldb = m.NP; s.b_trans = 1;
+        s.C = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)(kb + 1) * NB; s.ldc = m.NP;
+        s.batch = 1; s.lower_only = 1;
+        if ((rc = launch_chol_step(ctx, m, kb + 1, s))) return rc;
+      }
     }
     const int rem2 = (int)(m.NP - (int64_t)oe * NB);
     if (rem2 > 0) {
@@ -308,7 +303,6 @@ int gpbo_destroy(gpbo_ctx* ctx) {
   if (ctx->mt_bits) (void)hipFree(ctx->mt_bits);
   if (ctx->mt_offset) (void)hipFree(ctx->mt_offset);
   if (ctx->mt_desc) (void)hipFree(ctx->mt_desc);
-  if (ctx->chol_flags) (void)hipFree(ctx->chol_flags);
 
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

@@ -112,8 +112,6 @@ struct gpbo_ctx {
   int64_t cap_ys = 0;
   void* red = nullptr;     // reduction scratch
   int64_t cap_red = 0;
-  int* chol_flags = nullptr;     // "inverse of diagonal block k is ready" words of the fused Cholesky steps
-  int64_t cap_chol_flags = 0;
   int* info_dev = nullptr; // potrf info word
   void* pinned = nullptr;  // pinned host staging: window 0 = fit/LML words (PIN_* below), windows 1..8 = gpbo_lml_batch groups
   void* pinned_aux = nullptr;   // last window of the same allocation: selection / candidate staging (PIN_AUX_*); never re-pointed
@@ -250,9 +248,8 @@ struct GemmArgs {
   int skip00;             // leave output tile (0, 0) alone (64x64-tile kernel only): a concurrent diagonal-block kernel owns it
 };
 int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g);
-// one launch: diagonal block kb (previous column's update applied by the workgroup itself) || the tiles of update g, whose
-// column-0 tiles then solve block column kb against the new inverse (flags: one zeroed int per block column)
-int launch_chol_step(gpbo_ctx* ctx, Model& m, int kb, const GemmArgs& g, int* flags);
+// diagonal block kb (with the previous block column's update applied by the workgroup itself) || the 64x64 tiles of update g
+int launch_chol_step(gpbo_ctx* ctx, Model& m, int kb, const GemmArgs& g);
 // posterior_kernel.hip
 int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std);
 int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std, double** dmu_dev, double** dsd_dev);
