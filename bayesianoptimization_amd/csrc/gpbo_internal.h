@@ -255,7 +255,7 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
 int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std, double** dmu_dev, double** dsd_dev);
 // posterior_kernel_v2.hip
 int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
-int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, int* part_chunks);
+int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
 int launch_kstar_slab(gpbo_ctx* ctx, Model& m, double* Kst, int64_t ldk, int64_t Mp, int64_t m0, int nchunks);
 // posterior_cov.hip
 int launch_posterior_cov(gpbo_ctx* ctx, Model& m, int64_t M, double y_std, double** cov_dev, int64_t* ld_cov);

@@ -106,7 +106,7 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
   int part_chunks = nchunks;   // row chunks the sum-of-squares partials are split into (fp32 path: 512-row chunks)
   if (use_f32) rc = launch_posterior_f32(ctx, m, Mp, nchunks, &part_chunks);
   else if (use_v2) rc = launch_posterior_v2(ctx, m, Mp, nchunks);
-  else rc = launch_posterior_v3(ctx, m, Mp, nchunks, &part_chunks);
+  else rc = launch_posterior_v3(ctx, m, Mp, nchunks);
   ev_end(ctx, T_POST_MAIN);
   if (rc) return rc;
   ev_begin(ctx, T_POST_FINAL);

@@ -49,16 +49,10 @@ struct PostArgs2 {
 // BK = train points per LDS stage (one s_barrier per stage): 16, or 32 for the slab kernel (half the barriers; the
 // triangular cut-off of a 16-row tile then rounds up to 32 columns — zeros of the packed W, a few per cent more MFMAs
 // in the diagonal chunk only).
-// NW = waves per workgroup: 8 (256-row chunks, two workgroups per CU) or, for the slab kernel, 16 (512-row chunks, one
-// workgroup per CU — the same 4 waves per SIMD, but one k* stage tile now feeds twice the MFMAs: half the slab re-reads
-// from HBM/L2 and half the LDS stores per flop).
-template <int DP, int KERNEL, int GEN, int BK = POST_BK, int NW = 8>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4))) void posterior_kernel_v2(PostArgs2 p) {
+template <int DP, int KERNEL, int GEN, int BK = POST_BK>
+__global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   static_assert(BK == 16 || (BK == 32 && GEN == 2), "32-point stages are built for the slab kernel only");
-  static_assert(NW == 8 || (NW == 16 && GEN == 2 && BK == 32), "16 waves are built for the slab kernel with 32-point stages");
-  constexpr int CROWS = 32 * NW;                   // W rows per workgroup chunk (POST_ROWS for NW = 8)
-  constexpr int CTILES = CROWS / 16;               // 16-row MFMA tiles per chunk
-  constexpr int E = BK / NW;                       // stage elements per thread (lane = candidate, wave = E train points)
+  constexpr int E = BK / 8;                        // stage elements per thread (lane = candidate, wave = E train points)
   constexpr int KP = BK / 8;                       // k-pairs (8 columns of W) per stage
   extern __shared__ __attribute__((aligned(16))) double smem2[];
   double* Ks = smem2;                              // [2][BK][V2_STRIDE]
@@ -72,13 +66,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
   const int ct = bid - (bid / p.n_ctiles) * p.n_ctiles;
   const bool last = (r == p.nchunks - 1);
   const int NP = p.NP;
-  const int k_end = min(NP, (r + 1) * CROWS);
+  const int k_end = min(NP, (r + 1) * POST_ROWS);
   const int n_stages = k_end / BK;
 
   // candidate tile -> LDS (thread t loads candidate t>>3, dims (t&7)*DP/8 ...)
   if constexpr (GEN != 2) {
     const double* src = p.Xcs + (int64_t)ct * V2_CANDS * DP;
-    for (int e = tid; e < V2_CANDS * DP; e += 64 * NW) {
+    for (int e = tid; e < V2_CANDS * DP; e += 512) {
       const int cnd = e / DP, t = e - cnd * DP;
       Xl[t * V2_CANDS + cnd] = src[e];
     }
@@ -87,8 +81,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
   // MFMA role.  A chunk holds 16 tiles of 16 rows; wave w owns tiles w and 15 - w (not two adjacent ones):
   // in the chunk's diagonal block a tile t only needs the stages up to its own rows, so the pairing gives
   // every wave the same (t+1) + (16-t) = 17 tile-stages of work instead of 3 ... 31.
-  const int tileA = r * CTILES + wave;                      // global 16-row tile index (the earlier one)
-  const int tileB = r * CTILES + CTILES - 1 - wave;         // the later one
+  const int tileA = r * (POST_ROWS / 16) + wave;            // global 16-row tile index (the earlier one)
+  const int tileB = r * (POST_ROWS / 16) + 15 - wave;       // the later one
   const int rowA0 = tileA * 16, rowB0 = tileB * 16;
   const bool activeA = rowA0 < NP, activeB = rowB0 < NP;    // false only in a ragged last chunk
   const int64_t pairs = NP / 8;
@@ -225,8 +219,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
   for (; s <= last_stage; ++s) stage(s, std::integral_constant<int, 0>{});
 
   // epilogue: per-candidate sum of squares over this chunk's rows, fixed order
-  double* red = Ks;                       // [NW][64]
-  double* mured = Ks + NW * V2_CANDS;     // [NW][64]
+  double* red = Ks;                       // [8][64]
+  double* mured = Ks + 8 * V2_CANDS;      // [8][64]
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) {
     double v = 0.0;
@@ -246,13 +240,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4, 4)))
   if (tid < V2_CANDS) {
     double v = 0.0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) v += red[w * V2_CANDS + tid];
+    for (int w = 0; w < 8; ++w) v += red[w * V2_CANDS + tid];
     const int64_t m = p.m0 + (int64_t)ct * V2_CANDS + tid;
     p.part[(int64_t)r * p.Mp + m] = v;
     if (GEN != 2 && last) {
       double u = 0.0;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) u += mured[w * V2_CANDS + tid];
+      for (int w = 0; w < 8; ++w) u += mured[w * V2_CANDS + tid];
       p.mu_part[m] = u;
     }
   }
@@ -326,8 +320,7 @@ int launch_kstar_slab(gpbo_ctx* ctx, Model& m, double* Kst, int64_t ldk, int64_t
 // Two-kernel pipeline per candidate slab: kstar_gen_kernel -> posterior_kernel_v2<.., GEN = 2>.
 // The slab width is bounded by a workspace budget (default 40 GB, GPBO_KSTAR_GB to override); mu partials
 // need nchunks x Mp doubles in ctx->mu_part (allocated by the caller).
-int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, int* part_chunks) {
-  *part_chunks = nchunks;
+int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
   // k* workspace: the candidate set is walked slab by slab; a slab only has to be wide enough to fill the chip
   // (4 GB = 131 072 candidates at N = 4096 = 2048 candidate tiles x 16 row chunks per launch); measured at C3: one 34 GB
   // slab 263.7 ms, eight 4 GB slabs 264.4 ms (round 1 A/B) — the big workspace bought nothing.  GPBO_KSTAR_GB overrides.
@@ -335,9 +328,6 @@ int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, int* p
   if (const char* e = getenv("GPBO_KSTAR_GB")) budget_gb = atof(e) > 0.0 ? atof(e) : budget_gb;
   // 32 train points per stage: 262.9 vs 264.0 ms per C3 launch (round-2 A/B, same box, same run); GPBO_POST_BK=16 restores 16
   static const int post_bk = (getenv("GPBO_POST_BK") && atoi(getenv("GPBO_POST_BK")) == 16) ? 16 : 32;
-  // 16 waves per workgroup (512-row chunks): GPBO_POST_WAVES=16|8; needs the 32-point stages and at least two chunks' worth of rows
-  static const int post_waves_env = getenv("GPBO_POST_WAVES") ? atoi(getenv("GPBO_POST_WAVES")) : 16;
-  const bool w16 = (post_waves_env == 16) && post_bk == 32 && m.NP >= 1024;
   size_t free_b = 0, total_b = 0;
   if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
     const double avail = ((double)free_b + (double)ctx->cap_kst * 8.0) * 0.8 / 1e9;
@@ -358,14 +348,9 @@ int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, int* p
     a.Wp = m.Wp; a.Xs = m.Xs; a.alpha = m.alpha; a.Xcs = ctx->Xcs; a.part = ctx->part;
     a.mu_part = ctx->mu_part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nchunks;
     a.n_ctiles = (int)(ldk / V2_CANDS); a.Kst = ctx->kst; a.ldk = ldk; a.m0 = m0;
-    if (w16) a.nchunks = (int)((m.NP + 511) / 512);
-    *part_chunks = a.nchunks;
-    const int64_t nblocks = (int64_t)a.n_ctiles * a.nchunks;
+    const int64_t nblocks = (int64_t)a.n_ctiles * nchunks;
     if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
-    if (w16) {
-      const size_t lds = (size_t)(2 * 32 * V2_STRIDE) * sizeof(double);
-      posterior_kernel_v2<4, 0, 2, 32, 16><<<dim3((unsigned)nblocks), dim3(1024), lds, ctx->stream>>>(a);
-    } else if (post_bk == 32) {
+    if (post_bk == 32) {
       const size_t lds = (size_t)(2 * 32 * V2_STRIDE) * sizeof(double);
       posterior_kernel_v2<4, 0, 2, 32><<<dim3((unsigned)nblocks), dim3(512), lds, ctx->stream>>>(a);
     } else {
