@@ -98,39 +98,59 @@ int launch_pack_w32(gpbo_ctx* ctx, Model& m) {
   return GPBO_OK;
 }
 
+// (train points staged through LDS and read back as broadcasts: see kstar_gen_kernel in posterior_kernel_v2.hip)
+constexpr int GEN32_CH = 64;
 template <int DP, int KERNEL>
 __global__ __launch_bounds__(256) void kstar_gen_f32_kernel(const double* __restrict__ Xs, const double* __restrict__ alpha,
                                                             const double* __restrict__ Xcs, float* __restrict__ Kst,
                                                             int64_t ldk, int NP, double* __restrict__ mu_part,
                                                             int64_t Mp, int64_t m0) {
+  __shared__ __attribute__((aligned(16))) double xs[GEN32_CH * DP];
+  __shared__ double al[GEN32_CH];
   const int64_t ml = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (ml >= ldk) return;
+  const bool live = ml < ldk;
   const int k0 = blockIdx.y * POST_ROWS, k1 = min(NP, k0 + POST_ROWS);
   double xc[DP];
-  const double* xcp = Xcs + (m0 + ml) * DP;
+  {
+    const double* xcp = Xcs + (m0 + (live ? ml : 0)) * DP;
 #pragma unroll
-  for (int t = 0; t < DP; t += 2) {
-    const double2 v = *reinterpret_cast<const double2*>(xcp + t);
-    xc[t] = v.x;
-    xc[t + 1] = v.y;
+    for (int t = 0; t < DP; t += 2) {
+      const double2 v = *reinterpret_cast<const double2*>(xcp + t);
+      xc[t] = v.x;
+      xc[t + 1] = v.y;
+    }
   }
   double mu = 0.0;
-  for (int k = k0; k < k1; k += 2) {
-    const double* xr = Xs + (int64_t)k * DP;
-    double d2a = 0.0, d2b = 0.0;
-#pragma unroll
-    for (int t = 0; t < DP; ++t) {
-      const double da = xc[t] - xr[t], db = xc[t] - xr[DP + t];
-      d2a = fma(da, da, d2a);
-      d2b = fma(db, db, d2b);
+  for (int kc = k0; kc < k1; kc += GEN32_CH) {
+    __syncthreads();
+    {
+      const double2* src = reinterpret_cast<const double2*>(Xs + (int64_t)kc * DP);
+      double2* dst = reinterpret_cast<double2*>(xs);
+      for (int e = threadIdx.x; e < GEN32_CH * DP / 2; e += 256) dst[e] = src[e];
+      if (threadIdx.x < GEN32_CH) al[threadIdx.x] = alpha[kc + threadIdx.x];
     }
-    const double ka = gpbo_kernel_value<KERNEL>(d2a), kb = gpbo_kernel_value<KERNEL>(d2b);
-    Kst[(int64_t)k * ldk + ml] = (float)ka;
-    Kst[(int64_t)(k + 1) * ldk + ml] = (float)kb;
-    mu = fma(ka, alpha[k], mu);
-    mu = fma(kb, alpha[k + 1], mu);
+    __syncthreads();
+    if (live) {
+#pragma unroll 2
+      for (int kk = 0; kk < GEN32_CH; kk += 2) {
+        const double* xr = xs + kk * DP;
+        double d2a = 0.0, d2b = 0.0;
+#pragma unroll
+        for (int t = 0; t < DP; ++t) {
+          const double da = xc[t] - xr[t], db = xc[t] - xr[DP + t];
+          d2a = fma(da, da, d2a);
+          d2b = fma(db, db, d2b);
+        }
+        const double ka = gpbo_kernel_value<KERNEL>(d2a), kb = gpbo_kernel_value<KERNEL>(d2b);
+        const int k = kc + kk;
+        Kst[(int64_t)k * ldk + ml] = (float)ka;
+        Kst[(int64_t)(k + 1) * ldk + ml] = (float)kb;
+        mu = fma(ka, al[kk], mu);
+        mu = fma(kb, al[kk + 1], mu);
+      }
+    }
   }
-  mu_part[(int64_t)blockIdx.y * Mp + m0 + ml] = mu;
+  if (live) mu_part[(int64_t)blockIdx.y * Mp + m0 + ml] = mu;
 }
 
 // RT = 16-row MFMA tiles per wave: 2 (wave = 32 rows, workgroup chunk = 256 rows) or 4 (64 rows / 512 rows: half
