@@ -13,6 +13,7 @@
 // bayes_opt/target_space.py:95-96): this mode trades ~1e-3 relative accuracy on sigma for throughput and is
 // checked against the fp64 goldens with that tolerance (tests/test_gpu_f32.py).
 #include <cstdlib>
+#include <type_traits>
 
 #include "gpbo_internal.h"
 
@@ -279,14 +280,18 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32(PostArgsF32 p) {
   }
 }
 
-// The same pipeline on v_mfma_f32_32x32x2_f32: wave = 64 rows x 64 candidates = 2 x 2 tiles of 32 x 32 (64 accumulator
-// VGPRs, as the 4 x 4 tiles of 16 x 16), workgroup chunk = 512 rows, 32 train points per stage.  A fragment: lane l holds
-// W[row l & 31][k l >> 5]; B fragment: k*[k l >> 5][candidate l & 31]; C/D: column l & 31, rows (reg & 3) + 8 (reg >> 2) +
-// 4 (l >> 5) (cdna_hip_programming.md §3) — so a lane already holds 16 rows of ONE candidate and the sum of squares
-// needs a single cross-lane add (lane ^ 32).
+// The same pipeline on v_mfma_f32_32x32x2_f32: workgroup chunk = 512 rows = 16 tiles of 32 rows, 8 waves, 32 train points
+// per stage.  Wave w owns tiles w and 15 - w (2 x 2 tiles of 32 x 32 with the 64 candidates = 64 accumulator VGPRs, as the
+// 4 x 4 tiles of 16 x 16): W is lower triangular, so inside the chunk's diagonal block a tile only needs the stages up to
+// its own rows, and the pairing gives every wave the same 17 tile-stages there (64 contiguous rows per wave gave wave 0 two
+// stages and wave 7 sixteen: the workgroup ran at the pace of its last wave).  The stage loop is three branch-free loops
+// (both tiles / later tile / none), look-ahead indices clamped instead of tested — the structure of posterior_kernel_v2.
+// A fragment: lane l holds W[row l & 31][k l >> 5]; B fragment: k*[k l >> 5][candidate l & 31]; C/D: column l & 31, rows
+// (reg & 3) + 8 (reg >> 2) + 4 (l >> 5) (cdna_hip_programming.md §3) — so a lane already holds 16 rows of ONE candidate and
+// the sum of squares needs a single cross-lane add (lane ^ 32).
 __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
   __shared__ __attribute__((aligned(16))) float Ks[2 * F32_BK * F32_STRIDE];   // 20 KiB
-  constexpr int WROWS = 64, CROWS = 512;
+  constexpr int CROWS = 512, CT = CROWS / 32;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -295,13 +300,15 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
   const int ct = bid - (bid / p.n_ctiles) * p.n_ctiles;
   const int NP = p.NP;
   const int k_end = min(NP, (r + 1) * CROWS);
-  const int n_stages = (k_end + F32_BK - 1) / F32_BK;
-  const int wrow0 = r * CROWS + wave * WROWS;
-  const bool active = wrow0 < NP;
+  const int n_stages = k_end / F32_BK;                    // NP is a multiple of 64
+  const int tileA = r * CT + wave, tileB = r * CT + CT - 1 - wave;    // global 32-row tiles (earlier / later)
+  const int rowA0 = tileA * 32, rowB0 = tileB * 32;
+  const bool activeA = rowA0 < NP, activeB = rowB0 < NP;   // false only in a ragged last chunk
   const int64_t quads = NP / 16;
-  const int wrow_ld = active ? wrow0 : (NP - WROWS);
+  const int tA = activeA ? tileA : 0, tB = activeB ? tileB : 0;        // inactive tiles stream tile 0 (sums dropped)
   // packed: [slab64][quad][tile2][half2][lane] float4
-  const f4* wp = reinterpret_cast<const f4*>(p.Wp) + (int64_t)(wrow_ld / 64) * quads * 256 + lane;
+  const f4* wpA = reinterpret_cast<const f4*>(p.Wp) + ((int64_t)(tA >> 1) * quads * 4 + (tA & 1) * 2) * 64 + lane;
+  const f4* wpB = reinterpret_cast<const f4*>(p.Wp) + ((int64_t)(tB >> 1) * quads * 4 + (tB & 1) * 2) * 64 + lane;
 
   f16v acc[2][2];
 #pragma unroll
@@ -322,22 +329,26 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
   };
   auto loadA = [&](int kquad, f4(&a)[2][2]) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) a[t][h] = wp[(((int64_t)kquad * 2 + t) * 2 + h) * 64];
+    for (int h = 0; h < 2; ++h) {
+      a[0][h] = wpA[((int64_t)kquad * 4 + h) * 64];
+      a[1][h] = wpB[((int64_t)kquad * 4 + h) * 64];
+    }
   };
-  auto mma_quad = [&](int buf, int qq, const f4(&a)[2][2]) {
+  // MODE 2: both tiles, 1: the later tile only
+  auto mma_quad = [&](int buf, int qq, const f4(&a)[2][2], auto mode) {
+    constexpr int MODE = decltype(mode)::value;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float* kb = Ks + (buf * F32_BK + qq * 16 + h * 8 + 2 * e + (lane >> 5)) * F32_STRIDE + (lane & 31);
         const float b0 = kb[0], b1 = kb[32];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][h][e], b0, acc[t][0], 0, 0, 0);
-          acc[t][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][h][e], b1, acc[t][1], 0, 0, 0);
+        if constexpr (MODE == 2) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][h][e], b0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][h][e], b1, acc[0][1], 0, 0, 0);
         }
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][h][e], b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][h][e], b1, acc[1][1], 0, 0, 0);
       }
   };
 
@@ -350,49 +361,44 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
   loadA(0, aA);
   __syncthreads();
 
-  const int n_full = r * (CROWS / F32_BK);
-  int s = 0;
-  for (; s < n_full; ++s) {
-    const int buf = s & 1;
+  const int last_stage = n_stages - 1;
+  const int last_quad = (int)quads - 1;
+  auto stage = [&](int st, auto mode) {
+    constexpr int MODE = decltype(mode)::value;
+    const int buf = st & 1;
     float kv[4];
-    loadA(2 * s + 1, aB);
-    ld_stage(s + 1, kv);
+    if constexpr (MODE > 0) loadA(min(2 * st + 1, last_quad), aB);
+    ld_stage(min(st + 1, last_stage), kv);
     __builtin_amdgcn_sched_barrier(0);
-    mma_quad(buf, 0, aA);
-    loadA(2 * s + 2, aA);
-    mma_quad(buf, 1, aB);
-    st_stage(kv, buf ^ 1);
+    if constexpr (MODE > 0) mma_quad(buf, 0, aA, mode);
+    if constexpr (MODE > 0) loadA(min(2 * st + 2, last_quad), aA);
+    if constexpr (MODE > 0) mma_quad(buf, 1, aB, mode);
+    st_stage(kv, buf ^ 1);      // after the last LDS read of this stage (for st == last_stage nobody reads it)
     __syncthreads();
-  }
-  for (; s < n_stages; ++s) {
-    const int buf = s & 1;
-    const bool has_next = (s + 1 < n_stages);
-    const bool domma = (s * F32_BK <= wrow0 + WROWS - 1);
-    const bool domma_next = has_next && ((s + 1) * F32_BK <= wrow0 + WROWS - 1);
-    if (domma) loadA(2 * s + 1, aB);
-    float kv[4];
-    if (has_next) ld_stage(s + 1, kv);
-    if (domma) {
-      mma_quad(buf, 0, aA);
-      mma_quad(buf, 1, aB);
-    }
-    if (has_next) st_stage(kv, buf ^ 1);
-    if (domma_next) loadA(2 * s + 2, aA);
-    __syncthreads();
-  }
+  };
+  using both_t = std::integral_constant<int, 2>;
+  using later_t = std::integral_constant<int, 1>;
+  // stages 0 .. sA: both tiles; sA + 1 .. sB: the later tile only; beyond: none (W is lower triangular)
+  const int sA = min(last_stage, (rowA0 + 31) / F32_BK);
+  const int sB = min(last_stage, (rowB0 + 31) / F32_BK);
+  int s = 0;
+  for (; s <= sA; ++s) stage(s, both_t{});
+  for (; s <= sB; ++s) stage(s, later_t{});
+  for (; s <= last_stage; ++s) stage(s, std::integral_constant<int, 0>{});
 
-  // epilogue: squares in fp32 per lane (32 rows of one candidate), everything beyond that in fp64, fixed order
+  // epilogue: squares in fp32 per lane (16 rows of one candidate per tile), everything beyond that in fp64, fixed order
   double* red = reinterpret_cast<double*>(Ks);   // [8][64] doubles = 4 KiB
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    float vs = 0.f;
+    float va = 0.f, vb = 0.f;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) vs = fmaf(acc[t][u][e], acc[t][u][e], vs);
-    double v = (double)vs;
+    for (int e = 0; e < 16; ++e) {
+      va = fmaf(acc[0][u][e], acc[0][u][e], va);
+      vb = fmaf(acc[1][u][e], acc[1][u][e], vb);
+    }
+    double v = (activeA ? (double)va : 0.0) + (activeB ? (double)vb : 0.0);
     v += __shfl_xor(v, 32);
-    if (lane < 32) red[wave * F32_CANDS + u * 32 + lane] = active ? v : 0.0;
+    if (lane < 32) red[wave * F32_CANDS + u * 32 + lane] = v;
   }
   __syncthreads();
   if (tid < F32_CANDS) {
