@@ -289,8 +289,13 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32(PostArgsF32 p) {
 // A fragment: lane l holds W[row l & 31][k l >> 5]; B fragment: k*[k l >> 5][candidate l & 31]; C/D: column l & 31, rows
 // (reg & 3) + 8 (reg >> 2) + 4 (l >> 5) (cdna_hip_programming.md §3) — so a lane already holds 16 rows of ONE candidate and
 // the sum of squares needs a single cross-lane add (lane ^ 32).
+// BKX train points per stage (one workgroup barrier per stage): 64 — the f32 matrix pipe runs twice as fast as the f64
+// one, so the fixed per-stage cost (barrier, LDS stores, waits) weighs twice as much; 32-point stages left it 12 % idle.
+template <int BKX>
 __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
-  __shared__ __attribute__((aligned(16))) float Ks[2 * F32_BK * F32_STRIDE];   // 20 KiB
+  __shared__ __attribute__((aligned(16))) float Ks[2 * BKX * F32_STRIDE];   // 40 KiB at BKX = 64
+  constexpr int EX = BKX / 8;      // slab elements per thread per stage
+  constexpr int QX = BKX / 16;     // k-quads (16 columns of W) per stage
   constexpr int CROWS = 512, CT = CROWS / 32;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
   const int ct = bid - (bid / p.n_ctiles) * p.n_ctiles;
   const int NP = p.NP;
   const int k_end = min(NP, (r + 1) * CROWS);
-  const int n_stages = k_end / F32_BK;                    // NP is a multiple of 64
+  const int n_stages = k_end / BKX;                       // NP is a multiple of 64
   const int tileA = r * CT + wave, tileB = r * CT + CT - 1 - wave;    // global 32-row tiles (earlier / later)
   const int rowA0 = tileA * 32, rowB0 = tileB * 32;
   const bool activeA = rowA0 < NP, activeB = rowB0 < NP;   // false only in a ragged last chunk
@@ -318,14 +323,14 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
 
-  auto ld_stage = [&](int stage, float (&kv)[4]) {
-    const float* src = p.Kst + (int64_t)(stage * F32_BK + wave * 4) * p.ldk + (int64_t)ct * F32_CANDS + lane;
+  auto ld_stage = [&](int stage, float (&kv)[EX]) {
+    const float* src = p.Kst + (int64_t)(stage * BKX + wave * EX) * p.ldk + (int64_t)ct * F32_CANDS + lane;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) kv[e] = src[(int64_t)e * p.ldk];
+    for (int e = 0; e < EX; ++e) kv[e] = src[(int64_t)e * p.ldk];
   };
-  auto st_stage = [&](const float (&kv)[4], int buf) {
+  auto st_stage = [&](const float (&kv)[EX], int buf) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) Ks[(buf * F32_BK + wave * 4 + e) * F32_STRIDE + lane] = kv[e];
+    for (int e = 0; e < EX; ++e) Ks[(buf * BKX + wave * EX + e) * F32_STRIDE + lane] = kv[e];
   };
   auto loadA = [&](int kquad, f4(&a)[2][2]) {
 #pragma unroll
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float* kb = Ks + (buf * F32_BK + qq * 16 + h * 8 + 2 * e + (lane >> 5)) * F32_STRIDE + (lane & 31);
+        const float* kb = Ks + (buf * BKX + qq * 16 + h * 8 + 2 * e + (lane >> 5)) * F32_STRIDE + (lane & 31);
         const float b0 = kb[0], b1 = kb[32];
         if constexpr (MODE == 2) {
           acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][h][e], b0, acc[0][0], 0, 0, 0);
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
   };
 
   {
-    float kv0[4];
+    float kv0[EX];
     ld_stage(0, kv0);
     st_stage(kv0, 0);
   }
@@ -366,21 +371,31 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
   auto stage = [&](int st, auto mode) {
     constexpr int MODE = decltype(mode)::value;
     const int buf = st & 1;
-    float kv[4];
-    if constexpr (MODE > 0) loadA(min(2 * st + 1, last_quad), aB);
+    float kv[EX];
+    if constexpr (MODE > 0) loadA(min(QX * st + 1, last_quad), aB);
     ld_stage(min(st + 1, last_stage), kv);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (MODE > 0) mma_quad(buf, 0, aA, mode);
-    if constexpr (MODE > 0) loadA(min(2 * st + 2, last_quad), aA);
-    if constexpr (MODE > 0) mma_quad(buf, 1, aB, mode);
+    // k-quads alternate between the two fragment registers; each is refilled (two quads ahead) right after its use — the
+    // last one of the stage at the top of the next stage
+    if constexpr (MODE > 0) {
+#pragma unroll
+      for (int qq = 0; qq < QX; ++qq) {
+        if (qq & 1) mma_quad(buf, qq, aB, mode);
+        else mma_quad(buf, qq, aA, mode);
+        if (qq + 1 < QX || (qq & 1) == 0) {
+          if (qq & 1) loadA(min(QX * st + qq + 2, last_quad), aB);
+          else loadA(min(QX * st + qq + 2, last_quad), aA);
+        }
+      }
+    }
     st_stage(kv, buf ^ 1);      // after the last LDS read of this stage (for st == last_stage nobody reads it)
     __syncthreads();
   };
   using both_t = std::integral_constant<int, 2>;
   using later_t = std::integral_constant<int, 1>;
   // stages 0 .. sA: both tiles; sA + 1 .. sB: the later tile only; beyond: none (W is lower triangular)
-  const int sA = min(last_stage, (rowA0 + 31) / F32_BK);
-  const int sB = min(last_stage, (rowB0 + 31) / F32_BK);
+  const int sA = min(last_stage, (rowA0 + 31) / BKX);
+  const int sB = min(last_stage, (rowB0 + 31) / BKX);
   int s = 0;
   for (; s <= sA; ++s) stage(s, both_t{});
   for (; s <= sB; ++s) stage(s, later_t{});
@@ -462,7 +477,7 @@ int launch_posterior_f32(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, int* 
     a.nchunks = rt2 ? nchunks : (int)((m.NP + 511) / 512);
     const int64_t nblocks = (int64_t)a.n_ctiles * a.nchunks;
     if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
-    if (mf32) posterior_kernel_f32x<<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
+    if (mf32) posterior_kernel_f32x<64><<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
     else if (rt2) posterior_kernel_f32<2><<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
     else posterior_kernel_f32<4><<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
     GPBO_HIP(ctx, hipGetLastError());
