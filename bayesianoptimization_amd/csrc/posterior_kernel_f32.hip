@@ -289,11 +289,11 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32(PostArgsF32 p) {
 // A fragment: lane l holds W[row l & 31][k l >> 5]; B fragment: k*[k l >> 5][candidate l & 31]; C/D: column l & 31, rows
 // (reg & 3) + 8 (reg >> 2) + 4 (l >> 5) (cdna_hip_programming.md §3) — so a lane already holds 16 rows of ONE candidate and
 // the sum of squares needs a single cross-lane add (lane ^ 32).
-// BKX train points per stage (one workgroup barrier per stage): 64 — the f32 matrix pipe runs twice as fast as the f64
-// one, so the fixed per-stage cost (barrier, LDS stores, waits) weighs twice as much; 32-point stages left it 12 % idle.
+// BKX train points per stage (one workgroup barrier per stage).  Measured on the C5 shard (two GPs): BKX = 32 276.3 ms,
+// BKX = 64 286.4 ms (twice the slab loads in flight per thread, 122 VGPRs) — 32 it is.
 template <int BKX>
 __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
-  __shared__ __attribute__((aligned(16))) float Ks[2 * BKX * F32_STRIDE];   // 40 KiB at BKX = 64
+  __shared__ __attribute__((aligned(16))) float Ks[2 * BKX * F32_STRIDE];   // 20 KiB at BKX = 32
   constexpr int EX = BKX / 8;      // slab elements per thread per stage
   constexpr int QX = BKX / 16;     // k-quads (16 columns of W) per stage
   constexpr int CROWS = 512, CT = CROWS / 32;
@@ -477,7 +477,7 @@ int launch_posterior_f32(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, int* 
     a.nchunks = rt2 ? nchunks : (int)((m.NP + 511) / 512);
     const int64_t nblocks = (int64_t)a.n_ctiles * a.nchunks;
     if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
-    if (mf32) posterior_kernel_f32x<64><<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
+    if (mf32) posterior_kernel_f32x<32><<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
     else if (rt2) posterior_kernel_f32<2><<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
     else posterior_kernel_f32<4><<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
     GPBO_HIP(ctx, hipGetLastError());
