@@ -17,7 +17,7 @@ eng = GpEngine(0)
 rows = {}
 for name, shard in (("C1", 1), ("C2", 1), ("C3", 1), ("C4", 8), ("C5", 8)):
     w = W.ALL[name]
-    g = np.load(os.path.join(ROOT, "tests", "golden", f"{'C3' if name == 'C4' else name}.npz"))
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"{name + '_s0' if name in ('C4', 'C5') else name}.npz"))
     ls = float(g["length_scale"][0])
     X, y, c = W.make_observations(w)
     M = w.M // shard
