@@ -58,7 +58,9 @@ def _fingerprint() -> str:
             h.update(n.encode())
             h.update(open(p, "rb").read())
     h.update(repr(sorted(SOURCES.items())).encode())
-    h.update(" ".join(COMMON).encode())
+    # flags without the absolute include paths: the same sources must give the same fingerprint wherever the tree lies
+    # (the GPU box runs from a scratch copy; profiles/ stamps its PMC summaries with this value)
+    h.update(" ".join(f for f in COMMON if not f.startswith("-I")).encode())
     return h.hexdigest()
 
 
