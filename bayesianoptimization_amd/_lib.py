@@ -56,6 +56,7 @@ SIGNATURES = {
     "gpbo_posterior": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, _c_double_p, _c_double_p]),
     "gpbo_predict": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int64, C.c_int, C.c_double, C.c_double,
                                _c_double_p, _c_double_p]),
+    "gpbo_take_negative_variance_flag": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "gpbo_predict_cov": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int64, C.c_int, C.c_double, C.c_double,
                                    _c_double_p, _c_double_p]),
     "gpbo_predict_grad": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int64, C.c_int, C.c_double, C.c_double,

@@ -277,6 +277,11 @@ int gpbo_create(int device, gpbo_ctx** out) {
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->info_dev, sizeof(int));
   if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, PIN_WINDOWS * PIN_WINDOW, hipHostMallocDefault);
   if (e == hipSuccess) ctx->pinned_aux = (char*)ctx->pinned + (PIN_WINDOWS - 1) * PIN_WINDOW;
+  if (e == hipSuccess) {
+    int* host_flag = (int*)((char*)ctx->pinned_aux + PIN_AUX_NEGVAR);
+    *host_flag = 0;
+    e = hipHostGetDevicePointer((void**)&ctx->negvar, host_flag, 0);
+  }
   if (e != hipSuccess) {
     set_global_error(std::string("gpbo_create: ") + hipGetErrorString(e));
     delete ctx;
@@ -843,6 +848,15 @@ int gpbo_predict(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d, do
   int rc = gpbo_set_candidates(ctx, Xc, M, d);
   if (rc) return rc;
   return gpbo_posterior(ctx, slot, y_mean, y_std, mu, sd);
+}
+
+int gpbo_take_negative_variance_flag(gpbo_ctx* ctx, int* seen) {
+  if (!ctx || !seen) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_take_negative_variance_flag: null argument");
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the finalize kernels of every enqueued posterior have written it
+  int* flag = (int*)((char*)ctx->pinned_aux + PIN_AUX_NEGVAR);
+  *seen = *flag;
+  *flag = 0;
+  return GPBO_OK;
 }
 
 int gpbo_predict_cov(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d, double y_mean, double y_std,

@@ -28,18 +28,27 @@ __global__ __launch_bounds__(256) void posterior_finalize_kernel(const double* _
                                                                  int nchunks, int n_mu, int64_t Mp, int64_t M,
                                                                  double y_mean, double y_std,
                                                                  double* __restrict__ mu,
-                                                                 double* __restrict__ sd) {
+                                                                 double* __restrict__ sd, int* __restrict__ negvar) {
   const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (m >= M) return;
   double ss = 0.0;
   for (int r = 0; r < nchunks; ++r) ss += part[(int64_t)r * Mp + m];
   double var = 1.0 - ss;
-  if (var < 0.0) var = 0.0;          // _gpr.py:479-485 (NaN stays NaN, as in numpy)
+  if (var < 0.0) {                   // _gpr.py:479-485 (NaN stays NaN, as in numpy); the host warns as sklearn does
+    *negvar = 1;
+    var = 0.0;
+  }
   var = var * (y_std * y_std);
   sd[m] = sqrt(var);
   double mun = 0.0;
   for (int q = 0; q < n_mu; ++q) mun += mu_part[(int64_t)q * Mp + m];
   mu[m] = y_std * mun + y_mean;
+}
+
+// GPBO_POST_PAIR=1: pair-co-scheduled block mapping of the slab GEMMs (gpbo_internal.h: post_block_map)
+int post_pair_mode() {
+  static const int mode = (getenv("GPBO_POST_PAIR") && getenv("GPBO_POST_PAIR")[0] == '1') ? 1 : 0;
+  return mode;
 }
 
 static int ensure_posterior_outputs(gpbo_ctx* ctx, Model& m, int64_t Mp) {
@@ -111,7 +120,7 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
   if (rc) return rc;
   ev_begin(ctx, T_POST_FINAL);
   posterior_finalize_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream>>>(
-      ctx->part, ctx->mu_part, part_chunks, n_mu, Mp, M, y_mean, y_std, m.mu, m.sd);
+      ctx->part, ctx->mu_part, part_chunks, n_mu, Mp, M, y_mean, y_std, m.mu, m.sd, ctx->negvar);
   ev_end(ctx, T_POST_FINAL);
   GPBO_HIP(ctx, hipGetLastError());
   m.M_post = M;

@@ -40,6 +40,7 @@ struct PostArgs2 {
   const double* Kst;   // GEN == 2: materialised k* slab [NP][ldk], candidate-contiguous
   int64_t ldk;
   int64_t m0;          // first candidate of the slab (outputs are indexed m0 + local)
+  int pair;            // slab kernel only: block-id mapping that co-schedules the two chunks of a pair on one XCD
 };
 
 // GEN = 1: k* generated in the kernel (fused).  GEN = 2: k* read from a slab materialised by
@@ -61,9 +62,8 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int bid = blockIdx.x;
-  const int r = p.nchunks - 1 - bid / p.n_ctiles;   // heaviest row chunks first
-  const int ct = bid - (bid / p.n_ctiles) * p.n_ctiles;
+  int r, ct;                                        // heaviest row chunks first (post_block_map, gpbo_internal.h)
+  if (!post_block_map(blockIdx.x, p.nchunks, p.n_ctiles, GEN == 2 ? p.pair : 0, r, ct)) return;
   const bool last = (r == p.nchunks - 1);
   const int NP = p.NP;
   const int k_end = min(NP, (r + 1) * POST_ROWS);
@@ -340,11 +340,11 @@ int launch_kstar_slab(gpbo_ctx* ctx, Model& m, double* Kst, int64_t ldk, int64_t
 }
 
 // Two-kernel pipeline per candidate slab: kstar_gen_kernel -> posterior_kernel_v2<.., GEN = 2>.
-// The slab width is bounded by a workspace budget (default 40 GB, GPBO_KSTAR_GB to override); mu partials
+// The slab width is bounded by a workspace budget (default 4 GB, GPBO_KSTAR_GB to override); mu partials
 // need nchunks x Mp doubles in ctx->mu_part (allocated by the caller).
 int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
   // k* workspace: the candidate set is walked slab by slab; a slab only has to be wide enough to fill the chip
-  // (4 GB = 131 072 candidates at N = 4096 = 2048 candidate tiles x 16 row chunks per launch); measured at C3: one 34 GB
+  // (4e9 B = 121 984 candidates at N = 4096 = 1906 candidate tiles x 16 row chunks per launch); measured at C3: one 34 GB
   // slab 263.7 ms, eight 4 GB slabs 264.4 ms (round 1 A/B) — the big workspace bought nothing.  GPBO_KSTAR_GB overrides.
   double budget_gb = 4.0;
   if (const char* e = getenv("GPBO_KSTAR_GB")) budget_gb = atof(e) > 0.0 ? atof(e) : budget_gb;
@@ -370,7 +370,8 @@ int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
     a.Wp = m.Wp; a.Xs = m.Xs; a.alpha = m.alpha; a.Xcs = ctx->Xcs; a.part = ctx->part;
     a.mu_part = ctx->mu_part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nchunks;
     a.n_ctiles = (int)(ldk / V2_CANDS); a.Kst = ctx->kst; a.ldk = ldk; a.m0 = m0;
-    const int64_t nblocks = (int64_t)a.n_ctiles * nchunks;
+    a.pair = post_pair_mode();
+    const int64_t nblocks = post_grid_blocks(nchunks, a.n_ctiles, a.pair);
     if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
     if (post_bk == 32) {
       const size_t lds = (size_t)(2 * 32 * V2_STRIDE) * sizeof(double);
@@ -414,7 +415,7 @@ int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
   a.Wp = m.Wp; a.Xs = m.Xs; a.alpha = m.alpha; a.Xcs = ctx->Xcs; a.part = ctx->part;
   a.mu_part = ctx->mu_part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nchunks;
   a.n_ctiles = (int)(Mp / V2_CANDS);
-  a.Kst = nullptr; a.ldk = 0; a.m0 = 0;
+  a.Kst = nullptr; a.ldk = 0; a.m0 = 0; a.pair = 0;
   const int64_t nblocks = (int64_t)a.n_ctiles * nchunks;
   if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
   if (m.kernel == GPBO_KERNEL_MATERN25) return launch_v2_k<GPBO_KERNEL_MATERN25>(ctx, m.DP, a, nblocks);

@@ -97,7 +97,7 @@ static void launch_gemv(gpbo_ctx* ctx, Model& m, const double* ks, double* vsq, 
 __global__ __launch_bounds__(256) void finalize_small_kernel(const double* __restrict__ vsq, const double* __restrict__ ks,
                                                              const double* __restrict__ alpha, int64_t NP,
                                                              double y_mean, double y_std, double* __restrict__ mu,
-                                                             double* __restrict__ sd) {
+                                                             double* __restrict__ sd, int* __restrict__ negvar) {
   __shared__ double sh[4];
   const int c = blockIdx.x;
   double s = 0.0, m = 0.0;
@@ -118,7 +118,10 @@ __global__ __launch_bounds__(256) void finalize_small_kernel(const double* __res
   }
   if (threadIdx.x == 0) {
     double var = 1.0 - tot[0];
-    if (var < 0.0) var = 0.0;
+    if (var < 0.0) {
+      *negvar = 1;
+      var = 0.0;
+    }
     var = var * (y_std * y_std);
     sd[c] = sqrt(var);
     mu[c] = y_std * tot[1] + y_mean;
@@ -155,7 +158,7 @@ int launch_posterior_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double
     else launch_gemv<16, 2>(ctx, m, ksp, vp);
   }
   GPBO_HIP(ctx, hipGetLastError());
-  finalize_small_kernel<<<dim3((unsigned)M), dim3(256), 0, ctx->stream>>>(vsq, ks, m.alpha, m.NP, y_mean, y_std, m.mu, m.sd);
+  finalize_small_kernel<<<dim3((unsigned)M), dim3(256), 0, ctx->stream>>>(vsq, ks, m.alpha, m.NP, y_mean, y_std, m.mu, m.sd, ctx->negvar);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
@@ -281,7 +284,8 @@ __global__ __launch_bounds__(256) void grad_small_kernel(const double* __restric
                                                          const double* __restrict__ alpha, const double* __restrict__ ls,
                                                          int DP, int d, int64_t NP, int M, double y_mean, double y_std,
                                                          double* __restrict__ mu, double* __restrict__ sd,
-                                                         double* __restrict__ dmu, double* __restrict__ dsd) {
+                                                         double* __restrict__ dmu, double* __restrict__ dsd,
+                                                         int* __restrict__ negvar) {
   extern __shared__ __attribute__((aligned(16))) double gs_smem[];   // [2][256] partial sums | [8] scalars
   const int c = blockIdx.x;
   const int t = threadIdx.x % DP, kl = threadIdx.x / DP, nkl = 256 / DP;
@@ -319,7 +323,10 @@ __global__ __launch_bounds__(256) void grad_small_kernel(const double* __restric
   }
   __syncthreads();
   double var = 1.0 - tot[0];
-  if (var < 0.0) var = 0.0;
+  if (var < 0.0) {
+    if (threadIdx.x == 0) *negvar = 1;
+    var = 0.0;
+  }
   const double sdn = sqrt(var);
   if (threadIdx.x == 0) {
     sd[c] = sqrt(var * (y_std * y_std));
@@ -371,7 +378,7 @@ int launch_posterior_grad_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, d
   const size_t lds = (size_t)(512 + 8) * sizeof(double);
   grad_small_kernel<<<dim3((unsigned)M), dim3(256), lds, ctx->stream>>>(m.Xs, ctx->Xcs, fs, vb, ks, partial, m.alpha, m.ls,
                                                                          m.DP, m.d, m.NP, M, y_mean, y_std, m.mu, m.sd,
-                                                                         dmu_dev, dsd_dev);
+                                                                         dmu_dev, dsd_dev, ctx->negvar);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }

@@ -227,6 +227,13 @@ class GpEngine:
         self.set_candidates(Xc)
         return self.posterior(slot, y_mean, y_std, fetch=True)
 
+    def take_negative_variance_flag(self):
+        """True when a posterior / predict since the last call clipped a NEGATIVE variance — sklearn's warning
+        condition (_gpr.py:479-485); clears the flag (gpbo_take_negative_variance_flag)."""
+        seen = C.c_int(0)
+        self._check(self._lib.gpbo_take_negative_variance_flag(self._h, C.byref(seen)))
+        return bool(seen.value)
+
     def predict_cov(self, Xc, slot=0, y_mean=0.0, y_std=1.0):
         """(mu (M,), cov (M,M)) as GaussianProcessRegressor.predict(return_cov=True) (gpbo_predict_cov)."""
         Xc = np.ascontiguousarray(Xc, dtype=np.float64)

@@ -412,13 +412,15 @@ class HipGPR(GaussianProcessRegressor):
             mean, cov = self._engine().predict_cov(self._tx(X), slot=self.slot, y_mean=float(self._y_train_mean),
                                                    y_std=float(self._y_train_std))
             return mean, cov
-        mean, std = self._engine().predict(self._tx(X), slot=self.slot, y_mean=float(self._y_train_mean),
-                                           y_std=float(self._y_train_std))
+        eng = self._engine()
         if return_std:
-            # _gpr.py:479-485: sklearn warns when it clips NEGATIVE variances.  The device clips inside the finalize kernel,
-            # so the sign is gone by the time std arrives; a clipped variance comes back as exactly 0.0, which an
-            # unclipped one (1 - |W k*|^2 in fp64 at a point that is not a training point) practically never is
-            if np.any(std == 0.0):
+            eng.take_negative_variance_flag()          # clear: only this call's clips count
+        mean, std = eng.predict(self._tx(X), slot=self.slot, y_mean=float(self._y_train_mean),
+                                y_std=float(self._y_train_std))
+        if return_std:
+            # _gpr.py:479-485: sklearn warns when it clips NEGATIVE variances (a variance of exactly 0 is silent).  The
+            # device clips inside its finalize kernel, which records that it did
+            if eng.take_negative_variance_flag():
                 warnings.warn("Predicted variances smaller than 0. Setting those variances to 0.", stacklevel=2)
             return mean, std
         return mean

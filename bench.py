@@ -195,7 +195,9 @@ def pmc_summary_for(w):
     (scripts/profile_pmc.sh -> scripts/pmc_summary.py), trusted only when the summary was taken from the very kernel
     sources this run uses (the library's build fingerprint is stamped into the summary)."""
     from bayesianoptimization_amd.build import _fingerprint
-    ppath = os.path.join(ROOT, "profiles", f"r02_pmc_{w.name}.json")
+    # C4 is C3's GP over the same 2^20 candidates per GPU with another acquisition function: its dominant kernels
+    # (and their launches) are the ones profiled for C3
+    ppath = os.path.join(ROOT, "profiles", f"r02_pmc_{'C3' if w.name == 'C4' else w.name}.json")
     if not os.path.exists(ppath):
         return None, "no PMC summary for this config under profiles/ (scripts/profile_pmc.sh)"
     pm = json.load(open(ppath))

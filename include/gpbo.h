@@ -161,6 +161,12 @@ int gpbo_posterior(gpbo_ctx* ctx, int slot, double y_mean, double y_std, double*
 int gpbo_predict(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d, double y_mean,
                  double y_std, double* mu, double* sd);
 
+/* sklearn warns "Predicted variances smaller than 0. Setting those variances to 0." when it clips a NEGATIVE
+ * variance (_gpr.py:479-485).  The device clips inside its finalize kernels; this reports (and clears) whether any
+ * gpbo_posterior / gpbo_predict / gpbo_predict_grad since the last call clipped one, so the host can warn on exactly
+ * sklearn's condition.  Synchronises the context's stream. */
+int gpbo_take_negative_variance_flag(gpbo_ctx* ctx, int* seen);
+
 /* Replaces GaussianProcessRegressor.predict(X, return_cov=True) (_gpr.py:443-447, 458-469; reached from
  * BayesianOptimization.predict(..., return_cov=True), bayes_opt/bayesian_optimization.py:238) for a host batch:
  * cov (M,M) row-major = (k(X, X) - V^T V) * y_std^2 with V = L^-1 K*^T formed as two MFMA GEMMs on the device (no clipping,

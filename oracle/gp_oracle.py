@@ -109,6 +109,14 @@ def predict(gp: GPState, Xc: np.ndarray):
     return mean, np.sqrt(var)
 
 
+def negative_variances(gp: GPState, Xc: np.ndarray) -> int:
+    """How many predicted variances sklearn would clip (and warn about): y_var < 0 before the clip, _gpr.py:479-485."""
+    Xc = np.asarray(Xc, dtype=np.float64).reshape(-1, gp.X.shape[1])
+    Kt = kernel_matrix(gp.kind, Xc, gp.X, gp.length_scale)
+    V = solve_triangular(gp.L, Kt.T, lower=True, check_finite=False)
+    return int(np.count_nonzero(np.ones(Xc.shape[0]) - np.einsum("ij,ji->i", V.T, V) < 0))
+
+
 def predict_cov(gp: GPState, Xc: np.ndarray):
     """(mean, covariance) as GaussianProcessRegressor.predict(return_cov=True) (_gpr.py:443-469)."""
     Xc = np.asarray(Xc, dtype=np.float64).reshape(-1, gp.X.shape[1])

@@ -117,12 +117,17 @@ class FakeEngine:
         self.calls.append(("posterior", slot))
         mu, sd = O.predict(self.models[slot], self.Xc)
         mu, sd = y_std * mu + y_mean, sd * y_std
+        self.negvar = getattr(self, "negvar", False) or bool(O.negative_variances(self.models[slot], self.Xc))
         self.post[slot] = (mu, sd)
         return (mu, sd) if fetch else (None, None)
 
     def predict(self, Xc, slot=0, y_mean=0.0, y_std=1.0):
         self.set_candidates(Xc)
         return self.posterior(slot, y_mean, y_std, True)
+
+    def take_negative_variance_flag(self):
+        seen, self.negvar = getattr(self, "negvar", False), False
+        return seen
 
     def predict_cov(self, Xc, slot=0, y_mean=0.0, y_std=1.0):
         self.calls.append(("predict_cov", slot, np.shape(Xc)))

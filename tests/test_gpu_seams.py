@@ -350,3 +350,45 @@ def test_theta_search_in_lockstep_on_the_device(engine):
                     engine=engine, lml_on_device=True, theta_lockstep=lockstep).fit(sp.params, sp.target)
         out[lockstep] = (gp.kernel_.theta.copy(), gp.log_marginal_likelihood_value_, rs.uniform())
     assert np.array_equal(out[True][0], out[False][0]) and out[True][1:] == out[False][1:]
+
+
+def test_predict_warns_on_negative_variances_only_like_sklearn(engine):
+    """sklearn warns when it clips a NEGATIVE predicted variance (_gpr.py:479-485) — not on a variance of zero.  The
+    device's finalize kernels record the clip (gpbo_take_negative_variance_flag).  fp64: neither sklearn nor the device
+    clips anything on this model, so neither warns.  The fp32 posterior mode at the training points of a model with
+    noise 1e-8 (true variance far below the mode's 5e-6 error) does clip — flag, exact zeros and the warning appear
+    together, and the flag is cleared by reading it."""
+    import warnings
+
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import Matern
+
+    from bayesianoptimization_amd.gpr import HipGPR
+
+    rs = np.random.RandomState(3)
+    X = rs.uniform(size=(600, 3))
+    y = np.sin(3 * X.sum(axis=1))
+    Xq = np.concatenate([X] * 3)                     # 1800 queries: above every small-batch limit -> the MFMA paths
+    k = Matern(nu=2.5, length_scale=0.7)
+
+    def warned(gp):
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            _, sd = gp.predict(Xq, return_std=True)
+        return any("Predicted variances smaller than 0" in str(r.message) for r in rec), sd
+
+    sk_w, sd_s = warned(GaussianProcessRegressor(kernel=k, alpha=1e-8, normalize_y=True, optimizer=None).fit(X, y))
+    d_w, sd_d = warned(HipGPR(kernel=k, alpha=1e-8, normalize_y=True, optimizer=None, engine=engine).fit(X, y))
+    assert d_w == sk_w and not d_w
+    assert not (sd_d == 0).any() and not (sd_s == 0).any()
+    assert engine.take_negative_variance_flag() is False
+
+    f_w, sd_f = warned(HipGPR(kernel=k, alpha=1e-8, normalize_y=True, optimizer=None, engine=engine, precision="f32").fit(X, y))
+    assert f_w and (sd_f == 0).any()
+    assert engine.take_negative_variance_flag() is False       # predict() consumed it
+    # the small-batch (GEMV) kernels carry the flag too: a 3-point batch in fp64 does not clip
+    gp = HipGPR(kernel=k, alpha=1e-8, normalize_y=True, optimizer=None, engine=engine).fit(X, y)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        gp.predict(X[:3], return_std=True)
+    assert not rec
