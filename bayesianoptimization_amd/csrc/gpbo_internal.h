@@ -133,35 +133,6 @@ namespace gpbo {
 // LML evaluation; gpbo_lml_batch re-points ctx->pinned at windows 1..GPBO_LML_BATCH_MAX for its groups (their own
 // sub-layout, PIN_LANE_* in gpbo_api.hip); the LAST window (ctx->pinned_aux) belongs to the selection and candidate
 // entry points, so that no two subsystems share a byte whatever stays in flight.
-// ---- posterior GEMM grids: block id -> (row chunk r, candidate tile ct) -------------------------------------------
-// pair = 0: chunk-major, heaviest chunk first; the workgroups resident at any time share a chunk (its rows of W come
-// out of L2) and every chunk re-reads its k* rows from HBM.
-// pair = 1: the two chunks 2p+1, 2p of a candidate tile sit 8 block ids apart.  Workgroups are handed to the 8 XCDs
-// round-robin by block id, so the two land on the same XCD back to back, walk the same k* rows at the same pace and
-// the second one's reads hit that XCD's L2: half the k* re-reads from HBM, the kernel itself unchanged.
-#ifdef __HIPCC__
-__device__ __forceinline__ bool post_block_map(int bid, int nchunks, int n_ctiles, int pair, int& r, int& ct) {
-  if (!pair) {
-    const int q = bid / n_ctiles;
-    r = nchunks - 1 - q;
-    ct = bid - q * n_ctiles;
-    return true;
-  }
-  const int half = (bid >> 3) & 1;
-  const int q = ((bid >> 4) << 3) | (bid & 7);
-  const int pr = q / n_ctiles;
-  ct = q - pr * n_ctiles;
-  r = nchunks - 1 - (2 * pr + half);
-  return r >= 0;
-}
-#endif
-inline int64_t post_grid_blocks(int nchunks, int n_ctiles, int pair) {
-  if (!pair) return (int64_t)nchunks * n_ctiles;
-  const int64_t q = (int64_t)((nchunks + 1) / 2) * n_ctiles;
-  return (q + 7) / 8 * 16;
-}
-int post_pair_mode();   // GPBO_POST_PAIR (posterior_kernel.hip)
-
 constexpr size_t PIN_WINDOW = 16384;
 constexpr int PIN_WINDOWS = 2 + GPBO_LML_BATCH_MAX;
 // window 0

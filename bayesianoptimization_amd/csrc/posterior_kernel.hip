@@ -45,12 +45,6 @@ __global__ __launch_bounds__(256) void posterior_finalize_kernel(const double* _
   mu[m] = y_std * mun + y_mean;
 }
 
-// GPBO_POST_PAIR=1: pair-co-scheduled block mapping of the slab GEMMs (gpbo_internal.h: post_block_map)
-int post_pair_mode() {
-  static const int mode = (getenv("GPBO_POST_PAIR") && getenv("GPBO_POST_PAIR")[0] == '1') ? 1 : 0;
-  return mode;
-}
-
 static int ensure_posterior_outputs(gpbo_ctx* ctx, Model& m, int64_t Mp) {
   if (Mp > m.cap_M) {
     if (m.mu) { GPBO_HIP(ctx, hipFree(m.mu)); m.mu = nullptr; }

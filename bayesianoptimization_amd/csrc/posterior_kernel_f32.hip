@@ -46,7 +46,6 @@ struct PostArgsF32 {
   int n_ctiles;
   int64_t ldk;
   int64_t m0;
-  int pair;             // block-id mapping (post_block_map, gpbo_internal.h)
 };
 
 // W -> fp32 A fragments of v_mfma_f32_16x16x4_f32: for slab s (32 rows), k-quad q (16 columns), tile t (16 rows):
@@ -166,8 +165,9 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32(PostArgsF32 p) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  int r, ct;
-  if (!post_block_map(blockIdx.x, p.nchunks, p.n_ctiles, p.pair, r, ct)) return;
+  const int bid = blockIdx.x;
+  const int r = p.nchunks - 1 - bid / p.n_ctiles;
+  const int ct = bid - (bid / p.n_ctiles) * p.n_ctiles;
   const int NP = p.NP;
   const int k_end = min(NP, (r + 1) * CROWS);
   const int n_stages = (k_end + F32_BK - 1) / F32_BK;   // NP is a multiple of 64, so k_end is a multiple of 32
@@ -300,8 +300,9 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  int r, ct;
-  if (!post_block_map(blockIdx.x, p.nchunks, p.n_ctiles, p.pair, r, ct)) return;
+  const int bid = blockIdx.x;
+  const int r = p.nchunks - 1 - bid / p.n_ctiles;
+  const int ct = bid - (bid / p.n_ctiles) * p.n_ctiles;
   const int NP = p.NP;
   const int k_end = min(NP, (r + 1) * CROWS);
   const int n_stages = k_end / BKX;                       // NP is a multiple of 64
@@ -474,8 +475,7 @@ int launch_posterior_f32(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, int* 
     const bool rt2 = (e && e[0] == '2') || m.NP < 512;
     const bool mf32 = f32_use_mfma32(m.NP);     // (the packed W of this fit was laid out for the same choice)
     a.nchunks = rt2 ? nchunks : (int)((m.NP + 511) / 512);
-    a.pair = post_pair_mode();
-    const int64_t nblocks = post_grid_blocks(a.nchunks, a.n_ctiles, a.pair);
+    const int64_t nblocks = (int64_t)a.n_ctiles * a.nchunks;
     if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
     if (mf32) posterior_kernel_f32x<32><<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);
     else if (rt2) posterior_kernel_f32<2><<<dim3((unsigned)nblocks), dim3(512), 0, ctx->stream>>>(a);

@@ -40,7 +40,6 @@ struct PostArgs2 {
   const double* Kst;   // GEN == 2: materialised k* slab [NP][ldk], candidate-contiguous
   int64_t ldk;
   int64_t m0;          // first candidate of the slab (outputs are indexed m0 + local)
-  int pair;            // slab kernel only: block-id mapping that co-schedules the two chunks of a pair on one XCD
 };
 
 // GEN = 1: k* generated in the kernel (fused).  GEN = 2: k* read from a slab materialised by
@@ -62,8 +61,13 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  int r, ct;                                        // heaviest row chunks first (post_block_map, gpbo_internal.h)
-  if (!post_block_map(blockIdx.x, p.nchunks, p.n_ctiles, GEN == 2 ? p.pair : 0, r, ct)) return;
+  // Heaviest row chunks first; the workgroups resident at any time share a chunk, so its rows of W come out of L2.
+  // (Round-2 A/B: mappings that put the two chunks of a candidate tile 1 ... 64 block ids apart, hoping the second
+  // chunk's k* reads would hit the first one's in L2, never lowered FETCH_SIZE — 3.5e11 ... 6.6e11 B against 3.3e11 —
+  // and cost up to 6 % of the time; removed.)
+  const int bid = blockIdx.x;
+  const int r = p.nchunks - 1 - bid / p.n_ctiles;
+  const int ct = bid - (bid / p.n_ctiles) * p.n_ctiles;
   const bool last = (r == p.nchunks - 1);
   const int NP = p.NP;
   const int k_end = min(NP, (r + 1) * POST_ROWS);
@@ -370,8 +374,7 @@ int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
     a.Wp = m.Wp; a.Xs = m.Xs; a.alpha = m.alpha; a.Xcs = ctx->Xcs; a.part = ctx->part;
     a.mu_part = ctx->mu_part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nchunks;
     a.n_ctiles = (int)(ldk / V2_CANDS); a.Kst = ctx->kst; a.ldk = ldk; a.m0 = m0;
-    a.pair = post_pair_mode();
-    const int64_t nblocks = post_grid_blocks(nchunks, a.n_ctiles, a.pair);
+    const int64_t nblocks = (int64_t)a.n_ctiles * nchunks;
     if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
     if (post_bk == 32) {
       const size_t lds = (size_t)(2 * 32 * V2_STRIDE) * sizeof(double);
@@ -415,7 +418,7 @@ int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
   a.Wp = m.Wp; a.Xs = m.Xs; a.alpha = m.alpha; a.Xcs = ctx->Xcs; a.part = ctx->part;
   a.mu_part = ctx->mu_part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nchunks;
   a.n_ctiles = (int)(Mp / V2_CANDS);
-  a.Kst = nullptr; a.ldk = 0; a.m0 = 0; a.pair = 0;
+  a.Kst = nullptr; a.ldk = 0; a.m0 = 0;
   const int64_t nblocks = (int64_t)a.n_ctiles * nchunks;
   if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
   if (m.kernel == GPBO_KERNEL_MATERN25) return launch_v2_k<GPBO_KERNEL_MATERN25>(ctx, m.DP, a, nblocks);
