@@ -157,6 +157,23 @@ def suggest_latency(w, X, y, eng, M, reps=3):
                 ts.append((time.perf_counter() - t0) * 1e3)
             res[f"n_smart_{n_smart}"] = float(np.median(ts[1:]))      # first call: allocations
     res["note"] = "median of 3 after one warm-up; fixed theta; candidates = the reference's RandomState stream, generated on the device"
+    # ... and as BayesianOptimization itself configures its GP (bayesian_optimization.py: Matern(nu=2.5), alpha=1e-6,
+    # normalize_y=True, n_restarts_optimizer=5): every suggest() then also runs sklearn's theta search — 1 + 5 L-BFGS-B
+    # runs over the log-marginal likelihood, here with the LML and its gradient on the device (gpbo_lml_batch lanes)
+    try:
+        gp_t = HipGPR(kernel=Matern(nu=2.5), alpha=1e-6, normalize_y=True, n_restarts_optimizer=5,
+                      random_state=np.random.RandomState(1), engine=eng, incremental=False)
+        ts = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for rep in range(3):
+                t0 = time.perf_counter()
+                fn.suggest(gp_t, sp, n_random=M, n_smart=10, fit_gp=True, random_state=np.random.RandomState(7 + rep))
+                ts.append((time.perf_counter() - t0) * 1e3)
+        res["n_smart_10_with_theta_search"] = float(np.median(ts[1:]))
+    except Exception as e:  # noqa: BLE001
+        res["n_smart_10_with_theta_search"] = None
+        res["theta_search_error"] = repr(e)
     return res
 
 
