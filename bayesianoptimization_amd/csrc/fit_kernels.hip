@@ -8,6 +8,7 @@
 //   trtri         W = L^-1: turns the per-candidate solve_triangular (_gpr.py:454-456) into a GEMM
 //   trmv          alpha = cho_solve((L, True), y)           _gpr.py:360-364, as W^T (W y)
 #include <cstdlib>
+#include <utility>
 
 #include "gpbo_internal.h"
 
@@ -390,12 +391,16 @@ int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb) {
 //   C = alpha * A(m,k) * op(B) + beta * C ;  A row-major; B row-major (k,n), or (n,k) if b_trans.
 // Fragment layout (cdna_hip_programming.md §3): A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15],
 // D lane l, reg r = D[(l>>4) + 4r][l&15].
+typedef double d2v __attribute__((ext_vector_type(2)));
+
 template <bool BT, bool AT>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn, int zl, int bz) {
   if (g.lower_only && bn > bm) return;
   if (g.skip00 && bn == 0 && bm == 0) return;      // tile (0, 0) belongs to the diagonal-block workgroup of the same launch
-  __shared__ double As[16][68];
-  __shared__ double Bs[16][68];
+  // two LDS stages: the global loads of stage s+1 are issued before the MFMAs of stage s and parked in the other buffer
+  // afterwards — one barrier per 16-deep stage (round 1: one buffer, two barriers, loads exposed in front of every stage)
+  __shared__ __attribute__((aligned(16))) double As[2][16][68];
+  __shared__ __attribute__((aligned(16))) double Bs[2][16][68];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t lo = (int64_t)zl * g.lane_stride;
   const double* A = g.A + lo + (int64_t)bz * g.strideA + (AT ? (int64_t)bm * 64 : (int64_t)bm * 64 * g.lda);
@@ -413,62 +418,56 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn
     for (int u = 0; u < 2; ++u) acc[t][u] = d4{0.0, 0.0, 0.0, 0.0};
   const int arow = tid >> 2, akq = (tid & 3) * 4;
   const int brow = tid >> 4, bnq = (tid & 15) * 4;
-  for (int k0 = kbeg; k0 < kend; k0 += 16) {
-    double2 a01, a23;
+  const double* asrc = AT ? A + (int64_t)(kbeg + brow) * g.lda + bnq : A + (int64_t)arow * g.lda + kbeg + akq;
+  const double* bsrc = BT ? B + (int64_t)arow * g.ldb + kbeg + akq : B + (int64_t)(kbeg + brow) * g.ldb + bnq;
+  const int64_t astep = AT ? (int64_t)16 * g.lda : 16, bstep = BT ? 16 : (int64_t)16 * g.ldb;
+  auto gload = [&](int st, d2v(&ra)[2], d2v(&rb)[2]) {
+    const d2v* ap = reinterpret_cast<const d2v*>(asrc + (int64_t)st * astep);
+    const d2v* bp = reinterpret_cast<const d2v*>(bsrc + (int64_t)st * bstep);
+    ra[0] = ap[0]; ra[1] = ap[1];
+    rb[0] = bp[0]; rb[1] = bp[1];
+  };
+  auto lstore = [&](int buf, const d2v(&ra)[2], const d2v(&rb)[2]) {
     if (AT) {
-      const double* ap = A + (int64_t)(k0 + brow) * g.lda + bnq;
-      a01 = *reinterpret_cast<const double2*>(ap);
-      a23 = *reinterpret_cast<const double2*>(ap + 2);
+      *reinterpret_cast<d2v*>(&As[buf][brow][bnq]) = ra[0];
+      *reinterpret_cast<d2v*>(&As[buf][brow][bnq + 2]) = ra[1];
     } else {
-      const double* ap = A + (int64_t)arow * g.lda + k0 + akq;
-      a01 = *reinterpret_cast<const double2*>(ap);
-      a23 = *reinterpret_cast<const double2*>(ap + 2);
-    }
-    double2 b01, b23;
-    if (BT) {
-      const double* bp = B + (int64_t)arow * g.ldb + k0 + akq;
-      b01 = *reinterpret_cast<const double2*>(bp);
-      b23 = *reinterpret_cast<const double2*>(bp + 2);
-    } else {
-      const double* bp = B + (int64_t)(k0 + brow) * g.ldb + bnq;
-      b01 = *reinterpret_cast<const double2*>(bp);
-      b23 = *reinterpret_cast<const double2*>(bp + 2);
-    }
-    __syncthreads();
-    if (AT) {
-      As[brow][bnq + 0] = a01.x;
-      As[brow][bnq + 1] = a01.y;
-      As[brow][bnq + 2] = a23.x;
-      As[brow][bnq + 3] = a23.y;
-    } else {
-      As[akq + 0][arow] = a01.x;
-      As[akq + 1][arow] = a01.y;
-      As[akq + 2][arow] = a23.x;
-      As[akq + 3][arow] = a23.y;
+      As[buf][akq + 0][arow] = ra[0].x; As[buf][akq + 1][arow] = ra[0].y;
+      As[buf][akq + 2][arow] = ra[1].x; As[buf][akq + 3][arow] = ra[1].y;
     }
     if (BT) {
-      Bs[akq + 0][arow] = b01.x;
-      Bs[akq + 1][arow] = b01.y;
-      Bs[akq + 2][arow] = b23.x;
-      Bs[akq + 3][arow] = b23.y;
+      Bs[buf][akq + 0][arow] = rb[0].x; Bs[buf][akq + 1][arow] = rb[0].y;
+      Bs[buf][akq + 2][arow] = rb[1].x; Bs[buf][akq + 3][arow] = rb[1].y;
     } else {
-      Bs[brow][bnq + 0] = b01.x;
-      Bs[brow][bnq + 1] = b01.y;
-      Bs[brow][bnq + 2] = b23.x;
-      Bs[brow][bnq + 3] = b23.y;
+      *reinterpret_cast<d2v*>(&Bs[buf][brow][bnq]) = rb[0];
+      *reinterpret_cast<d2v*>(&Bs[buf][brow][bnq + 2]) = rb[1];
     }
+  };
+  const int nst = (kend - kbeg) / 16;
+  if (nst > 0) {
+    d2v ra[2], rb[2];
+    gload(0, ra, rb);
+    lstore(0, ra, rb);
     __syncthreads();
+    const int last = nst - 1;
+    for (int st = 0; st < nst; ++st) {
+      const int buf = st & 1;
+      gload(min(st + 1, last), ra, rb);            // clamped look-ahead keeps the body branch-free
+      __builtin_amdgcn_sched_barrier(0);           // keep the global loads at the top of the stage
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int kr = kk * 4 + (lane >> 4);
-      const double a0 = As[kr][wm + (lane & 15)];
-      const double a1 = As[kr][wm + 16 + (lane & 15)];
-      const double b0 = Bs[kr][wn + (lane & 15)];
-      const double b1 = Bs[kr][wn + 16 + (lane & 15)];
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      for (int kk = 0; kk < 4; ++kk) {
+        const int kr = kk * 4 + (lane >> 4);
+        const double a0 = As[buf][kr][wm + (lane & 15)];
+        const double a1 = As[buf][kr][wm + 16 + (lane & 15)];
+        const double b0 = Bs[buf][kr][wn + (lane & 15)];
+        const double b1 = Bs[buf][kr][wn + 16 + (lane & 15)];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      }
+      lstore(buf ^ 1, ra, rb);    // the other buffer: everyone finished reading it before the previous barrier
+      __syncthreads();
     }
   }
 #pragma unroll
@@ -489,7 +488,13 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn
 template <bool BT, bool AT>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   const int zl = blockIdx.z / g.batch, bz = blockIdx.z - zl * g.batch;   // lane mode: z = lane * batch + b
-  gemm_tile_body<BT, AT>(g, (int)blockIdx.y, (int)blockIdx.x, zl, bz);
+  // Longest k-ranges first (workgroups are handed out in block-id order, x fastest).  A lower triangular: row tile bm
+  // multiplies bm + 1 k-tiles -> rows from the bottom up.  B lower triangular: column tile bn starts at k-tile bn -> the
+  // grid is transposed (x = row tile), so all tiles of column 0 go first, then column 1, ...
+  int bm = (int)blockIdx.y, bn = (int)blockIdx.x;
+  if (g.a_lower) bm = (int)(gridDim.y - 1 - blockIdx.y);
+  if (g.b_lower) { bm = (int)blockIdx.x; bn = (int)blockIdx.y; }
+  gemm_tile_body<BT, AT>(g, bm, bn, zl, bz);
 }
 
 // One step of the blocked Cholesky inside an outer panel, as ONE launch: workgroup 0 factors (and inverts) diagonal
@@ -547,12 +552,13 @@ int launch_chol_step(gpbo_ctx* ctx, Model& m, int kb, const GemmArgs& g_in) {
 constexpr int G2_B = 128, G2_BK = 16, G2_LD = 144;
 constexpr int G2_TILE = G2_BK * G2_LD;   // doubles per operand tile
 
-typedef double d2v __attribute__((ext_vector_type(2)));
 
 template <bool BT, bool AT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm128_f64_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double g2_smem[];   // [2 buffers][A | B][16][144]
-  const int bn = blockIdx.x, bm = blockIdx.y;
+  int bn = blockIdx.x, bm = blockIdx.y;                             // long k-ranges first (see gemm_f64_kernel)
+  if (g.a_lower) bm = (int)(gridDim.y - 1 - blockIdx.y);
+  if (g.b_lower) { bm = (int)blockIdx.x; bn = (int)blockIdx.y; }
   if (g.lower_only && bn > bm) return;
   const int zl = blockIdx.z / g.batch, bz = blockIdx.z - zl * g.batch;   // lane mode: z = lane * batch + b
   const int tid = threadIdx.x, lane = tid & 63;
@@ -697,7 +703,15 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
   // but the 64x64 kernel wins where there are too few 128-blocks to fill 256 CUs (1024^3: 15 vs 28) and on rank-64 panel
   // updates (8 vs 15), so: deep k and at least ~a chip's worth of 128x128 blocks.
   const int64_t blocks128 = (int64_t)((g.m + 127) / 128) * ((g.n + 127) / 128) * g.batch * g.lanes / (g.lower_only ? 2 : 1);
-  if (gemm128_enabled() && g.m >= 128 && g.n >= 128 && g.k >= 256 && blocks128 >= 192) {
+  // Triangular operands give every tile another k-length (W = L^-1, W^T W): a grid of at most one 128x128 tile per
+  // workgroup slot (512) ends on its longest tiles while most CUs idle, so such products take the 64x64 tiles (4x as
+  // many, each a quarter of the work, handed out longest first).  Measured (r02 fit probe): W = L^-1 at N = 4096
+  // 0.93 -> 0.82 ms; with deeper grids (N = 8192: 1024 tiles) the 128x128 kernel wins, 3.91 vs 4.11 ms.
+  // GPBO_TRI64=0 turns the rule off (A/B runs).
+  static const bool tri64 = !(getenv("GPBO_TRI64") && getenv("GPBO_TRI64")[0] == '0');
+  const bool triangular = g.a_lower || g.b_lower || g.k_from_tile;
+  const bool prefer64 = tri64 && triangular && blocks128 < 512;
+  if (gemm128_enabled() && !prefer64 && g.m >= 128 && g.n >= 128 && g.k >= 256 && blocks128 >= 192) {
     constexpr size_t lds = (size_t)4 * G2_TILE * sizeof(double);   // 73 728 B
     static bool attr_set = false;
     if (!attr_set) {
@@ -710,6 +724,7 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
       attr_set = true;
     }
     dim3 grid((unsigned)((g.n + 127) / 128), (unsigned)((g.m + 127) / 128), (unsigned)(g.batch * g.lanes));
+    if (g.b_lower) std::swap(grid.x, grid.y);
     if (g.b_trans)
       gemm128_f64_kernel<true, false><<<grid, dim3(512), lds, ctx->stream>>>(g);
     else if (g.a_trans)
@@ -720,6 +735,7 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
     return GPBO_OK;
   }
   dim3 grid((unsigned)(g.n / 64), (unsigned)(g.m / 64), (unsigned)(g.batch * g.lanes));
+  if (g.b_lower) std::swap(grid.x, grid.y);
   if (g.b_trans)
     gemm_f64_kernel<true, false><<<grid, dim3(256), 0, ctx->stream>>>(g);
   else if (g.a_trans)
