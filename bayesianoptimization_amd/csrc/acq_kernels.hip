@@ -128,82 +128,91 @@ __device__ Key block_reduce_key(Key k, Key* sh) {
   return r;
 }
 
-__global__ __launch_bounds__(SEL_BLOCK) void select_pass_kernel(const double* __restrict__ ys, int64_t M,
-                                                                const SelState* __restrict__ st,
-                                                                Key* __restrict__ partial,
-                                                                int64_t* __restrict__ nan_partial,
-                                                                int want_nan) {
+// Selection = argmin, min and argsort(ys)[:k] (acquisition.py:313-317) in TWO launches (round 1: two launches per pick).
+// select_block_topk_kernel: every workgroup keeps its SEL_BLOCK * SEL_ITEMS values in registers and extracts its own k
+// smallest keys, in order, by k block reductions; select_merge_topk_kernel: one workgroup extracts the k smallest of the
+// nblocks * k survivors the same way.  The order is key_less throughout — lexicographic (value, index), NaNs last — so the
+// result is the one k global passes give.  Empty slots carry the sentinel {NaN, INT64_MAX}, which sorts after every key.
+__global__ __launch_bounds__(SEL_BLOCK) void select_block_topk_kernel(const double* __restrict__ ys, int64_t M, int k,
+                                                                      Key* __restrict__ partial,
+                                                                      int64_t* __restrict__ nan_partial) {
   __shared__ Key sh[SEL_BLOCK / 64];
   __shared__ int64_t shn[SEL_BLOCK / 64];
-  const Key prev = st->prev;
-  const bool has_prev = prev.i >= 0;
-  Key best;
-  best.v = std::numeric_limits<double>::quiet_NaN();
-  best.i = INT64_MAX;
+  const int64_t base = (int64_t)blockIdx.x * (SEL_BLOCK * SEL_ITEMS) + threadIdx.x;
+  double v[SEL_ITEMS];
   int64_t fn = INT64_MAX;
-  const int64_t base = (int64_t)blockIdx.x * (SEL_BLOCK * SEL_ITEMS);
-#pragma unroll 4
-  for (int it = 0; it < SEL_ITEMS; ++it) {
-    const int64_t m = base + (int64_t)it * SEL_BLOCK + threadIdx.x;
-    if (m < M) {
-      Key k;
-      k.v = ys[m];
-      k.i = m;
-      if (want_nan && k.v != k.v && m < fn) fn = m;
-      if (!has_prev || key_less(prev, k)) best = key_min(best, k);
-    }
-  }
-  Key r = block_reduce_key(best, sh);
-  if (threadIdx.x == 0) partial[blockIdx.x] = r;
-  if (want_nan) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const int64_t o = __shfl_xor(fn, off);
-      fn = o < fn ? o : fn;
+  for (int it = 0; it < SEL_ITEMS; ++it) {
+    const int64_t m = base + (int64_t)it * SEL_BLOCK;
+    v[it] = (m < M) ? ys[m] : 0.0;
+    if (m < M && v[it] != v[it] && m < fn) fn = m;
+  }
+  Key prev;
+  prev.v = 0.0; prev.i = -1;
+  for (int t = 0; t < k; ++t) {
+    Key best;
+    best.v = std::numeric_limits<double>::quiet_NaN();
+    best.i = INT64_MAX;
+#pragma unroll
+    for (int it = 0; it < SEL_ITEMS; ++it) {
+      Key c;
+      c.v = v[it];
+      c.i = base + (int64_t)it * SEL_BLOCK;
+      if (c.i < M && (prev.i < 0 || key_less(prev, c))) best = key_min(best, c);
     }
-    if ((threadIdx.x & 63) == 0) shn[threadIdx.x >> 6] = fn;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int64_t f = shn[0];
-      for (int w = 1; w < SEL_BLOCK / 64; ++w) f = shn[w] < f ? shn[w] : f;
-      nan_partial[blockIdx.x] = f;
-    }
+    const Key r = block_reduce_key(best, sh);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * k + t] = r;
+    prev = r;     // the sentinel sorts after everything: once it is picked, every later pick is the sentinel too
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const int64_t o = __shfl_xor(fn, off);
+    fn = o < fn ? o : fn;
+  }
+  if ((threadIdx.x & 63) == 0) shn[threadIdx.x >> 6] = fn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t f = shn[0];
+    for (int w = 1; w < SEL_BLOCK / 64; ++w) f = shn[w] < f ? shn[w] : f;
+    nan_partial[blockIdx.x] = f;
   }
 }
 
-__global__ __launch_bounds__(SEL_BLOCK) void select_final_kernel(const Key* __restrict__ partial,
-                                                                 const int64_t* __restrict__ nan_partial,
-                                                                 int nblocks, SelState* st,
-                                                                 Key* __restrict__ picks, int pass,
-                                                                 int want_nan) {
+__global__ __launch_bounds__(SEL_BLOCK) void select_merge_topk_kernel(const Key* __restrict__ partial,
+                                                                      const int64_t* __restrict__ nan_partial,
+                                                                      int nblocks, int k, SelState* st,
+                                                                      Key* __restrict__ picks) {
   __shared__ Key sh[SEL_BLOCK / 64];
-  Key best;
-  best.v = std::numeric_limits<double>::quiet_NaN();
-  best.i = INT64_MAX;
+  __shared__ int64_t shn[SEL_BLOCK / 64];
+  const int64_t n = (int64_t)nblocks * k;
+  Key prev;
+  prev.v = 0.0; prev.i = -1;
+  for (int t = 0; t < k; ++t) {
+    Key best;
+    best.v = std::numeric_limits<double>::quiet_NaN();
+    best.i = INT64_MAX;
+    for (int64_t j = threadIdx.x; j < n; j += SEL_BLOCK) {
+      const Key c = partial[j];
+      if (c.i != INT64_MAX && (prev.i < 0 || key_less(prev, c))) best = key_min(best, c);
+    }
+    const Key r = block_reduce_key(best, sh);
+    if (threadIdx.x == 0) picks[t] = r;
+    prev = r;
+  }
   int64_t fn = INT64_MAX;
-  for (int b = threadIdx.x; b < nblocks; b += SEL_BLOCK) {
-    best = key_min(best, partial[b]);
-    if (want_nan) fn = nan_partial[b] < fn ? nan_partial[b] : fn;
-  }
-  Key r = block_reduce_key(best, sh);
-  if (want_nan) {
-    __shared__ int64_t shn[SEL_BLOCK / 64];
+  for (int b = threadIdx.x; b < nblocks; b += SEL_BLOCK) fn = nan_partial[b] < fn ? nan_partial[b] : fn;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const int64_t o = __shfl_xor(fn, off);
-      fn = o < fn ? o : fn;
-    }
-    if ((threadIdx.x & 63) == 0) shn[threadIdx.x >> 6] = fn;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int64_t f = shn[0];
-      for (int w = 1; w < SEL_BLOCK / 64; ++w) f = shn[w] < f ? shn[w] : f;
-      st->first_nan = f;
-    }
+  for (int off = 32; off >= 1; off >>= 1) {
+    const int64_t o = __shfl_xor(fn, off);
+    fn = o < fn ? o : fn;
   }
+  if ((threadIdx.x & 63) == 0) shn[threadIdx.x >> 6] = fn;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    picks[pass] = r;
-    st->prev = r;
+    int64_t f = shn[0];
+    for (int w = 1; w < SEL_BLOCK / 64; ++w) f = shn[w] < f ? shn[w] : f;
+    st->first_nan = f;
+    st->prev = prev;
   }
 }
 
@@ -214,8 +223,8 @@ static int enqueue_acq_select(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_
   if ((rc = ensure(ctx, &ctx->ys, &ctx->cap_ys, M))) return rc;
   const int nblocks = (int)((M + SEL_BLOCK * SEL_ITEMS - 1) / (SEL_BLOCK * SEL_ITEMS));
   const int npass = k_seeds > 0 ? k_seeds : 1;
-  // scratch layout: SelState | picks[npass] | partial[nblocks] | nan_partial[nblocks]
-  const int64_t bytes = sizeof(SelState) + sizeof(Key) * (npass + (int64_t)nblocks) + sizeof(int64_t) * nblocks + 64;
+  // scratch layout: SelState | picks[npass] | partial[nblocks][npass] | nan_partial[nblocks]
+  const int64_t bytes = sizeof(SelState) + sizeof(Key) * (npass + (int64_t)nblocks * npass) + sizeof(int64_t) * nblocks + 64;
   {
     char* p = (char*)ctx->red;
     int64_t cap = ctx->cap_red;
@@ -227,7 +236,7 @@ static int enqueue_acq_select(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_
   SelState* st = (SelState*)base;
   Key* picks = (Key*)(base + sizeof(SelState));
   Key* partial = picks + npass;
-  int64_t* nan_partial = (int64_t*)(partial + nblocks);
+  int64_t* nan_partial = (int64_t*)(partial + (int64_t)nblocks * npass);
 
   AcqDev d;
   d.acq = a.acq; d.param = a.param; d.y_max = a.y_max; d.n_constraints = a.n_constraints;
@@ -235,17 +244,8 @@ static int enqueue_acq_select(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_
   acq_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream>>>(d, M, ctx->ys);
   GPBO_HIP(ctx, hipGetLastError());
 
-  SelState init;
-  init.prev.v = 0.0; init.prev.i = -1; init.first_nan = INT64_MAX;
-  static_assert(sizeof(SelState) <= 32, "SelState outgrew its pinned window");
-  SelState* hinit = (SelState*)((char*)ctx->pinned_aux + PIN_AUX_SEL_INIT);
-  *hinit = init;
-  GPBO_HIP(ctx, hipMemcpyAsync(st, hinit, sizeof(SelState), hipMemcpyHostToDevice, ctx->stream));
-  for (int pass = 0; pass < npass; ++pass) {
-    const int want_nan = pass == 0;
-    select_pass_kernel<<<dim3((unsigned)nblocks), dim3(SEL_BLOCK), 0, ctx->stream>>>(ctx->ys, M, st, partial, nan_partial, want_nan);
-    select_final_kernel<<<dim3(1), dim3(SEL_BLOCK), 0, ctx->stream>>>(partial, nan_partial, nblocks, st, picks, pass, want_nan);
-  }
+  select_block_topk_kernel<<<dim3((unsigned)nblocks), dim3(SEL_BLOCK), 0, ctx->stream>>>(ctx->ys, M, npass, partial, nan_partial);
+  select_merge_topk_kernel<<<dim3(1), dim3(SEL_BLOCK), 0, ctx->stream>>>(partial, nan_partial, nblocks, npass, st, picks);
   GPBO_HIP(ctx, hipGetLastError());
   *st_out = st; *picks_out = picks; *npass_out = npass;
   return GPBO_OK;

@@ -145,7 +145,7 @@ static_assert(PIN_LS + PIN_LS_BYTES <= PIN_INFO, "length scales overlap the info
 static_assert(PIN_INFO + sizeof(int) <= PIN_LML_OUT, "info word overlaps the LML scalars");
 static_assert(PIN_LML_OUT + PIN_LML_OUT_BYTES <= PIN_WINDOW, "LML scalars leave the window");
 // aux window
-constexpr size_t PIN_AUX_SEL_INIT = 0;                               // SelState the selection passes start from (24 B)
+constexpr size_t PIN_AUX_SEL_INIT = 0;                               // (free since the selection became two launches: 32 B)
 constexpr size_t PIN_AUX_SEL_OUT = 256;                              // SelState + picks[GPBO_MAX_SEEDS + 1] coming back
 constexpr size_t PIN_AUX_SEL_OUT_BYTES = 32 + 16 * (GPBO_MAX_SEEDS + 1);
 constexpr size_t PIN_AUX_CAND = 2048;                                // [lo | hi (or hi - lo)][GPBO_MAX_DIM] doubles | MT19937 key[624]
