@@ -224,6 +224,10 @@ int ensure(gpbo_ctx* ctx, T** p, int64_t* cap, int64_t need) {
   return GPBO_OK;
 }
 
+// k* slab budget in bytes: GPBO_KSTAR_GB (default 4), clipped to 80 % of what the device could give the slab —
+// hipMemGetInfo is asked only when the slab buffer would have to grow (it costs tens of microseconds per call).
+int64_t kstar_slab_budget_bytes(gpbo_ctx* ctx, int64_t want_bytes_if_unlimited);   // posterior_kernel.hip
+
 // ---- launchers implemented in the kernel translation units ---------------------------------
 // fit_kernels.hip
 int launch_prescale(gpbo_ctx* ctx, const double* X, int64_t n, int d, int DP, const double* ls,

@@ -45,6 +45,20 @@ __global__ __launch_bounds__(256) void posterior_finalize_kernel(const double* _
   mu[m] = y_std * mun + y_mean;
 }
 
+int64_t kstar_slab_budget_bytes(gpbo_ctx* ctx, int64_t want_bytes_if_unlimited) {
+  const char* e = getenv("GPBO_KSTAR_GB");      // read per call: the slab-loop test changes it between passes
+  const double budget_gb = (e && atof(e) > 0.0) ? atof(e) : 4.0;
+  int64_t budget = (int64_t)(budget_gb * 1e9);
+  const int64_t want = want_bytes_if_unlimited < budget ? want_bytes_if_unlimited : budget;
+  if (want <= ctx->cap_kst * 8) return budget;          // the buffer we hold is already big enough
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+    const int64_t avail = (int64_t)(((double)free_b + (double)ctx->cap_kst * 8.0) * 0.8);
+    if (avail < budget) budget = avail;
+  }
+  return budget;
+}
+
 static int ensure_posterior_outputs(gpbo_ctx* ctx, Model& m, int64_t Mp) {
   if (Mp > m.cap_M) {
     if (m.mu) { GPBO_HIP(ctx, hipFree(m.mu)); m.mu = nullptr; }

@@ -448,14 +448,8 @@ static int launch_gen32_k(gpbo_ctx* ctx, Model& m, float* Kst, int64_t ldk, int6
 // fp32 pipeline per candidate slab; the slab buffer (ctx->kst, sized in doubles) is shared with the fp64 path.
 int launch_posterior_f32(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, int* part_chunks) {
   *part_chunks = nchunks;
-  double budget_gb = 4.0;     // as the fp64 path: a slab only has to fill the chip (posterior_kernel_v2.hip)
-  if (const char* e = getenv("GPBO_KSTAR_GB")) budget_gb = atof(e) > 0.0 ? atof(e) : budget_gb;
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-    const double avail = ((double)free_b + (double)ctx->cap_kst * 8.0) * 0.8 / 1e9;
-    if (avail < budget_gb) budget_gb = avail;
-  }
-  int64_t ms = (int64_t)(budget_gb * 1e9 / ((double)m.NP * 4.0));
+  const int64_t budget = kstar_slab_budget_bytes(ctx, Mp * m.NP * 4);   // as the fp64 path (posterior_kernel_v2.hip)
+  int64_t ms = budget / (m.NP * 4);
   ms = ms / 128 * 128;
   if (ms < 128) GPBO_FAIL(ctx, GPBO_ERR_HIP, "posterior: not enough device memory for one k* slab");
   if (ms > Mp) ms = Mp;

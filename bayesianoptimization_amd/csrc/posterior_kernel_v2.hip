@@ -350,16 +350,10 @@ int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
   // k* workspace: the candidate set is walked slab by slab; a slab only has to be wide enough to fill the chip
   // (4e9 B = 121 984 candidates at N = 4096 = 1906 candidate tiles x 16 row chunks per launch); measured at C3: one 34 GB
   // slab 263.7 ms, eight 4 GB slabs 264.4 ms (round 1 A/B) — the big workspace bought nothing.  GPBO_KSTAR_GB overrides.
-  double budget_gb = 4.0;
-  if (const char* e = getenv("GPBO_KSTAR_GB")) budget_gb = atof(e) > 0.0 ? atof(e) : budget_gb;
   // 32 train points per stage: 262.9 vs 264.0 ms per C3 launch (round-2 A/B, same box, same run); GPBO_POST_BK=16 restores 16
   static const int post_bk = (getenv("GPBO_POST_BK") && atoi(getenv("GPBO_POST_BK")) == 16) ? 16 : 32;
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-    const double avail = ((double)free_b + (double)ctx->cap_kst * 8.0) * 0.8 / 1e9;
-    if (avail < budget_gb) budget_gb = avail;
-  }
-  int64_t ms = (int64_t)(budget_gb * 1e9 / ((double)m.NP * 8.0));
+  const int64_t budget = kstar_slab_budget_bytes(ctx, Mp * m.NP * 8);
+  int64_t ms = budget / (m.NP * 8);
   ms = ms / 128 * 128;
   if (ms < 128) GPBO_FAIL(ctx, GPBO_ERR_HIP, "posterior: not enough device memory for one k* slab");
   if (ms > Mp) ms = Mp;
