@@ -373,11 +373,10 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, 
 constexpr size_t PD_LDS_BYTES = (size_t)(64 * PD_S * 2 + 32 * PD_S + 64 + 8) * sizeof(double);
 
 int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!(ctx->func_attrs & ATTR_POTRF_DIAG)) {
     GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_diag_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)PD_LDS_BYTES));
-    attr_set = true;
+    ctx->func_attrs |= ATTR_POTRF_DIAG;
   }
   potrf_diag_kernel<<<dim3((unsigned)ctx->lanes), dim3(256), PD_LDS_BYTES, ctx->stream>>>(m.L, m.NP, kb, m.dinv, ctx->info_dev,
                                                                                             ctx->lane_stride);
@@ -521,11 +520,10 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* L, int64_t ld, i
 int launch_chol_step(gpbo_ctx* ctx, Model& m, int kb, const GemmArgs& g_in) {
   GemmArgs g = g_in;
   g.lanes = 1; g.lane_stride = 0; g.batch = 1; g.skip00 = 1;
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!(ctx->func_attrs & ATTR_CHOL_STEP)) {
     GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(chol_step_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)PD_LDS_BYTES));
-    attr_set = true;
+    ctx->func_attrs |= ATTR_CHOL_STEP;
   }
   const int tiles_m = g.m / 64, tiles_n = g.n / 64;
   chol_step_kernel<<<dim3((unsigned)(1 + tiles_m * tiles_n)), dim3(256), PD_LDS_BYTES, ctx->stream>>>(
@@ -713,15 +711,14 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
   const bool prefer64 = tri64 && triangular && blocks128 < 512;
   if (gemm128_enabled() && !prefer64 && g.m >= 128 && g.n >= 128 && g.k >= 256 && blocks128 >= 192) {
     constexpr size_t lds = (size_t)4 * G2_TILE * sizeof(double);   // 73 728 B
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!(ctx->func_attrs & ATTR_GEMM128)) {
       GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_f64_kernel<true, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_f64_kernel<false, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_f64_kernel<false, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
+      ctx->func_attrs |= ATTR_GEMM128;
     }
     dim3 grid((unsigned)((g.n + 127) / 128), (unsigned)((g.m + 127) / 128), (unsigned)(g.batch * g.lanes));
     if (g.b_lower) std::swap(grid.x, grid.y);

@@ -116,6 +116,9 @@ struct gpbo_ctx {
   void* pinned = nullptr;  // pinned host staging: window 0 = fit/LML words (PIN_* below), windows 1..8 = gpbo_lml_batch groups
   void* pinned_aux = nullptr;   // last window of the same allocation: selection / candidate staging (PIN_AUX_*); never re-pointed
   int* negvar = nullptr;        // device-visible address of the PIN_AUX_NEGVAR word
+  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: one bit per kernel family, per context (a
+  // process-wide flag would leave every device but the first of a gpbo_group at the 64 KiB default)
+  unsigned func_attrs = 0;
   gpbo::EventPair ev[gpbo::T_COUNT];
   // RCCL
   void* comm = nullptr;
@@ -127,6 +130,8 @@ struct gpbo_ctx {
 };
 
 namespace gpbo {
+
+constexpr unsigned ATTR_POTRF_DIAG = 1u, ATTR_CHOL_STEP = 2u, ATTR_GEMM128 = 4u, ATTR_MT_JUMP = 8u;
 
 // ---- pinned host staging layout -------------------------------------------------------------------------------
 // ONE allocation of PIN_WINDOWS windows of PIN_WINDOW bytes.  Window 0 (ctx->pinned) carries the words of a fit /
