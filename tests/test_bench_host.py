@@ -1,0 +1,109 @@
+"""Host-side pieces of bench.py and of the one-process-per-GPU rendezvous (no GPU): the reference answer a sharded job is
+compared with, the failure line, the PMC-summary guard, and the file rendezvous of the RCCL unique id."""
+import importlib.util
+import io
+import json
+import multiprocessing as mp
+import os
+import sys
+import types
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_reference_golden_merges_shards_as_one_concatenated_pass():
+    """C4 at n GPUs = shards 0..n-1; the reference over the concatenated candidates would return the first global minimum
+    and a stable top-k: the merge of the per-shard goldens by (value, global index)."""
+    b = _bench()
+    M = 1 << 20
+    one = b.reference_golden("C4", 1, M)
+    g0 = np.load(os.path.join(GOLD, "C4_s0.npz"))
+    assert one["argmin"] == int(g0["argmin"]) and one["min"] == float(g0["min"])
+    assert np.array_equal(one["top_idx"][:16], g0["topk_idx"][:16])
+    for n in (2, 4, 8):
+        got = b.reference_golden("C4", n, M)
+        vals = np.concatenate([np.load(os.path.join(GOLD, f"C4_s{r}.npz"))["topk_val"] for r in range(n)])
+        idx = np.concatenate([np.load(os.path.join(GOLD, f"C4_s{r}.npz"))["topk_idx"].astype(np.int64) + r * M for r in range(n)])
+        o = np.lexsort((idx, vals))
+        assert got["argmin"] == int(idx[o[0]]) and got["min"] == float(vals[o[0]])
+        assert np.array_equal(got["top_idx"][:10], idx[o][:10])
+        assert np.all(np.diff(got["top_val"][:64]) >= 0)
+        assert f"s{n - 1}" in got["source"]
+    # another shard size than the goldens were generated for: no reference, no parity block
+    assert b.reference_golden("C4", 2, M // 2) is None
+    assert b.reference_golden("C3", 2, M) is None and b.reference_golden("C3", 1, M)["argmin"] == 941430
+
+
+def test_failed_line_is_loud_and_well_formed():
+    b = _bench()
+    args = types.SimpleNamespace(steps=5, warmup=2, config=None)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        b.emit_failed(args, 8, "RCCL bootstrap failed")
+    d = json.loads(buf.getvalue())
+    assert d["config"]["collective"] == "FAILED" and d["value"] is None and d["n_gpus"] == 8
+    assert d["metric"] == b.METRIC and "RCCL" in d["error"]
+
+
+def test_pmc_summary_is_used_only_for_the_library_it_was_taken_with(tmp_path, monkeypatch):
+    b = _bench()
+    from bayesianoptimization_amd import build
+    w = types.SimpleNamespace(name="C3")
+    pm, note = b.pmc_summary_for(w)
+    meta = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_C3.json")))["_meta"]
+    if meta["source_fingerprint"] == build._fingerprint():
+        assert pm is not None and "same kernel sources" in note
+    else:
+        assert pm is None and "another state" in note
+    monkeypatch.setattr(build, "_fingerprint", lambda: "0" * 64)
+    pm, note = b.pmc_summary_for(w)
+    assert pm is None and "another state of the kernel sources" in note
+    # C4 runs the kernels profiled for C3 (same GP, same candidates per GPU)
+    monkeypatch.undo()
+    assert b.pmc_summary_for(types.SimpleNamespace(name="C4"))[1].startswith("profiles/r02_pmc_C3.json") or \
+        "r02_pmc_C3.json" in b.pmc_summary_for(types.SimpleNamespace(name="C4"))[1]
+
+
+def _peer(rank, key, rdzv_dir, q):
+    os.environ["GPBO_RDZV_DIR"] = rdzv_dir
+    sys.path.insert(0, ROOT)
+    from bayesianoptimization_amd import rendezvous
+    uid = rendezvous.share_unique_id(rank, lambda: bytes(range(128)), key=key, timeout=30.0)
+    q.put((rank, uid))
+
+
+def test_file_rendezvous_ships_the_unique_id_to_every_rank(tmp_path):
+    from bayesianoptimization_amd import rendezvous
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    key = f"test_{os.getpid()}"
+    procs = [ctx.Process(target=_peer, args=(r, key, str(tmp_path), q)) for r in (1, 2, 0)]   # rank 0 starts last
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == got[2] == bytes(range(128))
+    os.environ["GPBO_RDZV_DIR"] = str(tmp_path)
+    try:
+        rendezvous.cleanup(0, key=key)
+        assert not [f for f in os.listdir(tmp_path) if f.endswith(".id")]
+        with pytest.raises(TimeoutError):
+            rendezvous.share_unique_id(1, None, key=key, timeout=0.2)
+        with pytest.raises(ValueError):
+            rendezvous.share_unique_id(0, lambda: b"short", key=key)
+    finally:
+        os.environ.pop("GPBO_RDZV_DIR", None)
