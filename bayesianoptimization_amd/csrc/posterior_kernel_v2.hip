@@ -24,7 +24,12 @@ namespace gpbo {
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int V2_CANDS = 64;
-constexpr int V2_STRIDE = 80;  // doubles per k-row of the stage tile: 64 + 16 -> rows 32 banks apart
+// Stage tile in LDS: [k-quad q][candidate group jt (16)][k in quad (4)][candidate in group (16)] doubles, i.e. blocks of
+// 64 doubles = 512 B holding exactly what ONE B-fragment read of v_mfma_f64_16x16x4_f64 takes (lane l -> element l of
+// block (q, jt)).  Every read of a stage — and of both stage buffers — is then the lane's own constant address plus a
+// multiple of 512 B, which ds_read2st64_b64 carries as an immediate: no address arithmetic per read, and a wave reads
+// 512 contiguous bytes (no bank conflicts).  (Round 1: [k][80] rows: 12 VALU instructions per stage for addresses.)
+constexpr int V2_STRIDE = 64;  // doubles per k-row equivalent: a stage of BK points takes BK * 64 doubles
 
 struct PostArgs2 {
   const double* Wp;
@@ -41,6 +46,8 @@ struct PostArgs2 {
   int64_t ldk;
   int64_t m0;          // first candidate of the slab (outputs are indexed m0 + local)
 };
+
+constexpr int BUF_FLAGS = 0x00020000;   // gfx9 buffer descriptor word 3: raw buffer, 32-bit data format
 
 // GEN = 1: k* generated in the kernel (fused).  GEN = 2: k* read from a slab materialised by
 // kstar_gen_kernel (the fp64 VALU work of the generation shares the FP64 datapath with the MFMAs — measured:
@@ -92,8 +99,14 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   const int64_t pairs = NP / 8;
   // packed W: [slab of 32 rows][k-pair][tile of 16 rows][lane] double2 ; inactive tiles stream tile 0 (dropped later)
   const int tA = activeA ? tileA : 0, tB = activeB ? tileB : 0;
-  const double2* wpA = reinterpret_cast<const double2*>(p.Wp) + ((int64_t)(tA >> 1) * pairs * 2 + (tA & 1)) * 64 + lane;
-  const double2* wpB = reinterpret_cast<const double2*>(p.Wp) + ((int64_t)(tB >> 1) * pairs * 2 + (tB & 1)) * 64 + lane;
+  // Both operand streams are read through buffer descriptors: wave-uniform base in SGPRs, the lane as a constant 32-bit
+  // offset, the walk along k as the instruction's scalar offset — no per-lane 64-bit address arithmetic in the MFMA loop
+  // (12 v_lshl_add_u64 per stage with flat global loads; fp64 MFMAs and other VALU work do not overlap on this part).
+  const double2* wpA = reinterpret_cast<const double2*>(p.Wp) + ((int64_t)(tA >> 1) * pairs * 2 + (tA & 1)) * 64;
+  const double2* wpB = reinterpret_cast<const double2*>(p.Wp) + ((int64_t)(tB >> 1) * pairs * 2 + (tB & 1)) * 64;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(wpA), 0, 0x7fffffff, BUF_FLAGS);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(wpB), 0, 0x7fffffff, BUF_FLAGS);
+  const unsigned voff16 = (unsigned)lane * 16u, voff8 = (unsigned)lane * 8u;
 
   d4 acc[2][4];
 #pragma unroll
@@ -111,9 +124,12 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
       return;
     }
     if constexpr (GEN == 2) {
-      const double* src = p.Kst + (int64_t)j0 * p.ldk + (int64_t)ct * V2_CANDS + lane;
+      const double* src = p.Kst + (int64_t)j0 * p.ldk + (int64_t)ct * V2_CANDS;       // wave-uniform
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(src), 0, 0x7fffffff, BUF_FLAGS);
+      const unsigned row = (unsigned)p.ldk * 8u;                                       // ldk * 8 * (E - 1) < 2^31 (slab budget)
 #pragma unroll
-      for (int e = 0; e < E; ++e) kv[e] = src[(int64_t)e * p.ldk];
+      for (int e = 0; e < E; ++e)
+        kv[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff8, (unsigned)e * row, 0));
       return;
     }
     const double* xr = p.Xs + (int64_t)j0 * DP;  // wave-uniform -> scalar loads
@@ -146,13 +162,16 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   };
   auto gen_store = [&](const double (&kv)[E], int buf) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) Ks[(buf * BK + wave * E + e) * V2_STRIDE + lane] = kv[e];
+    for (int e = 0; e < E; ++e) {
+      const int k = wave * E + e;     // train point of the stage this thread generated / fetched for candidate `lane`
+      Ks[((buf * (BK / 4) + (k >> 2)) * 4 + (lane >> 4)) * 64 + (k & 3) * 16 + (lane & 15)] = kv[e];
+    }
   };
 
   // A fragments for one k-pair (8 columns): [tile] double2 = 8 VGPRs
   auto loadA = [&](int kpair, double2(&a)[2]) {
-    a[0] = wpA[(int64_t)kpair * 128];
-    a[1] = wpB[(int64_t)kpair * 128];
+    a[0] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rsA, voff16, (unsigned)kpair * 2048u, 0));
+    a[1] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rsB, voff16, (unsigned)kpair * 2048u, 0));
   };
   // MODE 2: both tiles, 1: only the later tile (B), compile-time so that the hot loop stays one basic block
   auto mma_pair = [&](int buf, int pp, const double2(&a)[2], auto mode) {
@@ -162,10 +181,10 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
       const int q = pp * 2 + e;
       const double a0 = e ? a[0].y : a[0].x;
       const double a1 = e ? a[1].y : a[1].x;
-      const double* kb = Ks + (buf * BK + q * 4 + (lane >> 4)) * V2_STRIDE + (lane & 15);
+      const double* kb = Ks + (buf * (BK / 4) + q) * 256 + lane;
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
-        const double b = kb[jt * 16];
+        const double b = kb[jt * 64];
         if constexpr (MODE == 2) acc[0][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][jt], 0, 0, 0);
         acc[1][jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][jt], 0, 0, 0);
       }
