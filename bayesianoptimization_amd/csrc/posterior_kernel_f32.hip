@@ -293,7 +293,10 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32(PostArgsF32 p) {
 // BKX = 64 286.4 ms (twice the slab loads in flight per thread, 122 VGPRs) — 32 it is.
 template <int BKX>
 __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
-  __shared__ __attribute__((aligned(16))) float Ks[2 * BKX * F32_STRIDE];   // 20 KiB at BKX = 32
+  // Stage tile: [k-pair][candidate half (32)][k in pair (2)][candidate (32)] floats = blocks of 64 floats (256 B) holding
+  // exactly one B-fragment read of v_mfma_f32_32x32x2_f32 (lane l -> element l), so every read of both stage buffers is the
+  // lane's constant address + an immediate multiple of 256 B (ds_read2st64_b32) — as in posterior_kernel_v2.
+  __shared__ __attribute__((aligned(16))) float Ks[2 * BKX * 64];   // 16 KiB at BKX = 32
   constexpr int EX = BKX / 8;      // slab elements per thread per stage
   constexpr int QX = BKX / 16;     // k-quads (16 columns of W) per stage
   constexpr int CROWS = 512, CT = CROWS / 32;
@@ -312,8 +315,14 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
   const int64_t quads = NP / 16;
   const int tA = activeA ? tileA : 0, tB = activeB ? tileB : 0;        // inactive tiles stream tile 0 (sums dropped)
   // packed: [slab64][quad][tile2][half2][lane] float4
-  const f4* wpA = reinterpret_cast<const f4*>(p.Wp) + ((int64_t)(tA >> 1) * quads * 4 + (tA & 1) * 2) * 64 + lane;
-  const f4* wpB = reinterpret_cast<const f4*>(p.Wp) + ((int64_t)(tB >> 1) * quads * 4 + (tB & 1) * 2) * 64 + lane;
+  // operands through buffer descriptors: wave-uniform bases, the lane as a constant offset, the walk along k as scalar
+  // offsets (no per-lane 64-bit address arithmetic between the MFMAs; see posterior_kernel_v2.hip)
+  const f4* wpA = reinterpret_cast<const f4*>(p.Wp) + ((int64_t)(tA >> 1) * quads * 4 + (tA & 1) * 2) * 64;
+  const f4* wpB = reinterpret_cast<const f4*>(p.Wp) + ((int64_t)(tB >> 1) * quads * 4 + (tB & 1) * 2) * 64;
+  constexpr int BUF_FLAGS = 0x00020000;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<f4*>(wpA), 0, 0x7fffffff, BUF_FLAGS);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<f4*>(wpB), 0, 0x7fffffff, BUF_FLAGS);
+  const unsigned voff16 = (unsigned)lane * 16u, voff4 = (unsigned)lane * 4u;
 
   f16v acc[2][2];
 #pragma unroll
@@ -324,19 +333,26 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
       for (int e = 0; e < 16; ++e) acc[t][u][e] = 0.f;
 
   auto ld_stage = [&](int stage, float (&kv)[EX]) {
-    const float* src = p.Kst + (int64_t)(stage * BKX + wave * EX) * p.ldk + (int64_t)ct * F32_CANDS + lane;
+    const float* src = p.Kst + (int64_t)(stage * BKX + wave * EX) * p.ldk + (int64_t)ct * F32_CANDS;   // wave-uniform
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7fffffff, BUF_FLAGS);
+    const unsigned row = (unsigned)p.ldk * 4u;
 #pragma unroll
-    for (int e = 0; e < EX; ++e) kv[e] = src[(int64_t)e * p.ldk];
+    for (int e = 0; e < EX; ++e)
+      kv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff4, (unsigned)e * row, 0));
   };
   auto st_stage = [&](const float (&kv)[EX], int buf) {
 #pragma unroll
-    for (int e = 0; e < EX; ++e) Ks[(buf * BKX + wave * EX + e) * F32_STRIDE + lane] = kv[e];
+    for (int e = 0; e < EX; ++e) {
+      const int k = wave * EX + e;
+      Ks[((buf * (BKX / 2) + (k >> 1)) * 2 + (lane >> 5)) * 64 + (k & 1) * 32 + (lane & 31)] = kv[e];
+    }
   };
   auto loadA = [&](int kquad, f4(&a)[2][2]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      a[0][h] = wpA[((int64_t)kquad * 4 + h) * 64];
-      a[1][h] = wpB[((int64_t)kquad * 4 + h) * 64];
+      const unsigned so = (unsigned)kquad * 4096u + (unsigned)h * 1024u;
+      a[0][h] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsA, voff16, so, 0));
+      a[1][h] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsB, voff16, so, 0));
     }
   };
   // MODE 2: both tiles, 1: the later tile only
@@ -346,8 +362,8 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_f32x(PostArgsF32 p) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float* kb = Ks + (buf * BKX + qq * 16 + h * 8 + 2 * e + (lane >> 5)) * F32_STRIDE + (lane & 31);
-        const float b0 = kb[0], b1 = kb[32];
+        const float* kb = Ks + ((buf * (BKX / 2) + qq * 8 + h * 4 + e) * 2) * 64 + lane;
+        const float b0 = kb[0], b1 = kb[64];
         if constexpr (MODE == 2) {
           acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][h][e], b0, acc[0][0], 0, 0, 0);
           acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][h][e], b1, acc[0][1], 0, 0, 0);
