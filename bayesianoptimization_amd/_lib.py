@@ -34,6 +34,9 @@ SIGNATURES = {
     "gpbo_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "gpbo_fit": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, C.c_int64, C.c_int, C.c_int,
                            _c_double_p, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)]),
+    "gpbo_fit_begin": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, C.c_int64, C.c_int, C.c_int,
+                                 _c_double_p, C.c_int, C.c_double, C.c_int]),
+    "gpbo_fit_wait": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "gpbo_fit_append": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int64, C.c_int, _c_double_p, C.c_int64,
                                   C.POINTER(C.c_int)]),
     "gpbo_lml": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, C.c_int64, C.c_int, C.c_int, _c_double_p,

@@ -298,6 +298,8 @@ int gpbo_destroy(gpbo_ctx* ctx) {
   gpbo_comm_destroy(ctx);
   for (auto& m : ctx->models) free_model(m);
   for (auto& st : ctx->lml_stream) if (st) (void)hipStreamDestroy(st);
+  for (auto& st : ctx->slot_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  if (ctx->info_slots) (void)hipFree(ctx->info_slots);
   for (auto& ln : ctx->lml_lane) if (ln.exec) (void)hipGraphExecDestroy(ln.exec);
   if (ctx->lml_slab) (void)hipFree(ctx->lml_slab);
   if (ctx->lml_X) (void)hipFree(ctx->lml_X);
@@ -458,8 +460,8 @@ static int factorize(gpbo_ctx* ctx, Model& m, const char* who, const double* X, 
   return enqueue_factor(ctx, m, X, y_norm, nullptr, nullptr, noise, info_host);
 }
 
-// Tail shared by gpbo_fit and gpbo_fit_append: pack W for the posterior kernels, wait, resolve the pivot check.
-static int finish_fit(gpbo_ctx* ctx, Model& m, int* info_h, int* info) {
+// Tail shared by the fit entry points: pack W for the posterior kernels (enqueue), then wait and resolve the pivot check.
+static int finish_enqueue(gpbo_ctx* ctx, Model& m) {
   int rc;
   if ((rc = launch_pack_w(ctx, m))) return rc;
   if (m.precision == GPBO_F32) {   // fp32 posterior: W rounded to fp32 in f32-MFMA fragment order (fit itself is fp64)
@@ -467,7 +469,11 @@ static int finish_fit(gpbo_ctx* ctx, Model& m, int* info_h, int* info) {
     if ((rc = launch_pack_w32(ctx, m))) return rc;
   }
   ev_end(ctx, T_FIT);
-  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return GPBO_OK;
+}
+
+static int finish_wait(gpbo_ctx* ctx, Model& m, hipStream_t stream, int* info_h, int* info) {
+  GPBO_HIP(ctx, hipStreamSynchronize(stream));
   if (*info_h != 0) {
     if (info) *info = *info_h;
     char b[160];
@@ -478,6 +484,28 @@ static int finish_fit(gpbo_ctx* ctx, Model& m, int* info_h, int* info) {
   return GPBO_OK;
 }
 
+static int finish_fit(gpbo_ctx* ctx, Model& m, int* info_h, int* info) {
+  int rc = finish_enqueue(ctx, m);
+  if (rc) return rc;
+  return finish_wait(ctx, m, ctx->stream, info_h, info);
+}
+
+// a slot whose gpbo_fit_begin has not been waited for must not be refitted or read
+static int no_pending_fit(gpbo_ctx* ctx, int slot, const char* who) {
+  if (ctx->pending_info[slot])
+    GPBO_FAIL(ctx, GPBO_ERR_STATE, std::string(who) + ": the slot has a pending gpbo_fit_begin (call gpbo_fit_wait first)");
+  return GPBO_OK;
+}
+
+static int wait_all_pending_fits(gpbo_ctx* ctx) {
+  for (int s = 0; s < GPBO_MAX_MODELS; ++s)
+    if (ctx->pending_info[s]) {
+      int rc = gpbo_fit_wait(ctx, s, nullptr);
+      if (rc) return rc;
+    }
+  return GPBO_OK;
+}
+
 int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d,
              int kernel, const double* length_scale, int n_ls, double noise, int precision,
              int* info) {
@@ -485,9 +513,51 @@ int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int
   int* info_h = nullptr;
   int rc = check_slot(ctx, slot);
   if (rc) return rc;
+  if ((rc = no_pending_fit(ctx, slot, "gpbo_fit"))) return rc;
   rc = factorize(ctx, ctx->models[slot], "gpbo_fit", X, y_norm, N, d, kernel, length_scale, n_ls, noise, precision, &info_h);
   if (rc) return rc;
   return finish_fit(ctx, ctx->models[slot], info_h, info);
+}
+
+int gpbo_fit_begin(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d, int kernel,
+                   const double* length_scale, int n_ls, double noise, int precision) {
+  int rc = check_slot(ctx, slot);
+  if (rc) return rc;
+  if ((rc = no_pending_fit(ctx, slot, "gpbo_fit_begin"))) return rc;
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->slot_stream[slot]) GPBO_HIP(ctx, hipStreamCreateWithFlags(&ctx->slot_stream[slot], hipStreamNonBlocking));
+  if (!ctx->info_slots) GPBO_HIP(ctx, hipMalloc((void**)&ctx->info_slots, GPBO_MAX_MODELS * sizeof(int)));
+  // the slot's own stream, pinned window and pivot word for the duration of the enqueue (as a gpbo_lml_batch group)
+  hipStream_t stream0 = ctx->stream;
+  void* pinned0 = ctx->pinned;
+  int* info0 = ctx->info_dev;
+  const bool timing0 = ctx->no_timing;
+  ctx->stream = ctx->slot_stream[slot];
+  ctx->pinned = (char*)pinned0 + PIN_LANE_WINDOW * (size_t)(1 + slot);
+  ctx->info_dev = ctx->info_slots + slot;
+  ctx->no_timing = true;            // the timing events belong to the main stream's calls
+  int* info_h = nullptr;
+  Model& m = ctx->models[slot];
+  rc = factorize(ctx, m, "gpbo_fit_begin", X, y_norm, N, d, kernel, length_scale, n_ls, noise, precision, &info_h);
+  if (rc == GPBO_OK) rc = finish_enqueue(ctx, m);
+  ctx->stream = stream0; ctx->pinned = pinned0; ctx->info_dev = info0; ctx->no_timing = timing0;
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->slot_stream[slot]);     // nothing of a half-enqueued fit may still be running
+    return rc;
+  }
+  ctx->pending_info[slot] = info_h;
+  return GPBO_OK;
+}
+
+int gpbo_fit_wait(gpbo_ctx* ctx, int slot, int* info) {
+  if (info) *info = 0;
+  int rc = check_slot(ctx, slot);
+  if (rc) return rc;
+  if (!ctx->pending_info[slot]) GPBO_FAIL(ctx, GPBO_ERR_STATE, "gpbo_fit_wait: the slot has no pending gpbo_fit_begin");
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  int* info_h = ctx->pending_info[slot];
+  ctx->pending_info[slot] = nullptr;
+  return finish_wait(ctx, ctx->models[slot], ctx->slot_stream[slot], info_h, info);
 }
 
 int gpbo_fit_append(gpbo_ctx* ctx, int slot, const double* x_new, int64_t n_new, int d,
@@ -495,6 +565,7 @@ int gpbo_fit_append(gpbo_ctx* ctx, int slot, const double* x_new, int64_t n_new,
   if (info) *info = 0;
   int rc = check_slot(ctx, slot);
   if (rc) return rc;
+  if ((rc = no_pending_fit(ctx, slot, "gpbo_fit_append"))) return rc;
   Model& m = ctx->models[slot];
   if (!m.fitted) GPBO_FAIL(ctx, GPBO_ERR_STATE, "gpbo_fit_append: slot has no fitted model (call gpbo_fit first)");
   if (n_new < 0 || !y_norm || (n_new > 0 && !x_new)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit_append: NULL input or n_new < 0");
@@ -611,6 +682,7 @@ int gpbo_lml(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int
   if (!lml || (eval_gradient && !grad)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml: NULL output");
   int rc = check_slot(ctx, slot);
   if (rc) return rc;
+  if ((rc = no_pending_fit(ctx, slot, "gpbo_lml"))) return rc;
   int* info_h = nullptr;
   double* out_h = nullptr;
   // the slot is left "unfitted": its W is not packed for the posterior kernel
@@ -628,6 +700,10 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
   if (n_theta < 1 || n_theta > GPBO_LML_BATCH_MAX) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: n_theta out of range [1, 8]");
   if (!lml || !length_scales || (eval_gradient && !grad) || (!X) != (!y_norm))
     GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_lml_batch: NULL argument");
+  {
+    int rcw = wait_all_pending_fits(ctx);   // their pinned windows are the ones the lane groups are about to use
+    if (rcw) return rcw;
+  }
   const bool reuse_inputs = !X;     // X == y_norm == NULL: the inputs of the previous call are still on the device
   if (reuse_inputs && (ctx->lml_N != N || ctx->lml_d != d))
     GPBO_FAIL(ctx, GPBO_ERR_STATE, "gpbo_lml_batch: no resident inputs of this shape (pass X and y_norm)");

@@ -75,6 +75,11 @@ struct gpbo_ctx {
   // gpbo_lml_batch: its stream (lml_stream[0]); the lanes' buffers live in lml_slab
   hipStream_t lml_stream[GPBO_LML_BATCH_MAX] = {};
   bool no_timing = false;   // batch lanes do not touch the timing events
+  // gpbo_fit_begin / gpbo_fit_wait: a slot's fit enqueued on the slot's own stream, its staging words in pinned window
+  // 1 + slot (the windows gpbo_lml_batch uses for its groups — it waits for pending fits first), its pivot word in info_slots
+  hipStream_t slot_stream[GPBO_MAX_MODELS] = {};
+  int* info_slots = nullptr;                       // device: GPBO_MAX_MODELS potrf info words
+  int* pending_info[GPBO_MAX_MODELS] = {};         // host (pinned) word a pending fit's pivot check lands in; null = none
   // Lane mode (gpbo_lml_batch): every fit/LML launcher runs its kernel for `lanes` models at once; model l's buffers
   // sit l * lane_stride doubles behind the ones of the Model passed in (one slab, same layout per lane)
   int lanes = 1;

@@ -466,6 +466,7 @@ int launch_posterior_f32(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, int* 
   *part_chunks = nchunks;
   const int64_t budget = kstar_slab_budget_bytes(ctx, Mp * m.NP * 4);   // as the fp64 path (posterior_kernel_v2.hip)
   int64_t ms = budget / (m.NP * 4);
+  if (ms > (int64_t)160 * 1000 * 1000) ms = (int64_t)160 * 1000 * 1000;   // 32-bit buffer offsets of a stage's rows (f32x kernel)
   ms = ms / 128 * 128;
   if (ms < 128) GPBO_FAIL(ctx, GPBO_ERR_HIP, "posterior: not enough device memory for one k* slab");
   if (ms > Mp) ms = Mp;

@@ -373,6 +373,8 @@ int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
   static const int post_bk = (getenv("GPBO_POST_BK") && atoi(getenv("GPBO_POST_BK")) == 16) ? 16 : 32;
   const int64_t budget = kstar_slab_budget_bytes(ctx, Mp * m.NP * 8);
   int64_t ms = budget / (m.NP * 8);
+  // the slab kernel addresses a stage's rows as 32-bit buffer offsets: 3 rows of ldk doubles must stay below 2^31 bytes
+  if (ms > (int64_t)80 * 1000 * 1000) ms = (int64_t)80 * 1000 * 1000;
   ms = ms / 128 * 128;
   if (ms < 128) GPBO_FAIL(ctx, GPBO_ERR_HIP, "posterior: not enough device memory for one k* slab");
   if (ms > Mp) ms = Mp;

@@ -5,6 +5,7 @@ stays resident in HBM across posterior / acquisition calls.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import json
 
@@ -37,6 +38,8 @@ class GpEngine:
         self.world_size = 1
         self.rank = 0
         self._serial: dict[int, int] = {}    # slot -> number of times its factorisation was rewritten
+        self._overlap_depth = 0              # > 0 inside overlapped_fits()
+        self._pending_fits: set[int] = set()  # slots with a gpbo_fit_begin not yet waited for
 
     # -- lifecycle ---------------------------------------------------------------------------
     def __deepcopy__(self, memo):
@@ -71,6 +74,7 @@ class GpEngine:
             _lib.raise_for_status(self._lib, self._h, rc, info)
 
     def synchronize(self):
+        self._settle()
         self._check(self._lib.gpbo_synchronize(self._h))
 
     def device_info(self) -> dict:
@@ -89,15 +93,65 @@ class GpEngine:
             raise ValueError("X and y have inconsistent numbers of samples")
         ls = np.ascontiguousarray(np.atleast_1d(np.asarray(length_scale, dtype=np.float64)))
         info = C.c_int(0)
+        self._settle(slot)
         self._touch(slot)
+        if self._overlap_depth > 0:
+            # inside overlapped_fits(): enqueue on the slot's own stream and return; waited for (and checked) at the end
+            # of the block or by the first call that reads the slot
+            rc = self._lib.gpbo_fit_begin(self._h, int(slot), dptr(X), dptr(y_norm), X.shape[0], X.shape[1], int(kernel),
+                                          dptr(ls), int(ls.shape[0]), float(noise), int(precision))
+            self._check(rc)
+            self._pending_fits.add(int(slot))
+            return self._touch(slot)
         rc = self._lib.gpbo_fit(self._h, int(slot), dptr(X), dptr(y_norm), X.shape[0], X.shape[1], int(kernel),
                                 dptr(ls), int(ls.shape[0]), float(noise), int(precision), C.byref(info))
         self._check(rc, info.value)
         return self._touch(slot)
 
+    @contextlib.contextmanager
+    def overlapped_fits(self):
+        """`fit()` calls inside the block are enqueued on their slots' own streams (gpbo_fit_begin) and overlap on the
+        device — the target GP and the constraint GPs of one suggest() (bayes_opt/acquisition.py:84-86).  Leaving the
+        block waits for all of them; a kernel matrix that is not positive definite raises there (np.linalg.LinAlgError
+        with sklearn's hint, as fit() does).  Any call that reads a slot in between waits for that slot first."""
+        self._overlap_depth += 1
+        try:
+            yield self
+        finally:
+            self._overlap_depth -= 1
+            if self._overlap_depth == 0:
+                self.wait_fits()
+
+    def wait_fits(self):
+        """Wait for every pending gpbo_fit_begin; all are waited for before the first failure is raised."""
+        first = None
+        for slot in sorted(self._pending_fits):
+            try:
+                self._wait_fit(slot)
+            except Exception as e:  # noqa: BLE001
+                first = first or e
+        if first is not None:
+            raise first
+
+    def _wait_fit(self, slot: int):
+        self._pending_fits.discard(int(slot))
+        info = C.c_int(0)
+        rc = self._lib.gpbo_fit_wait(self._h, int(slot), C.byref(info))
+        self._check(rc, info.value)
+
+    def _settle(self, slot=None):
+        """Before a call reads or rewrites a slot (None: any slot): its pending fit, if any, has to be complete."""
+        if not self._pending_fits:
+            return
+        if slot is None:
+            self.wait_fits()
+        elif int(slot) in self._pending_fits:
+            self._wait_fit(int(slot))
+
     def fit_append(self, x_new, y_norm, slot: int = 0):
         """Grow the slot's fitted model by the rows `x_new` at unchanged kernel/length scale/noise (gpbo_fit_append);
         `y_norm` = ALL normalised targets, old and new.  `x_new` may be empty (new targets for the same inputs)."""
+        self._settle(slot)
         y_norm = np.ascontiguousarray(y_norm, dtype=np.float64).ravel()
         x_new = np.ascontiguousarray(x_new, dtype=np.float64)
         if x_new.ndim != 2:
@@ -113,6 +167,7 @@ class GpEngine:
         """[(lml, grad)] for every row of `length_scales` (n_theta x n_ls), evaluated side by side on the device
         (gpbo_lml_batch); each entry is bitwise what `lml()` returns for that row.  Model slots are not touched.
         reuse_inputs=True: (X, y_norm) are the arrays of the previous call and are not uploaded again."""
+        self._settle()
         X = np.ascontiguousarray(X, dtype=np.float64)
         y_norm = np.ascontiguousarray(y_norm, dtype=np.float64).ravel()
         ls = np.ascontiguousarray(np.atleast_2d(np.asarray(length_scales, dtype=np.float64)))
@@ -137,6 +192,7 @@ class GpEngine:
 
     def lml(self, X, y_norm, kernel: int, length_scale, noise: float, eval_gradient=True, slot: int = 0):
         """(log marginal likelihood, d/dlog(length_scale)) at theta (sklearn _gpr.py:575-652). Clobbers the slot's fit."""
+        self._settle(slot)
         X = np.ascontiguousarray(X, dtype=np.float64)
         y_norm = np.ascontiguousarray(y_norm, dtype=np.float64).ravel()
         ls = np.ascontiguousarray(np.atleast_1d(np.asarray(length_scale, dtype=np.float64)))
@@ -156,15 +212,19 @@ class GpEngine:
         return out
 
     def get_K(self, n, slot=0):
+        self._settle(slot)
         return self._square(self._lib.gpbo_get_K, slot, n)
 
     def get_L(self, n, slot=0):
+        self._settle(slot)
         return self._square(self._lib.gpbo_get_L, slot, n)
 
     def get_Linv(self, n, slot=0):
+        self._settle(slot)
         return self._square(self._lib.gpbo_get_Linv, slot, n)
 
     def get_alpha(self, n, slot=0):
+        self._settle(slot)
         out = np.empty(n, dtype=np.float64)
         self._check(self._lib.gpbo_get_alpha(self._h, int(slot), dptr(out)))
         return out
@@ -217,6 +277,7 @@ class GpEngine:
 
     def posterior(self, slot=0, y_mean=0.0, y_std=1.0, fetch=True):
         """mu, sd for the resident candidates (sklearn _gpr.py:443-494). fetch=False keeps them on device."""
+        self._settle(slot)
         M = self.n_candidates
         mu = np.empty(M) if fetch else None
         sd = np.empty(M) if fetch else None
@@ -236,6 +297,7 @@ class GpEngine:
 
     def predict_cov(self, Xc, slot=0, y_mean=0.0, y_std=1.0):
         """(mu (M,), cov (M,M)) as GaussianProcessRegressor.predict(return_cov=True) (gpbo_predict_cov)."""
+        self._settle(slot)
         Xc = np.ascontiguousarray(Xc, dtype=np.float64)
         M, d = Xc.shape
         mu, cov = np.empty(M), np.empty((M, M))
@@ -247,6 +309,7 @@ class GpEngine:
 
     def predict_grad(self, Xc, slot=0, y_mean=0.0, y_std=1.0):
         """(mu (M,), sd (M,), dmu (M,d), dsd (M,d)) for a small host batch (M <= 256): gpbo_predict_grad."""
+        self._settle(slot)
         Xc = np.ascontiguousarray(Xc, dtype=np.float64)
         M, d = Xc.shape
         mu, sd = np.empty(M), np.empty(M)

@@ -18,6 +18,7 @@ with its finite-difference gradient evaluated as one device batch per iteration 
 from __future__ import annotations
 
 import abc
+import contextlib
 import threading
 import warnings
 
@@ -216,13 +217,24 @@ class AcquisitionFunction(abc.ABC):
             "Custom AcquisitionFunction subclasses must implement their own set_acquisition_params method.")
 
     def _fit_gp(self, gp, target_space) -> None:
-        """Fit the target GP, then the constraint GPs, warnings silenced (acquisition.py:79-86)."""
+        """Fit the target GP, then the constraint GPs, warnings silenced (acquisition.py:79-86).  With a constraint the
+        device factorisations of the 1 + n_constraints GPs are enqueued side by side (GpEngine.overlapped_fits: each is a
+        latency-bound chain, so they overlap) and waited for when the block ends — a non-positive-definite kernel
+        matrix raises np.linalg.LinAlgError here, still inside suggest(), as in the reference."""
+        cons = target_space.constraint
+        eng = None
+        if cons is not None and hasattr(gp, "_engine"):
+            try:
+                eng = gp._engine()
+            except Exception:  # noqa: BLE001
+                eng = None
+        overlap = eng.overlapped_fits() if hasattr(eng, "overlapped_fits") else contextlib.nullcontext()
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            gp.fit(target_space.params, target_space.target)
-            cons = target_space.constraint
-            if cons is not None:
-                cons.fit(target_space.params, target_space._constraint_values)
+            with overlap:
+                gp.fit(target_space.params, target_space.target)
+                if cons is not None:
+                    cons.fit(target_space.params, target_space._constraint_values)
 
     # ---- suggest ------------------------------------------------------------------------------------
     def suggest(self, gp, target_space, n_random: int | None = None, n_smart: int = 10, fit_gp: bool = True,

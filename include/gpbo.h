@@ -90,6 +90,17 @@ int gpbo_fit(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int
 int gpbo_fit_append(gpbo_ctx* ctx, int slot, const double* x_new, int64_t n_new, int d,
                     const double* y_norm, int64_t n_total, int* info);
 
+/* gpbo_fit in two halves, for the fits that one suggest() makes back to back — the target GP and the constraint GPs
+ * (bayes_opt/acquisition.py:84-86: `gp.fit(...)`, then `constraint.fit(...)` -> constraint.py:148-151, one GP per
+ * constraint).  gpbo_fit_begin enqueues the whole fit of `slot` on the slot's own stream and returns; gpbo_fit_wait
+ * waits for it and resolves the positive-definiteness check (GPBO_ERR_NOT_PD, *info as gpbo_fit).  A factorisation at
+ * these sizes is a chain of short dependent kernels that leaves most of the chip idle, so several of them in flight
+ * overlap almost perfectly (N = 8192: two fits 26.6 ms one after the other).  Between the two calls the slot must not be
+ * used; every slot's result is bitwise the one gpbo_fit gives. */
+int gpbo_fit_begin(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d, int kernel,
+                   const double* length_scale, int n_ls, double noise, int precision);
+int gpbo_fit_wait(gpbo_ctx* ctx, int slot, int* info);
+
 /* Log marginal likelihood and its gradient with respect to log(length_scale) at the given theta.
  * Replaces one L-BFGS-B evaluation of GaussianProcessRegressor.log_marginal_likelihood(theta,
  * eval_gradient=True) (_gpr.py:575-652; Matern/RBF gradients kernels.py:1764-1766, 1567-1582), the inner

@@ -544,3 +544,68 @@ def test_predict_cov_equals_sklearn_return_cov(engine, N, d, kernel, ls, M):
     assert np.max(np.abs(cov - cov.T)) < 1e-12 * np.max(np.abs(cov_s))
     _, sd = gp.predict(Xq, return_std=True)
     assert np.max(np.abs(np.sqrt(np.clip(np.diag(cov), 0, None)) - sd)) < 1e-6 * np.max(sd)
+
+
+def test_overlapped_fits_are_bitwise_the_sequential_fits(engine):
+    """gpbo_fit_begin / gpbo_fit_wait (GpEngine.overlapped_fits): the target GP and the constraint GPs of one suggest()
+    (acquisition.py:84-86) factorised side by side on their slots' own streams.  Every slot must hold bitwise what gpbo_fit
+    gives it; a read inside the block waits for that slot only; a non-PD matrix raises when the block ends while the other
+    slots' fits stand; misuse of the two entry points is reported."""
+    import ctypes as C
+
+    from bayesianoptimization_amd import _lib
+    from bayesianoptimization_amd.engine import F32, F64
+
+    N, d = 1500, 6
+    X, y = _data(N, d)
+    y2 = np.cos(2.0 * X.sum(axis=1))
+    y3 = X[:, 0] - X[:, 1] ** 2
+    jobs = [(0, y, O.MATERN25, 0.9, F64), (1, y2, O.RBF, 0.7, F64), (2, y3, O.MATERN25, 1.3, F32)]
+
+    def norm(v):
+        return (v - v.mean()) / v.std()
+
+    ref = {}
+    for slot, yy, kern, ls, prec in jobs:
+        engine.fit(X, norm(yy), kern, ls, 1e-6, slot=slot, precision=prec)
+        ref[slot] = (engine.get_L(N, slot), engine.get_Linv(N, slot), engine.get_alpha(N, slot))
+    Xq = np.random.RandomState(3).uniform(size=(3000, d))
+    post_ref = {slot: engine.predict(Xq, slot) for slot, *_ in jobs}
+
+    with engine.overlapped_fits():
+        for slot, yy, kern, ls, prec in jobs:
+            engine.fit(X, norm(yy), kern, ls, 1e-6, slot=slot, precision=prec)
+        assert engine._pending_fits == {0, 1, 2}
+        mu1, sd1 = engine.predict(Xq, 1)                    # reads slot 1: waits for slot 1 only
+        assert engine._pending_fits == {0, 2}
+        assert np.array_equal(mu1, post_ref[1][0]) and np.array_equal(sd1, post_ref[1][1])
+    assert not engine._pending_fits
+    for slot, *_ in jobs:
+        L, Wm, a = engine.get_L(N, slot), engine.get_Linv(N, slot), engine.get_alpha(N, slot)
+        assert np.array_equal(L, ref[slot][0]) and np.array_equal(Wm, ref[slot][1]) and np.array_equal(a, ref[slot][2])
+        mu, sd = engine.predict(Xq, slot)
+        assert np.array_equal(mu, post_ref[slot][0]) and np.array_equal(sd, post_ref[slot][1])
+
+    # not positive definite: duplicate rows, no noise -> LinAlgError when the block ends; slot 0's fit stands
+    Xbad = np.array([[0.1, 0.2], [0.1, 0.2], [0.5, 0.5]])
+    with pytest.raises(np.linalg.LinAlgError, match="not returning a positive definite matrix"):
+        with engine.overlapped_fits():
+            engine.fit(X, norm(y), O.MATERN25, 0.9, 1e-6, slot=0)
+            engine.fit(Xbad, np.zeros(3), O.MATERN25, 1.0, 0.0, slot=1)
+    assert not engine._pending_fits
+    assert np.array_equal(engine.get_L(N, 0), ref[0][0])
+    with pytest.raises(Exception):
+        engine.posterior(1)                                  # slot 1 is unfitted
+
+    # the C entry points refuse misuse
+    lib = _lib.load_library()
+    info = C.c_int(0)
+    assert lib.gpbo_fit_wait(engine._h, 0, C.byref(info)) == _lib.ERR_STATE
+    yn = np.ascontiguousarray(norm(y))
+    ls = np.array([0.9])
+    Xc_ = np.ascontiguousarray(X)
+    assert lib.gpbo_fit_begin(engine._h, 0, _lib.dptr(Xc_), _lib.dptr(yn), N, d, O.MATERN25, _lib.dptr(ls), 1, 1e-6, 0) == _lib.GPBO_OK
+    assert lib.gpbo_fit_begin(engine._h, 0, _lib.dptr(Xc_), _lib.dptr(yn), N, d, O.MATERN25, _lib.dptr(ls), 1, 1e-6, 0) == _lib.ERR_STATE
+    assert lib.gpbo_fit(engine._h, 0, _lib.dptr(Xc_), _lib.dptr(yn), N, d, O.MATERN25, _lib.dptr(ls), 1, 1e-6, 0, C.byref(info)) == _lib.ERR_STATE
+    assert lib.gpbo_fit_wait(engine._h, 0, C.byref(info)) == _lib.GPBO_OK and info.value == 0
+    assert np.array_equal(engine.get_L(N, 0), ref[0][0])
