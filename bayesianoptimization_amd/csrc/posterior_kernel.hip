@@ -112,11 +112,14 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
       return GPBO_OK;
     }
   }
-  // v2 = fused generation (one kernel); v3 = k* slab + GEMM.  Default: v3 once k* would be regenerated by
-  // >= 3 row chunks (NP > 512), v2 below that (the second launch costs more than the regeneration saves).
+  // v2 = fused generation (one kernel); v3 = k* slab + GEMM.  Default: v3 as soon as k* would be generated twice (two row
+  // chunks, NP > 256): the fp64 VALU work of the generation runs instead of MFMAs, not beside them, and the slab GEMM's
+  // loop carries no other VALU work (posterior_kernel_v2.hip).  Measured at M = 65 536 (scripts/r02_small_n_posterior_ab.py):
+  // NP = 512: v3 0.37-0.39 ms vs v2 0.40-0.42; NP = 256: v2 0.12 vs v3 0.14 (one chunk: nothing is generated twice).
   // GPBO_POST_KERNEL=2|3 forces one of them (A/B runs).
   const char* kv = getenv("GPBO_POST_KERNEL");
-  const bool use_v2 = kv ? (kv[0] == '2') : (nchunks <= 2);
+  // (two chunks and a small batch — the host optimisers' rounds of ~100 points: the second launch is not worth it)
+  const bool use_v2 = kv ? (kv[0] == '2') : (nchunks <= 1 || (nchunks == 2 && Mp < 8192));
   const bool use_f32 = (m.precision == GPBO_F32);   // fp32 slab + f32 MFMA GEMM (posterior_kernel_f32.hip)
   const int n_mu = (use_f32 || !use_v2) ? nchunks : 1;
   ev_begin(ctx, T_POST_MAIN);
