@@ -8,6 +8,7 @@
 //   trtri         W = L^-1: turns the per-candidate solve_triangular (_gpr.py:454-456) into a GEMM
 //   trmv          alpha = cho_solve((L, True), y)           _gpr.py:360-364, as W^T (W y)
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 
 #include "gpbo_internal.h"
@@ -547,13 +548,25 @@ int launch_chol_step(gpbo_ctx* ctx, Model& m, int kb, const GemmArgs& g_in) {
 //     load, two 16-byte LDS stores.
 // Same flags as gemm_f64_kernel.  m, n multiples of 64 (a ragged last 128-block clamps its loads and drops the
 // stores), k multiple of 16.  With lower_only the diagonal blocks skip the wave tiles strictly above the diagonal.
-constexpr int G2_B = 128, G2_BK = 16, G2_LD = 144;
-constexpr int G2_TILE = G2_BK * G2_LD;   // doubles per operand tile
+constexpr int G2_B = 128, G2_BK = 16;
+// LDS stage: [operand A | B][k-quad q (4)][16-row / 16-column group (8)][k in quad (4)][row / column in group (16)] doubles,
+// i.e. blocks of 64 doubles = 512 B holding exactly one fragment read of v_mfma_f64_16x16x4_f64 (lane l -> element l).
+// Every fragment read of both stage buffers is one of two loop-invariant per-lane addresses (A, B) plus an immediate
+// multiple of 512 B (ds_read2st64_b64, conflict-free: a wave reads 512 contiguous bytes); the staging stores hit their
+// 128-byte bank windows 4- to 8-fold (groups lie 512 B apart), i.e. take twice their minimum — 8 stores against 24
+// fragment reads and 32 MFMAs per wave and stage.  The operands arrive through buffer descriptors with
+// the k-walk folded into the per-stage descriptor base (SALU): the MFMA loop carries no address arithmetic on the VALU
+// (round 2 first version: [k][144] rows and flat global loads, 0.6 non-MFMA VALU instructions per MFMA; the same change
+// as in posterior_kernel_v2.hip, where it was worth 4 %).
+constexpr int G2_OP = 4 * 8 * 64;        // doubles per operand per stage buffer (2048 = 16 KiB)
+constexpr int G2_TILE = G2_OP;           // (LDS bytes = 4 * G2_TILE * 8)
+constexpr int G2_BUF_FLAGS = 0x00020000; // gfx9 raw buffer descriptor word 3
 
+typedef unsigned int g2_u4 __attribute__((ext_vector_type(4)));
 
 template <bool BT, bool AT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm128_f64_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) double g2_smem[];   // [2 buffers][A | B][16][144]
+  extern __shared__ __attribute__((aligned(16))) double g2_smem[];   // [2 buffers][A | B][G2_OP]
   int bn = blockIdx.x, bm = blockIdx.y;                             // long k-ranges first (see gemm_f64_kernel)
   if (g.a_lower) bm = (int)(gridDim.y - 1 - blockIdx.y);
   if (g.b_lower) { bm = (int)blockIdx.x; bn = (int)blockIdx.y; }
@@ -573,59 +586,69 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
   const bool idle = g.lower_only && bm == bn && wn >= wm + 32;   // wave tile strictly above the diagonal
 
-  // global -> register staging addresses
-  const double* asrc; const double* bsrc; int64_t astep, bstep;
-  int a_l0, b_l0;   // LDS offsets (doubles) inside a tile
-  if (AT) {   // A given as (k, m): col-type
+  // ---- global -> registers: wave-uniform tile base (advanced per stage by scalar arithmetic) + a constant per-lane offset
+  const double* abase; const double* bbase; int64_t astep, bstep;   // doubles
+  unsigned avoff, bvoff;                                            // bytes
+  int a_st, b_st;                                                   // LDS store index (doubles) inside an operand tile
+  auto blk = [](int q, int grp, int kk4, int x16) { return (q * 8 + grp) * 64 + kk4 * 16 + x16; };
+  if (AT) {   // A given as (k, m): thread = (k row kk, 4 consecutive m)
     const int kk = tid >> 5, c4 = (tid & 31) * 4;
     int col = bm * G2_B + c4;
     if (col >= g.m) col = g.m - 4;
-    asrc = A + (int64_t)(kbeg + kk) * g.lda + col;
+    abase = A + (int64_t)kbeg * g.lda + (int64_t)bm * G2_B;
+    avoff = (unsigned)(((int64_t)kk * g.lda + (col - bm * G2_B)) * 8);
     astep = (int64_t)G2_BK * g.lda;
-    a_l0 = kk * G2_LD + c4;
-  } else {    // A (m, k): row-type
-    const int row = tid & 127, kq = (tid >> 7) * 4;
+    a_st = blk(kk >> 2, c4 >> 4, kk & 3, c4 & 15);
+  } else {    // A (m, k): thread = (row, 4 consecutive k = one k-quad)
+    const int row = tid & 127, qs = tid >> 7;
     int r = bm * G2_B + row;
     if (r >= g.m) r = g.m - 1;
-    asrc = A + (int64_t)r * g.lda + kbeg + kq;
+    abase = A + (int64_t)bm * G2_B * g.lda + kbeg;
+    avoff = (unsigned)(((int64_t)(r - bm * G2_B) * g.lda + qs * 4) * 8);
     astep = G2_BK;
-    a_l0 = kq * G2_LD + row;
+    a_st = blk(qs, row >> 4, 0, row & 15);     // k = 4 qs + j goes to a_st + 16 j
   }
-  if (BT) {   // B given as (n, k): row-type
-    const int row = tid & 127, kq = (tid >> 7) * 4;
+  if (BT) {   // B given as (n, k)
+    const int row = tid & 127, qs = tid >> 7;
     int r = bn * G2_B + row;
     if (r >= g.n) r = g.n - 1;
-    bsrc = B + (int64_t)r * g.ldb + kbeg + kq;
+    bbase = B + (int64_t)bn * G2_B * g.ldb + kbeg;
+    bvoff = (unsigned)(((int64_t)(r - bn * G2_B) * g.ldb + qs * 4) * 8);
     bstep = G2_BK;
-    b_l0 = kq * G2_LD + row;
-  } else {    // B (k, n): col-type
+    b_st = blk(qs, row >> 4, 0, row & 15);
+  } else {    // B (k, n)
     const int kk = tid >> 5, c4 = (tid & 31) * 4;
     int col = bn * G2_B + c4;
     if (col >= g.n) col = g.n - 4;
-    bsrc = B + (int64_t)(kbeg + kk) * g.ldb + col;
+    bbase = B + (int64_t)kbeg * g.ldb + (int64_t)bn * G2_B;
+    bvoff = (unsigned)(((int64_t)kk * g.ldb + (col - bn * G2_B)) * 8);
     bstep = (int64_t)G2_BK * g.ldb;
-    b_l0 = kk * G2_LD + c4;
+    b_st = blk(kk >> 2, c4 >> 4, kk & 3, c4 & 15);
   }
   auto gload = [&](int st, d2v(&ra)[2], d2v(&rb)[2]) {
-    const d2v* ap = reinterpret_cast<const d2v*>(asrc + (int64_t)st * astep);
-    const d2v* bp = reinterpret_cast<const d2v*>(bsrc + (int64_t)st * bstep);
-    ra[0] = ap[0]; ra[1] = ap[1];
-    rb[0] = bp[0]; rb[1] = bp[1];
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(abase + (int64_t)st * astep), 0,
+                                                                         0x7fffffff, G2_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(bbase + (int64_t)st * bstep), 0,
+                                                                         0x7fffffff, G2_BUF_FLAGS);
+    ra[0] = __builtin_bit_cast(d2v, __builtin_amdgcn_raw_buffer_load_b128(rsa, avoff, 0, 0));
+    ra[1] = __builtin_bit_cast(d2v, __builtin_amdgcn_raw_buffer_load_b128(rsa, avoff + 16u, 0, 0));
+    rb[0] = __builtin_bit_cast(d2v, __builtin_amdgcn_raw_buffer_load_b128(rsb, bvoff, 0, 0));
+    rb[1] = __builtin_bit_cast(d2v, __builtin_amdgcn_raw_buffer_load_b128(rsb, bvoff + 16u, 0, 0));
   };
   auto lstore = [&](int buf, const d2v(&ra)[2], const d2v(&rb)[2]) {
-    double* As = g2_smem + buf * 2 * G2_TILE;
-    double* Bs = As + G2_TILE;
+    double* As = g2_smem + buf * 2 * G2_OP;
+    double* Bs = As + G2_OP;
     if (AT) {
-      *reinterpret_cast<d2v*>(As + a_l0) = ra[0];
-      *reinterpret_cast<d2v*>(As + a_l0 + 2) = ra[1];
+      *reinterpret_cast<d2v*>(As + a_st) = ra[0];
+      *reinterpret_cast<d2v*>(As + a_st + 2) = ra[1];
     } else {
-      As[a_l0] = ra[0].x; As[a_l0 + G2_LD] = ra[0].y; As[a_l0 + 2 * G2_LD] = ra[1].x; As[a_l0 + 3 * G2_LD] = ra[1].y;
+      As[a_st] = ra[0].x; As[a_st + 16] = ra[0].y; As[a_st + 32] = ra[1].x; As[a_st + 48] = ra[1].y;
     }
     if (BT) {
-      Bs[b_l0] = rb[0].x; Bs[b_l0 + G2_LD] = rb[0].y; Bs[b_l0 + 2 * G2_LD] = rb[1].x; Bs[b_l0 + 3 * G2_LD] = rb[1].y;
+      Bs[b_st] = rb[0].x; Bs[b_st + 16] = rb[0].y; Bs[b_st + 32] = rb[1].x; Bs[b_st + 48] = rb[1].y;
     } else {
-      *reinterpret_cast<d2v*>(Bs + b_l0) = rb[0];
-      *reinterpret_cast<d2v*>(Bs + b_l0 + 2) = rb[1];
+      *reinterpret_cast<d2v*>(Bs + b_st) = rb[0];
+      *reinterpret_cast<d2v*>(Bs + b_st + 2) = rb[1];
     }
   };
 
@@ -641,21 +664,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     lstore(0, ra, rb);
     __syncthreads();
     const int last = nst - 1;
-    const int fo = (lane >> 4) * G2_LD + (lane & 15);
+    // per-lane fragment addresses: the wave's first row / column group, the lane's slot in a block
+    const double* fa = g2_smem + (wm >> 4) * 64 + lane;
+    const double* fb = g2_smem + G2_OP + (wn >> 4) * 64 + lane;
     for (int st = 0; st < nst; ++st) {
       const int buf = st & 1;
       gload(min(st + 1, last), ra, rb);            // clamped look-ahead keeps the body branch-free
       __builtin_amdgcn_sched_barrier(0);           // keep the global loads at the top of the stage
       if (!idle) {
-        const double* As = g2_smem + buf * 2 * G2_TILE + fo;
-        const double* Bs = As + G2_TILE;
+        const double* fas = fa + buf * 2 * G2_OP;  // the stage buffer: two address updates per stage, the rest immediates
+        const double* fbs = fb + buf * 2 * G2_OP;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const double a0 = As[q * 4 * G2_LD + wm];
-          const double a1 = As[q * 4 * G2_LD + wm + 16];
+          const double a0 = fas[q * 512];
+          const double a1 = fas[q * 512 + 64];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const double b = Bs[q * 4 * G2_LD + wn + 16 * u];
+            const double b = fbs[q * 512 + 64 * u];
             acc[0][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][u], 0, 0, 0);
             acc[1][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][u], 0, 0, 0);
           }
@@ -710,7 +735,7 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
   const bool triangular = g.a_lower || g.b_lower || g.k_from_tile;
   const bool prefer64 = tri64 && triangular && blocks128 < 512;
   if (gemm128_enabled() && !prefer64 && g.m >= 128 && g.n >= 128 && g.k >= 256 && blocks128 >= 192) {
-    constexpr size_t lds = (size_t)4 * G2_TILE * sizeof(double);   // 73 728 B
+    constexpr size_t lds = (size_t)4 * G2_TILE * sizeof(double);   // 65 536 B
     if (!(ctx->func_attrs & ATTR_GEMM128)) {
       GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_f64_kernel<true, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
