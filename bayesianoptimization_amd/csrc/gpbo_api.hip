@@ -350,11 +350,6 @@ static hipError_t lane_memset(gpbo_ctx* ctx, void* p, size_t bytes) {
   if (ctx->lanes == 1) return hipMemsetAsync(p, 0, bytes, ctx->stream);
   return hipMemset2DAsync(p, (size_t)ctx->lane_stride * sizeof(double), 0, bytes, (size_t)ctx->lanes, ctx->stream);
 }
-static hipError_t lane_copy_d2d(gpbo_ctx* ctx, void* dst, const void* src, size_t bytes) {
-  if (ctx->lanes == 1) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream);
-  const size_t pitch = (size_t)ctx->lane_stride * sizeof(double);
-  return hipMemcpy2DAsync(dst, pitch, src, pitch, bytes, (size_t)ctx->lanes, hipMemcpyDeviceToDevice, ctx->stream);
-}
 static hipError_t lane_h2d(gpbo_ctx* ctx, void* dst, const void* src_host, size_t host_pitch, size_t bytes) {
   if (ctx->lanes == 1) return hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, ctx->stream);
   return hipMemcpy2DAsync(dst, (size_t)ctx->lane_stride * sizeof(double), src_host, host_pitch, bytes, (size_t)ctx->lanes,
@@ -380,7 +375,6 @@ static_assert(PIN_LANE_OUT + GPBO_LML_BATCH_MAX * PIN_OUT_PITCH <= PIN_WINDOW, "
 // K, L, W = L^-1 and alpha from the device-resident scaled inputs m.Xs / targets m.yn (m.N, m.NP, m.kernel set).
 static int factor_resident(gpbo_ctx* ctx, Model& m, double noise, int** info_host) {
   int rc;
-  const int64_t NP = m.NP;
   m.noise = noise;
   GPBO_HIP(ctx, lane_memset(ctx, ctx->info_dev, sizeof(int)));
   ev_begin(ctx, T_KMAT);

@@ -155,12 +155,10 @@ static_assert(PIN_LS + PIN_LS_BYTES <= PIN_INFO, "length scales overlap the info
 static_assert(PIN_INFO + sizeof(int) <= PIN_LML_OUT, "info word overlaps the LML scalars");
 static_assert(PIN_LML_OUT + PIN_LML_OUT_BYTES <= PIN_WINDOW, "LML scalars leave the window");
 // aux window
-constexpr size_t PIN_AUX_SEL_INIT = 0;                               // (free since the selection became two launches: 32 B)
 constexpr size_t PIN_AUX_SEL_OUT = 256;                              // SelState + picks[GPBO_MAX_SEEDS + 1] coming back
 constexpr size_t PIN_AUX_SEL_OUT_BYTES = 32 + 16 * (GPBO_MAX_SEEDS + 1);
 constexpr size_t PIN_AUX_CAND = 2048;                                // [lo | hi (or hi - lo)][GPBO_MAX_DIM] doubles | MT19937 key[624]
 constexpr size_t PIN_AUX_CAND_BYTES = 2 * GPBO_MAX_DIM * sizeof(double) + 624 * sizeof(uint32_t);
-static_assert(PIN_AUX_SEL_INIT + 32 <= PIN_AUX_SEL_OUT, "selection init overlaps its results");
 static_assert(PIN_AUX_SEL_OUT + PIN_AUX_SEL_OUT_BYTES <= PIN_AUX_CAND, "selection results overlap the candidate staging");
 constexpr size_t PIN_AUX_NEGVAR = 8192;                              // int: a finalize kernel clipped a NEGATIVE variance (_gpr.py:479-485)
 static_assert(PIN_AUX_CAND + PIN_AUX_CAND_BYTES <= PIN_AUX_NEGVAR, "candidate staging overlaps the clipped-variance flag");

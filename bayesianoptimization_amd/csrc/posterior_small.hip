@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void grad_small_kernel(const double* __restric
     sd[c] = sqrt(var * (y_std * y_std));
     mu[c] = y_std * tot[1] + y_mean;
   }
-  if (threadIdx.x < d) {
+  if ((int)threadIdx.x < d) {
     double a = 0.0, b = 0.0;
     for (int q = 0; q < nkl; ++q) {
       a += gs_smem[q * DP + threadIdx.x];

@@ -1,4 +1,5 @@
-import os, sys, time, json
+import os
+import sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from bayesianoptimization_amd import workloads as W
