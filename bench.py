@@ -286,7 +286,15 @@ def main():
         barrier_max = lambda v: (eng.synchronize(), v)[1]  # noqa: E731
     else:
         dev = int(os.environ.get("GPBO_BENCH_DEVICE", local_rank))
-        eng = GpEngine(dev)
+        try:
+            eng = GpEngine(dev)
+        except Exception as e:  # noqa: BLE001
+            why = f"rank {rank}: no usable device {dev} ({e!r}); --gpus {n_gpus} needs {n_gpus} GPUs on this node"
+            log(f"[bench] {why}")
+            if rank == 0:
+                emit_failed(args, n_gpus, why)
+            sys.stdout.flush()
+            sys.exit(3)
         if mode == "ranks":
             state = {"ok": False, "err": None}
 
