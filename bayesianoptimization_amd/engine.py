@@ -117,7 +117,16 @@ class GpEngine:
         self._overlap_depth += 1
         try:
             yield self
-        finally:
+        except BaseException:
+            # something else failed inside the block: still leave no fit in flight, but let THAT error propagate
+            self._overlap_depth -= 1
+            if self._overlap_depth == 0:
+                try:
+                    self.wait_fits()
+                except Exception:  # noqa: BLE001
+                    pass
+            raise
+        else:
             self._overlap_depth -= 1
             if self._overlap_depth == 0:
                 self.wait_fits()
