@@ -277,6 +277,8 @@ int gpbo_create(int device, gpbo_ctx** out) {
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->info_dev, sizeof(int));
   if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, PIN_WINDOWS * PIN_WINDOW, hipHostMallocDefault);
   if (e == hipSuccess) ctx->pinned_aux = (char*)ctx->pinned + (PIN_WINDOWS - 1) * PIN_WINDOW;
+  if (e == hipSuccess) e = hipHostMalloc(&ctx->small_pinned, SMALL_PIN_BYTES, hipHostMallocDefault);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->small_ev, hipEventDisableTiming);
   if (e == hipSuccess) {
     int* host_flag = (int*)((char*)ctx->pinned_aux + PIN_AUX_NEGVAR);
     *host_flag = 0;
@@ -299,6 +301,8 @@ int gpbo_destroy(gpbo_ctx* ctx) {
   for (auto& m : ctx->models) free_model(m);
   for (auto& st : ctx->lml_stream) if (st) (void)hipStreamDestroy(st);
   for (auto& st : ctx->slot_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+  if (ctx->small_ev) (void)hipEventDestroy(ctx->small_ev);
+  if (ctx->small_pinned) (void)hipHostFree(ctx->small_pinned);
   if (ctx->info_slots) (void)hipFree(ctx->info_slots);
   for (auto& ln : ctx->lml_lane) if (ln.exec) (void)hipGraphExecDestroy(ln.exec);
   if (ctx->lml_slab) (void)hipFree(ctx->lml_slab);
@@ -892,8 +896,18 @@ int gpbo_set_candidates(gpbo_ctx* ctx, const double* Xc, int64_t M, int d) {
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
   if ((rc = ensure(ctx, &ctx->Xc, &ctx->cap_Xc, M * d))) return rc;
-  GPBO_HIP(ctx, hipMemcpyAsync(ctx->Xc, Xc, (size_t)M * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const size_t bytes = (size_t)M * d * sizeof(double);
+  if (bytes <= SMALL_PIN_IN) {
+    // small batch: through the pinned block, no stream synchronisation (the block is reused only after its last copy)
+    if (ctx->small_ev_pending) GPBO_HIP(ctx, hipEventSynchronize(ctx->small_ev));
+    memcpy(ctx->small_pinned, Xc, bytes);
+    GPBO_HIP(ctx, hipMemcpyAsync(ctx->Xc, ctx->small_pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    GPBO_HIP(ctx, hipEventRecord(ctx->small_ev, ctx->stream));
+    ctx->small_ev_pending = true;
+  } else {
+    GPBO_HIP(ctx, hipMemcpyAsync(ctx->Xc, Xc, bytes, hipMemcpyHostToDevice, ctx->stream));
+    GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   ctx->M = M;
   ctx->d_c = d;
   for (auto& m : ctx->models) m.M_post = -1;
@@ -907,8 +921,19 @@ int gpbo_posterior(gpbo_ctx* ctx, int slot, double y_mean, double y_std, double*
   if (ctx->M < 1) GPBO_FAIL(ctx, GPBO_ERR_STATE, "posterior: no candidates resident (call gpbo_set_candidates)");
   if (ctx->d_c != m.d) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "posterior: candidate dimension differs from the fitted model");
   if ((rc = launch_posterior(ctx, m, ctx->M, y_mean, y_std))) return rc;
-  if (mu) GPBO_HIP(ctx, hipMemcpyAsync(mu, m.mu, (size_t)ctx->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  if (sd) GPBO_HIP(ctx, hipMemcpyAsync(sd, m.sd, (size_t)ctx->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  const size_t bytes = (size_t)ctx->M * sizeof(double);
+  if ((mu || sd) && bytes <= SMALL_PIN_OUT) {      // small batch: results land in the pinned block, then in the caller's arrays
+    double* hmu = (double*)((char*)ctx->small_pinned + SMALL_PIN_IN);
+    double* hsd = (double*)((char*)ctx->small_pinned + SMALL_PIN_IN + SMALL_PIN_OUT);
+    if (mu) GPBO_HIP(ctx, hipMemcpyAsync(hmu, m.mu, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (sd) GPBO_HIP(ctx, hipMemcpyAsync(hsd, m.sd, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (mu) memcpy(mu, hmu, bytes);
+    if (sd) memcpy(sd, hsd, bytes);
+    return GPBO_OK;
+  }
+  if (mu) GPBO_HIP(ctx, hipMemcpyAsync(mu, m.mu, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (sd) GPBO_HIP(ctx, hipMemcpyAsync(sd, m.sd, bytes, hipMemcpyDeviceToHost, ctx->stream));
   if (mu || sd) GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return GPBO_OK;
 }

@@ -121,6 +121,12 @@ struct gpbo_ctx {
   void* pinned = nullptr;  // pinned host staging: window 0 = fit/LML words (PIN_* below), windows 1..8 = gpbo_lml_batch groups
   void* pinned_aux = nullptr;   // last window of the same allocation: selection / candidate staging (PIN_AUX_*); never re-pointed
   int* negvar = nullptr;        // device-visible address of the PIN_AUX_NEGVAR word
+  // small batches (the host optimisers' rounds: tens to hundreds of points per call, hundreds of calls per suggest):
+  // candidates and results cross PCIe through this pinned block instead of the caller's pageable arrays — the runtime
+  // stages pageable copies through its own buffers and blocks on them, ~15-20 us per copy
+  void* small_pinned = nullptr;          // SMALL_PIN_BYTES: [candidates in | mu out | sd out]
+  hipEvent_t small_ev = nullptr;         // the last H2D out of small_pinned has completed
+  bool small_ev_pending = false;
   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: one bit per kernel family, per context (a
   // process-wide flag would leave every device but the first of a gpbo_group at the 64 KiB default)
   unsigned func_attrs = 0;
@@ -136,6 +142,8 @@ struct gpbo_ctx {
 
 namespace gpbo {
 
+constexpr size_t SMALL_PIN_IN = 128 * 1024, SMALL_PIN_OUT = 32 * 1024;   // bytes: candidates in; mu, sd out (each)
+constexpr size_t SMALL_PIN_BYTES = SMALL_PIN_IN + 2 * SMALL_PIN_OUT;
 constexpr unsigned ATTR_POTRF_DIAG = 1u, ATTR_CHOL_STEP = 2u, ATTR_GEMM128 = 4u, ATTR_MT_JUMP = 8u;
 
 // ---- pinned host staging layout -------------------------------------------------------------------------------
