@@ -475,6 +475,8 @@ class GroupEngine(GpEngine):
         self.world_size = len(devices)
         self.rank = 0
         self._serial = {}
+        self._overlap_depth = 0     # group fits are synchronous on every device: overlapped_fits() is a plain block
+        self._pending_fits = set()  # (never filled: the inherited accessors only look at it)
         self._resident = False      # the group's candidate shards are in place (a small predict on device 0 clobbers them)
         self.collective = self._lib.gpbo_group_collective(g).decode()
 
@@ -490,6 +492,23 @@ class GroupEngine(GpEngine):
 
     def synchronize(self):
         self._gcheck(self._lib.gpbo_group_synchronize(self._g))
+
+    @contextlib.contextmanager
+    def overlapped_fits(self):
+        """gpbo_group_fit factorises on every device and returns when all are done: nothing is left in flight, so the
+        block is a plain block (the single-device engine overlaps the slots' fits here)."""
+        yield self
+
+    def take_negative_variance_flag(self):
+        """OR of the clipped-variance flags of ALL member devices (a sharded posterior runs on every one of them);
+        clears each.  Same warning condition as the single-device path (sklearn _gpr.py:479-485)."""
+        any_seen = False
+        for r in range(self.world_size):
+            seen = C.c_int(0)
+            h = C.c_void_p(self._lib.gpbo_group_ctx(self._g, r))
+            self._check(self._lib.gpbo_take_negative_variance_flag(h, C.byref(seen)))
+            any_seen = any_seen or bool(seen.value)
+        return any_seen
 
     def member_timings(self, rank: int) -> dict:
         ms = (C.c_float * 8)()

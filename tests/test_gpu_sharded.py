@@ -275,3 +275,39 @@ def test_device_group_draws_the_reference_candidate_stream_shard_by_shard(device
         assert dev.uniform() == ref.uniform()
     finally:
         grp.close()
+
+
+def test_device_group_through_the_seams_with_constraint_and_theta_search(engine):
+    """a GroupEngine behind HipGPR / HipConstraintModel / the fused acquisition, the way
+    accelerate(optimizer, devices=[...]) wires it — constraint GP (overlapped_fits), theta search on the device
+    (lml / lml_batch), L_ / alpha_ accessors, return_cov and the clipped-variance flag all run on the group and give
+    what the single-device engine gives."""
+    from sklearn.gaussian_process.kernels import Matern
+
+    from bayesianoptimization_amd import fused_acquisition as A
+    from bayesianoptimization_amd.constraint_model import HipConstraintModel
+    from bayesianoptimization_amd.float_space import FloatSpace
+    from bayesianoptimization_amd.gpr import HipGPR
+
+    w = W.C5S
+    X, y, c = W.make_observations(w)
+
+    def run(eng):
+        cons = HipConstraintModel(None, -np.inf, w.constraint_ub, engine=eng, random_state=1)
+        sp = FloatSpace(w.pbounds(), constraint=cons)
+        sp.register_bulk(X, y, c)
+        gp = HipGPR(kernel=Matern(nu=2.5), alpha=w.noise, normalize_y=True, n_restarts_optimizer=2,
+                    random_state=np.random.RandomState(5), engine=eng)
+        fn = A.ExpectedImprovement(xi=w.acq_param)
+        x = fn.suggest(gp, sp, n_random=20000, n_smart=0, random_state=np.random.RandomState(7))
+        with eng.overlapped_fits():
+            pass
+        cov = gp.predict(X[:8], return_cov=True)[1]
+        return x, gp.kernel_.theta.copy(), np.array(gp.L_), np.array(gp.alpha_), cov, eng.take_negative_variance_flag()
+
+    single = run(engine)
+    with GroupEngine([0, 0]) as grp:
+        group = run(grp)
+    for a, b in zip(single[:5], group[:5]):
+        assert np.array_equal(a, b)
+    assert single[5] == group[5]
