@@ -25,6 +25,7 @@ ARCH = "gfx950"
 SOURCES = {
     "gpbo_api.hip": [],
     "fit_kernels.hip": [],
+    "chol_kernels.hip": [],
     "posterior_kernel.hip": [],
     "posterior_kernel_v2.hip": [],
     "posterior_small.hip": [],

@@ -12,10 +12,9 @@
 #include <utility>
 
 #include "gpbo_internal.h"
+#include "gemm_tile.h"
 
 namespace gpbo {
-
-typedef double d4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------------
 // X / length_scale into a zero-padded [n_pad][DP] image (true division, as numpy does).
@@ -385,106 +384,6 @@ int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb) {
   return GPBO_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// fp64 MFMA GEMM, 64x64 output tile per 256-thread workgroup (4 waves, 32x32 each as 2x2
-// v_mfma_f64_16x16x4_f64 tiles), BK = 16, operands staged k-major in LDS.
-//   C = alpha * A(m,k) * op(B) + beta * C ;  A row-major; B row-major (k,n), or (n,k) if b_trans.
-// Fragment layout (cdna_hip_programming.md §3): A lane l = A[l&15][l>>4], B lane l = B[l>>4][l&15],
-// D lane l, reg r = D[(l>>4) + 4r][l&15].
-typedef double d2v __attribute__((ext_vector_type(2)));
-
-template <bool BT, bool AT>
-__device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn, int zl, int bz) {
-  if (g.lower_only && bn > bm) return;
-  if (g.skip00 && bn == 0 && bm == 0) return;      // tile (0, 0) belongs to the diagonal-block workgroup of the same launch
-  // two LDS stages: the global loads of stage s+1 are issued before the MFMAs of stage s and parked in the other buffer
-  // afterwards — one barrier per 16-deep stage (round 1: one buffer, two barriers, loads exposed in front of every stage)
-  __shared__ __attribute__((aligned(16))) double As[2][16][68];
-  __shared__ __attribute__((aligned(16))) double Bs[2][16][68];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int64_t lo = (int64_t)zl * g.lane_stride;
-  const double* A = g.A + lo + (int64_t)bz * g.strideA + (AT ? (int64_t)bm * 64 : (int64_t)bm * 64 * g.lda);
-  const double* B = g.B + lo + (int64_t)bz * g.strideB + (BT ? (int64_t)bn * 64 * g.ldb : (int64_t)bn * 64);
-  double* C = g.C + lo + (int64_t)bz * g.strideC;
-  int kbeg = 0, kend = g.k;
-  if (g.a_lower) kend = min(kend, (bm + 1) * 64);
-  if (g.b_lower) kbeg = bn * 64;
-  if (g.k_from_tile) kbeg = max(bm, bn) * 64;   // both operands vanish above their diagonal tiles
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-  d4 acc[2][2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int u = 0; u < 2; ++u) acc[t][u] = d4{0.0, 0.0, 0.0, 0.0};
-  const int arow = tid >> 2, akq = (tid & 3) * 4;
-  const int brow = tid >> 4, bnq = (tid & 15) * 4;
-  const double* asrc = AT ? A + (int64_t)(kbeg + brow) * g.lda + bnq : A + (int64_t)arow * g.lda + kbeg + akq;
-  const double* bsrc = BT ? B + (int64_t)arow * g.ldb + kbeg + akq : B + (int64_t)(kbeg + brow) * g.ldb + bnq;
-  const int64_t astep = AT ? (int64_t)16 * g.lda : 16, bstep = BT ? 16 : (int64_t)16 * g.ldb;
-  auto gload = [&](int st, d2v(&ra)[2], d2v(&rb)[2]) {
-    const d2v* ap = reinterpret_cast<const d2v*>(asrc + (int64_t)st * astep);
-    const d2v* bp = reinterpret_cast<const d2v*>(bsrc + (int64_t)st * bstep);
-    ra[0] = ap[0]; ra[1] = ap[1];
-    rb[0] = bp[0]; rb[1] = bp[1];
-  };
-  auto lstore = [&](int buf, const d2v(&ra)[2], const d2v(&rb)[2]) {
-    if (AT) {
-      *reinterpret_cast<d2v*>(&As[buf][brow][bnq]) = ra[0];
-      *reinterpret_cast<d2v*>(&As[buf][brow][bnq + 2]) = ra[1];
-    } else {
-      As[buf][akq + 0][arow] = ra[0].x; As[buf][akq + 1][arow] = ra[0].y;
-      As[buf][akq + 2][arow] = ra[1].x; As[buf][akq + 3][arow] = ra[1].y;
-    }
-    if (BT) {
-      Bs[buf][akq + 0][arow] = rb[0].x; Bs[buf][akq + 1][arow] = rb[0].y;
-      Bs[buf][akq + 2][arow] = rb[1].x; Bs[buf][akq + 3][arow] = rb[1].y;
-    } else {
-      *reinterpret_cast<d2v*>(&Bs[buf][brow][bnq]) = rb[0];
-      *reinterpret_cast<d2v*>(&Bs[buf][brow][bnq + 2]) = rb[1];
-    }
-  };
-  const int nst = (kend - kbeg) / 16;
-  if (nst > 0) {
-    d2v ra[2], rb[2];
-    gload(0, ra, rb);
-    lstore(0, ra, rb);
-    __syncthreads();
-    const int last = nst - 1;
-    for (int st = 0; st < nst; ++st) {
-      const int buf = st & 1;
-      gload(min(st + 1, last), ra, rb);            // clamped look-ahead keeps the body branch-free
-      __builtin_amdgcn_sched_barrier(0);           // keep the global loads at the top of the stage
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int kr = kk * 4 + (lane >> 4);
-        const double a0 = As[buf][kr][wm + (lane & 15)];
-        const double a1 = As[buf][kr][wm + 16 + (lane & 15)];
-        const double b0 = Bs[buf][kr][wn + (lane & 15)];
-        const double b1 = Bs[buf][kr][wn + 16 + (lane & 15)];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-      }
-      lstore(buf ^ 1, ra, rb);    // the other buffer: everyone finished reading it before the previous barrier
-      __syncthreads();
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t row = (int64_t)bm * 64 + wm + 16 * t + (lane >> 4) + 4 * r;
-        const int64_t colx = (int64_t)bn * 64 + wn + 16 * u + (lane & 15);
-        double* cp = C + row * g.ldc + colx;
-        double v = g.alpha * acc[t][u][r];
-        if (g.beta != 0.0) v += g.beta * (*cp);
-        *cp = v;
-      }
-}
-
 template <bool BT, bool AT>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   const int zl = blockIdx.z / g.batch, bz = blockIdx.z - zl * g.batch;   // lane mode: z = lane * batch + b
@@ -494,7 +393,8 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   int bm = (int)blockIdx.y, bn = (int)blockIdx.x;
   if (g.a_lower) bm = (int)(gridDim.y - 1 - blockIdx.y);
   if (g.b_lower) { bm = (int)blockIdx.x; bn = (int)blockIdx.y; }
-  gemm_tile_body<BT, AT>(g, bm, bn, zl, bz);
+  __shared__ __attribute__((aligned(16))) double gt_lds[GT_LDS_DOUBLES];
+  gemm_tile_body<BT, AT>(g, bm, bn, zl, bz, gt_lds);
 }
 
 // One step of the blocked Cholesky inside an outer panel, as ONE launch: workgroup 0 factors (and inverts) diagonal
@@ -515,7 +415,8 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* L, int64_t ld, i
   }
   const int b = (int)blockIdx.x - 1;
   const int bm = b / tiles_n, bn = b - bm * tiles_n;
-  gemm_tile_body<true, false>(g, bm, bn, 0, 0);
+  __shared__ __attribute__((aligned(16))) double gt_lds[GT_LDS_DOUBLES];
+  gemm_tile_body<true, false>(g, bm, bn, 0, 0, gt_lds);
 }
 
 int launch_chol_step(gpbo_ctx* ctx, Model& m, int kb, const GemmArgs& g_in) {

@@ -155,10 +155,14 @@ static int cholesky_fused(gpbo_ctx* ctx, Model& m, int outer) {
 // update is HBM-bound on exactly that traffic).  GPBO_CHOL_OUTER=64 restores the one-level algorithm (A/B runs); default
 // 512.  GPBO_CHOL_FUSED=0 selects the three-launch schedule (A/B runs; lane mode — several models per launch, inside
 // gpbo_lml_batch — always uses it).
-static int cholesky(gpbo_ctx* ctx, Model& m) {
+static int cholesky(gpbo_ctx* ctx, Model& m, int variant = -1) {
   int outer = 512;
   if (const char* e = getenv("GPBO_CHOL_OUTER")) outer = atoi(e);
   if (outer < NB || outer % NB) outer = NB;
+  // variant 3 (default): 128-column steps, chol_kernels.hip; 2: the round-2 schedules below (GPBO_CHOL=2 for A/B runs)
+  static const int env_variant = getenv("GPBO_CHOL") ? atoi(getenv("GPBO_CHOL")) : 3;
+  if (variant < 0) variant = env_variant;
+  if (variant >= 3 && outer >= 2 * NB && outer % (2 * NB) == 0) return launch_cholesky128(ctx, m, outer, nullptr);
   static const bool fused_off = getenv("GPBO_CHOL_FUSED") && getenv("GPBO_CHOL_FUSED")[0] == '0';
   if (fused_off || ctx->lanes != 1 || outer < 2 * NB) return cholesky_serial(ctx, m, outer);
   return cholesky_fused(ctx, m, outer);
@@ -1027,6 +1031,51 @@ int gpbo_last_timings(gpbo_ctx* ctx, float* ms, int n) {
     }
   }
   return GPBO_OK;
+}
+
+int gpbo_debug_cholesky(gpbo_ctx* ctx, const double* A, int64_t n, int variant, int iters, double* L_out, double* dinv_out,
+                        long long* stamps_out, double* ms_out, int* info_out) {
+  if (!ctx || !A || n < 64 || n % 64 || iters < 1) return GPBO_ERR_INVALID;
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  Model m;
+  int rc = alloc_model(ctx, m, n, 4);
+  if (rc) return rc;
+  m.N = m.NP = n; m.d = 1; m.DP = 4;
+  long long* stamps_dev = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const size_t sq = (size_t)n * n * sizeof(double);
+  auto done = [&](int code) {
+    if (stamps_dev) (void)hipFree(stamps_dev);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    free_model(m);
+    return code;
+  };
+  if (hipMalloc((void**)&stamps_dev, 8 * sizeof(long long)) != hipSuccess) return done(GPBO_ERR_HIP);
+  (void)hipMemset(stamps_dev, 0, 8 * sizeof(long long));
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  if (hipMemcpy(m.K, A, sq, hipMemcpyHostToDevice) != hipSuccess) return done(GPBO_ERR_HIP);
+  double best = 1e30;
+  for (int it = 0; it < iters && !rc; ++it) {
+    (void)hipMemcpyAsync(m.L, m.K, sq, hipMemcpyDeviceToDevice, ctx->stream);
+    (void)hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream);
+    (void)hipEventRecord(e0, ctx->stream);
+    if (variant >= 3 && it == 0) rc = launch_cholesky128(ctx, m, 512, stamps_dev);
+    else rc = cholesky(ctx, m, variant);
+    (void)hipEventRecord(e1, ctx->stream);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return done(GPBO_ERR_HIP);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  if (rc) return done(rc);
+  if (ms_out) *ms_out = best;
+  if (L_out && hipMemcpy(L_out, m.L, sq, hipMemcpyDeviceToHost) != hipSuccess) return done(GPBO_ERR_HIP);
+  if (dinv_out && hipMemcpy(dinv_out, m.dinv, (size_t)(n / 64) * 4096 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+    return done(GPBO_ERR_HIP);
+  if (stamps_out && hipMemcpy(stamps_out, stamps_dev, 8 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return done(GPBO_ERR_HIP);
+  if (info_out && hipMemcpy(info_out, ctx->info_dev, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return done(GPBO_ERR_HIP);
+  return done(GPBO_OK);
 }
 
 int gpbo_debug_gemm(gpbo_ctx* ctx, int m, int n, int k, double alpha, const double* A,

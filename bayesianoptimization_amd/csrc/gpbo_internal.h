@@ -144,7 +144,7 @@ namespace gpbo {
 
 constexpr size_t SMALL_PIN_IN = 128 * 1024, SMALL_PIN_OUT = 32 * 1024;   // bytes: candidates in; mu, sd out (each)
 constexpr size_t SMALL_PIN_BYTES = SMALL_PIN_IN + 2 * SMALL_PIN_OUT;
-constexpr unsigned ATTR_POTRF_DIAG = 1u, ATTR_CHOL_STEP = 2u, ATTR_GEMM128 = 4u, ATTR_MT_JUMP = 8u;
+constexpr unsigned ATTR_POTRF_DIAG = 1u, ATTR_CHOL_STEP = 2u, ATTR_GEMM128 = 4u, ATTR_MT_JUMP = 8u, ATTR_CHOL128 = 16u;
 
 // ---- pinned host staging layout -------------------------------------------------------------------------------
 // ONE allocation of PIN_WINDOWS windows of PIN_WINDOW bytes.  Window 0 (ctx->pinned) carries the words of a fit /
@@ -268,11 +268,15 @@ struct GemmArgs {
   int b_lower;            // B is lower triangular (k == n, not transposed): k-loop starts at the column tile
   int a_trans;            // A given as (k,m) row-major (C = A^T B)
   int k_from_tile;        // k-loop starts at max(row tile, column tile): W^T W with W lower triangular
-  int skip00;             // leave output tile (0, 0) alone (64x64-tile kernel only): a concurrent diagonal-block kernel owns it
+  int skip00;             // leave the leading skip00 x skip00 output tiles alone (64x64-tile kernel only): the diagonal-block
+                          // workgroup of the same launch (or an earlier launch) owns them
 };
 int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g);
 // diagonal block kb (with the previous block column's update applied by the workgroup itself) || the 64x64 tiles of update g
 int launch_chol_step(gpbo_ctx* ctx, Model& m, int kb, const GemmArgs& g);
+// chol_kernels.hip: blocked Cholesky of m.L in place + inverted 64x64 diagonal blocks (128-column steps, `outer`-column panels);
+// stamps (device, >= 8 words, may be null): in-kernel clocks of the first diagonal workgroup
+int launch_cholesky128(gpbo_ctx* ctx, Model& m, int outer, long long* stamps);
 // posterior_kernel.hip
 int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std);
 int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std, double** dmu_dev, double** dsd_dev);
