@@ -56,13 +56,13 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // its rank-1 updates in column order whatever the timing, so the result is deterministic.
 template <bool FOLLOW>
 __device__ __forceinline__ void factor_quarter(double (&a)[16], double (&a2)[16], double* __restrict__ Lc, double* __restrict__ Lc2,
-                                               double* __restrict__ rdiag, volatile int* bad, volatile int* pub, volatile int* broken,
-                                               const int i, const int q, const int col0) {
+                                               double* __restrict__ rdiag, int* bad, int* pub, int* broken,
+                                               const int i, const int q, const int col0, long long* stamp = nullptr) {
   {
     const int need = 16 * q;
     int applied = 0, spins = 0;
     while (applied < need) {
-      int avail = *pub;
+      int avail = __hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       GPBO_LDS_ORDER();
       if (avail <= applied) {
         if (++spins > (1 << 22)) {   // cannot happen while the owner wave runs; never hang the GPU on a bug
@@ -118,9 +118,12 @@ __device__ __forceinline__ void factor_quarter(double (&a)[16], double (&a2)[16]
       a2[jj] = l2;
       Lc2[j * DS + i] = l2;
     }
-    if (i == 0) rdiag[col0 + j] = rs;    // 1 / L[j][j] for the inverse (saves its dependent fp64 divisions)
     GPBO_LDS_ORDER();
-    if (i == 0) *pub = j + 1;
+    if (i == 0) {
+      rdiag[col0 + j] = rs;    // 1 / L[j][j] for the inverse (saves its dependent fp64 divisions)
+      GPBO_LDS_ORDER();
+      __hip_atomic_store(pub, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     GPBO_LDS_ORDER();
 #pragma unroll
     for (int cc = jj + 1; cc < 16; ++cc) {
@@ -129,6 +132,7 @@ __device__ __forceinline__ void factor_quarter(double (&a)[16], double (&a2)[16]
       if (FOLLOW) a2[cc] = fma(-l2, lc, a2[cc]);
     }
   }
+  if (stamp && i == 0 && q == 0) *stamp = clock64();
   if (badcol && i == 0 && *bad == 0) *bad = badcol;
 }
 
@@ -211,7 +215,7 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
   double* LcX = smem + C128_LCX;
   double* Wr = smem + C128_WR;
   double* rdiag = smem + C128_RDIAG;
-  volatile int* flags = reinterpret_cast<volatile int*>(smem + C128_FLAGS);
+  int* flags = reinterpret_cast<int*>(smem + C128_FLAGS);
   const int tid = threadIdx.x;
   const int i = tid & 63;
   const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -245,8 +249,8 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
   __syncthreads();
   if (stamps && tid == 0) stamps[1] = clock64();
   // ---- columns 0..63: L00 and (with two blocks) L10 = A10 L00^-T riding along
-  if (two) factor_quarter<true>(a0, a1, Lc0, LcX, rdiag, &flags[0], &flags[1], &flags[2], i, q, 0);
-  else factor_quarter<false>(a0, a1, Lc0, LcX, rdiag, &flags[0], &flags[1], &flags[2], i, q, 0);
+  if (two) factor_quarter<true>(a0, a1, Lc0, LcX, rdiag, &flags[0], &flags[1], &flags[2], i, q, 0, stamps ? stamps + 7 : nullptr);
+  else factor_quarter<false>(a0, a1, Lc0, LcX, rdiag, &flags[0], &flags[1], &flags[2], i, q, 0, stamps ? stamps + 7 : nullptr);
   {
     // the wave's 16 columns are final: rows straight from registers (128 contiguous bytes per thread, zeros above the diagonal)
     double2* d0 = reinterpret_cast<double2*>(A + (int64_t)i * ld + 16 * q);

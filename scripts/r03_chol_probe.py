@@ -32,9 +32,9 @@ def probe():
     from bayesianoptimization_amd.engine import MATERN25, GpEngine
     eng = GpEngine(0)
     out = {"chol": {}, "fit": {}, "variant_env": os.environ.get("GPBO_CHOL", "3")}
-    for n in (64, 128, 192, 256, 512, 576, 1024, 2048, 4096, 8192):
+    for n in (64, 128, 192, 512, 576, 1024, 2048, 4096, 8192):
         for kind in ("random", "kernel"):
-            if kind == "random" and n > 2048:
+            if kind == "random" and n not in (128, 576):
                 continue
             A = spd(n, 1, kind)
             Lref = np.linalg.cholesky(A)
@@ -51,6 +51,7 @@ def probe():
                 if variant == 3:
                     d = np.diff(stamps[:7])
                     rec["stamps_cycles"] = {PHASES[i]: int(d[i]) for i in range(6)}
+                    rec["stamps_cycles"]["wave 0: its 16 columns of the first factorisation"] = int(stamps[7] - stamps[1])
                     L2 = eng.debug_cholesky(A, variant=3, iters=1)[0]
                     rec["bitwise_repeat"] = bool(np.array_equal(L, L2))
             out["chol"][f"{n}/{kind}"] = rec
