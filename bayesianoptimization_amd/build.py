@@ -37,6 +37,7 @@ SOURCES = {
     "mt19937.hip": ["-ffp-contract=off"],      # lo + (hi - lo) * u as NumPy computes it
     "mt_jump.hip": [],                         # jump-ahead polynomials (host) + sub-stream start states (device)
     "probe.hip": [],
+    "latency_probe.hip": [],
     "comm.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",

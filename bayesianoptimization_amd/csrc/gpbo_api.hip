@@ -1143,6 +1143,12 @@ int gpbo_debug_gemm_bench(gpbo_ctx* ctx, int m, int n, int k, int b_trans, int a
   return rc;
 }
 
+int gpbo_debug_latency_probe(gpbo_ctx* ctx, long long* out, int n) {
+  if (!ctx || !out || n < 1) return GPBO_ERR_INVALID;
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  return run_latency_probe(ctx, out, n);
+}
+
 int gpbo_mfma_f64_peak(gpbo_ctx* ctx, int iters, double* tflops) {
   if (!ctx || !tflops || iters < 1) return GPBO_ERR_INVALID;
   GPBO_HIP(ctx, hipSetDevice(ctx->device));

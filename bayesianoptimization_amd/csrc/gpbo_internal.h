@@ -324,6 +324,8 @@ int run_mfma_peak(gpbo_ctx* ctx, int iters, double* tflops);
 int run_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);
 int run_hybrid_probe(gpbo_ctx* ctx, int iters, int cfg, double* out3);
 int run_mfma_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, double* out4);
+// latency_probe.hip
+int run_latency_probe(gpbo_ctx* ctx, long long* out_host, int n);
 
 inline void ev_begin(gpbo_ctx* ctx, int slot) {
   if (ctx->no_timing) return;

@@ -367,6 +367,11 @@ class GpEngine:
                                                   stamps.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(ms), C.byref(info)))
         return np.tril(Lo), dinv, stamps, ms.value, info.value
 
+    def latency_probe(self, n=16):
+        out = np.zeros(32, dtype=np.int64)
+        self._check(self._lib.gpbo_debug_latency_probe(self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), int(n)))
+        return out[:n]
+
     def debug_gemm(self, A, B, C_in=None, alpha=1.0, beta=0.0, b_trans=False):
         A = np.ascontiguousarray(A, dtype=np.float64)
         B = np.ascontiguousarray(B, dtype=np.float64)

@@ -288,6 +288,9 @@ int gpbo_debug_gemm(gpbo_ctx* ctx, int m, int n, int k, double alpha, const doub
  * the flops); a_trans: A given as (k,m). */
 int gpbo_debug_gemm_bench(gpbo_ctx* ctx, int m, int n, int k, int b_trans, int a_trans, int lower_only, int iters,
                           double* out);
+/* Single-wave instruction latency / issue-cost probe: out[t] = shader cycles for 64 copies of pattern t (latency_probe.hip
+ * lists the patterns; t = 0 is the empty bracket).  n <= 32. */
+int gpbo_debug_latency_probe(gpbo_ctx* ctx, long long* out, int n);
 /* Sustained v_mfma_f64_16x16x4_f64 rate in TFLOP/s over `iters` dependent-chain-free MFMAs. */
 int gpbo_mfma_f64_peak(gpbo_ctx* ctx, int iters, double* tflops);
 /* The same MFMA stream with in-kernel clocks. out[4] = { TFLOP/s, shader cycles per MFMA per SIMD,
