@@ -24,12 +24,12 @@ namespace gpbo {
 
 // ---- LDS layout of the diagonal-block workgroup (doubles) --------------------------------------------------------
 constexpr int DS = 80;                                   // stride of the column-major images: a fragment's four k-rows fall 32 banks apart
-constexpr int C128_LC0 = 0;                              // [64][DS]  L00:  Lc0[j * DS + i] = L[i][j]
-constexpr int C128_LCX = 64 * DS;                        // [64][DS]  L10 during the first factorisation and the SYRK, then L11
-constexpr int C128_WR = 2 * 64 * DS;                     // SYRK exchange [64][81], then the waves' 16x16 diagonal inverses [4][4][272]
+constexpr int C128_IMG = 64 * DS + 64;                   // one image: 64 columns + room for the last column's marker overflow (factor_quarter)
+constexpr int C128_LC0 = 0;                              // L00:  Lc0[j * DS + i] = L[i][j], Lc0[j * DS + 64] = 1 / L[j][j]
+constexpr int C128_LCX = C128_IMG;                       // L10 during the first factorisation and the SYRK, then L11
+constexpr int C128_WR = 2 * C128_IMG;                    // SYRK exchange [64][81], then the waves' 16x16 diagonal inverses [4][4][272]
 constexpr int C128_WR_DOUBLES = 5248;
-constexpr int C128_RDIAG = C128_WR + C128_WR_DOUBLES;    // [128] reciprocal pivots
-constexpr int C128_FLAGS = C128_RDIAG + 128;             // ints: [0] bad pivot, [1] columns published (first factorisation), [2] broken hand-off, [3] published (second)
+constexpr int C128_FLAGS = C128_WR + C128_WR_DOUBLES;    // ints: [0] broken hand-off
 constexpr int C128_LDS_DOUBLES = C128_FLAGS + 8;
 constexpr size_t C128_LDS_BYTES = (size_t)C128_LDS_DOUBLES * sizeof(double);
 static_assert(C128_WR_DOUBLES >= 64 * 81 && C128_WR_DOUBLES >= 4 * 4 * 272, "exchange area too small");
@@ -42,112 +42,164 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-// LDS is one in-order pipeline per CU: a wave's stores are performed in issue order, so "column, then counter" needs no
+// LDS is one in-order pipeline per CU: a wave's stores are performed in issue order, so "column, then marker" needs no
 // s_waitcnt between the two (an atomic release store would put one on the chain, 64 times per block) — only the
 // compiler has to keep the order.
 #define GPBO_LDS_ORDER() asm volatile("" ::: "memory")
+#define GPBO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// What one step costs (scripts/r03_latency_probe.py, one wave on its SIMD): EVERY VALU instruction — v_fma_f64 dependent
+// or not, v_readlane_b32, v_cndmask, v_mov — occupies the wave for 4 cycles, v_rsq_f64 16, a dependent v_writelane_b32
+// (what an SGPR spill turns into) 28; an LDS write -> read round trip is ~90 cycles.  So the factorisation of a column
+// is priced in INSTRUCTIONS: the first version of this routine spent ~110 per column (selects for the diagonal / the
+// zero upper part, an exec-masked pivot/counter store, a per-column pivot test, 2 v_readlane per broadcast multiplier,
+// spilled SGPRs) = 720 cycles per column; this one ~35.
+//
 // One quarter (16 columns, wave q) of the right-looking factorisation of a 64-column panel held row-per-lane:
 // thread (row i, quarter q) keeps a[0..15] = A[i][16q .. 16q+15]; with FOLLOW a second row (i + 64, the block below the
 // diagonal one) rides along in a2 — the same multipliers, no pivots of its own (that is the panel solve of block row 1,
 // L10 = A10 L00^-T, done by substitution in the shadow of the factorisation).  The wave first applies the columns left
-// of its own as their owners publish them (column-major LDS image + counter), then factors its 16 columns inside the
-// wave (pivot and multipliers by v_readlane), publishing each column the moment it is final.  Every element receives
-// its rank-1 updates in column order whatever the timing, so the result is deterministic.
+// of its own as their owners publish them, then factors its 16 columns inside the wave, publishing each column the
+// moment it is final.  Every element receives its rank-1 updates in column order whatever the timing, so the result is
+// deterministic.
+//
+// Column image: Lc[j * DS + i] = L[i][j] for i < 64, and Lc[j * DS + 64] = 1 / L[j][j] — the reciprocal pivot doubles as
+// the "column j is complete" marker (zero-initialised; written by ALL lanes right behind the column, slots 64..127, no
+// exec mask: the overflow lands in the next column's rows 0..47, which are written later and read only after that).
+// Elements above the diagonal are NOT zeroed on the way (they never reach the lower triangle); the caller zeroes the
+// registers before the global store.  A non-positive pivot gives a non-finite reciprocal (v_rsq_f64 of <= 0) that
+// spreads to everything behind it; the caller finds the first one afterwards (LAPACK's info) — no test on the chain.
 template <bool FOLLOW>
 __device__ __forceinline__ void factor_quarter(double (&a)[16], double (&a2)[16], double* __restrict__ Lc, double* __restrict__ Lc2,
-                                               double* __restrict__ rdiag, int* bad, int* pub, int* broken,
-                                               const int i, const int q, const int col0, long long* stamp = nullptr) {
+                                               int* broken, const int i, const int q, long long* stamp = nullptr) {
   {
     const int need = 16 * q;
-    int applied = 0, spins = 0;
-    while (applied < need) {
-      int avail = __hip_atomic_load(pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    int k = 0, spins = 0;
+    const double* prow0 = Lc + 16 * q;      // L[16q + cc][k] = prow0[k * DS + cc]: the same address for every lane
+    while (k < need) {
+      // columns are published in order: the marker of column k + 3 vouches for k .. k + 3
+      const double m4 = Lc[(k + 3) * DS + 64];
       GPBO_LDS_ORDER();
-      if (avail <= applied) {
-        if (++spins > (1 << 22)) {   // cannot happen while the owner wave runs; never hang the GPU on a bug
-          if (i == 0) *broken = 1;
-          break;
+      if (m4 != 0.0) {
+        double li[4], li2[4], p[4][16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          li[u] = Lc[(k + u) * DS + i];
+          li2[u] = FOLLOW ? Lc2[(k + u) * DS + i] : 0.0;
+#pragma unroll
+          for (int cc = 0; cc < 16; ++cc) p[u][cc] = prow0[(k + u) * DS + cc];
         }
-        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int cc = 0; cc < 16; ++cc) {
+            a[cc] = fma(-li[u], p[u][cc], a[cc]);
+            if (FOLLOW) a2[cc] = fma(-li2[u], p[u][cc], a2[cc]);
+          }
+        k += 4;
         continue;
       }
-      if (avail > need) avail = need;
-      for (int k = applied; k < avail; ++k) {
+      const double m1 = Lc[k * DS + 64];
+      GPBO_LDS_ORDER();
+      if (m1 != 0.0) {
         const double li = Lc[k * DS + i];
-        double li2 = 0.0;
-        if (FOLLOW) li2 = Lc2[k * DS + i];
-        const double* prow = Lc + k * DS + 16 * q;      // L[16q + cc][k]: the same address for every lane
+        const double li2 = FOLLOW ? Lc2[k * DS + i] : 0.0;
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) {
-          const double p = prow[cc];
+          const double p = prow0[k * DS + cc];
           a[cc] = fma(-li, p, a[cc]);
           if (FOLLOW) a2[cc] = fma(-li2, p, a2[cc]);
         }
+        k += 1;
+        continue;
       }
-      applied = avail;
+      if (++spins > (1 << 22)) {   // cannot happen while the owner wave runs; never hang the GPU on a bug
+        if (i == 0) *broken = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
     }
   }
   double pivsrc = a[0];        // lane j of this holds the pivot of the wave's next column
-  int badcol = 0;
+  double pend[16];             // multipliers of the PREVIOUS column fetched from LDS, applied one column later
+#pragma unroll
+  for (int cc = 0; cc < 16; ++cc) pend[cc] = 0.0;
+  double lprev = 0.0, l2prev = 0.0;
+  double* col = Lc + 16 * q * DS + i;        // column 16q + jj of the image: col[jj * DS]
+  double* col2 = Lc2 + 16 * q * DS + i;
+  const double* bro = Lc + 16 * q * DS + 16 * q;   // bro[jj * DS + cc] = L[16q + cc][16q + jj]
 #pragma unroll
   for (int jj = 0; jj < 16; ++jj) {
     const int j = 16 * q + jj;
-    double piv = readlane_f64(pivsrc, j);
-    const bool ok = piv > 0.0;
-    badcol = (!ok && badcol == 0) ? col0 + j + 1 : badcol;
-    piv = ok ? piv : 1.0;
-    // 1/sqrt(piv): v_rsq_f64 seed + two Newton steps; the column is scaled by the reciprocal (as LAPACK's dpotf2 does)
+    const double piv = readlane_f64(pivsrc, j);
+    // 1/sqrt(piv): v_rsq_f64 seed (2^-23) + two Newton steps y <- y + y (1/2 - (piv/2) y^2); the column is scaled by
+    // the reciprocal (as LAPACK's dpotf2 does) — the diagonal element too (piv * rs)
+    const double h = 0.5 * piv;
     double rs = __builtin_amdgcn_rsq(piv);
-    double e = fma(-piv * rs, rs, 1.0);
-    rs = fma(0.5 * rs, e, rs);
-    e = fma(-piv * rs, rs, 1.0);
-    rs = fma(0.5 * rs, e, rs);
-    double dg = piv * rs;
-    dg = fma(fma(-dg, dg, piv), 0.5 * rs, dg);
-    double l = (i == j) ? dg : a[jj] * rs;
-    l = (i >= j) ? l : 0.0;
+    rs = fma(rs, fma(-h, rs * rs, 0.5), rs);
+    rs = fma(rs, fma(-h, rs * rs, 0.5), rs);
+    const double l = a[jj] * rs;
     // the NEXT pivot first: in lane j + 1 the rank-1 update of element (j+1, j+1) is fma(-l, l, .) — the same bits the
-    // general update below produces there — so the chain does not wait for the broadcast of l
+    // general update produces there (all updates of earlier columns are already in a[jj + 1]) — so the chain does not
+    // wait for the broadcast of l
     if (jj < 15) pivsrc = fma(-l, l, a[jj + 1]);
     a[jj] = l;
-    Lc[j * DS + i] = l;
+    col[jj * DS] = l;
+    col[jj * DS + 64] = rs;
     double l2 = 0.0;
     if (FOLLOW) {
       l2 = a2[jj] * rs;
       a2[jj] = l2;
-      Lc2[j * DS + i] = l2;
+      col2[jj * DS] = l2;
     }
     GPBO_LDS_ORDER();
-    if (i == 0) {
-      rdiag[col0 + j] = rs;    // 1 / L[j][j] for the inverse (saves its dependent fp64 divisions)
-      GPBO_LDS_ORDER();
-      __hip_atomic_store(pub, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    GPBO_LDS_ORDER();
+    GPBO_SCHED_FENCE();
+    // (1) the previous column's far multipliers (cc >= jj + 2), requested one column ago: their LDS latency is covered by
+    //     the chain above instead of standing in front of it
+    if (jj >= 1) {
 #pragma unroll
-    for (int cc = jj + 1; cc < 16; ++cc) {
+      for (int cc = jj + 2; cc < 16; ++cc) {
+        a[cc] = fma(-lprev, pend[cc], a[cc]);
+        if (FOLLOW) a2[cc] = fma(-l2prev, pend[cc], a2[cc]);
+      }
+    }
+    // (2) request this column's far multipliers (cc >= jj + 3): broadcast reads of the column just written
+#pragma unroll
+    for (int cc = jj + 3; cc < 16; ++cc) pend[cc] = bro[jj * DS + cc];
+    lprev = l;
+    l2prev = l2;
+    // (3) the two nearest columns by v_readlane (needed before their turn comes)
+#pragma unroll
+    for (int cc = jj + 1; cc < 16 && cc <= jj + 2; ++cc) {
       const double lc = readlane_f64(l, 16 * q + cc);   // L[16q + cc][j]
       a[cc] = fma(-l, lc, a[cc]);
       if (FOLLOW) a2[cc] = fma(-l2, lc, a2[cc]);
     }
+    GPBO_SCHED_FENCE();
   }
   if (stamp && i == 0 && q == 0) *stamp = clock64();
-  if (badcol && i == 0 && *bad == 0) *bad = badcol;
 }
 
-// The four 16x16 diagonal blocks of a 64x64 lower factor (column-major image Lc, reciprocal pivots rd) inverted by ONE
+// After a factorisation: info (1-based column within the image, 0 = fine) = the first column whose reciprocal pivot is
+// not a positive finite number.  One wave; lane j looks at column j.
+__device__ __forceinline__ int first_bad_column(const double* __restrict__ Lc, const int lane) {
+  const double r = Lc[lane * DS + 64];
+  const bool bad = !(r > 0.0 && r < 1.7976931348623157e308);
+  const unsigned long long mask = __ballot(bad);
+  return mask ? (int)__ffsll((long long)mask) : 0;
+}
+
+// The four 16x16 diagonal blocks of a 64x64 lower factor (column-major image Lc with its reciprocal pivots) inverted by ONE
 // wave: lane (b = lane >> 4, c = lane & 15) runs the forward substitution for column c of inv(L_bb) and parks it
 // k-major in the wave's own tile set, Dk[b][k = c][m] with stride 17 (the layout the MFMA A-fragment reads).
-__device__ __forceinline__ void diag16_inverses(const double* __restrict__ Lc, const double* __restrict__ rd, double* __restrict__ Dk,
-                                                const int lane) {
+__device__ __forceinline__ void diag16_inverses(const double* __restrict__ Lc, double* __restrict__ Dk, const int lane) {
   const int b = lane >> 4, c = lane & 15;
   double w[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) w[r] = (r == c) ? 1.0 : 0.0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const double wk = w[k] * rd[16 * b + k];
+    const double wk = w[k] * Lc[(16 * b + k) * DS + 64];
     w[k] = wk;
 #pragma unroll
     for (int r = k + 1; r < 16; ++r) w[r] = fma(-Lc[(16 * b + k) * DS + 16 * b + r], wk, w[r]);
@@ -195,8 +247,8 @@ __device__ __forceinline__ void inverse_colblock(const double* __restrict__ Lc, 
     for (int rr = 0; rr < 4; ++rr) Wout[(16 * r + lk + 4 * rr) * 64 + 16 * C + lr] = X[r][rr];
 }
 
-__device__ __forceinline__ void inverse_wave(const double* Lc, const double* rd, double* Dk, double* Wout, const int q, const int lane) {
-  diag16_inverses(Lc, rd, Dk, lane);
+__device__ __forceinline__ void inverse_wave(const double* Lc, double* Dk, double* Wout, const int q, const int lane) {
+  diag16_inverses(Lc, Dk, lane);
   GPBO_LDS_ORDER();   // the wave reads back its own tiles: same-wave LDS accesses are performed in order
   switch (q) {
     case 0: inverse_colblock<0>(Lc, Dk, Wout, lane); break;
@@ -214,7 +266,6 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
   double* Lc0 = smem + C128_LC0;
   double* LcX = smem + C128_LCX;
   double* Wr = smem + C128_WR;
-  double* rdiag = smem + C128_RDIAG;
   int* flags = reinterpret_cast<int*>(smem + C128_FLAGS);
   const int tid = threadIdx.x;
   const int i = tid & 63;
@@ -222,7 +273,11 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
   const bool two = nblk == 2;
   double* A = L + (int64_t)kb * 64 * ld + (int64_t)kb * 64;
   if (stamps && tid == 0) stamps[0] = clock64();
-  if (tid < 4) flags[tid] = 0;
+  if (tid < 64) {          // column markers: nothing published yet
+    Lc0[tid * DS + 64] = 0.0;
+    LcX[tid * DS + 64] = 0.0;
+  }
+  if (tid == 0) flags[0] = 0;
   double a0[16], a1[16], b[16];
   {
     const double2* s0 = reinterpret_cast<const double2*>(A + (int64_t)i * ld + 16 * q);
@@ -249,10 +304,12 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
   __syncthreads();
   if (stamps && tid == 0) stamps[1] = clock64();
   // ---- columns 0..63: L00 and (with two blocks) L10 = A10 L00^-T riding along
-  if (two) factor_quarter<true>(a0, a1, Lc0, LcX, rdiag, &flags[0], &flags[1], &flags[2], i, q, 0, stamps ? stamps + 7 : nullptr);
-  else factor_quarter<false>(a0, a1, Lc0, LcX, rdiag, &flags[0], &flags[1], &flags[2], i, q, 0, stamps ? stamps + 7 : nullptr);
+  if (two) factor_quarter<true>(a0, a1, Lc0, LcX, &flags[0], i, q, stamps ? stamps + 7 : nullptr);
+  else factor_quarter<false>(a0, a1, Lc0, LcX, &flags[0], i, q, stamps ? stamps + 7 : nullptr);
   {
     // the wave's 16 columns are final: rows straight from registers (128 contiguous bytes per thread, zeros above the diagonal)
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) a0[cc] = (i >= 16 * q + cc) ? a0[cc] : 0.0;
     double2* d0 = reinterpret_cast<double2*>(A + (int64_t)i * ld + 16 * q);
 #pragma unroll
     for (int h = 0; h < 8; ++h) d0[h] = make_double2(a0[2 * h], a0[2 * h + 1]);
@@ -292,24 +349,35 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
     for (int cc = 0; cc < 16; ++cc) b[cc] -= Wr[i * 81 + 16 * q + cc];
     __syncthreads();   // the exchange area is re-used for the waves' diagonal inverses; the L10 image makes room for L11
     // ---- columns 64..127: L11; then, while the later quarters are still being factored, column block q of inv(L00)
-    factor_quarter<false>(b, a1, LcX, LcX, rdiag, &flags[0], &flags[3], &flags[2], i, q, 64);
+    factor_quarter<false>(b, a1, LcX, LcX, &flags[0], i, q);
     {
+#pragma unroll
+      for (int cc = 0; cc < 16; ++cc) b[cc] = (i >= 16 * q + cc) ? b[cc] : 0.0;
       double2* d2 = reinterpret_cast<double2*>(A + (int64_t)(64 + i) * ld + 64 + 16 * q);
 #pragma unroll
       for (int h = 0; h < 8; ++h) d2[h] = make_double2(b[2 * h], b[2 * h + 1]);
     }
     if (stamps && tid == 0) stamps[4] = clock64();
-    inverse_wave(Lc0, rdiag, Wr + q * 4 * 272, dinv + (int64_t)kb * 4096, q, lane);
+    inverse_wave(Lc0, Wr + q * 4 * 272, dinv + (int64_t)kb * 4096, q, lane);
     __syncthreads();
     if (stamps && tid == 0) stamps[5] = clock64();
-    inverse_wave(LcX, rdiag + 64, Wr + q * 4 * 272, dinv + (int64_t)(kb + 1) * 4096, q, lane);
+    inverse_wave(LcX, Wr + q * 4 * 272, dinv + (int64_t)(kb + 1) * 4096, q, lane);
   } else {
-    inverse_wave(Lc0, rdiag, Wr + q * 4 * 272, dinv + (int64_t)kb * 4096, q, lane);
+    inverse_wave(Lc0, Wr + q * 4 * 272, dinv + (int64_t)kb * 4096, q, lane);
   }
-  if (tid == 0) {
-    if (flags[2] && *info == 0) *info = -1 - kb;                    // broken hand-off (never seen): surfaces as an error
-    else if (flags[0] && *info == 0) *info = kb * 64 + flags[0];    // LAPACK potrf: order of the first non-positive minor
-    if (stamps) stamps[6] = clock64();
+  if (q == 0) {
+    // LAPACK potrf: order of the first non-positive leading minor (the images are complete: the second inverse / the only one
+    // started behind a barrier or, for a single block, reads what this wave's own loop already waited for)
+    int bad = first_bad_column(Lc0, lane);
+    if (two && bad == 0) {
+      const int bad2 = first_bad_column(LcX, lane);
+      bad = bad2 ? 64 + bad2 : 0;
+    }
+    if (tid == 0) {
+      if (flags[0] && *info == 0) *info = -1 - kb;                  // broken hand-off (never seen): surfaces as an error
+      else if (bad && *info == 0) *info = kb * 64 + bad;
+      if (stamps) stamps[6] = clock64();
+    }
   }
 }
 
