@@ -33,7 +33,7 @@ constexpr int C128_FLAGS = C128_WR + C128_WR_DOUBLES;    // ints: [0] broken han
 constexpr int C128_LDS_DOUBLES = C128_FLAGS + 8;
 constexpr size_t C128_LDS_BYTES = (size_t)C128_LDS_DOUBLES * sizeof(double);
 static_assert(C128_WR_DOUBLES >= 64 * 81 && C128_WR_DOUBLES >= 4 * 4 * 272, "exchange area too small");
-static_assert(C128_LDS_DOUBLES >= GT_LDS_DOUBLES, "the update tiles of the step launch alias the same dynamic LDS");
+static_assert(C128_LDS_DOUBLES >= 2 * GT_LDS_DOUBLES, "the update tiles of the step launch alias the same dynamic LDS");
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const unsigned long long u = (unsigned long long)__double_as_longlong(v);
@@ -77,26 +77,26 @@ __device__ __forceinline__ void factor_quarter(double (&a)[16], double (&a2)[16]
     int k = 0, spins = 0;
     const double* prow0 = Lc + 16 * q;      // L[16q + cc][k] = prow0[k * DS + cc]: the same address for every lane
     while (k < need) {
-      // columns are published in order: the marker of column k + 3 vouches for k .. k + 3
-      const double m4 = Lc[(k + 3) * DS + 64];
+      // columns are published in order: the marker of column k + 1 vouches for k and k + 1
+      const double m2 = Lc[(k + 1) * DS + 64];
       GPBO_LDS_ORDER();
-      if (m4 != 0.0) {
-        double li[4], li2[4], p[4][16];
+      if (m2 != 0.0) {
+        double li[2], li2[2], p[2][16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 2; ++u) {
           li[u] = Lc[(k + u) * DS + i];
           li2[u] = FOLLOW ? Lc2[(k + u) * DS + i] : 0.0;
 #pragma unroll
           for (int cc = 0; cc < 16; ++cc) p[u][cc] = prow0[(k + u) * DS + cc];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
           for (int cc = 0; cc < 16; ++cc) {
             a[cc] = fma(-li[u], p[u][cc], a[cc]);
             if (FOLLOW) a2[cc] = fma(-li2[u], p[u][cc], a2[cc]);
           }
-        k += 4;
+        k += 2;
         continue;
       }
       const double m1 = Lc[k * DS + 64];
@@ -180,6 +180,92 @@ __device__ __forceinline__ void factor_quarter(double (&a)[16], double (&a2)[16]
   if (stamp && i == 0 && q == 0) *stamp = clock64();
 }
 
+// The riding rows (block row 1 of a two-block diagonal workgroup) as waves of their own: L10 = A10 L00^-T by substitution,
+// wave q the columns 16q .. 16q+15 of rows 64 .. 127 (thread = row), consuming the owners' columns as they are published.
+// For a column k left of the wave's quarter the update needs L10[i][k] from the follower wave that owns it: the L10
+// image Lc2 carries markers of its own (same convention as the L00 image).  In the wave's own quarter the marker read
+// returns the reciprocal pivot itself.  Reads of column j + 1 (marker, then multipliers) are issued before column j is
+// processed: if the marker was already set they are valid (LDS serves a wave's reads in order), else they are repeated.
+__device__ __forceinline__ void follow_quarter(double (&a2)[16], const double* __restrict__ Lc, double* __restrict__ Lc2, int* broken,
+                                               const int i, const int q) {
+  const double* prow0 = Lc + 16 * q;      // L00[16q + cc][k] = prow0[k * DS + cc]
+  {
+    const int need = 16 * q;
+    int k = 0, spins = 0;
+    while (k < need) {
+      const double m4 = Lc2[(k + 3) * DS + 64];
+      GPBO_LDS_ORDER();
+      if (m4 != 0.0) {
+        double li[4], p[4][16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          li[u] = Lc2[(k + u) * DS + i];
+#pragma unroll
+          for (int cc = 0; cc < 16; ++cc) p[u][cc] = prow0[(k + u) * DS + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int cc = 0; cc < 16; ++cc) a2[cc] = fma(-li[u], p[u][cc], a2[cc]);
+        k += 4;
+        continue;
+      }
+      const double m1 = Lc2[k * DS + 64];
+      GPBO_LDS_ORDER();
+      if (m1 != 0.0) {
+        const double li = Lc2[k * DS + i];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) a2[cc] = fma(-li, prow0[k * DS + cc], a2[cc]);
+        k += 1;
+        continue;
+      }
+      if (++spins > (1 << 22)) {
+        if (i == 0) *broken = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  const double* bro = Lc + 16 * q * DS + 16 * q;   // bro[jj * DS + cc] = L00[16q + cc][16q + jj]; bro[jj * DS + 64 - 16q] = its marker
+  const double* mk = Lc + 16 * q * DS + 64;         // mk[jj * DS] = 1 / L00[j][j], 0 while column j is not complete
+  double* col2 = Lc2 + 16 * q * DS + i;
+  double rs = mk[0], pc[16];
+  GPBO_LDS_ORDER();
+#pragma unroll
+  for (int cc = 1; cc < 16; ++cc) pc[cc] = bro[cc];
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) {
+    int spins = 0;
+    while (rs == 0.0) {     // not published when the look-ahead read it: poll, then fetch the multipliers again
+      if (++spins > (1 << 22)) {
+        if (i == 0) *broken = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+      rs = mk[jj * DS];
+      GPBO_LDS_ORDER();
+#pragma unroll
+      for (int cc = jj + 1; cc < 16; ++cc) pc[cc] = bro[jj * DS + cc];
+    }
+    double rsn = 0.0, pn[16];
+    if (jj < 15) {          // look-ahead: column j + 1
+      rsn = mk[(jj + 1) * DS];
+      GPBO_LDS_ORDER();
+#pragma unroll
+      for (int cc = jj + 2; cc < 16; ++cc) pn[cc] = bro[(jj + 1) * DS + cc];
+    }
+    const double l2 = a2[jj] * rs;
+    a2[jj] = l2;
+    col2[jj * DS] = l2;
+    col2[jj * DS + 64] = rs;          // marker of the L10 column (all lanes, see factor_quarter)
+#pragma unroll
+    for (int cc = jj + 1; cc < 16; ++cc) a2[cc] = fma(-l2, pc[cc], a2[cc]);
+    rs = rsn;
+#pragma unroll
+    for (int cc = jj + 2; cc < 16; ++cc) pc[cc] = pn[cc];
+  }
+}
+
 // After a factorisation: info (1-based column within the image, 0 = fine) = the first column whose reciprocal pivot is
 // not a positive finite number.  One wave; lane j looks at column j.
 __device__ __forceinline__ int first_bad_column(const double* __restrict__ Lc, const int lane) {
@@ -259,7 +345,12 @@ __device__ __forceinline__ void inverse_wave(const double* Lc, double* Dk, doubl
 }
 
 // Diagonal block of `nblk` (1 or 2) 64-blocks starting at block kb, all earlier updates applied: factor in place, write
-// inv(L_kk) (and inv(L_kk+1)) to dinv.  256 threads = 4 waves; no launch, five workgroup barriers.
+// inv(L_kk) (and inv(L_kk+1)) to dinv.  512 threads = 8 waves, no launch inside, five workgroup barriers:
+//   waves 0-3 ("owners", thread = row i of the block being factored, wave = column quarter): potf2 of A00, later of A11
+//   waves 4-7 ("followers", thread = row 64 + i): L10 riding along (follow_quarter), later inv(L00) while A11 is factored
+// Quarter 3's follower sits in wave 4 — by the usual cyclic wave placement on the SIMD of owner 0, which has been idle
+// longest when the chain reaches the last quarter (a wave issues one VALU instruction per 4 cycles whatever it is, so a
+// follower sharing the SIMD of the owner that currently carries the chain would take its issue slots).
 __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64_t ld, const int kb, const int nblk,
                                              double* __restrict__ dinv, int* __restrict__ info, double* __restrict__ smem,
                                              long long* __restrict__ stamps) {
@@ -269,7 +360,9 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
   int* flags = reinterpret_cast<int*>(smem + C128_FLAGS);
   const int tid = threadIdx.x;
   const int i = tid & 63;
-  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool owner = w < 4;
+  const int q = owner ? w : 7 - w;          // column quarter
   const bool two = nblk == 2;
   double* A = L + (int64_t)kb * 64 * ld + (int64_t)kb * 64;
   if (stamps && tid == 0) stamps[0] = clock64();
@@ -278,96 +371,98 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
     LcX[tid * DS + 64] = 0.0;
   }
   if (tid == 0) flags[0] = 0;
-  double a0[16], a1[16], b[16];
-  {
-    const double2* s0 = reinterpret_cast<const double2*>(A + (int64_t)i * ld + 16 * q);
+  double a[16], b[16];     // owners: rows of A00, A11; followers: rows of A10
 #pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      const double2 v = s0[h];
-      a0[2 * h] = v.x;
-      a0[2 * h + 1] = v.y;
-    }
-    if (two) {
-      const double2* s1 = reinterpret_cast<const double2*>(A + (int64_t)(64 + i) * ld + 16 * q);
-      const double2* s2 = reinterpret_cast<const double2*>(A + (int64_t)(64 + i) * ld + 64 + 16 * q);
+  for (int h = 0; h < 16; ++h) b[h] = 0.0;
+  {
+    const int64_t row = owner ? i : 64 + i;
+    const double2* s0 = reinterpret_cast<const double2*>(A + row * ld + 16 * q);
+    if (owner || two) {
 #pragma unroll
       for (int h = 0; h < 8; ++h) {
-        const double2 v = s1[h], u = s2[h];
-        a1[2 * h] = v.x; a1[2 * h + 1] = v.y;
-        b[2 * h] = u.x; b[2 * h + 1] = u.y;
+        const double2 v = s0[h];
+        a[2 * h] = v.x;
+        a[2 * h + 1] = v.y;
       }
     } else {
 #pragma unroll
-      for (int h = 0; h < 16; ++h) { a1[h] = 0.0; b[h] = 0.0; }
+      for (int h = 0; h < 16; ++h) a[h] = 0.0;
+    }
+    if (owner && two) {
+      const double2* s2 = reinterpret_cast<const double2*>(A + (int64_t)(64 + i) * ld + 64 + 16 * q);
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const double2 u = s2[h];
+        b[2 * h] = u.x;
+        b[2 * h + 1] = u.y;
+      }
     }
   }
   __syncthreads();
   if (stamps && tid == 0) stamps[1] = clock64();
-  // ---- columns 0..63: L00 and (with two blocks) L10 = A10 L00^-T riding along
-  if (two) factor_quarter<true>(a0, a1, Lc0, LcX, &flags[0], i, q, stamps ? stamps + 7 : nullptr);
-  else factor_quarter<false>(a0, a1, Lc0, LcX, &flags[0], i, q, stamps ? stamps + 7 : nullptr);
-  {
+  // ---- columns 0..63: L00 by the owners, L10 = A10 L00^-T by the followers behind them
+  if (owner) {
+    factor_quarter<false>(a, b, Lc0, Lc0, &flags[0], i, q, stamps ? stamps + 7 : nullptr);
     // the wave's 16 columns are final: rows straight from registers (128 contiguous bytes per thread, zeros above the diagonal)
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) a0[cc] = (i >= 16 * q + cc) ? a0[cc] : 0.0;
+    for (int cc = 0; cc < 16; ++cc) a[cc] = (i >= 16 * q + cc) ? a[cc] : 0.0;
     double2* d0 = reinterpret_cast<double2*>(A + (int64_t)i * ld + 16 * q);
 #pragma unroll
-    for (int h = 0; h < 8; ++h) d0[h] = make_double2(a0[2 * h], a0[2 * h + 1]);
-    if (two) {
-      double2* d1 = reinterpret_cast<double2*>(A + (int64_t)(64 + i) * ld + 16 * q);
+    for (int h = 0; h < 8; ++h) d0[h] = make_double2(a[2 * h], a[2 * h + 1]);
+  } else if (two) {
+    follow_quarter(a, Lc0, LcX, &flags[0], i, q);
+    double2* d1 = reinterpret_cast<double2*>(A + (int64_t)(64 + i) * ld + 16 * q);
 #pragma unroll
-      for (int h = 0; h < 8; ++h) d1[h] = make_double2(a1[2 * h], a1[2 * h + 1]);
-    }
+    for (int h = 0; h < 8; ++h) d1[h] = make_double2(a[2 * h], a[2 * h + 1]);
   }
   __syncthreads();
   if (stamps && tid == 0) stamps[2] = clock64();
   const int lane = i, lr = lane & 15, lk = lane >> 4;
   if (two) {
-    // ---- SYRK: U = L10 L10^T, the ten lower 16x16 tiles over the four waves (3, 3, 2, 2), operands out of the LcX image
-    {
-      const int t0 = (q == 0) ? 0 : (q == 1) ? 3 : (q == 2) ? 6 : 8;
-      const int nt = (q < 2) ? 3 : 2;
-      for (int u = 0; u < nt; ++u) {
-        const int t = t0 + u;                       // linear lower index: ti (ti + 1) / 2 + tj
-        const int ti = (t >= 6) ? 3 : (t >= 3) ? 2 : (t >= 1) ? 1 : 0;
-        const int tj = t - ti * (ti + 1) / 2;
-        d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+    // ---- SYRK: U = L10 L10^T, the ten lower 16x16 tiles over the eight waves, operands out of the LcX image
+    for (int t = w; t < 10; t += 8) {             // linear lower index: ti (ti + 1) / 2 + tj
+      const int ti = (t >= 6) ? 3 : (t >= 3) ? 2 : (t >= 1) ? 1 : 0;
+      const int tj = t - ti * (ti + 1) / 2;
+      d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int g = 0; g < 16; g += 2) {
-          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(LcX[(4 * g + lk) * DS + 16 * ti + lr], LcX[(4 * g + lk) * DS + 16 * tj + lr], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(LcX[(4 * g + 4 + lk) * DS + 16 * ti + lr], LcX[(4 * g + 4 + lk) * DS + 16 * tj + lr], acc1, 0, 0, 0);
-        }
-        const d4 acc = acc0 + acc1;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) Wr[(16 * ti + lk + 4 * rr) * 81 + 16 * tj + lr] = acc[rr];
+      for (int g = 0; g < 16; g += 2) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(LcX[(4 * g + lk) * DS + 16 * ti + lr], LcX[(4 * g + lk) * DS + 16 * tj + lr], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(LcX[(4 * g + 4 + lk) * DS + 16 * ti + lr], LcX[(4 * g + 4 + lk) * DS + 16 * tj + lr], acc1, 0, 0, 0);
       }
+      const d4 acc = acc0 + acc1;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Wr[(16 * ti + lk + 4 * rr) * 81 + 16 * tj + lr] = acc[rr];
     }
     __syncthreads();
     if (stamps && tid == 0) stamps[3] = clock64();
     // elements above the diagonal pick up whatever the exchange area holds: they never reach the lower triangle
+    if (owner) {
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) b[cc] -= Wr[i * 81 + 16 * q + cc];
-    __syncthreads();   // the exchange area is re-used for the waves' diagonal inverses; the L10 image makes room for L11
-    // ---- columns 64..127: L11; then, while the later quarters are still being factored, column block q of inv(L00)
-    factor_quarter<false>(b, a1, LcX, LcX, &flags[0], i, q);
-    {
+      for (int cc = 0; cc < 16; ++cc) b[cc] -= Wr[i * 81 + 16 * q + cc];
+    }
+    if (tid < 64) LcX[tid * DS + 64] = 0.0;      // the L10 image makes room for L11: its markers start over
+    __syncthreads();   // the exchange area is re-used for the waves' diagonal inverses
+    // ---- columns 64..127: L11 by the owners; inv(L00) by the followers meanwhile
+    if (owner) {
+      factor_quarter<false>(b, a, LcX, LcX, &flags[0], i, q);
 #pragma unroll
       for (int cc = 0; cc < 16; ++cc) b[cc] = (i >= 16 * q + cc) ? b[cc] : 0.0;
       double2* d2 = reinterpret_cast<double2*>(A + (int64_t)(64 + i) * ld + 64 + 16 * q);
 #pragma unroll
       for (int h = 0; h < 8; ++h) d2[h] = make_double2(b[2 * h], b[2 * h + 1]);
+      if (stamps && tid == 0) stamps[4] = clock64();
+    } else {
+      inverse_wave(Lc0, Wr + (w - 4) * 4 * 272, dinv + (int64_t)kb * 4096, w - 4, lane);
     }
-    if (stamps && tid == 0) stamps[4] = clock64();
-    inverse_wave(Lc0, Wr + q * 4 * 272, dinv + (int64_t)kb * 4096, q, lane);
     __syncthreads();
     if (stamps && tid == 0) stamps[5] = clock64();
-    inverse_wave(LcX, Wr + q * 4 * 272, dinv + (int64_t)(kb + 1) * 4096, q, lane);
+    if (owner) inverse_wave(LcX, Wr + w * 4 * 272, dinv + (int64_t)(kb + 1) * 4096, w, lane);
   } else {
-    inverse_wave(Lc0, Wr + q * 4 * 272, dinv + (int64_t)kb * 4096, q, lane);
+    if (owner) inverse_wave(Lc0, Wr + w * 4 * 272, dinv + (int64_t)kb * 4096, w, lane);
   }
-  if (q == 0) {
+  if (w == 0) {
     // LAPACK potrf: order of the first non-positive leading minor (the images are complete: the second inverse / the only one
-    // started behind a barrier or, for a single block, reads what this wave's own loop already waited for)
+    // started behind a barrier)
     int bad = first_bad_column(Lc0, lane);
     if (two && bad == 0) {
       const int bad2 = first_bad_column(LcX, lane);
@@ -381,10 +476,11 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
   }
 }
 
-// One launch = diagonal block(s) kb (workgroup 0) || the 64x64 tiles of the previous column block's in-panel update
-// (every tile but the leading skip00 x skip00 ones, which chol128_diag_update_kernel has already brought up to date).
-__global__ __launch_bounds__(256) void chol128_step_kernel(double* L, int64_t ld, int kb, int nblk, double* dinv, int* info,
-                                                            GemmArgs g, int tiles_n, int64_t lane_stride, long long* stamps) {
+// One launch = diagonal block(s) kb (workgroup 0) || the 64x64 tiles of the previous column block's in-panel update, two per
+// 512-thread workgroup (every tile but the leading skip00 x skip00 ones, which chol128_diag_update_kernel has already
+// brought up to date).
+__global__ __launch_bounds__(512) void chol128_step_kernel(double* L, int64_t ld, int kb, int nblk, double* dinv, int* info,
+                                                            GemmArgs g, int tiles_n, int tiles, int64_t lane_stride, long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) double c128_smem[];
   const int zl = (int)blockIdx.y;
   if (blockIdx.x == 0) {
@@ -392,9 +488,14 @@ __global__ __launch_bounds__(256) void chol128_step_kernel(double* L, int64_t ld
                  c128_smem, stamps);
     return;
   }
-  const int t = (int)blockIdx.x - 1;
-  const int bm = t / tiles_n, bn = t - bm * tiles_n;
-  gemm_tile_body<true, false>(g, bm, bn, zl, 0, c128_smem);
+  const int half = (int)(threadIdx.x >> 8);
+  const int t = 2 * ((int)blockIdx.x - 1) + half;
+  int bm = t / tiles_n, bn = t - bm * tiles_n;
+  const bool mine = t < tiles && !(g.lower_only && bn > bm) && !(bn < g.skip00 && bm < g.skip00);
+  if (!mine) { bm = g.skip00; bn = 0; }      // a tile that exists (rows below the next diagonal block): loads only, same barrier count
+  GemmArgs h = g;
+  h.lower_only = 0; h.skip00 = 0;            // decided above
+  gemm_tile_body<true, false>(h, bm, bn, zl, 0, c128_smem + half * GT_LDS_DOUBLES, (int)(threadIdx.x & 255), mine);
 }
 
 // Panel solve below a 128-column diagonal block, in place: X = A inv(L_blk)^T with L_blk = [[L00, 0], [L10, L11]], i.e.
@@ -538,8 +639,8 @@ static int launch_step(gpbo_ctx* ctx, Model& m, int kb, int nblk, const GemmArgs
     tiles_n = g.n / 64;
     tiles = (g.m / 64) * tiles_n;
   }
-  chol128_step_kernel<<<dim3((unsigned)(1 + tiles), (unsigned)ctx->lanes), dim3(256), C128_LDS_BYTES, ctx->stream>>>(
-      m.L, m.NP, kb, nblk, m.dinv, ctx->info_dev, g, tiles_n, ctx->lane_stride, stamps);
+  chol128_step_kernel<<<dim3((unsigned)(1 + (tiles + 1) / 2), (unsigned)ctx->lanes), dim3(512), C128_LDS_BYTES, ctx->stream>>>(
+      m.L, m.NP, kb, nblk, m.dinv, ctx->info_dev, g, tiles_n, tiles, ctx->lane_stride, stamps);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }

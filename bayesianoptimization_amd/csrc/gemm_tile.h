@@ -19,7 +19,11 @@ constexpr int GT_LDS_DOUBLES = 2 * 2 * 16 * 68;   // two stages x (A | B) x [16]
 typedef double d2v __attribute__((ext_vector_type(2)));
 
 template <bool BT, bool AT>
-__device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn, int zl, int bz, double* lds) {
+// `tid` = the thread's index inside the 256 threads working on this tile (a 512-thread workgroup runs two tiles side by
+// side, each with its own LDS area and the same number of barriers); `write` false = go through the motions on a valid
+// tile but leave C alone (the partner half of such a workgroup when it has no tile of its own).
+__device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn, int zl, int bz, double* lds, const int tid = threadIdx.x,
+                                               const bool write = true) {
   if (g.lower_only && bn > bm) return;
   if (bn < g.skip00 && bm < g.skip00) return;      // the leading skip00 x skip00 tiles belong to other workgroups / launches
   // two LDS stages: the global loads of stage s+1 are issued before the MFMAs of stage s and parked in the other buffer
@@ -27,7 +31,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn
   typedef double (*stage_t)[16][68];
   stage_t As = reinterpret_cast<stage_t>(lds);                    // [2][16][68]
   stage_t Bs = reinterpret_cast<stage_t>(lds + 2 * 16 * 68);      // [2][16][68]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wave = tid >> 6, lane = tid & 63;
   const int64_t lo = (int64_t)zl * g.lane_stride;
   const double* A = g.A + lo + (int64_t)bz * g.strideA + (AT ? (int64_t)bm * 64 : (int64_t)bm * 64 * g.lda);
   const double* B = g.B + lo + (int64_t)bz * g.strideB + (BT ? (int64_t)bn * 64 * g.ldb : (int64_t)bn * 64);
@@ -96,6 +100,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn
       __syncthreads();
     }
   }
+  if (!write) return;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
