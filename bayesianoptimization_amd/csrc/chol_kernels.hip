@@ -492,7 +492,7 @@ __global__ __launch_bounds__(512) void chol128_step_kernel(double* L, int64_t ld
   const int t = 2 * ((int)blockIdx.x - 1) + half;
   int bm = t / tiles_n, bn = t - bm * tiles_n;
   const bool mine = t < tiles && !(g.lower_only && bn > bm) && !(bn < g.skip00 && bm < g.skip00);
-  if (!mine) { bm = g.skip00; bn = 0; }      // a tile that exists (rows below the next diagonal block): loads only, same barrier count
+  if (!mine) { bm = g.m / 64 - 1; bn = 0; }   // a tile that exists (the last row tile): loads only, same barrier count
   GemmArgs h = g;
   h.lower_only = 0; h.skip00 = 0;            // decided above
   gemm_tile_body<true, false>(h, bm, bn, zl, 0, c128_smem + half * GT_LDS_DOUBLES, (int)(threadIdx.x & 255), mine);
@@ -638,6 +638,7 @@ static int launch_step(gpbo_ctx* ctx, Model& m, int kb, int nblk, const GemmArgs
     g.lanes = ctx->lanes; g.lane_stride = ctx->lane_stride; g.batch = 1;
     tiles_n = g.n / 64;
     tiles = (g.m / 64) * tiles_n;
+    if (g.m / 64 <= g.skip00 && tiles_n <= g.skip00) tiles = 0;   // nothing but the block the diagonal workgroup owns
   }
   chol128_step_kernel<<<dim3((unsigned)(1 + (tiles + 1) / 2), (unsigned)ctx->lanes), dim3(512), C128_LDS_BYTES, ctx->stream>>>(
       m.L, m.NP, kb, nblk, m.dinv, ctx->info_dev, g, tiles_n, tiles, ctx->lane_stride, stamps);

@@ -94,7 +94,7 @@ if __name__ == "__main__":
     res = {}
     for flag in ("3", "2"):
         env = dict(os.environ, GPBO_CHOL=flag)
-        p = subprocess.run([sys.executable, __file__, "--child"], env=env, capture_output=True, text=True)
+        p = subprocess.run([sys.executable, __file__, "--child"], env=env, capture_output=True, text=True, timeout=110)
         sys.stderr.write(p.stderr[-3000:])
         for line in p.stdout.splitlines():
             if line.startswith("JSON"):

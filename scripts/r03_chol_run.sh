@@ -3,10 +3,10 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r03_chol; rm -rf $O; mkdir -p $O
-timeout 600 python scripts/r03_chol_probe.py > $O/probe.log 2>&1; cp gpurun_out/r03_chol_probe.json $O/ 2>/dev/null
+timeout 240 python scripts/r03_chol_probe.py > $O/probe.log 2>&1; cp gpurun_out/r03_chol_probe.json $O/ 2>/dev/null
 grep "chol=3" $O/probe.log | cut -c1-900
 for n in 4096 512; do
-  timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_$n -o chol -- python scripts/r03_chol_trace.py $n 3 > $O/trace_$n.log 2>&1
-  f=$(find $O/trace_$n -name '*kernel_stats.csv' | head -1)
-  echo "== kernel stats n=$n"; [ -n "$f" ] && cut -d, -f1-7 "$f" | head -12
+  timeout 120 rocprofv3 --kernel-trace --stats -d $O/trace_$n -o chol -- python scripts/r03_chol_trace.py $n 3 > $O/trace_$n.log 2>&1
+  f=$(find $O/trace_$n -name '*results.db' | head -1)
+  echo "== kernel stats n=$n"; [ -n "$f" ] && python scripts/rocpd_summary.py "$f" | cut -c1-140 | head -9
 done
