@@ -70,10 +70,11 @@ P2 = Workload("P2", d=5, N=300, M=4096, kernel=RBF, acq=EI, acq_param=0.01, leng
 F1 = Workload("F1", d=3, N=60, M=4096, kernel=MATERN25, acq=UCB, acq_param=2.576, length_scale=None,
               y_noise=0.0)
 
-# Plateau cases (tie order): T1 — POI with xi = -3 saturates at exactly 1.0 wherever sigma is small, so the minimum of
-# -acq is shared by many candidates; T2 — EI with xi = 100 underflows to exactly 0 for every candidate.
-T1 = Workload("T1", d=2, N=60, M=4096, kernel=MATERN25, acq=POI, acq_param=-3.0, length_scale=0.4)
-T2 = Workload("T2", d=2, N=60, M=4096, kernel=MATERN25, acq=EI, acq_param=100.0, length_scale=0.4)
+# Plateau cases (tie order under exact ties, which np.argsort leaves unspecified): T1 — POI with xi = 100 underflows to
+# exactly 0 for every candidate; T2 — EI with xi = 5.36 underflows to exactly 0 for all but 9 of the 512 candidates
+# (z <= -39.5 for the rest; the 9 have z >= -34.8, i.e. normal numbers), so argsort[:16] crosses into the plateau.
+T1 = Workload("T1", d=2, N=60, M=4096, kernel=MATERN25, acq=POI, acq_param=100.0, length_scale=0.4)
+T2 = Workload("T2", d=2, N=60, M=512, kernel=MATERN25, acq=EI, acq_param=5.36, length_scale=0.4)
 
 ALL = {w.name: w for w in (C1, C2, C3, C4, C5, C5S, P1, P2, F1, T1, T2)}
 

@@ -22,6 +22,15 @@ def _run_case(engine, name, M=None):
     assert ym == g["y_mean"] and ys_ == g["y_std"]
     engine.fit(X, yn, w.kernel, g["length_scale"], w.noise, slot=0)
     assert rel_err(engine.get_alpha(w.N), g["alpha"]) < TOL
+    if "L_diag" in g:      # the factor itself against the reference's L_ (LAPACK dpotrf via sklearn _gpr.py:349), SURVEY §8c
+        L = engine.get_L(w.N)
+        assert rel_err(np.diag(L), g["L_diag"]) < 1e-10
+        assert rel_err(L[-1], g["L_lastrow"]) < 1e-10
+        assert abs(np.linalg.norm(L) - float(g["L_fro"])) < 1e-12 * float(g["L_fro"])
+        assert not np.triu(L, 1).any()
+        if "L" in g:
+            assert rel_err(L, g["L"]) < 1e-10
+        del L
     M = int(g["M_evaluated"]) if M is None else M
     Xc = W.make_candidates(w.bounds_array(), M, 7)
     engine.set_candidates(Xc)
@@ -73,6 +82,35 @@ def test_c5_shape_fp64_sample_matches_reference(engine):
     golden sample (the reference has no fp32 path; the full M=2^21 pass costs ~40 min of CPU)."""
     w, g, Xc, bi, bv, si, sv, ys = _run_case(engine, "C5")
     assert bi == int(g["argmin"]) and np.array_equal(si, g["topk_idx"])
+
+
+@pytest.mark.parametrize("name", ["T1", "T2"])
+def test_plateau_tie_order_against_reference(engine, name):
+    """Exact ties: T1 = POI underflowed to 0 for all 4096 candidates, T2 = EI underflowed to 0 for all but 9
+    of 512.  `ys.argmin()` (acquisition.py:313) is the lowest index by NumPy's definition and must be reproduced; for
+    `np.argsort(ys)[:k]` (acquisition.py:316) NumPy leaves the order of equal keys unspecified (the reference's own run
+    returned 4088..4095, 4080.. on T1) and the device returns the documented one: ascending value, then ascending index,
+    i.e. np.argsort(ys_reference, kind="stable").  The seed VALUES equal the reference's either way."""
+    w = W.ALL[name]
+    g = load_golden(name)
+    X, y, c = W.make_observations(w)
+    yn, ym, ys_ = O.normalize_targets(y)
+    engine.fit(X, yn, w.kernel, g["length_scale"], w.noise, slot=0)
+    M = int(g["M_evaluated"])
+    assert len(g["ys"]) == M
+    engine.set_candidates(W.make_candidates(w.bounds_array(), M, 7))
+    engine.posterior(0, ym, ys_, fetch=False)
+    bi, bv, si, sv, ys = engine.acq_argbest(w.acq, w.acq_param, float(np.max(y)), None, None, k_seeds=16, return_values=True)
+    ref = g["ys"]
+    assert np.array_equal(ys == 0, ref == 0)                       # the plateau is the same set, exactly zero
+    assert int((ref == 0).sum()) == {"T1": 4096, "T2": 503}[name]
+    nz = ref != 0
+    if nz.any():      # tails around 1e-158 .. 1e-267: |z| ~ 30, so a 1e-10 relative difference in sigma is 1e-7 here
+        assert np.max(np.abs(ys[nz] / ref[nz] - 1)) < 1e-6
+    assert bi == int(g["argmin"]) == int(np.argmin(ref))
+    assert np.array_equal(si, np.argsort(ref, kind="stable")[:16])
+    assert np.array_equal(np.sort(g["topk_idx"][ref[g["topk_idx"]] != 0]), np.sort(si[ref[si] != 0]))
+    assert np.allclose(sv, g["topk_val"], rtol=1e-6, atol=0)     # same values as the reference's seeds, other tie members
 
 
 def test_against_sklearn_live(engine):

@@ -271,6 +271,7 @@ def test_rccl_single_rank_roundtrip(engine):
 @pytest.mark.parametrize("N,d,kernel,ls", [
     (60, 3, O.MATERN25, 0.7), (200, 5, O.RBF, 0.6), (130, 4, O.MATERN25, [0.4, 0.7, 1.0, 1.3]),
     (257, 8, O.RBF, [0.8] * 8), (1, 2, O.MATERN25, 1.0), (700, 16, O.MATERN25, 1.5),
+    (2048, 16, O.MATERN25, 1.5), (4096, 16, O.MATERN25, 1.5),      # NP >= 2048: the per-lane-stream path of gpbo_lml_batch
 ])
 def test_lml_value_and_gradient_parity(engine, N, d, kernel, ls):
     """gpbo_lml vs sklearn's log_marginal_likelihood(theta, eval_gradient=True) (_gpr.py:575-652) via the
@@ -282,6 +283,12 @@ def test_lml_value_and_gradient_parity(engine, N, d, kernel, ls):
     assert abs(lml - lml_o) <= 1e-10 * max(1.0, abs(lml_o))
     assert np.max(np.abs(grad - grad_o)) <= 1e-7 * max(np.max(np.abs(grad_o)), 1e-12)
     assert engine.lml(X, yn, kernel, ls, 1e-6, eval_gradient=False) == lml
+    if N >= 2048:     # two lanes on their own streams: each bitwise the single evaluation
+        ls2 = np.array([[float(np.atleast_1d(ls)[0])], [0.9]])
+        (v0, g0), (v1, g1) = engine.lml_batch(X, yn, kernel, ls2, 1e-6)
+        assert v0 == lml and np.array_equal(g0, grad)
+        v1s, g1s = engine.lml(X, yn, kernel, 0.9, 1e-6)
+        assert v1 == v1s and np.array_equal(g1, g1s)
     with pytest.raises(_lib.GpboError):
         engine.posterior(0)   # gpbo_lml leaves the slot unfitted
 

@@ -99,26 +99,66 @@ def test_every_shard_and_their_merge_match_the_reference(engine, name):
         assert np.array_equal(m[2], ref_idx)
 
 
-def test_c5_full_shard_fp32_mode_against_the_fp64_reference(engine):
-    """BASELINE.json configs[4] as quoted (fp32): the full 2^18-candidate shard, two GPs.  The reference has no fp32
-    path, so the check is against its fp64 pass: values within the documented fp32 bound, and the arg-best the
-    reference picks (or, where fp32 rounding reorders near-ties, one of its 16 best) with the reference's value."""
+F32_ACQ_TOL = 1e-4      # of the shard's acquisition range; measured 2e-6 .. 9e-6 (profiles/r03_f32_shards.json)
+
+
+def _assert_order_agrees(si, ref_idx, ref_val, e, k):
+    """Positions whose reference value is separated from both neighbours by more than 2e must hold the reference's index;
+    inside a group of values closer than that, any member of the group is a correct answer for a pass whose values carry
+    an error of at most e."""
+    exact = True
+    for p in range(k):
+        lo = p == 0 or ref_val[p] - ref_val[p - 1] > 2 * e
+        hi = ref_val[p + 1] - ref_val[p] > 2 * e
+        if lo and hi:
+            assert si[p] == ref_idx[p], (p, si[:k], ref_idx[:k])
+        else:
+            group = {int(ref_idx[q]) for q in range(len(ref_idx)) if abs(ref_val[q] - ref_val[p]) <= 2 * e}
+            assert int(si[p]) in group, (p, si[:k], ref_idx[:k])
+            exact = exact and si[p] == ref_idx[p]
+    return exact
+
+
+def test_c5_every_shard_fp32_mode_against_the_fp64_reference(engine):
+    """BASELINE.json configs[4] as quoted (fp32): all 8 full 2^18-candidate shards, two GPs.  The reference has no fp32
+    path, so the check is against its fp64 pass over the same shard: every stored value within 1e-4 of the acquisition
+    range (10x the measured error), the arg-best and the 10 best indices the reference's own wherever its values are
+    further apart than twice that bound (every shard's top-2 gap is), and the merge of the shards = the reference's merge."""
+    import json
+
     w = W.C5
     shards = _shards("C5")
-    assert shards
-    g = shards[0]
-    post, lb, ub, y_max = _fit_config(engine, w, g, precision=F32)
-    bi, bv, si, sv, ys = _run_shard(engine, w, g, post, lb, ub, y_max, k=16)
-    rng_ = float(np.max(g["ys"]) - np.min(g["ys"]))
-    S = len(g["ys"])
-    assert np.max(np.abs(ys[:S] - g["ys"])) < 5e-3 * rng_
-    assert abs(bv - float(g["min"])) < 5e-3 * rng_
-    assert bi in set(g["topk_idx"][:16].tolist())
-    gap = float(g["topk_val"][1] - g["topk_val"][0])
-    if gap > 0.02 * rng_:
-        assert bi == int(g["argmin"])
-    # the 16 best of the fp32 pass are all among the reference's 64 best
-    assert set(si.tolist()) <= set(g["topk_idx"].tolist())
+    assert len(shards) == 8
+    post, lb, ub, y_max = _fit_config(engine, w, shards[0], precision=F32)
+    report, bis, bvs, sis, svs = {}, [], [], [], []
+    for g in shards:
+        M = int(g["M_evaluated"])
+        off = int(g["shard"]) * M
+        bi, bv, si, sv, ys = _run_shard(engine, w, g, post, lb, ub, y_max, k=16)
+        rng_ = float(np.max(g["ys"]) - np.min(g["ys"]))
+        e = F32_ACQ_TOL * rng_
+        S = len(g["ys"])
+        err = float(np.max(np.abs(ys[:S] - g["ys"])))
+        assert err <= e
+        assert abs(bv - float(g["min"])) <= e
+        ref_idx, ref_val = g["topk_idx"].astype(np.int64) + off, g["topk_val"]
+        gap = float(ref_val[1] - ref_val[0])
+        assert gap > 2 * e, "the exact-index claim below would be a coin flip"
+        assert bi == int(g["argmin"]) + off
+        exact10 = _assert_order_agrees(si, ref_idx, ref_val, e, 10)
+        # all M values through the reference's whole-shard summaries
+        assert not np.isnan(ys).any()
+        assert abs(ys.sum() - float(g["ys_sum"])) <= F32_ACQ_TOL * float(g["ys_abs_sum"])
+        assert np.max(np.abs(ys.reshape(-1, 4096).min(axis=1) - g["ys_block_min"])) <= e
+        report[f"s{int(g['shard'])}"] = {"max_abs_err_over_range": err / rng_, "min_rel_err": abs(bv - float(g["min"])) / abs(float(g["min"])),
+                                         "top10_exact": bool(exact10), "top2_gap_over_range": gap / rng_}
+        bis.append(bi); bvs.append(bv); sis.append(si); svs.append(sv)
+    ref_idx, ref_val = _reference_merge(shards, 16)
+    m = merge_best(bvs, bis, svs, sis, 16)
+    assert m[0] == ref_idx[0]
+    _assert_order_agrees(m[2], ref_idx, ref_val, F32_ACQ_TOL * float(np.max(shards[0]["ys"]) - np.min(shards[0]["ys"])), 10)
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(report, open("gpurun_out/r03_f32_shards.json", "w"), indent=1)
 
 
 @pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]], ids=["rccl-1dev", "virtual-2", "virtual-3"])
