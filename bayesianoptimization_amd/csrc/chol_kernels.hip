@@ -646,6 +646,57 @@ static int launch_step(gpbo_ctx* ctx, Model& m, int kb, int nblk, const GemmArgs
   return GPBO_OK;
 }
 
+// ---- look-ahead over the outer panels ----------------------------------------------------------------------------
+// The rank-`outer` trailing update of panel p only has to reach the NEXT panel's columns before that panel's chain can
+// start; the rest of it (T_b) is independent of the chain and runs on a second ("bulk") stream meanwhile:
+//     main:  chain(p) | [wait T_b(p-1)] T_a(p) | chain(p+1) | ...
+//     bulk:            [wait chain(p)]  T_b(p)
+// T_a(p) waits for T_b(p-1) because both accumulate into the next panel's columns and the order of the two rank-512
+// contributions is part of the result (bitwise the one-stream factor: same launches, same kernels, same order per tile).
+// Round 2 measured this with a plain second stream and dropped it: the bulk GEMM's workgroups hold every CU, so the
+// chain's small kernels queue behind them.  Here the bulk stream may be confined to a subset of the CUs
+// (hipExtStreamCreateWithCUMask; GPBO_CHOL_LA_CUS = how many of the device's CUs it may use, 0 = no mask), which keeps
+// the rest free for the chain at any moment.  GPBO_CHOL_LA=0 turns the look-ahead off (A/B runs).
+static int lookahead_min_np() {
+  static const int v = [] {
+    const char* e = getenv("GPBO_CHOL_LA");
+    if (e && e[0] == '0') return 1 << 30;
+    const char* f = getenv("GPBO_CHOL_LA_MIN_NP");
+    return f ? atoi(f) : 2048;
+  }();
+  return v;
+}
+
+static LookAhead* lookahead_for(gpbo_ctx* ctx, int n_events) {
+  LookAhead* la = nullptr;
+  for (auto& l : ctx->lookahead)
+    if (l.main == ctx->stream) la = &l;
+  if (!la) {
+    LookAhead l;
+    l.main = ctx->stream;
+    static const int cus = getenv("GPBO_CHOL_LA_CUS") ? atoi(getenv("GPBO_CHOL_LA_CUS")) : 0;
+    hipError_t e = hipErrorUnknown;
+    if (cus > 0) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && cus < prop.multiProcessorCount) {
+        std::vector<uint32_t> mask((size_t)(prop.multiProcessorCount + 31) / 32, 0u);
+        for (int b = 0; b < cus; ++b) mask[(size_t)b / 32] |= 1u << (b % 32);
+        e = hipExtStreamCreateWithCUMask(&l.bulk, (uint32_t)mask.size(), mask.data());
+      }
+    }
+    if (e != hipSuccess) e = hipStreamCreateWithFlags(&l.bulk, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    ctx->lookahead.push_back(l);
+    la = &ctx->lookahead.back();
+  }
+  while ((int)la->ev.size() < n_events) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    la->ev.push_back(ev);
+  }
+  return la;
+}
+
 // Blocked Cholesky of m.L (lower, in place), inverted 64x64 diagonal blocks to m.dinv: 128-column steps inside
 // `outer`-column panels (outer a multiple of 128), one rank-`outer` trailing update per panel.
 int launch_cholesky128(gpbo_ctx* ctx, Model& m, int outer, long long* stamps) {
@@ -653,6 +704,10 @@ int launch_cholesky128(gpbo_ctx* ctx, Model& m, int outer, long long* stamps) {
   const int per_outer = outer / NB;
   const unsigned lanes = (unsigned)ctx->lanes;
   int rc;
+  const int n_panels = (nblk + per_outer - 1) / per_outer;
+  LookAhead* la = (ctx->lanes == 1 && m.NP >= lookahead_min_np() && n_panels >= 3) ? lookahead_for(ctx, 2 * n_panels) : nullptr;
+  bool la_joined = true;
+  int pidx = 0;     // outer panel index
   for (int ob = 0; ob < nblk; ob += per_outer) {
     const int oe = (ob + per_outer < nblk) ? ob + per_outer : nblk;
     if ((rc = launch_step(ctx, m, ob, (oe - ob >= 2) ? 2 : 1, nullptr, stamps))) return rc;   // everything before the panel is applied
@@ -683,13 +738,43 @@ int launch_cholesky128(gpbo_ctx* ctx, Model& m, int outer, long long* stamps) {
     if (rem2 > 0) {
       const double* P = m.L + (int64_t)oe * NB * m.NP + (int64_t)ob * NB;
       GemmArgs t{};
-      t.m = rem2; t.n = rem2; t.k = (oe - ob) * NB; t.alpha = -1.0; t.beta = 1.0;
-      t.A = P; t.lda = m.NP; t.B = P; t.ldb = m.NP; t.b_trans = 1;
-      t.C = m.L + (int64_t)oe * NB * m.NP + (int64_t)oe * NB; t.ldc = m.NP;
+      t.k = (oe - ob) * NB; t.alpha = -1.0; t.beta = 1.0;
+      t.lda = m.NP; t.ldb = m.NP; t.b_trans = 1; t.ldc = m.NP;
       t.batch = 1; t.lower_only = 1;
-      if ((rc = launch_gemm(ctx, t))) return rc;
+      const int nw = rem2 < outer ? rem2 : outer;       // the next panel's columns
+      if (!la || rem2 <= nw) {
+        if (la && pidx > 0) GPBO_HIP(ctx, hipStreamWaitEvent(ctx->stream, la->ev[2 * (pidx - 1) + 1], 0));
+        t.m = rem2; t.n = rem2; t.A = P; t.B = P;
+        t.C = m.L + (int64_t)oe * NB * m.NP + (int64_t)oe * NB;
+        if ((rc = launch_gemm(ctx, t))) return rc;
+        la_joined = true;
+      } else {
+        // chain(p) is complete on main: the bulk stream may read the panel
+        GPBO_HIP(ctx, hipEventRecord(la->ev[2 * pidx], ctx->stream));
+        if (pidx > 0) GPBO_HIP(ctx, hipStreamWaitEvent(ctx->stream, la->ev[2 * (pidx - 1) + 1], 0));
+        t.m = rem2; t.n = nw; t.A = P; t.B = P;
+        t.C = m.L + (int64_t)oe * NB * m.NP + (int64_t)oe * NB;
+        if ((rc = launch_gemm(ctx, t))) return rc;        // T_a on main
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = la->bulk;
+        hipError_t e = hipStreamWaitEvent(la->bulk, la->ev[2 * pidx], 0);
+        if (e == hipSuccess) {
+          t.m = rem2 - nw; t.n = rem2 - nw; t.A = P + (int64_t)nw * m.NP; t.B = t.A;
+          t.C = m.L + ((int64_t)oe * NB + nw) * m.NP + ((int64_t)oe * NB + nw);
+          rc = launch_gemm(ctx, t);                          // T_b on bulk
+          if (rc == GPBO_OK) e = hipEventRecord(la->ev[2 * pidx + 1], la->bulk);
+        }
+        ctx->stream = main_stream;
+        if (rc) return rc;
+        GPBO_HIP(ctx, e);
+        la_joined = false;
+      }
     }
+    ++pidx;
   }
+  // nothing of the factorisation may still be in flight on the bulk stream when main goes on (it always joined above:
+  // the last update has no far part)
+  if (la && !la_joined && pidx > 0) GPBO_HIP(ctx, hipStreamWaitEvent(ctx->stream, la->ev[2 * (pidx - 1) + 1], 0));
   return GPBO_OK;
 }
 

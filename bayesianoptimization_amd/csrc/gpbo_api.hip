@@ -303,6 +303,11 @@ int gpbo_destroy(gpbo_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   gpbo_comm_destroy(ctx);
   for (auto& m : ctx->models) free_model(m);
+  for (auto& la : ctx->lookahead) {
+    if (la.bulk) { (void)hipStreamSynchronize(la.bulk); (void)hipStreamDestroy(la.bulk); }
+    for (auto ev : la.ev) (void)hipEventDestroy(ev);
+  }
+  ctx->lookahead.clear();
   for (auto& st : ctx->lml_stream) if (st) (void)hipStreamDestroy(st);
   for (auto& st : ctx->slot_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   if (ctx->small_ev) (void)hipEventDestroy(ctx->small_ev);

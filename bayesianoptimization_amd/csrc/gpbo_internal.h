@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "gpbo.h"
 
@@ -63,6 +64,14 @@ struct LmlLane {
 struct EventPair {
   hipEvent_t a = nullptr, b = nullptr;
   bool used = false;
+};
+
+// Cholesky look-ahead (chol_kernels.hip): the bulk stream that carries the far part of a rank-512 trailing update while
+// the next outer panel's chain runs on `main`, and the events the two streams hand each other.  One per main stream
+// (the context's own, a slot's, an LML lane's), created on first use.
+struct LookAhead {
+  hipStream_t main = nullptr, bulk = nullptr;
+  std::vector<hipEvent_t> ev;
 };
 
 }  // namespace gpbo
@@ -130,6 +139,7 @@ struct gpbo_ctx {
   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: one bit per kernel family, per context (a
   // process-wide flag would leave every device but the first of a gpbo_group at the 64 KiB default)
   unsigned func_attrs = 0;
+  std::vector<gpbo::LookAhead> lookahead;
   gpbo::EventPair ev[gpbo::T_COUNT];
   // RCCL
   void* comm = nullptr;

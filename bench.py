@@ -225,6 +225,88 @@ def pmc_summary_for(w):
     return pm, f"profiles/{os.path.basename(ppath)} (same kernel sources: fingerprint {_fingerprint()[:12]})"
 
 
+def run_extra_config(eng, name, steps=5, warmup=2):
+    """One more BASELINE.json config on the already-open single engine, after the headline's timed region: the same step
+    (fit at fixed theta + posterior + acquisition + arg-best/top-10 over the resident candidates; sharded configs: shard 0
+    = one GPU's share of the 8-GPU job), wall-clocked over `steps` steps between stream synchronisations, with the
+    dominant kernels' HIP-event time and the parity block against the reference's golden for exactly this job."""
+    w = W.ALL[name]
+    X, y, c = W.make_observations(w)
+    y_mean, y_std = float(np.mean(y)), float(np.std(y))
+    yn = (y - y_mean) / y_std
+    y_max = W.feasible_y_max(w, y, c)
+    M = w.M // 8 if w.name in SHARDED else w.M
+    prec = 1 if w.dtype == "f32" else 0
+    n_gp = 2 if w.constrained else 1
+    lb_c = ub_c = None
+    if w.constrained:
+        c_mean, c_std = float(np.mean(c)), float(np.std(c))
+        cn = (c - c_mean) / c_std
+        lb_c, ub_c = [-np.inf], [w.constraint_ub]
+    eng.set_candidates(W.make_candidates(w.bounds_array(), M, 7))
+    post = [0.0]
+
+    def step():
+        if w.constrained:
+            with eng.overlapped_fits():
+                eng.fit(X, yn, w.kernel, w.length_scale, w.noise, slot=0, precision=prec)
+                eng.fit(X, cn, W.MATERN25, w.constraint_length_scale, w.noise, slot=1, precision=prec)
+        else:
+            eng.fit(X, yn, w.kernel, w.length_scale, w.noise, slot=0, precision=prec)
+        eng.posterior(0, y_mean, y_std, fetch=False)
+        post[0] = eng.last_timings()["posterior_main"]
+        if w.constrained:
+            eng.posterior(1, c_mean, c_std, fetch=False)
+            post[0] += eng.last_timings()["posterior_main"]
+        return eng.acq_argbest(w.acq, w.acq_param, 0.0 if y_max is None else y_max, lb_c, ub_c, k_seeds=10)[:4]
+
+    for _ in range(warmup):
+        step()
+    eng.synchronize()
+    main_ms, fit_ms = 0.0, 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        best = step()
+        main_ms += post[0]
+        fit_ms += eng.last_timings()["fit"]
+    eng.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    main_ms /= steps
+    fl = flops_per_candidate(w.N, w.d, n_gp) * M
+    peak = FP32_MFMA_PEAK_TFLOPS if prec else FP64_MFMA_PEAK_TFLOPS
+    out = {"workload": f"{w.name}{' shard 0 of 8' if w.name in SHARDED else ''}: d={w.d} N={w.N} {W.ACQ_NAMES[w.acq]} M={M}, {n_gp} GP(s)",
+           "dtype": "f32" if prec else "f64", "steps": steps, "ms_per_step": ms, "value": M / (ms * 1e-3), "unit": "candidates/s",
+           "roofline": {"bound": "mfma", "posterior_ms": main_ms, "achieved": fl / (main_ms * 1e-3) / 1e12, "peak": peak,
+                        "unit": "TFLOP/s", "frac": fl / (main_ms * 1e-3) / 1e12 / peak,
+                        "frac_of_whole_step": fl / (ms * 1e-3) / 1e12 / peak},
+           "fit_ms": (fit_ms / steps) if not w.constrained else None}
+    g = reference_golden(w.name, 1, M)
+    if g is not None:
+        top10 = np.asarray(best[2], dtype=np.int64)
+        out["parity"] = {"argmin_equals_reference": bool(int(best[0]) == g["argmin"]),
+                         "top10_equals_reference": bool(np.array_equal(top10, g["top_idx"][:10])),
+                         "min_rel_err": float(abs(best[1] - g["min"]) / abs(g["min"])), "reference": g["source"],
+                         "arithmetic": "fp32 posterior vs the fp64 reference" if prec else "fp64"}
+    return out
+
+
+def suggest_in_child(n_gpus, config, timeout_s=150):
+    """`python bench.py --gpus N --suggest-only` in a fresh process without the launcher's RANK/WORLD_SIZE environment."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                        "TORCHELASTIC_RUN_ID", "GPBO_BENCH_DEVICE")}
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", str(n_gpus), "--config", config, "--suggest-only"],
+                           env=env, capture_output=True, text=True, timeout=timeout_s)
+        for line in p.stdout.splitlines():
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"error": f"child rc={p.returncode}: {p.stderr[-300:]}"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)}
+
+
 def emit_failed(args, n_gpus, why):
     print(json.dumps({"metric": METRIC, "value": None, "unit": "candidates/s", "n_gpus": n_gpus, "steps": args.steps,
                       "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
@@ -242,6 +324,9 @@ def main():
                          "8 x 2^20 at --gpus 8) when sharded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-suggest", action="store_true", help="skip the ms/suggest measurement after the timed region")
+    ap.add_argument("--suggest-only", action="store_true", help="(child of a multi-rank run) print only the suggest_ms object")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the other BASELINE.json configs (C2, C4 shard 0, C5 fp32 shard 0) run after the default headline")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -322,6 +407,13 @@ def main():
         sh.set_candidates_local(Xc, offset=rank * M)
         argbest = lambda: sh.argbest(w.acq, w.acq_param, 0.0 if y_max is None else y_max, lb_c, ub_c, k_seeds=10)  # noqa: E731
         barrier_max = (lambda v: eng.comm_allreduce_max(v)) if mode == "ranks" else (lambda v: (eng.synchronize(), v)[1])
+
+    if args.suggest_only:
+        res = suggest_latency(w, X, y, eng, M * n_gpus)
+        res["engine"] = (f"GroupEngine over {n_gpus} device(s) ({collective})" if mode == "group" else "GpEngine") + f", n_random = {M * n_gpus}"
+        print(json.dumps(res), flush=True)
+        eng.close()
+        return
 
     post_ms = [0.0]
     fits_ms = [0.0]
@@ -457,14 +549,33 @@ def main():
             except Exception as e:
                 log(f"[bench] cpu_baseline failed: {e!r}")
                 out["cpu_baseline"] = None
-        if mode == "single" and not w.constrained and not args.no_suggest:
+        if mode == "single" and args.config is None and not args.no_extra_configs:
+            # every other BASELINE.json config that fits one GPU, in the line the driver records (5 steps each, no CPU leg)
+            out["configs"] = {}
+            for key, nm in (("C2", "C2"), ("C4_s0", "C4"), ("C5_f32_s0", "C5")):
+                try:
+                    out["configs"][key] = run_extra_config(eng, nm)
+                except Exception as e:  # noqa: BLE001
+                    log(f"[bench] extra config {key} failed: {e!r}")
+                    out["configs"][key] = {"error": repr(e)}
+            eng.set_candidates(Xc)
+        if mode in ("single", "group") and not w.constrained and not args.no_suggest:
             # the other half of BASELINE.json's metric, ms/suggest: whole suggest() calls through the drop-in seams
             # (refit at fixed theta, candidates drawn from the caller's RandomState on the device, posterior, acquisition,
             # arg-best; with the reference's default 10 local searches and without) — outside the timed region above
             try:
-                out["suggest_ms"] = suggest_latency(w, X, y, eng, M)
+                # group mode: the same seams over the device group, as accelerate(optimizer, devices=[...]) installs it
+                # (one process, candidates sharded over the GPUs, n_random = the whole job's candidates)
+                out["suggest_ms"] = suggest_latency(w, X, y, eng, M * n_gpus)
+                if mode == "group":
+                    out["suggest_ms"]["engine"] = f"GroupEngine over {n_gpus} device(s), n_random = {M * n_gpus}"
             except Exception as e:  # noqa: BLE001
                 log(f"[bench] suggest latency failed: {e!r}")
+        if mode == "ranks" and not w.constrained and not args.no_suggest:
+            # ms/suggest for the same N GPUs: BayesianOptimization.suggest() is ONE process (accelerate(devices=[...]) ->
+            # GroupEngine), so rank 0 measures it in a child process that owns all N devices while the other ranks idle at
+            # the closing barrier; a child that fails or exceeds its deadline costs only this key
+            out["suggest_ms"] = suggest_in_child(n_gpus, w.name)
         print(json.dumps(out), flush=True)
     if mode == "ranks":
         barrier_max(0.0)

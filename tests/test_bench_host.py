@@ -107,3 +107,22 @@ def test_file_rendezvous_ships_the_unique_id_to_every_rank(tmp_path):
             rendezvous.share_unique_id(0, lambda: b"short", key=key)
     finally:
         os.environ.pop("GPBO_RDZV_DIR", None)
+
+
+def test_extra_config_goldens_exist_for_the_line_the_driver_runs():
+    """bench.py's `configs` block compares C2, C4 shard 0 and C5 shard 0 with these committed reference passes."""
+    b = _bench()
+    assert b.reference_golden("C2", 1, 65536)["source"].endswith("C2.npz")
+    assert b.reference_golden("C4", 1, 1 << 20)["argmin"] == int(np.load(os.path.join(GOLD, "C4_s0.npz"))["argmin"])
+    assert b.reference_golden("C5", 1, 1 << 18)["argmin"] == int(np.load(os.path.join(GOLD, "C5_s0.npz"))["argmin"])
+
+
+def test_suggest_child_failure_costs_only_its_key(monkeypatch):
+    """Multi-rank runs measure ms/suggest in a child process that owns all devices; without devices the child fails and the
+    parent gets an error record instead of an exception (the launcher's rank variables must not reach the child)."""
+    b = _bench()
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("GPBO_FORCE_NO_DEVICE", "1")
+    res = b.suggest_in_child(2, "C4", timeout_s=120)
+    assert isinstance(res, dict) and "error" in res
