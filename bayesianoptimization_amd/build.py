@@ -25,7 +25,7 @@ ARCH = "gfx950"
 SOURCES = {
     "gpbo_api.hip": [],
     "fit_kernels.hip": [],
-    "chol_kernels.hip": [],
+    "chol_kernels.hip": os.environ.get("GPBO_CHOL_EXTRA_FLAGS", "").split(),   # probe builds (scripts/r03_*): -D switches
     "posterior_kernel.hip": [],
     "posterior_kernel_v2.hip": [],
     "posterior_small.hip": [],

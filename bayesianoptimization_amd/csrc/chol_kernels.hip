@@ -27,12 +27,13 @@ constexpr int DS = 80;                                   // stride of the column
 constexpr int C128_IMG = 64 * DS + 64;                   // one image: 64 columns + room for the last column's marker overflow (factor_quarter)
 constexpr int C128_LC0 = 0;                              // L00:  Lc0[j * DS + i] = L[i][j], Lc0[j * DS + 64] = 1 / L[j][j]
 constexpr int C128_LCX = C128_IMG;                       // L10 during the first factorisation and the SYRK, then L11
-constexpr int C128_WR = 2 * C128_IMG;                    // SYRK exchange [64][81], then the waves' 16x16 diagonal inverses [4][4][272]
-constexpr int C128_WR_DOUBLES = 5248;
+constexpr int C128_WR = 2 * C128_IMG;                    // SYRK exchange [64][81], then the waves' 16x16 diagonal inverses [8][4][272]
+constexpr int C128_WR_DOUBLES = 8 * 4 * 272;    // 8704
 constexpr int C128_FLAGS = C128_WR + C128_WR_DOUBLES;    // ints: [0] broken hand-off
 constexpr int C128_LDS_DOUBLES = C128_FLAGS + 8;
 constexpr size_t C128_LDS_BYTES = (size_t)C128_LDS_DOUBLES * sizeof(double);
-static_assert(C128_WR_DOUBLES >= 64 * 81 && C128_WR_DOUBLES >= 4 * 4 * 272, "exchange area too small");
+static_assert(C128_WR_DOUBLES >= 64 * 81 && C128_WR_DOUBLES >= 8 * 4 * 272, "exchange area too small");
+static_assert(C128_LDS_BYTES <= 160 * 1024, "the diagonal workgroup's LDS exceeds a CU's 160 KiB");
 static_assert(C128_LDS_DOUBLES >= 2 * GT_LDS_DOUBLES, "the update tiles of the step launch alias the same dynamic LDS");
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -48,90 +49,166 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 #define GPBO_LDS_ORDER() asm volatile("" ::: "memory")
 #define GPBO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
-// What one step costs (scripts/r03_latency_probe.py, one wave on its SIMD): EVERY VALU instruction — v_fma_f64 dependent
-// or not, v_readlane_b32, v_cndmask, v_mov — occupies the wave for 4 cycles, v_rsq_f64 16, a dependent v_writelane_b32
-// (what an SGPR spill turns into) 28; an LDS write -> read round trip is ~90 cycles.  So the factorisation of a column
-// is priced in INSTRUCTIONS: the first version of this routine spent ~110 per column (selects for the diagonal / the
-// zero upper part, an exec-masked pivot/counter store, a per-column pivot test, 2 v_readlane per broadcast multiplier,
-// spilled SGPRs) = 720 cycles per column; this one ~35.
+// a[c] -= l * m_c and (the riding row) a2[c] -= l2 * m_c for N of the wave's own columns, m_c = the value of l in lane
+// C0 + c (the rows of the wave's diagonal 8x8 block sit in lanes 0..7): v_readlane_b32 into FIXED scalar registers,
+// consumed by the v_fma_f64 directly.  Written out because the compiler's version of the same thing hoists every
+// v_readlane of a column to the front, runs out of SGPRs (the GEMM half of the step kernel keeps ~60 live) and spills
+// them with v_writelane_b32 at 28 cycles apiece (scripts/r03_col_stamps.py: 2/3 of a column's time), and because a
+// v_readlane whose lane number comes from an SGPR instead of an inline constant is no faster.  The readlane -> fma
+// distance satisfies the 2 wait states a VALU-written SGPR needs before a VALU reads it.
+#define GPBO_RL(S, C) "v_readlane_b32 s" #S ", %[lo], %[" #C "]\n\tv_readlane_b32 s" GPBO_RL_NEXT_##S ", %[hi], %[" #C "]\n\t"
+#define GPBO_RL_NEXT_80 "81"
+#define GPBO_RL_NEXT_82 "83"
+#define GPBO_RL_NEXT_84 "85"
+#define GPBO_RL_NEXT_86 "87"
+__device__ __forceinline__ void split64(const double l, int& lo, int& hi) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(l);
+  lo = (int)(unsigned)u;
+  hi = (int)(unsigned)(u >> 32);
+}
+template <int C0, bool FOLLOW>
+__device__ __forceinline__ void bcast_fma4(double* a, double* a2, const double l, const double l2) {
+  int lo, hi;
+  split64(l, lo, hi);
+  if constexpr (FOLLOW) {
+    asm volatile(GPBO_RL(80, c0) GPBO_RL(82, c1) GPBO_RL(84, c2) GPBO_RL(86, c3)
+                 "v_fma_f64 %[a0], -%[l], s[80:81], %[a0]\n\tv_fma_f64 %[a1], -%[l], s[82:83], %[a1]\n\t"
+                 "v_fma_f64 %[a2], -%[l], s[84:85], %[a2]\n\tv_fma_f64 %[a3], -%[l], s[86:87], %[a3]\n\t"
+                 "v_fma_f64 %[b0], -%[l2], s[80:81], %[b0]\n\tv_fma_f64 %[b1], -%[l2], s[82:83], %[b1]\n\t"
+                 "v_fma_f64 %[b2], -%[l2], s[84:85], %[b2]\n\tv_fma_f64 %[b3], -%[l2], s[86:87], %[b3]\n\t"
+                 : [a0] "+v"(a[C0]), [a1] "+v"(a[C0 + 1]), [a2] "+v"(a[C0 + 2]), [a3] "+v"(a[C0 + 3]),
+                   [b0] "+v"(a2[C0]), [b1] "+v"(a2[C0 + 1]), [b2] "+v"(a2[C0 + 2]), [b3] "+v"(a2[C0 + 3])
+                 : [l] "v"(l), [l2] "v"(l2), [lo] "v"(lo), [hi] "v"(hi), [c0] "n"(C0), [c1] "n"(C0 + 1), [c2] "n"(C0 + 2), [c3] "n"(C0 + 3)
+                 : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87");
+  } else {
+    asm volatile(GPBO_RL(80, c0) GPBO_RL(82, c1) GPBO_RL(84, c2) GPBO_RL(86, c3)
+                 "v_fma_f64 %[a0], -%[l], s[80:81], %[a0]\n\tv_fma_f64 %[a1], -%[l], s[82:83], %[a1]\n\t"
+                 "v_fma_f64 %[a2], -%[l], s[84:85], %[a2]\n\tv_fma_f64 %[a3], -%[l], s[86:87], %[a3]\n\t"
+                 : [a0] "+v"(a[C0]), [a1] "+v"(a[C0 + 1]), [a2] "+v"(a[C0 + 2]), [a3] "+v"(a[C0 + 3])
+                 : [l] "v"(l), [lo] "v"(lo), [hi] "v"(hi), [c0] "n"(C0), [c1] "n"(C0 + 1), [c2] "n"(C0 + 2), [c3] "n"(C0 + 3)
+                 : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87");
+  }
+}
+template <int C0, bool FOLLOW>
+__device__ __forceinline__ void bcast_fma2(double* a, double* a2, const double l, const double l2) {
+  int lo, hi;
+  split64(l, lo, hi);
+  if constexpr (FOLLOW) {
+    asm volatile(GPBO_RL(80, c0) GPBO_RL(82, c1) "s_nop 0\n\t"
+                 "v_fma_f64 %[a0], -%[l], s[80:81], %[a0]\n\tv_fma_f64 %[a1], -%[l], s[82:83], %[a1]\n\t"
+                 "v_fma_f64 %[b0], -%[l2], s[80:81], %[b0]\n\tv_fma_f64 %[b1], -%[l2], s[82:83], %[b1]\n\t"
+                 : [a0] "+v"(a[C0]), [a1] "+v"(a[C0 + 1]), [b0] "+v"(a2[C0]), [b1] "+v"(a2[C0 + 1])
+                 : [l] "v"(l), [l2] "v"(l2), [lo] "v"(lo), [hi] "v"(hi), [c0] "n"(C0), [c1] "n"(C0 + 1)
+                 : "s80", "s81", "s82", "s83");
+  } else {
+    asm volatile(GPBO_RL(80, c0) GPBO_RL(82, c1) "s_nop 0\n\t"
+                 "v_fma_f64 %[a0], -%[l], s[80:81], %[a0]\n\tv_fma_f64 %[a1], -%[l], s[82:83], %[a1]\n\t"
+                 : [a0] "+v"(a[C0]), [a1] "+v"(a[C0 + 1])
+                 : [l] "v"(l), [lo] "v"(lo), [hi] "v"(hi), [c0] "n"(C0), [c1] "n"(C0 + 1)
+                 : "s80", "s81", "s82", "s83");
+  }
+}
+template <int C0, bool FOLLOW>
+__device__ __forceinline__ void bcast_fma1(double* a, double* a2, const double l, const double l2) {
+  int lo, hi;
+  split64(l, lo, hi);
+  if constexpr (FOLLOW) {
+    asm volatile(GPBO_RL(80, c0) "s_nop 1\n\t"
+                 "v_fma_f64 %[a0], -%[l], s[80:81], %[a0]\n\tv_fma_f64 %[b0], -%[l2], s[80:81], %[b0]\n\t"
+                 : [a0] "+v"(a[C0]), [b0] "+v"(a2[C0])
+                 : [l] "v"(l), [l2] "v"(l2), [lo] "v"(lo), [hi] "v"(hi), [c0] "n"(C0)
+                 : "s80", "s81");
+  } else {
+    asm volatile(GPBO_RL(80, c0) "s_nop 1\n\t"
+                 "v_fma_f64 %[a0], -%[l], s[80:81], %[a0]\n\t"
+                 : [a0] "+v"(a[C0])
+                 : [l] "v"(l), [lo] "v"(lo), [hi] "v"(hi), [c0] "n"(C0)
+                 : "s80", "s81");
+  }
+}
+// columns C0 .. 7 of the wave's own block, nearest first
+template <int C0, bool FOLLOW>
+__device__ __forceinline__ void bcast_fma_from(double* a, double* a2, const double l, const double l2) {
+  if constexpr (C0 + 4 <= 8) {
+    bcast_fma4<C0, FOLLOW>(a, a2, l, l2);
+    bcast_fma_from<C0 + 4, FOLLOW>(a, a2, l, l2);
+  } else if constexpr (C0 + 2 <= 8) {
+    bcast_fma2<C0, FOLLOW>(a, a2, l, l2);
+    bcast_fma_from<C0 + 2, FOLLOW>(a, a2, l, l2);
+  } else if constexpr (C0 + 1 <= 8) {
+    bcast_fma1<C0, FOLLOW>(a, a2, l, l2);
+  }
+}
+
+// What one step costs (scripts/r03_latency_probe.py, one wave on its SIMD): every plain VALU instruction — v_fma_f64
+// dependent or not, v_readlane_b32, v_mov — occupies the wave for 4 cycles, v_rsq_f64 16, a v_writelane_b32 (what an
+// SGPR spill turns into) 28, a ds_write2_b64 ~18; an LDS write -> read round trip is ~90 cycles and a broadcast
+// ds_read_b128 holds the LDS pipeline ~8 cycles.  The chain of one column (2 v_readlane of the pivot, v_rsq_f64, two
+// Newton steps, the scaling, the store, the next pivot) is ~100 cycles; everything else a wave issues stands in front
+// of the next column's chain, so a column is priced in INSTRUCTIONS on the owning wave and in LDS time for everybody
+// else.  Eight waves of eight columns: per column the owner spends ~100 + 3.5 x (2 readlane + 2 fma) and each wave
+// to its right 4 broadcast reads + 16 fma.
 //
-// One quarter (16 columns, wave q) of the right-looking factorisation of a 64-column panel held row-per-lane:
-// thread (row i, quarter q) keeps a[0..15] = A[i][16q .. 16q+15]; with FOLLOW a second row (i + 64, the block below the
-// diagonal one) rides along in a2 — the same multipliers, no pivots of its own (that is the panel solve of block row 1,
-// L10 = A10 L00^-T, done by substitution in the shadow of the factorisation).  The wave first applies the columns left
-// of its own as their owners publish them, then factors its 16 columns inside the wave, publishing each column the
-// moment it is final.  Every element receives its rank-1 updates in column order whatever the timing, so the result is
-// deterministic.
+// One block (8 columns, wave w) of the right-looking factorisation of a 64-column panel held row-per-lane: thread
+// (row i, wave w) keeps a[0..7] = A[i][8w .. 8w+7], and a second row (i + 64, the block below the diagonal one) rides
+// along in a2 — the same multipliers, no pivots of its own (that is the panel solve of block row 1, L10 = A10 L00^-T,
+// done by substitution in the shadow of the factorisation; the caller passes zeros when there is no such row).  The
+// wave first applies the columns left of its own as their owners publish them, then factors its 8 columns inside the
+// wave, publishing each column the moment it is final.  Every element receives its rank-1 updates in column order
+// whatever the timing, so the result is deterministic.  The wave's rows are ROTATED, row i = (lane + 8 w) mod 64, so
+// that the rows of its own diagonal 8x8 block sit in lanes 0..7 and every v_readlane names its lane by a constant.
 //
-// Column image: Lc[j * DS + i] = L[i][j] for i < 64, and Lc[j * DS + 64] = 1 / L[j][j] — the reciprocal pivot doubles as
-// the "column j is complete" marker (zero-initialised; written by ALL lanes right behind the column, slots 64..127, no
-// exec mask: the overflow lands in the next column's rows 0..47, which are written later and read only after that).
-// Elements above the diagonal are NOT zeroed on the way (they never reach the lower triangle); the caller zeroes the
-// registers before the global store.  A non-positive pivot gives a non-finite reciprocal (v_rsq_f64 of <= 0) that
-// spreads to everything behind it; the caller finds the first one afterwards (LAPACK's info) — no test on the chain.
+// Column images: Lc[j * DS + i] = L[i][j] for i < 64, Lc2[j * DS + i] = L[64 + i][j], and Lc[j * DS + 64] = 1 / L[j][j]
+// — the reciprocal pivot doubles as the "column j is complete (both images)" marker (zero-initialised; written by ALL
+// lanes right behind the two column stores, slots 64..127, no exec mask: the overflow lands in the next column's rows
+// 0..47, which are written later and read only after that).  Elements above the diagonal are NOT zeroed on the way
+// (they never reach the lower triangle); the caller zeroes the registers before the global store.  A non-positive
+// pivot gives a non-finite reciprocal (v_rsq_f64 of <= 0) that spreads to everything behind it; the caller finds the
+// first one afterwards (LAPACK's info) — no test on the chain.
 template <bool FOLLOW>
-__device__ __forceinline__ void factor_quarter(double (&a)[16], double (&a2)[16], double* __restrict__ Lc, double* __restrict__ Lc2,
-                                               int* broken, const int i, const int q, long long* stamp = nullptr) {
+__device__ __forceinline__ void factor_block8(double (&a)[8], double (&a2)[8], double* __restrict__ Lc, double* __restrict__ Lc2,
+                                              int* broken, const int i, const int w, long long* stamp = nullptr) {
   {
-    const int need = 16 * q;
-    int k = 0, spins = 0;
-    const double* prow0 = Lc + 16 * q;      // L[16q + cc][k] = prow0[k * DS + cc]: the same address for every lane
-    while (k < need) {
-      // columns are published in order: the marker of column k + 1 vouches for k and k + 1
-      const double m2 = Lc[(k + 1) * DS + 64];
-      GPBO_LDS_ORDER();
-      if (m2 != 0.0) {
-        double li[2], li2[2], p[2][16];
+    const double* prow0 = Lc + 8 * w;      // L[8w + cc][k] = prow0[k * DS + cc]: the same address for every lane
+    for (int k = 0; k < 8 * w; k += 2) {
+      // Columns are published in order: the marker of column k + 1 vouches for k and k + 1.  The data reads are issued
+      // right behind the marker read (LDS serves a wave's reads in order): if the marker was set they are valid,
+      // otherwise everything is read again.
+      double li[2], li2[2], p[2][8];
+      int spins = 0;
+      for (;;) {
+        const double m = Lc[(k + 1) * DS + 64];
+        GPBO_LDS_ORDER();
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           li[u] = Lc[(k + u) * DS + i];
           li2[u] = FOLLOW ? Lc2[(k + u) * DS + i] : 0.0;
 #pragma unroll
-          for (int cc = 0; cc < 16; ++cc) p[u][cc] = prow0[(k + u) * DS + cc];
+          for (int cc = 0; cc < 8; ++cc) p[u][cc] = prow0[(k + u) * DS + cc];
         }
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int cc = 0; cc < 16; ++cc) {
-            a[cc] = fma(-li[u], p[u][cc], a[cc]);
-            if (FOLLOW) a2[cc] = fma(-li2[u], p[u][cc], a2[cc]);
-          }
-        k += 2;
-        continue;
-      }
-      const double m1 = Lc[k * DS + 64];
-      GPBO_LDS_ORDER();
-      if (m1 != 0.0) {
-        const double li = Lc[k * DS + i];
-        const double li2 = FOLLOW ? Lc2[k * DS + i] : 0.0;
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) {
-          const double p = prow0[k * DS + cc];
-          a[cc] = fma(-li, p, a[cc]);
-          if (FOLLOW) a2[cc] = fma(-li2, p, a2[cc]);
+        GPBO_LDS_ORDER();
+        if (m != 0.0) break;
+        if (++spins > (1 << 22)) {   // cannot happen while the owner wave runs; never hang the GPU on a bug
+          if (i == 0) *broken = 1;
+          break;
         }
-        k += 1;
-        continue;
+        __builtin_amdgcn_s_sleep(1);
       }
-      if (++spins > (1 << 22)) {   // cannot happen while the owner wave runs; never hang the GPU on a bug
-        if (i == 0) *broken = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+          a[cc] = fma(-li[u], p[u][cc], a[cc]);
+          if (FOLLOW) a2[cc] = fma(-li2[u], p[u][cc], a2[cc]);
+        }
     }
   }
-  double pivsrc = a[0];        // lane j of this holds the pivot of the wave's next column
-  double pend[16];             // multipliers of the PREVIOUS column fetched from LDS, applied one column later
+  double pivsrc = a[0];        // lane jj of this holds the pivot of the wave's next column
+  double* col = Lc + 8 * w * DS + i;        // column 8w + jj of the image: col[jj * DS]
+  double* col2 = Lc2 + 8 * w * DS + i;
 #pragma unroll
-  for (int cc = 0; cc < 16; ++cc) pend[cc] = 0.0;
-  double lprev = 0.0, l2prev = 0.0;
-  double* col = Lc + 16 * q * DS + i;        // column 16q + jj of the image: col[jj * DS]
-  double* col2 = Lc2 + 16 * q * DS + i;
-  const double* bro = Lc + 16 * q * DS + 16 * q;   // bro[jj * DS + cc] = L[16q + cc][16q + jj]
-#pragma unroll
-  for (int jj = 0; jj < 16; ++jj) {
-    const int j = 16 * q + jj;
-    const double piv = readlane_f64(pivsrc, j);
+  for (int jj = 0; jj < 8; ++jj) {
+    const double piv = readlane_f64(pivsrc, jj);
     // 1/sqrt(piv): v_rsq_f64 seed (2^-23) + two Newton steps y <- y + y (1/2 - (piv/2) y^2); the column is scaled by
     // the reciprocal (as LAPACK's dpotf2 does) — the diagonal element too (piv * rs)
     const double h = 0.5 * piv;
@@ -139,13 +216,12 @@ __device__ __forceinline__ void factor_quarter(double (&a)[16], double (&a2)[16]
     rs = fma(rs, fma(-h, rs * rs, 0.5), rs);
     rs = fma(rs, fma(-h, rs * rs, 0.5), rs);
     const double l = a[jj] * rs;
-    // the NEXT pivot first: in lane j + 1 the rank-1 update of element (j+1, j+1) is fma(-l, l, .) — the same bits the
+    // the NEXT pivot first: in lane jj + 1 the rank-1 update of element (j+1, j+1) is fma(-l, l, .) — the same bits the
     // general update produces there (all updates of earlier columns are already in a[jj + 1]) — so the chain does not
     // wait for the broadcast of l
-    if (jj < 15) pivsrc = fma(-l, l, a[jj + 1]);
+    if (jj < 7) pivsrc = fma(-l, l, a[jj + 1]);
     a[jj] = l;
     col[jj * DS] = l;
-    col[jj * DS + 64] = rs;
     double l2 = 0.0;
     if (FOLLOW) {
       l2 = a2[jj] * rs;
@@ -153,117 +229,22 @@ __device__ __forceinline__ void factor_quarter(double (&a)[16], double (&a2)[16]
       col2[jj * DS] = l2;
     }
     GPBO_LDS_ORDER();
+    col[jj * DS + 64] = rs;
+    GPBO_LDS_ORDER();
     GPBO_SCHED_FENCE();
-    // (1) the previous column's far multipliers (cc >= jj + 2), requested one column ago: their LDS latency is covered by
-    //     the chain above instead of standing in front of it
-    if (jj >= 1) {
-#pragma unroll
-      for (int cc = jj + 2; cc < 16; ++cc) {
-        a[cc] = fma(-lprev, pend[cc], a[cc]);
-        if (FOLLOW) a2[cc] = fma(-l2prev, pend[cc], a2[cc]);
-      }
-    }
-    // (2) request this column's far multipliers (cc >= jj + 3): broadcast reads of the column just written
-#pragma unroll
-    for (int cc = jj + 3; cc < 16; ++cc) pend[cc] = bro[jj * DS + cc];
-    lprev = l;
-    l2prev = l2;
-    // (3) the two nearest columns by v_readlane (needed before their turn comes)
-#pragma unroll
-    for (int cc = jj + 1; cc < 16 && cc <= jj + 2; ++cc) {
-      const double lc = readlane_f64(l, 16 * q + cc);   // L[16q + cc][j]
-      a[cc] = fma(-l, lc, a[cc]);
-      if (FOLLOW) a2[cc] = fma(-l2, lc, a2[cc]);
+    switch (jj) {     // jj is a compile-time constant of the unrolled loop: only its own case survives
+      case 0: bcast_fma_from<1, FOLLOW>(a, a2, l, l2); break;
+      case 1: bcast_fma_from<2, FOLLOW>(a, a2, l, l2); break;
+      case 2: bcast_fma_from<3, FOLLOW>(a, a2, l, l2); break;
+      case 3: bcast_fma_from<4, FOLLOW>(a, a2, l, l2); break;
+      case 4: bcast_fma_from<5, FOLLOW>(a, a2, l, l2); break;
+      case 5: bcast_fma_from<6, FOLLOW>(a, a2, l, l2); break;
+      case 6: bcast_fma_from<7, FOLLOW>(a, a2, l, l2); break;
+      default: break;
     }
     GPBO_SCHED_FENCE();
   }
-  if (stamp && i == 0 && q == 0) *stamp = clock64();
-}
-
-// The riding rows (block row 1 of a two-block diagonal workgroup) as waves of their own: L10 = A10 L00^-T by substitution,
-// wave q the columns 16q .. 16q+15 of rows 64 .. 127 (thread = row), consuming the owners' columns as they are published.
-// For a column k left of the wave's quarter the update needs L10[i][k] from the follower wave that owns it: the L10
-// image Lc2 carries markers of its own (same convention as the L00 image).  In the wave's own quarter the marker read
-// returns the reciprocal pivot itself.  Reads of column j + 1 (marker, then multipliers) are issued before column j is
-// processed: if the marker was already set they are valid (LDS serves a wave's reads in order), else they are repeated.
-__device__ __forceinline__ void follow_quarter(double (&a2)[16], const double* __restrict__ Lc, double* __restrict__ Lc2, int* broken,
-                                               const int i, const int q) {
-  const double* prow0 = Lc + 16 * q;      // L00[16q + cc][k] = prow0[k * DS + cc]
-  {
-    const int need = 16 * q;
-    int k = 0, spins = 0;
-    while (k < need) {
-      const double m4 = Lc2[(k + 3) * DS + 64];
-      GPBO_LDS_ORDER();
-      if (m4 != 0.0) {
-        double li[4], p[4][16];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          li[u] = Lc2[(k + u) * DS + i];
-#pragma unroll
-          for (int cc = 0; cc < 16; ++cc) p[u][cc] = prow0[(k + u) * DS + cc];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int cc = 0; cc < 16; ++cc) a2[cc] = fma(-li[u], p[u][cc], a2[cc]);
-        k += 4;
-        continue;
-      }
-      const double m1 = Lc2[k * DS + 64];
-      GPBO_LDS_ORDER();
-      if (m1 != 0.0) {
-        const double li = Lc2[k * DS + i];
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) a2[cc] = fma(-li, prow0[k * DS + cc], a2[cc]);
-        k += 1;
-        continue;
-      }
-      if (++spins > (1 << 22)) {
-        if (i == 0) *broken = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
-  const double* bro = Lc + 16 * q * DS + 16 * q;   // bro[jj * DS + cc] = L00[16q + cc][16q + jj]; bro[jj * DS + 64 - 16q] = its marker
-  const double* mk = Lc + 16 * q * DS + 64;         // mk[jj * DS] = 1 / L00[j][j], 0 while column j is not complete
-  double* col2 = Lc2 + 16 * q * DS + i;
-  double rs = mk[0], pc[16];
-  GPBO_LDS_ORDER();
-#pragma unroll
-  for (int cc = 1; cc < 16; ++cc) pc[cc] = bro[cc];
-#pragma unroll
-  for (int jj = 0; jj < 16; ++jj) {
-    int spins = 0;
-    while (rs == 0.0) {     // not published when the look-ahead read it: poll, then fetch the multipliers again
-      if (++spins > (1 << 22)) {
-        if (i == 0) *broken = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-      rs = mk[jj * DS];
-      GPBO_LDS_ORDER();
-#pragma unroll
-      for (int cc = jj + 1; cc < 16; ++cc) pc[cc] = bro[jj * DS + cc];
-    }
-    double rsn = 0.0, pn[16];
-    if (jj < 15) {          // look-ahead: column j + 1
-      rsn = mk[(jj + 1) * DS];
-      GPBO_LDS_ORDER();
-#pragma unroll
-      for (int cc = jj + 2; cc < 16; ++cc) pn[cc] = bro[(jj + 1) * DS + cc];
-    }
-    const double l2 = a2[jj] * rs;
-    a2[jj] = l2;
-    col2[jj * DS] = l2;
-    col2[jj * DS + 64] = rs;          // marker of the L10 column (all lanes, see factor_quarter)
-#pragma unroll
-    for (int cc = jj + 1; cc < 16; ++cc) a2[cc] = fma(-l2, pc[cc], a2[cc]);
-    rs = rsn;
-#pragma unroll
-    for (int cc = jj + 2; cc < 16; ++cc) pc[cc] = pn[cc];
-  }
+  if (stamp && i == 0) stamp[w] = clock64();
 }
 
 // After a factorisation: info (1-based column within the image, 0 = fine) = the first column whose reciprocal pivot is
@@ -345,12 +326,12 @@ __device__ __forceinline__ void inverse_wave(const double* Lc, double* Dk, doubl
 }
 
 // Diagonal block of `nblk` (1 or 2) 64-blocks starting at block kb, all earlier updates applied: factor in place, write
-// inv(L_kk) (and inv(L_kk+1)) to dinv.  512 threads = 8 waves, no launch inside, five workgroup barriers:
-//   waves 0-3 ("owners", thread = row i of the block being factored, wave = column quarter): potf2 of A00, later of A11
-//   waves 4-7 ("followers", thread = row 64 + i): L10 riding along (follow_quarter), later inv(L00) while A11 is factored
-// Quarter 3's follower sits in wave 4 — by the usual cyclic wave placement on the SIMD of owner 0, which has been idle
-// longest when the chain reaches the last quarter (a wave issues one VALU instruction per 4 cycles whatever it is, so a
-// follower sharing the SIMD of the owner that currently carries the chain would take its issue slots).
+// inv(L_kk) (and inv(L_kk+1)) to dinv.  512 threads = 8 waves, no launch inside, five workgroup barriers.  Wave w,
+// thread = row i (rotated, see factor_block8):
+//   columns 8w .. 8w+7 of A00 with the same columns of A10 (row 64 + i) riding along  ->  L00, L10
+//   SYRK  A11 -= L10 L10^T  (MFMA out of the L10 image)
+//   columns 8w .. 8w+7 of A11  ->  L11
+//   waves 0-3: inv(L00), waves 4-7: inv(L11), one 16-column block each.
 __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64_t ld, const int kb, const int nblk,
                                              double* __restrict__ dinv, int* __restrict__ info, double* __restrict__ smem,
                                              long long* __restrict__ stamps) {
@@ -359,10 +340,9 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
   double* Wr = smem + C128_WR;
   int* flags = reinterpret_cast<int*>(smem + C128_FLAGS);
   const int tid = threadIdx.x;
-  const int i = tid & 63;
+  const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool owner = w < 4;
-  const int q = owner ? w : 7 - w;          // column quarter
+  const int i = (lane + 8 * w) & 63;        // the wave's diagonal 8x8 block in lanes 0..7; rows are what every address is computed from
   const bool two = nblk == 2;
   double* A = L + (int64_t)kb * 64 * ld + (int64_t)kb * 64;
   if (stamps && tid == 0) stamps[0] = clock64();
@@ -371,53 +351,52 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
     LcX[tid * DS + 64] = 0.0;
   }
   if (tid == 0) flags[0] = 0;
-  double a[16], b[16];     // owners: rows of A00, A11; followers: rows of A10
-#pragma unroll
-  for (int h = 0; h < 16; ++h) b[h] = 0.0;
+  double a[8], a2[8], b[8];     // rows of A00, A10, A11
   {
-    const int64_t row = owner ? i : 64 + i;
-    const double2* s0 = reinterpret_cast<const double2*>(A + row * ld + 16 * q);
-    if (owner || two) {
+    const double2* s0 = reinterpret_cast<const double2*>(A + (int64_t)i * ld + 8 * w);
 #pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        const double2 v = s0[h];
-        a[2 * h] = v.x;
-        a[2 * h + 1] = v.y;
-      }
-    } else {
-#pragma unroll
-      for (int h = 0; h < 16; ++h) a[h] = 0.0;
+    for (int h = 0; h < 4; ++h) {
+      const double2 v = s0[h];
+      a[2 * h] = v.x;
+      a[2 * h + 1] = v.y;
     }
-    if (owner && two) {
-      const double2* s2 = reinterpret_cast<const double2*>(A + (int64_t)(64 + i) * ld + 64 + 16 * q);
+    if (two) {
+      const double2* s1 = reinterpret_cast<const double2*>(A + (int64_t)(64 + i) * ld + 8 * w);
+      const double2* s2 = reinterpret_cast<const double2*>(A + (int64_t)(64 + i) * ld + 64 + 8 * w);
 #pragma unroll
-      for (int h = 0; h < 8; ++h) {
+      for (int h = 0; h < 4; ++h) {
+        const double2 v = s1[h];
+        a2[2 * h] = v.x;
+        a2[2 * h + 1] = v.y;
         const double2 u = s2[h];
         b[2 * h] = u.x;
         b[2 * h + 1] = u.y;
       }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 8; ++h) a2[h] = b[h] = 0.0;     // a zero row rides along
     }
   }
   __syncthreads();
   if (stamps && tid == 0) stamps[1] = clock64();
-  // ---- columns 0..63: L00 by the owners, L10 = A10 L00^-T by the followers behind them
-  if (owner) {
-    factor_quarter<false>(a, b, Lc0, Lc0, &flags[0], i, q, stamps ? stamps + 7 : nullptr);
-    // the wave's 16 columns are final: rows straight from registers (128 contiguous bytes per thread, zeros above the diagonal)
+  // ---- columns 0..63: L00, and L10 = A10 L00^-T in its shadow
+  factor_block8<true>(a, a2, Lc0, LcX, &flags[0], i, w, stamps ? stamps + 7 : nullptr);
+  {
+    // the wave's 8 columns are final: rows straight from registers (64 contiguous bytes per thread, zeros above the diagonal)
 #pragma unroll
-    for (int cc = 0; cc < 16; ++cc) a[cc] = (i >= 16 * q + cc) ? a[cc] : 0.0;
-    double2* d0 = reinterpret_cast<double2*>(A + (int64_t)i * ld + 16 * q);
+    for (int cc = 0; cc < 8; ++cc) a[cc] = (i >= 8 * w + cc) ? a[cc] : 0.0;
+    double2* d0 = reinterpret_cast<double2*>(A + (int64_t)i * ld + 8 * w);
 #pragma unroll
-    for (int h = 0; h < 8; ++h) d0[h] = make_double2(a[2 * h], a[2 * h + 1]);
-  } else if (two) {
-    follow_quarter(a, Lc0, LcX, &flags[0], i, q);
-    double2* d1 = reinterpret_cast<double2*>(A + (int64_t)(64 + i) * ld + 16 * q);
+    for (int h = 0; h < 4; ++h) d0[h] = make_double2(a[2 * h], a[2 * h + 1]);
+    if (two) {
+      double2* d1 = reinterpret_cast<double2*>(A + (int64_t)(64 + i) * ld + 8 * w);
 #pragma unroll
-    for (int h = 0; h < 8; ++h) d1[h] = make_double2(a[2 * h], a[2 * h + 1]);
+      for (int h = 0; h < 4; ++h) d1[h] = make_double2(a2[2 * h], a2[2 * h + 1]);
+    }
   }
   __syncthreads();
   if (stamps && tid == 0) stamps[2] = clock64();
-  const int lane = i, lr = lane & 15, lk = lane >> 4;
+  const int lr = lane & 15, lk = lane >> 4;
   if (two) {
     // ---- SYRK: U = L10 L10^T, the ten lower 16x16 tiles over the eight waves, operands out of the LcX image
     for (int t = w; t < 10; t += 8) {             // linear lower index: ti (ti + 1) / 2 + tj
@@ -436,33 +415,28 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
     __syncthreads();
     if (stamps && tid == 0) stamps[3] = clock64();
     // elements above the diagonal pick up whatever the exchange area holds: they never reach the lower triangle
-    if (owner) {
 #pragma unroll
-      for (int cc = 0; cc < 16; ++cc) b[cc] -= Wr[i * 81 + 16 * q + cc];
-    }
+    for (int cc = 0; cc < 8; ++cc) b[cc] -= Wr[i * 81 + 8 * w + cc];
     if (tid < 64) LcX[tid * DS + 64] = 0.0;      // the L10 image makes room for L11: its markers start over
     __syncthreads();   // the exchange area is re-used for the waves' diagonal inverses
-    // ---- columns 64..127: L11 by the owners; inv(L00) by the followers meanwhile
-    if (owner) {
-      factor_quarter<false>(b, a, LcX, LcX, &flags[0], i, q);
+    // ---- columns 64..127: L11
+    factor_block8<false>(b, a2, LcX, LcX, &flags[0], i, w);
 #pragma unroll
-      for (int cc = 0; cc < 16; ++cc) b[cc] = (i >= 16 * q + cc) ? b[cc] : 0.0;
-      double2* d2 = reinterpret_cast<double2*>(A + (int64_t)(64 + i) * ld + 64 + 16 * q);
+    for (int cc = 0; cc < 8; ++cc) b[cc] = (i >= 8 * w + cc) ? b[cc] : 0.0;
+    double2* d2 = reinterpret_cast<double2*>(A + (int64_t)(64 + i) * ld + 64 + 8 * w);
 #pragma unroll
-      for (int h = 0; h < 8; ++h) d2[h] = make_double2(b[2 * h], b[2 * h + 1]);
-      if (stamps && tid == 0) stamps[4] = clock64();
-    } else {
-      inverse_wave(Lc0, Wr + (w - 4) * 4 * 272, dinv + (int64_t)kb * 4096, w - 4, lane);
-    }
+    for (int h = 0; h < 4; ++h) d2[h] = make_double2(b[2 * h], b[2 * h + 1]);
+    if (stamps && tid == 0) stamps[4] = clock64();
     __syncthreads();
     if (stamps && tid == 0) stamps[5] = clock64();
-    if (owner) inverse_wave(LcX, Wr + w * 4 * 272, dinv + (int64_t)(kb + 1) * 4096, w, lane);
+    if (w < 4) inverse_wave(Lc0, Wr + w * 4 * 272, dinv + (int64_t)kb * 4096, w, lane);
+    else inverse_wave(LcX, Wr + w * 4 * 272, dinv + (int64_t)(kb + 1) * 4096, w - 4, lane);
   } else {
-    if (owner) inverse_wave(Lc0, Wr + w * 4 * 272, dinv + (int64_t)kb * 4096, w, lane);
+    if (w < 4) inverse_wave(Lc0, Wr + w * 4 * 272, dinv + (int64_t)kb * 4096, w, lane);
   }
   if (w == 0) {
-    // LAPACK potrf: order of the first non-positive leading minor (the images are complete: the second inverse / the only one
-    // started behind a barrier)
+    // LAPACK potrf: order of the first non-positive leading minor (the images are complete: the inverses started behind
+    // a barrier)
     int bad = first_bad_column(Lc0, lane);
     if (two && bad == 0) {
       const int bad2 = first_bad_column(LcX, lane);

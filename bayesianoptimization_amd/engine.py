@@ -356,12 +356,12 @@ class GpEngine:
         return {n: float(ms[i]) for i, n in enumerate(TIMING_NAMES)}
 
     def debug_cholesky(self, A, variant=3, iters=1):
-        """The device Cholesky alone (gpbo_debug_cholesky): returns (L lower n x n, dinv [n/64][64][64], stamps[8], ms, info)."""
+        """The device Cholesky alone (gpbo_debug_cholesky): returns (L lower n x n, dinv [n/64][64][64], stamps[16], ms, info)."""
         A = np.ascontiguousarray(A, dtype=np.float64)
         n = A.shape[0]
         Lo = np.empty((n, n))
         dinv = np.empty((n // 64, 64, 64))
-        stamps = np.zeros(8, dtype=np.int64)
+        stamps = np.zeros(16, dtype=np.int64)
         ms, info = C.c_double(0.0), C.c_int(0)
         self._check(self._lib.gpbo_debug_cholesky(self._h, dptr(A), n, int(variant), int(iters), dptr(Lo), dptr(dinv),
                                                   stamps.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(ms), C.byref(info)))

@@ -276,7 +276,7 @@ int gpbo_group_get_candidate_rows(gpbo_group* grp, const int64_t* idx, int n, do
 /* ---- device self-tests / micro-benchmarks (used by tests and bench headers) -------------- */
 /* The blocked Cholesky alone on an n x n matrix (n a multiple of 64, lower triangle read; replaces LAPACK dpotrf behind
  * sklearn _gpr.py:349): L_out = the factorised buffer (n x n row-major, lower triangle valid), dinv_out = the inverted
- * 64x64 diagonal blocks [n/64][64][64], stamps_out[8] = shader-clock stamps of the first diagonal workgroup's phases
+ * 64x64 diagonal blocks [n/64][64][64], stamps_out[16] = shader-clock stamps of the first diagonal workgroup's phases
  * (variant 3), ms_out = best of `iters` device times, info_out = LAPACK-style pivot info.  variant 3: round-3 schedule
  * (128-column steps), 2: round-2 schedule.  Any output pointer may be NULL. */
 int gpbo_debug_cholesky(gpbo_ctx* ctx, const double* A, int64_t n, int variant, int iters, double* L_out, double* dinv_out,
