@@ -48,6 +48,9 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // compiler has to keep the order.
 #define GPBO_LDS_ORDER() asm volatile("" ::: "memory")
 #define GPBO_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef GPBO_CHOL_POLL_SLEEP
+#define GPBO_CHOL_POLL_SLEEP 8      // x 64 cycles between two looks at a marker, cut short by the owner's s_wakeup
+#endif
 
 // a[c] -= l * m_c and (the riding row) a2[c] -= l2 * m_c for N of the wave's own columns, m_c = the value of l in lane
 // C0 + c (the rows of the wave's diagonal 8x8 block sit in lanes 0..7): v_readlane_b32 into FIXED scalar registers,
@@ -169,30 +172,29 @@ template <bool FOLLOW>
 __device__ __forceinline__ void factor_block8(double (&a)[8], double (&a2)[8], double* __restrict__ Lc, double* __restrict__ Lc2,
                                               int* broken, const int i, const int w, long long* stamp = nullptr) {
   {
+    // Catch-up, two columns per turn (columns are published in order: the marker of column k + 1 vouches for k and
+    // k + 1).  LDS time is what the waves compete for — a waiting wave that keeps re-reading slows the chain wave's
+    // stores — so a waiting wave reads ONE word, the marker, and sleeps until the owner's s_wakeup (sent behind every
+    // second column) or the sleep's own end; the data is read once, after the marker.
     const double* prow0 = Lc + 8 * w;      // L[8w + cc][k] = prow0[k * DS + cc]: the same address for every lane
     for (int k = 0; k < 8 * w; k += 2) {
-      // Columns are published in order: the marker of column k + 1 vouches for k and k + 1.  The data reads are issued
-      // right behind the marker read (LDS serves a wave's reads in order): if the marker was set they are valid,
-      // otherwise everything is read again.
-      double li[2], li2[2], p[2][8];
       int spins = 0;
-      for (;;) {
-        const double m = Lc[(k + 1) * DS + 64];
-        GPBO_LDS_ORDER();
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          li[u] = Lc[(k + u) * DS + i];
-          li2[u] = FOLLOW ? Lc2[(k + u) * DS + i] : 0.0;
-#pragma unroll
-          for (int cc = 0; cc < 8; ++cc) p[u][cc] = prow0[(k + u) * DS + cc];
-        }
-        GPBO_LDS_ORDER();
-        if (m != 0.0) break;
+      while (Lc[(k + 1) * DS + 64] == 0.0) {
         if (++spins > (1 << 22)) {   // cannot happen while the owner wave runs; never hang the GPU on a bug
           if (i == 0) *broken = 1;
           break;
         }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(GPBO_CHOL_POLL_SLEEP);
+        GPBO_LDS_ORDER();
+      }
+      GPBO_LDS_ORDER();
+      double li[2], li2[2], p[2][8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        li[u] = Lc[(k + u) * DS + i];
+        li2[u] = FOLLOW ? Lc2[(k + u) * DS + i] : 0.0;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) p[u][cc] = prow0[(k + u) * DS + cc];
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
@@ -203,6 +205,7 @@ __device__ __forceinline__ void factor_block8(double (&a)[8], double (&a2)[8], d
         }
     }
   }
+  __builtin_amdgcn_s_setprio(3);     // the chain: where two waves share a SIMD the arbiter should pick this one
   double pivsrc = a[0];        // lane jj of this holds the pivot of the wave's next column
   double* col = Lc + 8 * w * DS + i;        // column 8w + jj of the image: col[jj * DS]
   double* col2 = Lc2 + 8 * w * DS + i;
@@ -231,6 +234,7 @@ __device__ __forceinline__ void factor_block8(double (&a)[8], double (&a2)[8], d
     GPBO_LDS_ORDER();
     col[jj * DS + 64] = rs;
     GPBO_LDS_ORDER();
+    if (jj & 1) asm volatile("s_wakeup" ::: "memory");      // the store is in the LDS queue before any reader woken by this can queue its read
     GPBO_SCHED_FENCE();
     switch (jj) {     // jj is a compile-time constant of the unrolled loop: only its own case survives
       case 0: bcast_fma_from<1, FOLLOW>(a, a2, l, l2); break;
@@ -244,6 +248,7 @@ __device__ __forceinline__ void factor_block8(double (&a)[8], double (&a2)[8], d
     }
     GPBO_SCHED_FENCE();
   }
+  __builtin_amdgcn_s_setprio(0);
   if (stamp && i == 0) stamp[w] = clock64();
 }
 
@@ -624,7 +629,9 @@ static int launch_step(gpbo_ctx* ctx, Model& m, int kb, int nblk, const GemmArgs
 // The rank-`outer` trailing update of panel p only has to reach the NEXT panel's columns before that panel's chain can
 // start; the rest of it (T_b) is independent of the chain and runs on a second ("bulk") stream meanwhile:
 //     main:  chain(p) | [wait T_b(p-1)] T_a(p) | chain(p+1) | ...
-//     bulk:            [wait chain(p)]  T_b(p)
+//     bulk:                             [wait T_a(p)] T_b(p)
+// (T_b starts behind T_a, not beside it: side by side the two share the chip and T_a, which the chain waits for, takes
+// 106 us instead of ~45 at N = 4096)
 // T_a(p) waits for T_b(p-1) because both accumulate into the next panel's columns and the order of the two rank-512
 // contributions is part of the result (bitwise the one-stream factor: same launches, same kernels, same order per tile).
 // Round 2 measured this with a plain second stream and dropped it: the bulk GEMM's workgroups hold every CU, so the
@@ -636,7 +643,7 @@ static int lookahead_min_np() {
     const char* e = getenv("GPBO_CHOL_LA");
     if (e && e[0] == '0') return 1 << 30;
     const char* f = getenv("GPBO_CHOL_LA_MIN_NP");
-    return f ? atoi(f) : 2048;
+    return f ? atoi(f) : 4096;     // measured (scripts/r03_la_probe.py): 2048 0.709 -> 0.721 ms, 4096 1.82 -> 1.75, 8192 6.42 -> 6.17
   }();
   return v;
 }
@@ -679,7 +686,7 @@ int launch_cholesky128(gpbo_ctx* ctx, Model& m, int outer, long long* stamps) {
   const unsigned lanes = (unsigned)ctx->lanes;
   int rc;
   const int n_panels = (nblk + per_outer - 1) / per_outer;
-  LookAhead* la = (ctx->lanes == 1 && m.NP >= lookahead_min_np() && n_panels >= 3) ? lookahead_for(ctx, 2 * n_panels) : nullptr;
+  LookAhead* la = (ctx->lanes == 1 && !ctx->no_lookahead && m.NP >= lookahead_min_np() && n_panels >= 3) ? lookahead_for(ctx, 2 * n_panels) : nullptr;
   bool la_joined = true;
   int pidx = 0;     // outer panel index
   for (int ob = 0; ob < nblk; ob += per_outer) {
@@ -723,12 +730,11 @@ int launch_cholesky128(gpbo_ctx* ctx, Model& m, int outer, long long* stamps) {
         if ((rc = launch_gemm(ctx, t))) return rc;
         la_joined = true;
       } else {
-        // chain(p) is complete on main: the bulk stream may read the panel
-        GPBO_HIP(ctx, hipEventRecord(la->ev[2 * pidx], ctx->stream));
         if (pidx > 0) GPBO_HIP(ctx, hipStreamWaitEvent(ctx->stream, la->ev[2 * (pidx - 1) + 1], 0));
         t.m = rem2; t.n = nw; t.A = P; t.B = P;
         t.C = m.L + (int64_t)oe * NB * m.NP + (int64_t)oe * NB;
-        if ((rc = launch_gemm(ctx, t))) return rc;        // T_a on main
+        if ((rc = launch_gemm(ctx, t))) return rc;        // T_a on main, with the whole chip to itself:
+        GPBO_HIP(ctx, hipEventRecord(la->ev[2 * pidx], ctx->stream));   // the bulk stream starts behind it
         hipStream_t main_stream = ctx->stream;
         ctx->stream = la->bulk;
         hipError_t e = hipStreamWaitEvent(la->bulk, la->ev[2 * pidx], 0);

@@ -634,7 +634,10 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
   // GPBO_TRI64=0 turns the rule off (A/B runs).
   static const bool tri64 = !(getenv("GPBO_TRI64") && getenv("GPBO_TRI64")[0] == '0');
   const bool triangular = g.a_lower || g.b_lower || g.k_from_tile;
-  const bool prefer64 = tri64 && triangular && blocks128 < 512;
+  // ... and W^T W (k_from_tile: the first tile's k-loop is the whole N) takes them while one 128x128 tile per slot would make that
+  // tile the launch: N = 4096, 528 tiles: 1.04 ms, the longest tile alone 1.05 ms at a 512th of the chip's rate
+  static const int tri64_limit = getenv("GPBO_TRI64_LIMIT") ? atoi(getenv("GPBO_TRI64_LIMIT")) : 600;
+  const bool prefer64 = tri64 && triangular && (blocks128 < 512 || (g.k_from_tile && blocks128 < tri64_limit));
   if (gemm128_enabled() && !prefer64 && g.m >= 128 && g.n >= 128 && g.k >= 256 && blocks128 >= 192) {
     constexpr size_t lds = (size_t)4 * G2_TILE * sizeof(double);   // 65 536 B
     if (!(ctx->func_attrs & ATTR_GEMM128)) {

@@ -771,7 +771,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
   void* pinned0 = ctx->pinned;
   auto restore = [&]() {
     ctx->stream = stream0; ctx->red = red0; ctx->cap_red = cap_red0; ctx->info_dev = info0; ctx->pinned = pinned0;
-    ctx->lanes = 1; ctx->lane_stride = 0; ctx->no_timing = false;
+    ctx->lanes = 1; ctx->lane_stride = 0; ctx->no_timing = false; ctx->no_lookahead = false;
   };
   rc = GPBO_OK;
   for (int g = 0; g < n_groups && rc == GPBO_OK; ++g) {
@@ -795,6 +795,8 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
     ctx->pinned = window;
     ctx->lanes = gl; ctx->lane_stride = stride;
     ctx->no_timing = true;
+    static const bool la_lanes = getenv("GPBO_CHOL_LA_LANES") && getenv("GPBO_CHOL_LA_LANES")[0] == '1';
+    ctx->no_lookahead = n_groups > 1 && !la_lanes;
     auto enqueue = [&](double** oh, int** ih) {
       int r = enqueue_factor(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, ih);
       if (r == GPBO_OK) r = lml_tail(ctx, m, n_ls, eval_gradient, oh);

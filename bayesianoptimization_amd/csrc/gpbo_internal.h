@@ -84,6 +84,7 @@ struct gpbo_ctx {
   // gpbo_lml_batch: its stream (lml_stream[0]); the lanes' buffers live in lml_slab
   hipStream_t lml_stream[GPBO_LML_BATCH_MAX] = {};
   bool no_timing = false;   // batch lanes do not touch the timing events
+  bool no_lookahead = false;   // several lane streams in flight: the Cholesky look-ahead would only add streams to a full chip
   // gpbo_fit_begin / gpbo_fit_wait: a slot's fit enqueued on the slot's own stream, its staging words in pinned window
   // 1 + slot (the windows gpbo_lml_batch uses for its groups — it waits for pending fits first), its pivot word in info_slots
   hipStream_t slot_stream[GPBO_MAX_MODELS] = {};
