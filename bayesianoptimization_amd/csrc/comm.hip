@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <functional>
@@ -35,6 +36,7 @@ struct RcclApi {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;      // optional: the failure path works without it, it only cannot unblock a peer
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -64,6 +66,7 @@ static int load_rccl(gpbo_ctx* ctx) {
   g_rccl.AllGather = (decltype(g_rccl.AllGather))dlsym(h, "ncclAllGather");
   g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+  g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(h, "ncclCommAbort");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommInitAll || !g_rccl.AllGather || !g_rccl.AllReduce ||
       !g_rccl.CommDestroy)
@@ -106,6 +109,51 @@ static int comm_buffers(gpbo_ctx* ctx, int n_records, char** dsend, char** drecv
   return GPBO_OK;
 }
 
+// ---- failure path -------------------------------------------------------------------------------------------------
+// A collective only completes if every rank enters it.  Two rules keep one rank's trouble from becoming everybody's hang:
+//  (1) a rank whose LOCAL work failed still enters the all-gather, with a poisoned arg-best record (index INT64_MIN):
+//      every rank finishes the exchange, sees the poison and returns GPBO_ERR_COMM (the failing rank: its own code);
+//  (2) nobody waits for a collective without a deadline (GPBO_COMM_TIMEOUT_S, default 120): when it passes, the rank
+//      aborts its communicator (ncclCommAbort: the stuck kernel is released) and returns GPBO_ERR_COMM; the communicator
+//      is gone after that and every later collective call says so.
+constexpr int64_t POISON_INDEX = std::numeric_limits<int64_t>::min();
+
+static double env_seconds(const char* name, double dflt) {
+  const char* e = getenv(name);
+  if (!e) return dflt;
+  const double v = atof(e);
+  return v > 0.0 ? v : dflt;
+}
+
+static void abort_comm(gpbo_ctx* ctx) {
+  if (!ctx || !ctx->comm) return;
+  if (g_rccl.CommAbort) (void)g_rccl.CommAbort((ncclComm_t)ctx->comm);
+  ctx->comm = nullptr;       // never used again (not destroyed: ncclCommAbort has released it)
+  ctx->comm_lost = true;
+}
+
+// hipStreamSynchronize with a deadline; on expiry the communicator is aborted
+static int wait_collective(gpbo_ctx* ctx, const char* what) {
+  const double limit = env_seconds("GPBO_COMM_TIMEOUT_S", 120.0);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 0;; ++spin) {
+    const hipError_t e = hipStreamQuery(ctx->stream);
+    if (e == hipSuccess) return GPBO_OK;
+    if (e != hipErrorNotReady) {
+      abort_comm(ctx);
+      GPBO_HIP(ctx, e);
+    }
+    const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (waited > limit) {
+      abort_comm(ctx);
+      GPBO_FAIL(ctx, GPBO_ERR_COMM, std::string(what) + ": the collective did not complete within " + std::to_string((int)limit) +
+                                        " s (GPBO_COMM_TIMEOUT_S) — a peer never entered it; communicator aborted");
+    }
+    if (spin < 2000) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
 }  // namespace gpbo
 
 using namespace gpbo;
@@ -131,6 +179,7 @@ extern "C" int gpbo_comm_init(gpbo_ctx* ctx, const char id[128], int world_size,
   ncclComm_t comm = nullptr;
   GPBO_NCCL(ctx, g_rccl.CommInitRank(&comm, world_size, uid, rank));
   ctx->comm = comm;
+  ctx->comm_lost = false;
   ctx->world = world_size;
   ctx->rank = rank;
   return GPBO_OK;
@@ -151,7 +200,7 @@ extern "C" int gpbo_comm_allgather_best(gpbo_ctx* ctx, const double* vals, const
   GPBO_HIP(ctx, hipMemcpyAsync(dsend, host.data(), send_bytes, hipMemcpyHostToDevice, ctx->stream));
   GPBO_NCCL(ctx, g_rccl.AllGather(dsend, drecv, send_bytes, ncclChar, (ncclComm_t)ctx->comm, ctx->stream));
   GPBO_HIP(ctx, hipMemcpyAsync(hrecv, drecv, recv_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if ((rc = wait_collective(ctx, "comm_allgather_best"))) return rc;
   const BestRecord* all = (const BestRecord*)hrecv;
   for (int t = 0; t < n_records * ctx->world; ++t) { all_vals[t] = all[t].v; all_idxs[t] = all[t].i; }
   return GPBO_OK;
@@ -165,24 +214,66 @@ extern "C" int gpbo_comm_acq_argbest(gpbo_ctx* ctx, int acq, double acq_param, d
   int rc = build_acq_args(ctx, "comm_acq_argbest", acq, acq_param, y_max, n_constraints, lb, ub, k_seeds, best_idx,
                           best_val, seed_idx, seed_val, &a);
   if (rc) return rc;
+  if (ctx->comm_lost) GPBO_FAIL(ctx, GPBO_ERR_COMM, "comm_acq_argbest: the communicator was aborted after a failed collective");
   if (ctx->world > 1 && !ctx->comm) GPBO_FAIL(ctx, GPBO_ERR_STATE, "comm_acq_argbest: communicator not initialised");
   char *dsend, *drecv, *hrecv;
   const int n_records = 1 + k_seeds;
-  if ((rc = comm_buffers(ctx, n_records, &dsend, &drecv, &hrecv))) return rc;
+  if ((rc = comm_buffers(ctx, n_records, &dsend, &drecv, &hrecv))) {
+    abort_comm(ctx);       // no buffers to enter the exchange with: the peers' deadline ends their wait
+    return rc;
+  }
   const size_t send_bytes = sizeof(BestRecord) * (size_t)n_records, recv_bytes = send_bytes * (size_t)ctx->world;
   ev_begin(ctx, T_ACQ);
-  rc = launch_acq_records(ctx, a, ctx->M, k_seeds, index_offset, (BestRecord*)dsend);
-  if (rc) return rc;
+  int rc_local = launch_acq_records(ctx, a, ctx->M, k_seeds, index_offset, (BestRecord*)dsend);
+  if (const char* inj = getenv("GPBO_TEST_FAIL_ACQ_RANK"))          // tests: this rank pretends its local pass failed
+    if (rc_local == GPBO_OK && atoi(inj) == ctx->rank) {
+      ctx->err = "injected local failure (GPBO_TEST_FAIL_ACQ_RANK)";
+      rc_local = GPBO_ERR_HIP;
+    }
+  const std::string local_err = ctx->err;
+  if (rc_local != GPBO_OK && ctx->comm) {
+    // rule (1): enter the exchange anyway, with a poisoned record
+    std::vector<BestRecord> poison((size_t)n_records, BestRecord{std::numeric_limits<double>::quiet_NaN(), -1});
+    poison[0].i = POISON_INDEX;
+    if (hipMemcpyAsync(dsend, poison.data(), send_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) {     // the staging vector dies with this scope
+      (void)hipGetLastError();
+      ev_end(ctx, T_ACQ);
+      abort_comm(ctx);
+      ctx->err = local_err;
+      return rc_local;
+    }
+  } else if (rc_local != GPBO_OK) {
+    ev_end(ctx, T_ACQ);
+    return rc_local;
+  }
   const char* gathered = dsend;    // a single shard is its own union
   if (ctx->comm) {
-    GPBO_NCCL(ctx, g_rccl.AllGather(dsend, drecv, send_bytes, ncclChar, (ncclComm_t)ctx->comm, ctx->stream));
+    const ncclResult_t nr = g_rccl.AllGather(dsend, drecv, send_bytes, ncclChar, (ncclComm_t)ctx->comm, ctx->stream);
+    if (nr != ncclSuccess) {
+      ev_end(ctx, T_ACQ);
+      abort_comm(ctx);
+      GPBO_FAIL(ctx, GPBO_ERR_COMM, std::string("ncclAllGather failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(nr) : "?"));
+    }
     gathered = drecv;
   }
   ev_end(ctx, T_ACQ);
   GPBO_HIP(ctx, hipMemcpyAsync(hrecv, gathered, ctx->comm ? recv_bytes : send_bytes, hipMemcpyDeviceToHost, ctx->stream));
-  if (ys_out) GPBO_HIP(ctx, hipMemcpyAsync(ys_out, ctx->ys, (size_t)ctx->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  merge_records((const BestRecord*)hrecv, ctx->comm ? ctx->world : 1, k_seeds, best_idx, best_val, seed_idx, seed_val);
+  if (ys_out && rc_local == GPBO_OK)
+    GPBO_HIP(ctx, hipMemcpyAsync(ys_out, ctx->ys, (size_t)ctx->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx->comm) {
+    if ((rc = wait_collective(ctx, "comm_acq_argbest"))) return rc;
+  } else {
+    GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  const int world = ctx->comm ? ctx->world : 1;
+  const BestRecord* all = (const BestRecord*)hrecv;
+  for (int r = 0; r < world; ++r)
+    if (all[(size_t)r * n_records].i == POISON_INDEX) {
+      if (rc_local != GPBO_OK) { ctx->err = local_err; set_global_error(local_err); return rc_local; }
+      GPBO_FAIL(ctx, GPBO_ERR_COMM, "comm_acq_argbest: rank " + std::to_string(r) + " reported a local failure; no result for this step");
+    }
+  merge_records(all, world, k_seeds, best_idx, best_val, seed_idx, seed_val);
   return GPBO_OK;
 }
 
@@ -200,7 +291,7 @@ extern "C" int gpbo_comm_allreduce_max(gpbo_ctx* ctx, double* value) {
   GPBO_HIP(ctx, hipMemcpyAsync(dword, hword, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   GPBO_NCCL(ctx, g_rccl.AllReduce(dword, dword, 1, ncclDouble, ncclMax, (ncclComm_t)ctx->comm, ctx->stream));
   GPBO_HIP(ctx, hipMemcpyAsync(hword, dword, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if ((rc = wait_collective(ctx, "comm_allreduce_max"))) return rc;
   *value = *hword;
   return GPBO_OK;
 }
@@ -209,6 +300,7 @@ extern "C" int gpbo_comm_destroy(gpbo_ctx* ctx) {
   if (!ctx) return GPBO_ERR_INVALID;
   if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)ctx->comm);
   ctx->comm = nullptr;
+  ctx->comm_lost = false;
   ctx->world = 1;
   ctx->rank = 0;
   return GPBO_OK;
@@ -235,7 +327,19 @@ struct gpbo_group {
   int d = 0;
   std::vector<int64_t> row0;       // device r owns rows [row0[r], row0[r + 1])
 
+  bool broken = false;             // a job missed its deadline: communicators aborted, workers possibly stuck, nothing runs any more
+  bool no_device = false;          // self-test group without contexts (gpbo_group_debug_create)
+
+  // Every job has a deadline (GPBO_GROUP_TIMEOUT_S, default 300): a worker that never comes back — a collective a peer
+  // did not enter, a wedged device — turns into GPBO_ERR_COMM for the caller instead of a hung suggest().  The
+  // communicators are aborted (which releases workers blocked inside RCCL), the group is marked broken and every later
+  // call fails at once; gpbo_group_destroy then detaches whatever is still stuck.
   int run(std::function<int(int)> f) {
+    if (broken) {
+      err = "device group is broken (an earlier call missed its deadline or lost its communicator); create a new group";
+      set_global_error(err);
+      return GPBO_ERR_COMM;
+    }
     {
       std::lock_guard<std::mutex> lk(mu);
       job = std::move(f);
@@ -244,19 +348,36 @@ struct gpbo_group {
     }
     cv_job.notify_all();
     std::unique_lock<std::mutex> lk(mu);
-    cv_done.wait(lk, [&] { return pending == 0; });
+    const double limit = env_seconds("GPBO_GROUP_TIMEOUT_S", 300.0);
+    if (!cv_done.wait_for(lk, std::chrono::duration<double>(limit), [&] { return pending == 0; })) {
+      broken = true;
+      std::string late;
+      for (size_t r = 0; r < ctx.size(); ++r)
+        if (!done_flag[r]) late += (late.empty() ? "" : ", ") + std::to_string(r);
+      for (gpbo_ctx* c : ctx) abort_comm(c);
+      // released by the abort, the workers usually come back with an error within moments: give them that long, so that
+      // nothing of this call's stack is referenced afterwards
+      cv_done.wait_for(lk, std::chrono::seconds(5), [&] { return pending == 0; });
+      err = "device group: rank(s) " + late + " did not finish within " + std::to_string((int)limit) +
+            " s (GPBO_GROUP_TIMEOUT_S); communicators aborted, the group is unusable";
+      set_global_error(err);
+      return GPBO_ERR_COMM;
+    }
     for (size_t r = 0; r < ctx.size(); ++r)
       if (rcs[r] != GPBO_OK) {
-        err = "device " + std::to_string(devices[r]) + " (rank " + std::to_string(r) + "): " + ctx[r]->err;
+        err = "device " + std::to_string(no_device ? (int)r : devices[r]) + " (rank " + std::to_string(r) + "): " +
+              (ctx[r] ? ctx[r]->err : std::string("injected failure"));
         set_global_error(err);
+        if (rcs[r] == GPBO_ERR_COMM || (ctx[r] && ctx[r]->comm_lost)) broken = true;   // a lost communicator never comes back
         return rcs[r];
       }
     return GPBO_OK;
   }
+  std::vector<char> done_flag;
 };
 
 static void group_worker(gpbo_group* g, int rank) {
-  (void)hipSetDevice(g->devices[rank]);
+  if (!g->no_device) (void)hipSetDevice(g->devices[rank]);
   uint64_t seen = 0;
   for (;;) {
     std::function<int(int)> f;
@@ -266,11 +387,13 @@ static void group_worker(gpbo_group* g, int rank) {
       if (g->stop) return;
       seen = g->generation;
       f = g->job;
+      g->done_flag[rank] = 0;
     }
     const int rc = f(rank);
     {
       std::lock_guard<std::mutex> lk(g->mu);
       g->rcs[rank] = rc;
+      g->done_flag[rank] = 1;
       --g->pending;
     }
     g->cv_done.notify_all();
@@ -295,6 +418,7 @@ extern "C" int gpbo_group_create(int n_dev, const int* devices, gpbo_group** out
     if (e[0] == '1') g->virtual_ranks = true;
   g->devices.assign(devices, devices + n_dev);
   g->rcs.assign((size_t)n_dev, GPBO_OK);
+  g->done_flag.assign((size_t)n_dev, 1);
   auto cleanup = [&](int rc) {
     for (gpbo_ctx* c : g->ctx) gpbo_destroy(c);
     delete g;
@@ -332,10 +456,46 @@ extern "C" int gpbo_group_destroy(gpbo_group* g) {
     g->stop = true;
   }
   g->cv_job.notify_all();
+  bool stuck = false;
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    stuck = g->broken && g->pending > 0;
+  }
+  if (stuck) {
+    // a worker is still inside a call that never returns: it cannot be joined and its context cannot be torn down under
+    // it — leave both to the process (this group is only ever destroyed on the way out of a failed run)
+    for (auto& t : g->workers) t.detach();
+    return GPBO_OK;
+  }
   for (auto& t : g->workers) t.join();
-  for (gpbo_ctx* c : g->ctx) gpbo_destroy(c);
+  for (gpbo_ctx* c : g->ctx) if (c) gpbo_destroy(c);
   delete g;
   return GPBO_OK;
+}
+
+// Self-test seam (no device needed): a group of `n_ranks` workers without contexts, and a job in which rank `fail_rank`
+// returns `fail_code` and rank `hang_rank` sleeps `hang_ms` before returning — what a failed / wedged device looks like
+// to gpbo_group::run.  Either rank may be -1.
+extern "C" int gpbo_group_debug_create(int n_ranks, gpbo_group** out) {
+  if (!out || n_ranks < 1 || n_ranks > 64) return GPBO_ERR_INVALID;
+  gpbo_group* g = new gpbo_group();
+  g->no_device = true;
+  g->virtual_ranks = true;
+  g->collective = "none(self-test)";
+  g->ctx.assign((size_t)n_ranks, nullptr);
+  g->rcs.assign((size_t)n_ranks, GPBO_OK);
+  g->done_flag.assign((size_t)n_ranks, 1);
+  for (int r = 0; r < n_ranks; ++r) g->workers.emplace_back(group_worker, g, r);
+  *out = g;
+  return GPBO_OK;
+}
+
+extern "C" int gpbo_group_debug_run(gpbo_group* g, int fail_rank, int fail_code, int hang_rank, int hang_ms) {
+  if (!g) return GPBO_ERR_INVALID;
+  return g->run([=](int r) {
+    if (r == hang_rank) std::this_thread::sleep_for(std::chrono::milliseconds(hang_ms));
+    return r == fail_rank ? fail_code : (int)GPBO_OK;
+  });
 }
 
 extern "C" int gpbo_group_size(const gpbo_group* g) { return g ? (int)g->ctx.size() : 0; }

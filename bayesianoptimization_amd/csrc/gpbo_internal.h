@@ -144,6 +144,7 @@ struct gpbo_ctx {
   gpbo::EventPair ev[gpbo::T_COUNT];
   // RCCL
   void* comm = nullptr;
+  bool comm_lost = false;        // the communicator was aborted after a collective failed or timed out
   int world = 1, rank = 0;
   void* comm_buf = nullptr;      // device: [send records | gathered records | 8-byte reduction word]
   int64_t cap_comm_buf = 0;

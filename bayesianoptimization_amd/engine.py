@@ -507,6 +507,16 @@ class GroupEngine(GpEngine):
         if rc != _lib.GPBO_OK:
             _lib.raise_for_status(self._lib, None, rc, info, group=self._g)
 
+    def per_device_timings(self) -> list:
+        """`last_timings()` of every device of the group (HIP events on each device's own stream): a straggler shows here."""
+        out = []
+        for r in range(self.world_size):
+            ms = (C.c_float * 8)()
+            h = C.c_void_p(self._lib.gpbo_group_ctx(self._g, r))
+            self._check(self._lib.gpbo_last_timings(h, ms, 8))
+            out.append({n: float(ms[i]) for i, n in enumerate(TIMING_NAMES)})
+        return out
+
     def synchronize(self):
         self._gcheck(self._lib.gpbo_group_synchronize(self._g))
 

@@ -467,6 +467,18 @@ def main():
         kern_ms["posterior_main"] += post_ms[0] - tm["posterior_main"]   # both GPs' posterior launches
     barrier_max(0.0)
     elapsed = barrier_max(time.perf_counter() - t0)
+    per_rank = None
+    if mode == "ranks":
+        # every rank's stage times of its last step, gathered as (value, rank) records over the same RCCL communicator
+        tl = eng.last_timings()
+        try:
+            av, ai = eng.comm_allgather_best(np.array([tl["fit"], tl["posterior_main"], tl["acq_argbest"]]),
+                                             np.full(3, rank, dtype=np.int64))
+            av, ai = np.asarray(av).reshape(world, 3), np.asarray(ai).reshape(world, 3)
+            per_rank = [{"rank": int(ai[r, 0]), "fit": float(av[r, 0]), "posterior_main": float(av[r, 1]), "acq_argbest": float(av[r, 2])}
+                        for r in range(world)]
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] per-rank timings not gathered: {e!r}")
 
     if rank == 0:
         steps = args.steps
@@ -507,6 +519,12 @@ def main():
             "step_breakdown_ms": {k_: v / steps for k_, v in kern_ms.items()},
             "best": {"index": int(best[0]), "value": float(best[1])},
         }
+        # per-device stage times of the LAST timed step (HIP events on each device's own stream): a straggler is visible here
+        if mode == "group":
+            out["per_device_ms"] = [{"device": dv, "fit": t["fit"], "posterior_main": t["posterior_main"], "acq_argbest": t["acq_argbest"]}
+                                    for dv, t in zip(devs, eng.per_device_timings())]
+        elif mode == "ranks":
+            out["per_device_ms"] = per_rank
         if overlap:
             # `fit`, `kmat`, `cholesky`, `trtri` above = n_gp x ONE fit measured alone on the main stream; in the timed steps
             # the fits of the GPs run side by side:

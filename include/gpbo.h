@@ -272,6 +272,15 @@ int gpbo_group_acq_argbest(gpbo_group* grp, int acq, double acq_param, double y_
                            const double* lb, const double* ub, int k_seeds, int64_t* best_idx, double* best_val,
                            int64_t* seed_idx, double* seed_val, double* ys_out);
 int gpbo_group_get_candidate_rows(gpbo_group* grp, const int64_t* idx, int n, double* out);
+/* Failure path.  Every gpbo_group_* job has a deadline (GPBO_GROUP_TIMEOUT_S, default 300 s) and every wait for a
+ * collective has one (GPBO_COMM_TIMEOUT_S, default 120 s): a device that never comes back, or a peer that never enters
+ * the all-gather, turns into GPBO_ERR_COMM (communicators aborted with ncclCommAbort, the group / communicator unusable
+ * afterwards) instead of a hung suggest().  A rank whose LOCAL pass failed still enters the all-gather with a poisoned
+ * record, so that every rank returns an error from the same step.  Self-test seam, no device needed: a group of workers
+ * without contexts, and a job in which rank `fail_rank` returns `fail_code` and rank `hang_rank` sleeps `hang_ms`
+ * (either may be -1). */
+int gpbo_group_debug_create(int n_ranks, gpbo_group** out);
+int gpbo_group_debug_run(gpbo_group* grp, int fail_rank, int fail_code, int hang_rank, int hang_ms);
 
 /* ---- device self-tests / micro-benchmarks (used by tests and bench headers) -------------- */
 /* The blocked Cholesky alone on an n x n matrix (n a multiple of 64, lower triangle read; replaces LAPACK dpotrf behind

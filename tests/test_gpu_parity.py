@@ -268,6 +268,32 @@ def test_rccl_single_rank_roundtrip(engine):
         engine.world_size, engine.rank = 1, 0
 
 
+def test_rccl_local_failure_enters_the_exchange_and_surfaces_as_an_error(engine, monkeypatch):
+    """A rank whose local acquisition pass failed (here: injected) still enters ncclAllGather with a poisoned record, so
+    the collective completes on every rank and the call returns an error instead of leaving its peers blocked; the
+    communicator stays usable for the next step."""
+    from bayesianoptimization_amd.engine import GpEngine
+
+    X, y = _data(120, 3, seed=5)
+    yn, ym, ys = O.normalize_targets(y)
+    engine.fit(X, yn, O.MATERN25, 0.6, 1e-6)
+    engine.set_candidates(np.random.RandomState(6).uniform(size=(1000, 3)))
+    engine.posterior(0, ym, ys, fetch=False)
+    engine.comm_init(GpEngine.comm_unique_id(), 1, 0)
+    try:
+        good = engine.comm_acq_argbest(O.UCB, 2.0, k_seeds=4)
+        assert good[:2] == engine.acq_argbest(O.UCB, 2.0, k_seeds=4)[:2]
+        monkeypatch.setenv("GPBO_TEST_FAIL_ACQ_RANK", "0")
+        with pytest.raises(_lib.GpboError, match="injected local failure"):
+            engine.comm_acq_argbest(O.UCB, 2.0, k_seeds=4)
+        monkeypatch.delenv("GPBO_TEST_FAIL_ACQ_RANK")
+        again = engine.comm_acq_argbest(O.UCB, 2.0, k_seeds=4)
+        assert again[:2] == good[:2] and np.array_equal(again[2], good[2])
+    finally:
+        engine._lib.gpbo_comm_destroy(engine._h)
+        engine.world_size, engine.rank = 1, 0
+
+
 @pytest.mark.parametrize("N,d,kernel,ls", [
     (60, 3, O.MATERN25, 0.7), (200, 5, O.RBF, 0.6), (130, 4, O.MATERN25, [0.4, 0.7, 1.0, 1.3]),
     (257, 8, O.RBF, [0.8] * 8), (1, 2, O.MATERN25, 1.0), (700, 16, O.MATERN25, 1.5),
