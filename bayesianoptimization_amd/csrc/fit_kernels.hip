@@ -55,6 +55,12 @@ __device__ __forceinline__ double kernel_value(double d2) {
 // K (lower block triangle, 64x64 tiles): one workgroup per LOWER tile (linear block id -> (bi, bj), no idle
 // workgroups), 4x4 outputs per thread, the two point tiles staged k-major in LDS.  HBM-write bound: N^2/2 * 8 B.
 // `out` is K, or directly the buffer the Cholesky factorises in place (no K -> L copy on the fit path).
+// Not an HBM kernel despite what it writes: per element 2 DP + ~45 fp64 VALU operations (differences, sqrt, exp,
+// polynomial) = 16.5 us of VALU issue at N = 4096, d = 16 (38 us measured, 1.8 TB/s) and 93 us at N = 8192, d = 32 (160
+// measured) — at d = 32 the arithmetic alone caps the store rate at 2.9 TB/s = 0.46 of a copy's 6.29.  Round 3 measured a
+// row-walking variant (lane = column with its point in registers, the row's coordinates as SGPR operands through
+// s_load_dwordx16, one full 512-byte row segment per store, no LDS): the same bits, 44 / 158 us — no faster, 2x slower
+// at N <= 1024 (each row is a fresh scalar-cache miss) — and dropped it (scripts/r03_kmat_probe.py, profiles/r03_kmat_probe.json).
 template <int KERNEL>
 __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ Xs, int DP, int64_t N,
                                                    int64_t NP, double noise, double* __restrict__ K,
