@@ -97,6 +97,9 @@ SIGNATURES = {
                                          _c_double_p, C.c_int, _c_int64_p, _c_double_p, _c_int64_p, _c_double_p,
                                          _c_double_p]),
     "gpbo_group_get_candidate_rows": (C.c_int, [C.c_void_p, _c_int64_p, C.c_int, _c_double_p]),
+    "gpbo_polish_seeds": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, _c_double_p, _c_double_p, _c_double_p,
+                                    _c_double_p, _c_double_p, C.c_int, C.c_int, _c_double_p, _c_double_p, C.c_int, _c_double_p,
+                                    _c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gpbo_group_debug_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "gpbo_group_debug_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gpbo_debug_cholesky": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, C.c_int, C.c_int, _c_double_p, _c_double_p,

@@ -29,6 +29,7 @@ SOURCES = {
     "posterior_kernel.hip": [],
     "posterior_kernel_v2.hip": [],
     "posterior_small.hip": [],
+    "polish.hip": [],                          # gpbo_polish_seeds: the local-search stage as one C call (host optimiser, device evaluations)
     "posterior_kernel_f32.hip": [],
     "posterior_cov.hip": [],
     "lml_kernels.hip": [],

@@ -312,6 +312,7 @@ int gpbo_destroy(gpbo_ctx* ctx) {
   for (auto& st : ctx->slot_stream) if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
   if (ctx->small_ev) (void)hipEventDestroy(ctx->small_ev);
   if (ctx->small_pinned) (void)hipHostFree(ctx->small_pinned);
+  if (ctx->polish_pinned) (void)hipHostFree(ctx->polish_pinned);
   if (ctx->info_slots) (void)hipFree(ctx->info_slots);
   for (auto& ln : ctx->lml_lane) if (ln.exec) (void)hipGraphExecDestroy(ln.exec);
   if (ctx->lml_slab) (void)hipFree(ctx->lml_slab);

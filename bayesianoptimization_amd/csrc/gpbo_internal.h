@@ -135,6 +135,8 @@ struct gpbo_ctx {
   // candidates and results cross PCIe through this pinned block instead of the caller's pageable arrays — the runtime
   // stages pageable copies through its own buffers and blocks on them, ~15-20 us per copy
   void* small_pinned = nullptr;          // SMALL_PIN_BYTES: [candidates in | mu out | sd out]
+  void* polish_pinned = nullptr;         // gpbo_polish_seeds: per model [mu | sd | dmu | dsd] of a round coming back
+  int64_t cap_polish_pinned = 0;
   hipEvent_t small_ev = nullptr;         // the last H2D out of small_pinned has completed
   bool small_ev_pending = false;
   // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: one bit per kernel family, per context (a

@@ -329,6 +329,36 @@ class GpEngine:
         self._resident = False       # (device groups: the first device's candidate buffer was re-used)
         return mu, sd, dmu, dsd
 
+    def polish_seeds(self, acq: int, param: float, y_max, lb, ub, y_means, y_stds, seeds, box, max_iter: int = 0):
+        """gpbo_polish_seeds: the local searches of one suggest() in one call.  Returns (x (S,d), f (S,), status (S,) — 0/1
+        converged, 2 SciPy's success = False —, rounds)."""
+        self._settle()
+        seeds = np.ascontiguousarray(seeds, dtype=np.float64)
+        S, d = seeds.shape
+        lb = np.ascontiguousarray(np.atleast_1d(np.asarray(lb, dtype=np.float64))) if lb is not None else None
+        ub = np.ascontiguousarray(np.atleast_1d(np.asarray(ub, dtype=np.float64))) if ub is not None else None
+        n_c = 0 if lb is None else lb.shape[0]
+        ym = np.ascontiguousarray(np.atleast_1d(np.asarray(y_means, dtype=np.float64)))
+        ys = np.ascontiguousarray(np.atleast_1d(np.asarray(y_stds, dtype=np.float64)))
+        if ym.shape[0] != 1 + n_c or ys.shape[0] != 1 + n_c:
+            raise ValueError("one (y_mean, y_std) per model slot")
+        lo = np.ascontiguousarray(np.asarray(box, dtype=np.float64)[:, 0])
+        hi = np.ascontiguousarray(np.asarray(box, dtype=np.float64)[:, 1])
+        x = np.empty((S, d))
+        f = np.empty(S)
+        status = np.zeros(S, dtype=np.int32)
+        self.last_polish = {"nit": np.zeros(S, dtype=np.int32), "nfev": np.zeros(S, dtype=np.int32)}
+        rounds = C.c_int(0)
+        self._check(self._lib.gpbo_polish_seeds(self._h, int(acq), float(param), float(0.0 if y_max is None else y_max), n_c,
+                                                dptr(lb), dptr(ub), dptr(ym), dptr(ys), dptr(seeds), S, d, dptr(lo), dptr(hi),
+                                                int(max_iter), dptr(x), dptr(f), status.ctypes.data_as(C.POINTER(C.c_int)),
+                                                C.byref(rounds), self.last_polish["nit"].ctypes.data_as(C.POINTER(C.c_int)),
+                                                self.last_polish["nfev"].ctypes.data_as(C.POINTER(C.c_int))))
+        self.last_polish["rounds"] = rounds.value
+        self.n_candidates = S        # the candidate buffer held the rounds' trial points (at most S of them)
+        self._resident = False
+        return x, f, status, rounds.value
+
     # -- acquisition -----------------------------------------------------------------------------
     def acq_argbest(self, acq: int, param: float, y_max: float = 0.0, lb=None, ub=None, k_seeds: int = 0,
                     index_offset: int = 0, return_values: bool = False):

@@ -189,6 +189,10 @@ class AcquisitionFunction(abc.ABC):
     #: are no longer SciPy's finite-difference ones, so parity with the reference is statistical (equal or better
     #: acquisition value), not bit-wise.  Needs engine-backed GPs without input transform and a stock policy.
     analytic_gradient = False
+    # True: the whole local-search stage is ONE library call (gpbo_polish_seeds: projected L-BFGS on the host side of the C
+    # ABI, batched value + analytic gradient on the device, SciPy's stopping rule) — no SciPy, no Python between the
+    # rounds.  Not the reference's iterates: parity is statistical (the acquisition value at the returned point).
+    device_polish = False
     _acq_kind: int | None = None     # engine acquisition id of the stock policies; None = host formula only
 
     def __init__(self, random_state=None) -> None:
@@ -399,6 +403,21 @@ class AcquisitionFunction(abc.ABC):
 
     def _polish_seeds(self, acq, x_seeds, box):
         chain = getattr(self, "_fused", None)
+        if (self.device_polish and chain is not None and len(x_seeds) > 0 and chain[0].transform is None
+                and not np.any(box[:, 0] == box[:, 1]) and hasattr(chain[0]._engine(), "polish_seeds")
+                and len(x_seeds) <= _MAX_DEVICE_SEEDS):
+            cons = getattr(self, "_fused_constraint", None)
+            for model in chain:
+                model._ensure_resident()
+            lb, ub = (cons._lb, cons._ub) if cons is not None and len(chain) > 1 else (None, None)
+            xs, fs, status, _ = chain[0]._engine().polish_seeds(
+                self._acq_kind, self._acq_param(), getattr(self, "y_max", None), lb, ub,
+                [float(m._y_train_mean) for m in chain], [float(m._y_train_std) for m in chain], np.asarray(x_seeds), box)
+            ok = np.flatnonzero((status < 2) & np.isfinite(fs))         # SciPy's res.success
+            if ok.size == 0:
+                return None
+            k = ok[np.argmin(fs[ok])]                                  # the first of equal minima, as the reference's scan
+            return xs[k], fs[k]
         if (self.analytic_gradient and chain is not None and len(x_seeds) > 0 and chain[0].transform is None
                 and not np.any(box[:, 0] == box[:, 1])):
             cons = getattr(self, "_fused_constraint", None)

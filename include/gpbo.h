@@ -194,6 +194,24 @@ int gpbo_predict_cov(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d
 int gpbo_predict_grad(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int d, double y_mean, double y_std,
                       double* mu, double* sd, double* dmu, double* dsd);
 
+/* The local-search stage of a suggest() as ONE call.  Replaces AcquisitionFunction._smart_minimize for an all-continuous
+ * space (bayes_opt/acquisition.py:322-420: one scipy L-BFGS-B run per seed, every value a GP predict, every gradient d + 1
+ * of them): all `n_seeds` runs advance in lockstep, each round is one batched evaluation of
+ *   f(x) = -base_acq(mu0, sd0) [* prod_j (Phi((ub_j-mu_j)/sd_j) - Phi((lb_j-mu_j)/sd_j))]   and its gradient
+ * from the posteriors of slots 0..n_constraints and their input gradients (as gpbo_predict_grad), and the optimiser
+ * arithmetic (a projected L-BFGS with L-BFGS-B's stopping rule as SciPy configures it: 10 corrections, projected gradient
+ * 1e-5, relative reduction 1e7 eps, 20 line-search steps, max_iter <= 0 -> 15000 iterations) runs on the host in between.
+ * Not the reference's iterates: parity is statistical (acquisition value at the returned point).
+ * y_mean / y_std: (1 + n_constraints,) the targets' normalisation per slot; seeds (n_seeds,d), clipped into the box;
+ * box_lo < box_hi (d,).  Outputs per seed: x_out (n_seeds,d) inside the box, f_out, status_out (0: projected gradient
+ * below tolerance, 1: relative reduction below tolerance / no further progress, 2: iteration limit or a non-finite start —
+ * SciPy's success = False), n_rounds_out (optional) = batched evaluations issued; n_iter_out / n_eval_out (optional, per seed) =
+ * accepted steps / objective evaluations, SciPy's nit / nfev. */
+int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, double y_max, int n_constraints, const double* lb,
+                      const double* ub, const double* y_mean, const double* y_std, const double* seeds, int n_seeds, int d,
+                      const double* box_lo, const double* box_hi, int max_iter, double* x_out, double* f_out, int* status_out,
+                      int* n_rounds_out, int* n_iter_out, int* n_eval_out);
+
 /* ---- acquisition + arg-best ------------------------------------------------------------- */
 /* Replaces the _get_acq closure + base_acq + argmin/min/argsort[:k]
  * (bayes_opt/acquisition.py:198-217, 485, 660-661, 847-849, 312-317) and, when n_constraints > 0,
