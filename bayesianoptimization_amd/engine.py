@@ -102,6 +102,9 @@ class GpEngine:
                                           dptr(ls), int(ls.shape[0]), float(noise), int(precision))
             self._check(rc)
             self._pending_fits.add(int(slot))
+            # gpbo_fit_begin copies X / y asynchronously: the arrays it was given stay referenced until the fit is waited for
+            self._pending_inputs = getattr(self, "_pending_inputs", {})
+            self._pending_inputs[int(slot)] = (X, y_norm, ls)
             return self._touch(slot)
         rc = self._lib.gpbo_fit(self._h, int(slot), dptr(X), dptr(y_norm), X.shape[0], X.shape[1], int(kernel),
                                 dptr(ls), int(ls.shape[0]), float(noise), int(precision), C.byref(info))
@@ -146,6 +149,7 @@ class GpEngine:
         self._pending_fits.discard(int(slot))
         info = C.c_int(0)
         rc = self._lib.gpbo_fit_wait(self._h, int(slot), C.byref(info))
+        getattr(self, "_pending_inputs", {}).pop(int(slot), None)
         self._check(rc, info.value)
 
     def _settle(self, slot=None):

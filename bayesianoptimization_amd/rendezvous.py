@@ -17,7 +17,10 @@ import time
 def _path(key: str | None = None) -> str:
     base = os.environ.get("GPBO_RDZV_DIR", tempfile.gettempdir())
     if key is None:
-        key = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+        # (port, launcher pid) + the launcher's own run id / restart count when it has one: an elastic restart under the
+        # same launcher must not meet the previous attempt's file
+        key = (f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}"
+               f"_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}")
     return os.path.join(base, f"gpbo_rdzv_{key}.id")
 
 
@@ -28,8 +31,13 @@ def share_unique_id(rank: int, make_id, key: str | None = None, timeout: float =
         uid = bytes(make_id())
         if len(uid) != 128:
             raise ValueError("an RCCL unique id is 128 bytes")
+        try:
+            os.unlink(path)            # a leftover of a crashed run with the same key
+        except OSError:
+            pass
         tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as f:
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)     # nobody else's file, nobody else's to read
+        with os.fdopen(fd, "wb") as f:
             f.write(uid)
             f.flush()
             os.fsync(f.fileno())
@@ -39,8 +47,9 @@ def share_unique_id(rank: int, make_id, key: str | None = None, timeout: float =
     deadline = t_start + timeout
     while time.time() < deadline:
         try:
-            # a file older than this launch is a leftover of a crashed run with the same key
-            if os.path.getmtime(path) >= t_start - 300.0:
+            # a file older than this launch is a leftover of a crashed run with the same key (the ranks of one launch
+            # start within seconds of each other; rank 0 also removes any old file before it writes)
+            if os.path.getmtime(path) >= t_start - 60.0:
                 with open(path, "rb") as f:
                     uid = f.read()
                 if len(uid) == 128:

@@ -156,6 +156,22 @@ def suggest_latency(w, X, y, eng, M, reps=3):
                 fn.suggest(gp, sp, n_random=M, n_smart=n_smart, fit_gp=True, random_state=np.random.RandomState(7 + rep))
                 ts.append((time.perf_counter() - t0) * 1e3)
             res[f"n_smart_{n_smart}"] = float(np.median(ts[1:]))      # first call: allocations
+    # the local-search stage as one library call (gpbo_polish_seeds, accelerate(local_search="device")): statistical parity
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fn.device_polish = True
+            ts = []
+            for rep in range(reps + 1):
+                t0 = time.perf_counter()
+                fn.suggest(gp, sp, n_random=M, n_smart=10, fit_gp=True, random_state=np.random.RandomState(7 + rep))
+                ts.append((time.perf_counter() - t0) * 1e3)
+            res["n_smart_10_device_local_search"] = float(np.median(ts[1:]))
+    except Exception as e:  # noqa: BLE001
+        res["n_smart_10_device_local_search"] = None
+        res["device_local_search_error"] = repr(e)
+    finally:
+        fn.device_polish = False
     res["note"] = "median of 3 after one warm-up; fixed theta; candidates = the reference's RandomState stream, generated on the device"
     # ... and as BayesianOptimization itself configures its GP (bayesian_optimization.py: Matern(nu=2.5), alpha=1e-6,
     # normalize_y=True, n_restarts_optimizer=5): every suggest() then also runs sklearn's theta search — 1 + 5 L-BFGS-B
@@ -214,9 +230,11 @@ def pmc_summary_for(w):
     from bayesianoptimization_amd.build import _fingerprint
     # C4 is C3's GP over the same 2^20 candidates per GPU with another acquisition function: its dominant kernels
     # (and their launches) are the ones profiled for C3
-    ppath = os.path.join(ROOT, "profiles", f"r02_pmc_{'C3' if w.name == 'C4' else w.name}.json")
-    if not os.path.exists(ppath):
+    cfg = 'C3' if w.name == 'C4' else w.name
+    cands = sorted((p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith(f"_pmc_{cfg}.json")), reverse=True)
+    if not cands:
         return None, "no PMC summary for this config under profiles/ (scripts/profile_pmc.sh)"
+    ppath = os.path.join(ROOT, "profiles", cands[0])       # the latest round's
     pm = json.load(open(ppath))
     meta = pm.get("_meta", {})
     if meta.get("source_fingerprint") != _fingerprint():
@@ -287,6 +305,11 @@ def run_extra_config(eng, name, steps=5, warmup=2):
                          "top10_equals_reference": bool(np.array_equal(top10, g["top_idx"][:10])),
                          "min_rel_err": float(abs(best[1] - g["min"]) / abs(g["min"])), "reference": g["source"],
                          "arithmetic": "fp32 posterior vs the fp64 reference" if prec else "fp64"}
+    if name == "C2":      # the small config is where ms/suggest is a latency, not a throughput, number
+        try:
+            out["suggest_ms"] = suggest_latency(w, X, y, eng, M)
+        except Exception as e:  # noqa: BLE001
+            out["suggest_ms"] = {"error": repr(e)}
     return out
 
 

@@ -96,7 +96,9 @@ int gpbo_fit_append(gpbo_ctx* ctx, int slot, const double* x_new, int64_t n_new,
  * waits for it and resolves the positive-definiteness check (GPBO_ERR_NOT_PD, *info as gpbo_fit).  A factorisation at
  * these sizes is a chain of short dependent kernels that leaves most of the chip idle, so several of them in flight
  * overlap almost perfectly (N = 8192: two fits 26.6 ms one after the other).  Between the two calls the slot must not be
- * used; every slot's result is bitwise the one gpbo_fit gives. */
+ * used; every slot's result is bitwise the one gpbo_fit gives.  X and y_norm are copied with asynchronous transfers on
+ * the slot's stream: they must stay alive and unchanged until gpbo_fit_wait returns (pageable memory happens to be staged
+ * before the call returns, pinned or registered memory is not). */
 int gpbo_fit_begin(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int64_t N, int d, int kernel,
                    const double* length_scale, int n_ls, double noise, int precision);
 int gpbo_fit_wait(gpbo_ctx* ctx, int slot, int* info);
