@@ -176,6 +176,11 @@ __device__ __forceinline__ void factor_block8(double (&a)[8], double (&a2)[8], d
     // k + 1).  LDS time is what the waves compete for — a waiting wave that keeps re-reading slows the chain wave's
     // stores — so a waiting wave reads ONE word, the marker, and sleeps until the owner's s_wakeup (sent behind every
     // second column) or the sleep's own end; the data is read once, after the marker.
+    // Measured and dropped (scripts/r03_col_stamps.py, 64 columns + riding rows = 19 000 cycles with this loop): the next
+    // turn's reads issued before this turn's arithmetic (two register sets) 22 500; one column per turn 22 000; the
+    // multipliers by v_readlane from the rows just read (a third of the LDS traffic, twice the VALU work) 22 800 — every
+    // variant that makes the waiting waves faster makes the owner slower, through LDS time or through the SIMD the
+    // owner shares with one of them.
     const double* prow0 = Lc + 8 * w;      // L[8w + cc][k] = prow0[k * DS + cc]: the same address for every lane
     for (int k = 0; k < 8 * w; k += 2) {
       int spins = 0;
