@@ -293,7 +293,8 @@ int launch_chol_step(gpbo_ctx* ctx, Model& m, int kb, const GemmArgs& g);
 int launch_cholesky128(gpbo_ctx* ctx, Model& m, int outer, long long* stamps);
 // posterior_kernel.hip
 int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std);
-int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std, double** dmu_dev, double** dsd_dev);
+int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std, double** dmu_dev, double** dsd_dev,
+                          double** packed_dev = nullptr);   // packed: [dmu | dsd | mu | sd] contiguous (mu / sd not in the model's buffers)
 // posterior_kernel_v2.hip
 int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
 int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
@@ -326,7 +327,8 @@ int build_acq_args(gpbo_ctx* ctx, const char* who, int acq, double acq_param, do
 // posterior_small.hip
 int launch_posterior_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double y_std);
 int small_batch_limit(int64_t NP);   // largest M the GEMV path takes (posterior_small.hip)
-int launch_posterior_grad_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double y_std, double* dmu_dev, double* dsd_dev);
+int launch_posterior_grad_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double y_std, double* dmu_dev, double* dsd_dev,
+                                double* mu_out, double* sd_out);
 // lml_kernels.hip
 int launch_lml_terms(gpbo_ctx* ctx, Model& m, double* out2_dev);
 int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, double* partial, double* grad_dev);

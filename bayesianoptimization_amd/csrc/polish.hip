@@ -211,7 +211,7 @@ extern "C" int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, doubl
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
 
   const int n_models = 1 + n_constraints;
-  // pinned landing area: per model [mu | sd | dmu | dsd] for up to n_seeds points
+  // pinned landing area: per model [dmu | dsd | mu | sd] of a round (pitch = the round's live runs), room for n_seeds points
   const size_t per_model = (size_t)n_seeds * (2 + 2 * (size_t)d);
   const size_t need = per_model * (size_t)n_models * sizeof(double);
   if ((int64_t)need > ctx->cap_polish_pinned) {
@@ -248,21 +248,20 @@ extern "C" int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, doubl
     if (rc) return rc;
     for (int j = 0; j < n_models; ++j) {
       Model& m = ctx->models[j];
-      double *dmu_dev = nullptr, *dsd_dev = nullptr;
-      if ((rc = launch_posterior_grad(ctx, m, live, y_mean[j], y_std[j], &dmu_dev, &dsd_dev))) return rc;
-      double* o = land + per_model * (size_t)j;
-      GPBO_HIP(ctx, hipMemcpyAsync(o, m.mu, (size_t)live * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-      GPBO_HIP(ctx, hipMemcpyAsync(o + n_seeds, m.sd, (size_t)live * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-      GPBO_HIP(ctx, hipMemcpyAsync(o + 2 * (size_t)n_seeds, dmu_dev, (size_t)live * d * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-      GPBO_HIP(ctx, hipMemcpyAsync(o + 2 * (size_t)n_seeds + (size_t)n_seeds * d, dsd_dev, (size_t)live * d * sizeof(double),
+      double *dmu_dev = nullptr, *dsd_dev = nullptr, *packed = nullptr;
+      if ((rc = launch_posterior_grad(ctx, m, live, y_mean[j], y_std[j], &dmu_dev, &dsd_dev, &packed))) return rc;
+      // one copy per model and round: [dmu (live,d) | dsd (live,d) | mu (live) | sd (live)]; the scratch the kernels wrote
+      // to is shared by the models, so the copy of model j is enqueued before model j + 1's launches (same stream)
+      GPBO_HIP(ctx, hipMemcpyAsync(land + per_model * (size_t)j, packed, ((size_t)2 * live * d + 2 * (size_t)live) * sizeof(double),
                                    hipMemcpyDeviceToHost, ctx->stream));
     }
     GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // ---- f = -acq [* prod_j p_j] and its gradient (acquisition.py:198-217, 485, 660-661, 847-849; constraint.py:199-221)
     for (int t = 0; t < live; ++t) {
-      const double mu = land[t], sd = land[n_seeds + t];
-      const double* dmu = land + 2 * (size_t)n_seeds + (size_t)t * d;
-      const double* dsd = land + 2 * (size_t)n_seeds + (size_t)n_seeds * d + (size_t)t * d;
+      const double* o0 = land;
+      const double* dmu = o0 + (size_t)t * d;
+      const double* dsd = o0 + (size_t)live * d + (size_t)t * d;
+      const double mu = o0[2 * (size_t)live * d + t], sd = o0[2 * (size_t)live * d + live + t];
       double a, ca, cs;      // acq value; d acq = ca * dmu + cs * dsd
       if (acq == GPBO_ACQ_UCB) {
         a = mu + acq_param * sd; ca = 1.0; cs = acq_param;
@@ -281,9 +280,9 @@ extern "C" int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, doubl
         std::vector<double> pj((size_t)n_constraints), dp((size_t)n_constraints * d, 0.0);
         for (int j = 0; j < n_constraints; ++j) {
           const double* o = land + per_model * (size_t)(1 + j);
-          const double cm = o[t], csd = o[n_seeds + t];
-          const double* dcm = o + 2 * (size_t)n_seeds + (size_t)t * d;
-          const double* dcs = o + 2 * (size_t)n_seeds + (size_t)n_seeds * d + (size_t)t * d;
+          const double* dcm = o + (size_t)t * d;
+          const double* dcs = o + (size_t)live * d + (size_t)t * d;
+          const double cm = o[2 * (size_t)live * d + t], csd = o[2 * (size_t)live * d + live + t];
           double pv = 0.0;
           for (int side = 0; side < 2; ++side) {
             const double bound = side == 0 ? ub[j] : lb[j];

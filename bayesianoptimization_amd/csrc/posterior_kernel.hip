@@ -72,20 +72,26 @@ static int ensure_posterior_outputs(gpbo_ctx* ctx, Model& m, int64_t Mp) {
 }
 
 // mu, sd and their gradients in the (raw) inputs for the M resident candidates (M <= 256): posterior_small.hip
-int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std, double** dmu_dev, double** dsd_dev) {
+int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std, double** dmu_dev, double** dsd_dev,
+                          double** packed_dev) {
   const int64_t Mp = round_up(M, POST_CANDS);
   int rc;
   if ((rc = ensure(ctx, &ctx->Xcs, &ctx->cap_Xcs, Mp * m.DP))) return rc;
-  if ((rc = ensure(ctx, &ctx->mu_part, &ctx->cap_mu_part, std::max<int64_t>((int64_t)2 * M * m.d, Mp)))) return rc;
+  if ((rc = ensure(ctx, &ctx->mu_part, &ctx->cap_mu_part, std::max<int64_t>((int64_t)2 * M * m.d + 2 * M, Mp)))) return rc;
   if ((rc = ensure_posterior_outputs(ctx, m, Mp))) return rc;
   if ((rc = launch_prescale(ctx, ctx->Xc, M, m.d, m.DP, m.ls, ctx->Xcs, Mp))) return rc;
   *dmu_dev = ctx->mu_part;
   *dsd_dev = ctx->mu_part + M * m.d;
+  // packed_dev != NULL (gpbo_polish_seeds): mu and sd land right behind the gradients, [dmu | dsd | mu | sd], so that one
+  // copy brings a round's results back; the model's own mu / sd buffers are then NOT written
+  double* mu_out = packed_dev ? ctx->mu_part + 2 * M * m.d : m.mu;
+  double* sd_out = packed_dev ? mu_out + M : m.sd;
+  if (packed_dev) *packed_dev = ctx->mu_part;
   ev_begin(ctx, T_POST_MAIN);
-  rc = launch_posterior_grad_small(ctx, m, (int)M, y_mean, y_std, *dmu_dev, *dsd_dev);
+  rc = launch_posterior_grad_small(ctx, m, (int)M, y_mean, y_std, *dmu_dev, *dsd_dev, mu_out, sd_out);
   ev_end(ctx, T_POST_MAIN);
   if (rc) return rc;
-  m.M_post = M;
+  m.M_post = packed_dev ? -1 : M;
   return GPBO_OK;
 }
 

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void grad_small_kernel(const double* __restric
 // Requires ctx->Xcs to hold the scaled candidates; scratch in ctx->part.  Outputs on the device: m.mu, m.sd (M) and
 // dmu_dev, dsd_dev (M x d).
 int launch_posterior_grad_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double y_std, double* dmu_dev,
-                                double* dsd_dev) {
+                                double* dsd_dev, double* mu_out, double* sd_out) {
   if (M < 1 || M > GPBO_MAX_SEEDS * 4) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "posterior_grad: M out of range [1, 256]");
   int rc;
   const int64_t rows = (int64_t)M + 16;
@@ -377,7 +377,7 @@ int launch_posterior_grad_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, d
   GPBO_HIP(ctx, hipGetLastError());
   const size_t lds = (size_t)(512 + 8) * sizeof(double);
   grad_small_kernel<<<dim3((unsigned)M), dim3(256), lds, ctx->stream>>>(m.Xs, ctx->Xcs, fs, vb, ks, partial, m.alpha, m.ls,
-                                                                         m.DP, m.d, m.NP, M, y_mean, y_std, m.mu, m.sd,
+                                                                         m.DP, m.d, m.NP, M, y_mean, y_std, mu_out, sd_out,
                                                                          dmu_dev, dsd_dev, ctx->negvar);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
