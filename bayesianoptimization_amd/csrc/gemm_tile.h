@@ -75,15 +75,20 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn
   };
   const int nst = (kend - kbeg) / 16;
   if (nst > 0) {
-    d2v ra[2], rb[2];
-    gload(0, ra, rb);
-    lstore(0, ra, rb);
-    __syncthreads();
+    // Global loads run GT_PF stages ahead of the MFMAs (a ring of register sets; LDS stays double-buffered): with one
+    // stage of look-ahead a tile that has a CU to itself — the rank-512 update of the next panel's columns, the levels of
+    // W = L^-1, every product whose grid does not fill the chip — waited ~1.2 us per 16-deep stage for its operands
+    // (39 us for any k = 512 tile, however small the product); nothing changes in the arithmetic or its order.
+    constexpr int GT_PF = 3;
+    d2v ra[GT_PF][2], rb[GT_PF][2];
     const int last = nst - 1;
-    for (int st = 0; st < nst; ++st) {
+    gload(0, ra[0], rb[0]);
+    lstore(0, ra[0], rb[0]);
+#pragma unroll
+    for (int j = 1; j <= GT_PF; ++j) gload(min(j, last), ra[j % GT_PF], rb[j % GT_PF]);     // clamped: branch-free
+    __syncthreads();
+    auto stage = [&](const int st, d2v(&na)[2], d2v(&nb)[2]) {      // na / nb: the registers holding stage st + 1
       const int buf = st & 1;
-      gload(min(st + 1, last), ra, rb);            // clamped look-ahead keeps the body branch-free
-      __builtin_amdgcn_sched_barrier(0);           // keep the global loads at the top of the stage
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int kr = kk * 4 + (lane >> 4);
@@ -96,9 +101,17 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn
         acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
       }
-      lstore(buf ^ 1, ra, rb);    // the other buffer: everyone finished reading it before the previous barrier
+      lstore(buf ^ 1, na, nb);    // the other buffer: everyone finished reading it before the previous barrier
+      gload(min(st + 1 + GT_PF, last), na, nb);     // the set just emptied takes the stage GT_PF + 1 ahead
       __syncthreads();
+    };
+    int st = 0;
+    for (; st + GT_PF <= nst; st += GT_PF) {
+#pragma unroll
+      for (int j = 0; j < GT_PF; ++j) stage(st + j, ra[(j + 1) % GT_PF], rb[(j + 1) % GT_PF]);     // st is a multiple of GT_PF
     }
+    if (st < nst) stage(st, ra[1 % GT_PF], rb[1 % GT_PF]);
+    if (st + 1 < nst) stage(st + 1, ra[2 % GT_PF], rb[2 % GT_PF]);
   }
   if (!write) return;
 #pragma unroll
