@@ -42,7 +42,7 @@ SOURCES = {
     "comm.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
-          "-I" + INCLUDE, "-I" + CSRC, "-I/opt/rocm/include"]
+          "-I" + INCLUDE, "-I" + CSRC, "-I/opt/rocm/include"] + os.environ.get("GPBO_EXTRA_FLAGS", "").split()   # probe builds: -D switches
 
 
 def _hipcc() -> str:

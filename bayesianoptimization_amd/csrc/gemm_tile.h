@@ -79,7 +79,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn
     // stage of look-ahead a tile that has a CU to itself — the rank-512 update of the next panel's columns, the levels of
     // W = L^-1, every product whose grid does not fill the chip — waited ~1.2 us per 16-deep stage for its operands
     // (39 us for any k = 512 tile, however small the product); nothing changes in the arithmetic or its order.
-    constexpr int GT_PF = 3;
+#ifndef GPBO_GT_PF
+#define GPBO_GT_PF 3
+#endif
+    constexpr int GT_PF = GPBO_GT_PF;
     d2v ra[GT_PF][2], rb[GT_PF][2];
     const int last = nst - 1;
     gload(0, ra[0], rb[0]);
@@ -110,8 +113,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn
 #pragma unroll
       for (int j = 0; j < GT_PF; ++j) stage(st + j, ra[(j + 1) % GT_PF], rb[(j + 1) % GT_PF]);     // st is a multiple of GT_PF
     }
-    if (st < nst) stage(st, ra[1 % GT_PF], rb[1 % GT_PF]);
-    if (st + 1 < nst) stage(st + 1, ra[2 % GT_PF], rb[2 % GT_PF]);
+#pragma unroll
+    for (int j = 0; j < GT_PF - 1; ++j)
+      if (st + j < nst) stage(st + j, ra[(j + 1) % GT_PF], rb[(j + 1) % GT_PF]);
   }
   if (!write) return;
 #pragma unroll
