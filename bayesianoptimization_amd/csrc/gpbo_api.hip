@@ -155,10 +155,20 @@ static int cholesky_fused(gpbo_ctx* ctx, Model& m, int outer) {
 // update is HBM-bound on exactly that traffic).  GPBO_CHOL_OUTER=64 restores the one-level algorithm (A/B runs); default
 // 512.  GPBO_CHOL_FUSED=0 selects the three-launch schedule (A/B runs; lane mode — several models per launch, inside
 // gpbo_lml_batch — always uses it).
-static int cholesky(gpbo_ctx* ctx, Model& m, int variant = -1) {
-  int outer = 512;
+static int chol_outer_width(int64_t NP) {
+  // Outer panel width by size (scripts/r03_chol_probe.py under GPBO_CHOL_OUTER, round-3 schedule): up to NP = 2048 one
+  // panel — the rank-128 updates of the steps reach the whole trailing matrix, whose traffic is still small, and no
+  // latency-bound rank-`outer` GEMM stands between the steps (NP = 1024: 0.312 -> 0.283 ms, 2048: 0.683 -> 0.618); 1024 up
+  // to NP = 4096 (1.70 -> 1.66-1.68); 512 beyond (8192: 6.0 against 6.36 with 1024), where the trailing matrix no longer fits
+  // the caches and every pass over it counts.
+  int outer = NP <= 2048 ? (int)round_up(NP, 2 * NB) : (NP <= 4096 ? 1024 : 512);
   if (const char* e = getenv("GPBO_CHOL_OUTER")) outer = atoi(e);
   if (outer < NB || outer % NB) outer = NB;
+  return outer;
+}
+
+static int cholesky(gpbo_ctx* ctx, Model& m, int variant = -1) {
+  const int outer = chol_outer_width(m.NP);
   // variant 3 (default): 128-column steps, chol_kernels.hip; 2: the round-2 schedules below (GPBO_CHOL=2 for A/B runs)
   static const int env_variant = getenv("GPBO_CHOL") ? atoi(getenv("GPBO_CHOL")) : 3;
   if (variant < 0) variant = env_variant;
@@ -1068,7 +1078,7 @@ int gpbo_debug_cholesky(gpbo_ctx* ctx, const double* A, int64_t n, int variant, 
     (void)hipMemcpyAsync(m.L, m.K, sq, hipMemcpyDeviceToDevice, ctx->stream);
     (void)hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream);
     (void)hipEventRecord(e0, ctx->stream);
-    if (variant >= 3 && it == iters - 1) rc = launch_cholesky128(ctx, m, 512, stamps_dev);   // stamps: the last (warm) run
+    if (variant >= 3 && it == iters - 1) rc = launch_cholesky128(ctx, m, chol_outer_width(m.NP) % (2 * NB) ? 512 : chol_outer_width(m.NP), stamps_dev);   // stamps: the last (warm) run
     else rc = cholesky(ctx, m, variant);
     (void)hipEventRecord(e1, ctx->stream);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return done(GPBO_ERR_HIP);
