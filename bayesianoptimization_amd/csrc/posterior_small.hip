@@ -241,25 +241,76 @@ __global__ __launch_bounds__(256) void gemv_small_v_kernel(const double* __restr
     }
 }
 
+// The same product for long rows (NP >= 2048): the four waves of a workgroup share ONE pair of rows, each taking a quarter
+// of the k-range, and their partial sums are added in wave order — a wave of gemv_small_v_kernel walks a 4096-long row
+// in 64 dependent turns of ten loads (115 us per pass of 8 candidates at N = 4096, 1.1 TB/s); here in 16.
+template <int MS, int R>
+__global__ __launch_bounds__(256) void gemv_small_v4_kernel(const double* __restrict__ W, const double* __restrict__ ks,
+                                                            int64_t N, int64_t NP, double* __restrict__ vout) {
+  __shared__ double red[4][R][MS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i0 = (int64_t)blockIdx.x * R;
+  if (i0 >= NP) return;
+  ks += (int64_t)blockIdx.y * MS * NP;
+  vout += (int64_t)blockIdx.y * MS * NP;
+  double acc[R][MS];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < MS; ++c) acc[r][c] = 0.0;
+  const int64_t kmax = min(NP, i0 + R);
+  const int64_t quarter = ((kmax + 3) / 4 + 63) / 64 * 64;
+  const int64_t kb = (int64_t)wave * quarter, ke = min(kmax, kb + quarter);
+#pragma unroll 2
+  for (int64_t k = kb + lane; k < ke; k += 64) {
+    double w[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) w[r] = W[(i0 + r) * NP + k];
+#pragma unroll
+    for (int c = 0; c < MS; ++c) {
+      const double kv = ks[(int64_t)c * NP + k];
+#pragma unroll
+      for (int r = 0; r < R; ++r) acc[r][c] = fma(w[r], kv, acc[r][c]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int c = 0; c < MS; ++c) {
+      double v = acc[r][c];
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) red[wave][r][c] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < R * MS) {
+    const int r = threadIdx.x / MS, c = threadIdx.x % MS;
+    const double v = ((red[0][r][c] + red[1][r][c]) + red[2][r][c]) + red[3][r][c];
+    vout[(int64_t)c * NP + i0 + r] = (i0 + r < N) ? v : 0.0;
+  }
+}
+
 // partial[split][c][j] = sum over the split's rows i >= j of W[i][j] v[c][i]: 64 columns per workgroup, 4 row lanes,
 // GS candidates per pass (blockIdx.z), fixed summation order
-constexpr int GRAD_SPLITS = 16;
+constexpr int GRAD_SPLITS = 16;       // row splits for NP < 2048
+constexpr int GRAD_SPLITS_BIG = 32;   // ... from NP = 2048 on (with 8 row lanes per workgroup: 16 turns per thread at N = 4096 instead of 64)
 constexpr int GRAD_MS = 8;
 
-__global__ __launch_bounds__(256) void gemvt_small_kernel(const double* __restrict__ W, const double* __restrict__ v,
-                                                          int64_t NP, int M, double* __restrict__ partial) {
-  __shared__ double red[4][GRAD_MS][64];
+template <int ROWL>
+__global__ __launch_bounds__(64 * ROWL) void gemvt_small_kernel(const double* __restrict__ W, const double* __restrict__ v,
+                                                                int64_t NP, int M, int n_splits, double* __restrict__ partial) {
+  __shared__ double red[ROWL][GRAD_MS][64];
   const int ig = threadIdx.x >> 6, jl = threadIdx.x & 63;
   const int64_t j0 = (int64_t)blockIdx.x * 64;
   const int c0 = (int)blockIdx.z * GRAD_MS;
   const int64_t rows = NP - j0;
-  const int64_t chunk = (rows + GRAD_SPLITS - 1) / GRAD_SPLITS;
+  const int64_t chunk = (rows + n_splits - 1) / n_splits;
   const int64_t r0 = j0 + (int64_t)blockIdx.y * chunk;
   const int64_t r1 = min(NP, r0 + chunk);
   double acc[GRAD_MS];
 #pragma unroll
   for (int c = 0; c < GRAD_MS; ++c) acc[c] = 0.0;
-  for (int64_t i = r0 + ig; i < r1; i += 4) {
+  for (int64_t i = r0 + ig; i < r1; i += ROWL) {
     const double w = W[i * NP + j0 + jl];
 #pragma unroll
     for (int c = 0; c < GRAD_MS; ++c)
@@ -271,45 +322,71 @@ __global__ __launch_bounds__(256) void gemvt_small_kernel(const double* __restri
   if (ig == 0) {
 #pragma unroll
     for (int c = 0; c < GRAD_MS; ++c)
-      if (c0 + c < M)
-        partial[((int64_t)blockIdx.y * M + c0 + c) * NP + j0 + jl] = ((red[0][c][jl] + red[1][c][jl]) + red[2][c][jl]) + red[3][c][jl];
+      if (c0 + c < M) {
+        double sum = red[0][c][jl];
+#pragma unroll
+        for (int q = 1; q < ROWL; ++q) sum += red[q][c][jl];
+        partial[((int64_t)blockIdx.y * M + c0 + c) * NP + j0 + jl] = sum;
+      }
   }
 }
 
-// One workgroup per candidate.  Threads = DP dimensions x (256 / DP) k-lanes; u_k = sum over the splits (fixed order);
-// the two sums over k per dimension are reduced over the k-lanes in a fixed order.
+// The two k-sums per dimension.  Grid (candidate, k-slice): a slice of NP / GRAD_KSL train points per workgroup, threads =
+// DP dimensions x (256 / DP) k-lanes; u_k = sum over the splits (fixed order); per slice the sums are reduced over the
+// k-lanes in a fixed order and left in gpart[c][slice][2][DP]; grad_final_kernel adds the slices in order.  (One workgroup
+// per candidate until round 3: ten workgroups walking 4096 rows with 19 loads per turn were bound by their ten CUs'
+// load issue — 138 us of a 0.4 ms round at N = 4096.)
+constexpr int GRAD_KSL = 16;
 __global__ __launch_bounds__(256) void grad_small_kernel(const double* __restrict__ Xs, const double* __restrict__ Xcs,
-                                                         const double* __restrict__ fs, const double* __restrict__ vbuf,
-                                                         const double* __restrict__ ks, const double* __restrict__ partial,
-                                                         const double* __restrict__ alpha, const double* __restrict__ ls,
-                                                         int DP, int d, int64_t NP, int M, double y_mean, double y_std,
-                                                         double* __restrict__ mu, double* __restrict__ sd,
-                                                         double* __restrict__ dmu, double* __restrict__ dsd,
-                                                         int* __restrict__ negvar) {
-  extern __shared__ __attribute__((aligned(16))) double gs_smem[];   // [2][256] partial sums | [8] scalars
-  const int c = blockIdx.x;
+                                                         const double* __restrict__ fs, const double* __restrict__ partial,
+                                                         const double* __restrict__ alpha, int DP, int64_t NP, int M,
+                                                         int n_splits, double* __restrict__ gpart) {
+  __shared__ double gs_smem[2][256];
+  const int c = blockIdx.x, sl = blockIdx.y;
   const int t = threadIdx.x % DP, kl = threadIdx.x / DP, nkl = 256 / DP;
+  const int64_t per = (NP + GRAD_KSL - 1) / GRAD_KSL;
+  const int64_t k0 = (int64_t)sl * per, k1 = min(NP, k0 + per);
   const double xt = Xcs[(int64_t)c * DP + t];
   double gm = 0.0, gv = 0.0;
-  for (int64_t k = kl; k < NP; k += nkl) {
+  for (int64_t k = k0 + kl; k < k1; k += nkl) {
     double u = 0.0;
-#pragma unroll
-    for (int s = 0; s < GRAD_SPLITS; ++s) u += partial[((int64_t)s * M + c) * NP + k];
+#pragma unroll 16
+    for (int s = 0; s < n_splits; ++s) u += partial[((int64_t)s * M + c) * NP + k];
     const double f = fs[(int64_t)c * NP + k];
     const double df = (xt - Xs[k * DP + t]) * f;
     gm = fma(alpha[k], df, gm);
     gv = fma(u, df, gv);
   }
-  gs_smem[threadIdx.x] = gm;
-  gs_smem[256 + threadIdx.x] = gv;
-  // mean and sum of squares (the finalize_small arithmetic), one value per thread over i
+  gs_smem[0][threadIdx.x] = gm;
+  gs_smem[1][threadIdx.x] = gv;
+  __syncthreads();
+  if ((int)threadIdx.x < DP) {
+    double a = 0.0, b = 0.0;
+    for (int q = 0; q < nkl; ++q) {
+      a += gs_smem[0][q * DP + threadIdx.x];
+      b += gs_smem[1][q * DP + threadIdx.x];
+    }
+    double* o = gpart + (((int64_t)c * GRAD_KSL + sl) * 2) * DP;
+    o[threadIdx.x] = a;
+    o[DP + threadIdx.x] = b;
+  }
+}
+
+// One workgroup per candidate: mean and sum of squares (the finalize_small arithmetic), then the slices' sums in order.
+__global__ __launch_bounds__(256) void grad_final_kernel(const double* __restrict__ vbuf, const double* __restrict__ ks,
+                                                         const double* __restrict__ alpha, const double* __restrict__ ls,
+                                                         const double* __restrict__ gpart, int DP, int d, int64_t NP,
+                                                         double y_mean, double y_std, double* __restrict__ mu,
+                                                         double* __restrict__ sd, double* __restrict__ dmu,
+                                                         double* __restrict__ dsd, int* __restrict__ negvar) {
+  __shared__ double sh[8];
+  const int c = blockIdx.x;
   double s2 = 0.0, mm = 0.0;
   for (int64_t i = threadIdx.x; i < NP; i += 256) {
     const double vi = vbuf[(int64_t)c * NP + i];
     s2 = fma(vi, vi, s2);
     mm = fma(ks[(int64_t)c * NP + i], alpha[i], mm);
   }
-  double* sh = gs_smem + 512;
   double tot[2] = {s2, mm};
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
@@ -321,7 +398,6 @@ __global__ __launch_bounds__(256) void grad_small_kernel(const double* __restric
     __syncthreads();
     tot[q] = ((sh[0] + sh[1]) + sh[2]) + sh[3];
   }
-  __syncthreads();
   double var = 1.0 - tot[0];
   if (var < 0.0) {
     if (threadIdx.x == 0) *negvar = 1;
@@ -334,9 +410,10 @@ __global__ __launch_bounds__(256) void grad_small_kernel(const double* __restric
   }
   if ((int)threadIdx.x < d) {
     double a = 0.0, b = 0.0;
-    for (int q = 0; q < nkl; ++q) {
-      a += gs_smem[q * DP + threadIdx.x];
-      b += gs_smem[256 + q * DP + threadIdx.x];
+    for (int sl = 0; sl < GRAD_KSL; ++sl) {
+      const double* o = gpart + (((int64_t)c * GRAD_KSL + sl) * 2) * DP;
+      a += o[threadIdx.x];
+      b += o[DP + threadIdx.x];
     }
     const double inv_l = 1.0 / ls[threadIdx.x];
     dmu[(int64_t)c * d + threadIdx.x] = y_std * a * inv_l;
@@ -352,14 +429,17 @@ int launch_posterior_grad_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, d
   if (M < 1 || M > GPBO_MAX_SEEDS * 4) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "posterior_grad: M out of range [1, 256]");
   int rc;
   const int64_t rows = (int64_t)M + 16;
-  // ks | fs | v | partial[GRAD_SPLITS][M]
+  // ks | fs | v | partial[GRAD_SPLITS][M] | gpart[M][GRAD_KSL][2][DP]
+  const int64_t gpart_doubles = (int64_t)M * GRAD_KSL * 2 * m.DP;
+  const int n_splits = m.NP >= 2048 ? GRAD_SPLITS_BIG : GRAD_SPLITS;
   if ((rc = ensure(ctx, &ctx->part, &ctx->cap_part, std::max<int64_t>((int64_t)2 * (SMALL_MAX + 16) * m.NP,
-                                                                       (3 * rows + (int64_t)GRAD_SPLITS * M) * m.NP))))
+                                                                       (3 * rows + (int64_t)n_splits * M) * m.NP + gpart_doubles))))
     return rc;
   double* ks = ctx->part;
   double* fs = ks + rows * m.NP;
   double* vb = fs + rows * m.NP;
   double* partial = vb + rows * m.NP;
+  double* gpart = partial + (int64_t)n_splits * M * m.NP;
   const dim3 kgrid((unsigned)((m.NP + 255) / 256), (unsigned)((M + 15) / 16));
   if (m.kernel == GPBO_KERNEL_MATERN25)
     kstar_grad_small_kernel<GPBO_KERNEL_MATERN25><<<kgrid, dim3(256), 0, ctx->stream>>>(m.Xs, ctx->Xcs, m.DP, m.NP, m.N, M, ks, fs);
@@ -369,16 +449,21 @@ int launch_posterior_grad_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, d
   // v = W k*: passes of 8 candidates (a padded last pass reads/writes scratch rows that exist: rows = M + 16)
   {
     const unsigned gb = (unsigned)((m.NP / 2 + 3) / 4);
-    gemv_small_v_kernel<8, 2><<<dim3(gb, (unsigned)((M + 7) / 8)), dim3(256), 0, ctx->stream>>>(m.W, ks, m.N, m.NP, vb);
+    if (m.NP >= 2048)
+      gemv_small_v4_kernel<8, 2><<<dim3((unsigned)(m.NP / 2), (unsigned)((M + 7) / 8)), dim3(256), 0, ctx->stream>>>(m.W, ks, m.N, m.NP, vb);
+    else
+      gemv_small_v_kernel<8, 2><<<dim3(gb, (unsigned)((M + 7) / 8)), dim3(256), 0, ctx->stream>>>(m.W, ks, m.N, m.NP, vb);
     GPBO_HIP(ctx, hipGetLastError());
   }
-  gemvt_small_kernel<<<dim3((unsigned)(m.NP / 64), GRAD_SPLITS, (unsigned)((M + GRAD_MS - 1) / GRAD_MS)), dim3(256), 0,
-                       ctx->stream>>>(m.W, vb, m.NP, M, partial);
+  const dim3 tgrid((unsigned)(m.NP / 64), (unsigned)n_splits, (unsigned)((M + GRAD_MS - 1) / GRAD_MS));
+  if (m.NP >= 2048) gemvt_small_kernel<8><<<tgrid, dim3(512), 0, ctx->stream>>>(m.W, vb, m.NP, M, n_splits, partial);
+  else gemvt_small_kernel<4><<<tgrid, dim3(256), 0, ctx->stream>>>(m.W, vb, m.NP, M, n_splits, partial);
   GPBO_HIP(ctx, hipGetLastError());
-  const size_t lds = (size_t)(512 + 8) * sizeof(double);
-  grad_small_kernel<<<dim3((unsigned)M), dim3(256), lds, ctx->stream>>>(m.Xs, ctx->Xcs, fs, vb, ks, partial, m.alpha, m.ls,
-                                                                         m.DP, m.d, m.NP, M, y_mean, y_std, mu_out, sd_out,
-                                                                         dmu_dev, dsd_dev, ctx->negvar);
+  grad_small_kernel<<<dim3((unsigned)M, GRAD_KSL), dim3(256), 0, ctx->stream>>>(m.Xs, ctx->Xcs, fs, partial, m.alpha, m.DP, m.NP, M, n_splits,
+                                                                                gpart);
+  GPBO_HIP(ctx, hipGetLastError());
+  grad_final_kernel<<<dim3((unsigned)M), dim3(256), 0, ctx->stream>>>(vb, ks, m.alpha, m.ls, gpart, m.DP, m.d, m.NP, y_mean, y_std,
+                                                                      mu_out, sd_out, dmu_dev, dsd_dev, ctx->negvar);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
