@@ -100,6 +100,9 @@ SIGNATURES = {
     "gpbo_polish_seeds": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, _c_double_p, _c_double_p, _c_double_p,
                                     _c_double_p, _c_double_p, C.c_int, C.c_int, _c_double_p, _c_double_p, C.c_int, _c_double_p,
                                     _c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gpbo_debug_minimize_box": (C.c_int, [C.c_void_p, C.c_void_p, _c_double_p, C.c_int, C.c_int, _c_double_p, _c_double_p, C.c_int,
+                                          _c_double_p, _c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                          C.POINTER(C.c_int)]),
     "gpbo_group_debug_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "gpbo_group_debug_run": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "gpbo_debug_cholesky": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, C.c_int, C.c_int, _c_double_p, _c_double_p,

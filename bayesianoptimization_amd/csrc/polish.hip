@@ -183,11 +183,71 @@ void advance(Run& r, double ft, const double* gt, const double* lo, const double
   trial_point(r, lo, hi);
 }
 
+// All runs in lockstep: `eval(batch, live, f, g)` evaluates the objective and its gradient at the `live` trial points of the
+// round (rows of `batch`, d columns) in one go and returns a status code; the runs that are still alive get their answers
+// and leave their next request.  Shared by gpbo_polish_seeds (device evaluator) and gpbo_debug_minimize_box (host callback:
+// the optimiser alone, testable without a GPU).
+template <class Eval>
+int lockstep_minimize(Eval&& eval, const double* seeds, int n_seeds, int d, const double* box_lo, const double* box_hi, int max_iter,
+                      double* x_out, double* f_out, int* status_out, int* n_rounds_out, int* n_iter_out, int* n_eval_out) {
+  std::vector<Run> runs((size_t)n_seeds);
+  for (int s = 0; s < n_seeds; ++s) {
+    Run& r = runs[s];
+    r.d = d;
+    r.x.assign((size_t)d, 0.0); r.g.assign((size_t)d, 0.0); r.xt.assign((size_t)d, 0.0); r.dir.assign((size_t)d, 0.0);
+    r.S.assign((size_t)LBFGS_M * d, 0.0); r.Y.assign((size_t)LBFGS_M * d, 0.0);
+    for (int i = 0; i < d; ++i) r.xt[i] = std::min(std::max(seeds[(size_t)s * d + i], box_lo[i]), box_hi[i]);
+  }
+  std::vector<double> batch((size_t)n_seeds * d), fv((size_t)n_seeds), gv((size_t)n_seeds * d);
+  std::vector<int> who((size_t)n_seeds);
+  int rounds = 0;
+  for (;;) {
+    int live = 0;
+    for (int s = 0; s < n_seeds; ++s)
+      if (runs[s].phase != 2) {
+        std::copy(runs[s].xt.begin(), runs[s].xt.end(), batch.begin() + (size_t)live * d);
+        who[live++] = s;
+      }
+    if (live == 0) break;
+    ++rounds;
+    const int rc = eval(batch.data(), live, fv.data(), gv.data());
+    if (rc) return rc;
+    for (int t = 0; t < live; ++t) {
+      double* g = &gv[(size_t)t * d];
+      for (int i = 0; i < d; ++i) if (!std::isfinite(g[i])) g[i] = 0.0;
+      advance(runs[who[t]], fv[t], g, box_lo, box_hi, max_iter);
+    }
+    if (rounds > 4 * max_iter + 64) break;      // cannot happen (every run is bounded by max_iter * MAXLS); never spin
+  }
+  for (int s = 0; s < n_seeds; ++s) {
+    std::copy(runs[s].x.begin(), runs[s].x.end(), x_out + (size_t)s * d);
+    f_out[s] = runs[s].f;
+    status_out[s] = runs[s].phase == 2 ? runs[s].status : 2;
+    if (n_iter_out) n_iter_out[s] = runs[s].iter;
+    if (n_eval_out) n_eval_out[s] = runs[s].evals;
+  }
+  if (n_rounds_out) *n_rounds_out = rounds;
+  return GPBO_OK;
+}
+
 }  // namespace
 
 }  // namespace gpbo
 
 using namespace gpbo;
+
+extern "C" int gpbo_debug_minimize_box(gpbo_fg_callback fg, void* user, const double* seeds, int n_seeds, int d, const double* box_lo,
+                                       const double* box_hi, int max_iter, double* x_out, double* f_out, int* status_out,
+                                       int* n_rounds_out, int* n_iter_out, int* n_eval_out) {
+  if (!fg || !seeds || !box_lo || !box_hi || !x_out || !f_out || !status_out || n_seeds < 1 || n_seeds > GPBO_MAX_SEEDS || d < 1 ||
+      d > GPBO_MAX_DIM)
+    return GPBO_ERR_INVALID;
+  for (int i = 0; i < d; ++i)
+    if (!(box_lo[i] < box_hi[i])) return GPBO_ERR_INVALID;
+  if (max_iter < 1) max_iter = 15000;
+  return lockstep_minimize([&](const double* batch, int live, double* f, double* g) { return fg(batch, live, d, f, g, user); }, seeds,
+                           n_seeds, d, box_lo, box_hi, max_iter, x_out, f_out, status_out, n_rounds_out, n_iter_out, n_eval_out);
+}
 
 extern "C" int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, double y_max, int n_constraints, const double* lb,
                                  const double* ub, const double* y_mean, const double* y_std, const double* seeds, int n_seeds,
@@ -223,28 +283,9 @@ extern "C" int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, doubl
   }
   double* land = (double*)ctx->polish_pinned;
 
-  std::vector<Run> runs((size_t)n_seeds);
-  for (int s = 0; s < n_seeds; ++s) {
-    Run& r = runs[s];
-    r.d = d;
-    r.x.assign((size_t)d, 0.0); r.g.assign((size_t)d, 0.0); r.xt.assign((size_t)d, 0.0); r.dir.assign((size_t)d, 0.0);
-    r.S.assign((size_t)LBFGS_M * d, 0.0); r.Y.assign((size_t)LBFGS_M * d, 0.0);
-    for (int i = 0; i < d; ++i) r.xt[i] = std::min(std::max(seeds[(size_t)s * d + i], box_lo[i]), box_hi[i]);
-  }
-  std::vector<double> batch((size_t)n_seeds * d), fv((size_t)n_seeds), gv((size_t)n_seeds * d);
-  std::vector<int> who((size_t)n_seeds);
-  int rounds = 0;
-  for (;;) {
-    int live = 0;
-    for (int s = 0; s < n_seeds; ++s)
-      if (runs[s].phase != 2) {
-        std::copy(runs[s].xt.begin(), runs[s].xt.end(), batch.begin() + (size_t)live * d);
-        who[live++] = s;
-      }
-    if (live == 0) break;
-    ++rounds;
+  auto eval = [&](const double* batch, const int live, double* fv, double* gv) -> int {
     // ---- one batched evaluation: posterior + input gradient of every model at the live runs' trial points
-    int rc = gpbo_set_candidates(ctx, batch.data(), live, d);
+    int rc = gpbo_set_candidates(ctx, batch, live, d);
     if (rc) return rc;
     for (int j = 0; j < n_models; ++j) {
       Model& m = ctx->models[j];
@@ -273,7 +314,7 @@ extern "C" int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, doubl
         else { a = cdf; ca = pdf / sd; cs = -pdf * z / sd; }
       }
       double f = -a;
-      double* g = &gv[(size_t)t * d];
+      double* g = gv + (size_t)t * d;
       for (int i = 0; i < d; ++i) g[i] = -(ca * dmu[i] + cs * dsd[i]);
       if (n_constraints > 0) {
         double p = 1.0;
@@ -307,19 +348,10 @@ extern "C" int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, doubl
         }
         f *= p;
       }
-      for (int i = 0; i < d; ++i) if (!std::isfinite(g[i])) g[i] = 0.0;
       fv[t] = f;
     }
-    for (int t = 0; t < live; ++t) advance(runs[who[t]], fv[t], &gv[(size_t)t * d], box_lo, box_hi, max_iter);
-    if (rounds > 4 * max_iter + 64) break;      // cannot happen (every run is bounded by max_iter * MAXLS); never spin
-  }
-  for (int s = 0; s < n_seeds; ++s) {
-    std::copy(runs[s].x.begin(), runs[s].x.end(), x_out + (size_t)s * d);
-    f_out[s] = runs[s].f;
-    status_out[s] = runs[s].phase == 2 ? runs[s].status : 2;
-    if (n_iter_out) n_iter_out[s] = runs[s].iter;
-    if (n_eval_out) n_eval_out[s] = runs[s].evals;
-  }
-  if (n_rounds_out) *n_rounds_out = rounds;
-  return GPBO_OK;
+    return GPBO_OK;
+  };
+  return lockstep_minimize(eval, seeds, n_seeds, d, box_lo, box_hi, max_iter, x_out, f_out, status_out, n_rounds_out, n_iter_out,
+                           n_eval_out);
 }

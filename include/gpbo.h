@@ -214,6 +214,14 @@ int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, double y_max, in
                       const double* box_lo, const double* box_hi, int max_iter, double* x_out, double* f_out, int* status_out,
                       int* n_rounds_out, int* n_iter_out, int* n_eval_out);
 
+/* The optimiser of gpbo_polish_seeds alone, over a host objective (self-test seam: no device, no context): `fg` is called
+ * once per lockstep round with the trial points of the runs that are still alive — x (n_live,d) -> f (n_live), g (n_live,d) —
+ * and returns 0 or an error code that ends the call.  Same outputs as gpbo_polish_seeds. */
+typedef int (*gpbo_fg_callback)(const double* x, int n_live, int d, double* f, double* g, void* user);
+int gpbo_debug_minimize_box(gpbo_fg_callback fg, void* user, const double* seeds, int n_seeds, int d, const double* box_lo,
+                            const double* box_hi, int max_iter, double* x_out, double* f_out, int* status_out, int* n_rounds_out,
+                            int* n_iter_out, int* n_eval_out);
+
 /* ---- acquisition + arg-best ------------------------------------------------------------- */
 /* Replaces the _get_acq closure + base_acq + argmin/min/argsort[:k]
  * (bayes_opt/acquisition.py:198-217, 485, 660-661, 847-849, 312-317) and, when n_constraints > 0,
