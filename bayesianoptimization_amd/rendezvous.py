@@ -31,10 +31,11 @@ def share_unique_id(rank: int, make_id, key: str | None = None, timeout: float =
         uid = bytes(make_id())
         if len(uid) != 128:
             raise ValueError("an RCCL unique id is 128 bytes")
-        try:
-            os.unlink(path)            # a leftover of a crashed run with the same key
-        except OSError:
-            pass
+        for old in (path, path + ".done"):     # leftovers of a crashed run with the same key
+            try:
+                os.unlink(old)
+            except OSError:
+                pass
         tmp = f"{path}.{os.getpid()}.tmp"
         fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)     # nobody else's file, nobody else's to read
         with os.fdopen(fd, "wb") as f:
@@ -60,9 +61,35 @@ def share_unique_id(rank: int, make_id, key: str | None = None, timeout: float =
     raise TimeoutError(f"rank {rank}: no communicator id at {path} after {timeout:.0f} s (is rank 0 alive?)")
 
 
-def cleanup(rank: int, key: str | None = None) -> None:
+def mark_done(rank: int, key: str | None = None) -> None:
+    """Rank 0: tell the peers (host side, no device work) that everything it does alone after the timed region is over."""
     if rank == 0:
         try:
-            os.unlink(_path(key))
+            fd = os.open(_path(key) + ".done", os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+            os.close(fd)
         except OSError:
             pass
+
+
+def wait_done(rank: int, key: str | None = None, timeout: float = 150.0) -> bool:
+    """Ranks > 0: sleep on the host until rank 0 called mark_done (True) or `timeout` passed (False).  A peer that waited in
+    the closing collective instead would keep an RCCL kernel spinning on its GPU while rank 0's child process measures
+    ms/suggest on those very devices."""
+    if rank == 0:
+        return True
+    path = _path(key) + ".done"
+    deadline = time.time() + timeout
+    while time.time() < deadline:
+        if os.path.exists(path):
+            return True
+        time.sleep(0.05)
+    return False
+
+
+def cleanup(rank: int, key: str | None = None) -> None:
+    if rank == 0:
+        for path in (_path(key), _path(key) + ".done"):
+            try:
+                os.unlink(path)
+            except OSError:
+                pass

@@ -621,8 +621,13 @@ def main():
             out["suggest_ms"] = suggest_in_child(n_gpus, w.name)
         print(json.dumps(out), flush=True)
     if mode == "ranks":
+        # the other ranks sleep on the HOST while rank 0 measures ms/suggest in its child process (their GPUs stay idle for
+        # it: a collective entered now would spin on them), then everybody meets in one last collective
+        rendezvous.mark_done(rank)
+        if not rendezvous.wait_done(rank, timeout=float(os.environ.get("GPBO_BENCH_TAIL_TIMEOUT_S", "150"))):
+            log(f"[bench] rank {rank}: rank 0 did not report the end of its tail; entering the closing barrier anyway")
         try:
-            barrier_max(0.0)       # the other ranks wait here while rank 0 measures ms/suggest in its child process
+            barrier_max(0.0)
         except Exception as e:  # noqa: BLE001  (a closing barrier that fails changes nothing that was measured)
             log(f"[bench] rank {rank}: closing barrier: {e!r}")
         rendezvous.cleanup(rank)

@@ -109,6 +109,31 @@ def test_file_rendezvous_ships_the_unique_id_to_every_rank(tmp_path):
         os.environ.pop("GPBO_RDZV_DIR", None)
 
 
+def test_host_side_done_flag_keeps_the_peers_off_their_gpus_until_rank0_finished(tmp_path, monkeypatch):
+    """bench.py (one process per GPU): ranks > 0 sleep on a host flag while rank 0 measures ms/suggest alone; a flag that never
+    comes costs a bounded wait, a leftover flag of a crashed run is removed by the next launch's rank 0."""
+    import threading
+    import time
+    from bayesianoptimization_amd import rendezvous
+    monkeypatch.setenv("GPBO_RDZV_DIR", str(tmp_path))
+    key = f"done_{os.getpid()}"
+    assert rendezvous.wait_done(0, key=key, timeout=0.0) is True            # rank 0 never waits for itself
+    t0 = time.time()
+    assert rendezvous.wait_done(1, key=key, timeout=0.3) is False
+    assert 0.25 <= time.time() - t0 < 5.0
+    rendezvous.mark_done(1, key=key)                                         # only rank 0 may raise the flag
+    assert rendezvous.wait_done(1, key=key, timeout=0.1) is False
+    th = threading.Timer(0.2, rendezvous.mark_done, args=(0,), kwargs={"key": key})
+    th.start()
+    assert rendezvous.wait_done(3, key=key, timeout=30.0) is True
+    th.join()
+    rendezvous.share_unique_id(0, lambda: bytes(128), key=key)               # the next launch: stale flag gone, id published
+    assert rendezvous.wait_done(1, key=key, timeout=0.1) is False
+    rendezvous.mark_done(0, key=key)
+    rendezvous.cleanup(0, key=key)
+    assert os.listdir(tmp_path) == []
+
+
 def test_extra_config_goldens_exist_for_the_line_the_driver_runs():
     """bench.py's `configs` block compares C2, C4 shard 0 and C5 shard 0 with these committed reference passes."""
     b = _bench()
