@@ -108,6 +108,8 @@ SIGNATURES = {
     "gpbo_debug_cholesky": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, C.c_int, C.c_int, _c_double_p, _c_double_p,
                                       C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "gpbo_debug_latency_probe": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "gpbo_debug_select": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_void_p,
+                                    C.POINTER(C.c_int64), C.POINTER(C.c_float)]),
     "gpbo_debug_gemm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, _c_double_p, _c_double_p,
                                   C.c_int, C.c_double, _c_double_p]),
     "gpbo_debug_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

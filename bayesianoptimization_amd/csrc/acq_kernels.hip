@@ -216,13 +216,231 @@ __global__ __launch_bounds__(SEL_BLOCK) void select_merge_topk_kernel(const Key*
   }
 }
 
-// acq values + k selection passes enqueued on ctx->stream; SelState and picks[npass] stay in ctx->red
-static int enqueue_acq_select(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, SelState** st_out, Key** picks_out,
-                              int* npass_out) {
+// ------------------------------------------------------------------------------------------------
+// Selection, second form (the default; GPBO_SELECT_V2=0 switches back to the k passes above, gpbo_debug_select runs either).
+// The k block reductions above are a dependency chain: ~4 us per pick whatever M is (40 + 15 us of a 0.84 ms step at C2,
+// profiles/r02_trace_C2_kernel_stats.csv).  Here the picks of a workgroup come out together:
+//   1. every thread finds the smallest key among its own items;
+//   2. every wave ranks its 64 thread minima against each other (64 LDS broadcasts, no chain); the k-th smallest of one wave's
+//      minima bounds the workgroup's k-th smallest key from above, and so does tau = the least of the waves' bounds;
+//   3. the keys <= tau — at least k of them (the wave that set tau owns k), normally only a few more — go to an LDS list;
+//   4. every listed key counts the listed keys that sort before it: that count is its place among the picks.
+// Same order as key_less — (value, index), -0.0 == 0.0, NaN after every number, the empty slot {NaN, INT64_MAX} after
+// every NaN — through an order-preserving 64-bit image of the value, so the picks are the ones the k passes give.  A list
+// that would outgrow its LDS (values arranged so that one thread owns many of the smallest) falls back to the k passes.
+struct IKey {
+  unsigned long long kv;
+  int64_t i;
+};
+
+__device__ __forceinline__ unsigned long long order_bits(double v) {
+  if (v != v) return ~0ull;
+  const double c = (v == 0.0) ? 0.0 : v;             // -0.0 and 0.0 are one value to the order
+  const unsigned long long b = (unsigned long long)__double_as_longlong(c);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ bool ikey_less(const IKey& a, const IKey& b) { return a.kv < b.kv || (a.kv == b.kv && a.i < b.i); }
+__device__ __forceinline__ IKey ikey_sentinel() { IKey s; s.kv = ~0ull; s.i = INT64_MAX; return s; }
+__device__ __forceinline__ IKey ikey_of(const Key& k) {
+  IKey r;
+  r.i = k.i;
+  r.kv = (k.i == INT64_MAX) ? ~0ull : order_bits(k.v);
+  return r;
+}
+
+constexpr int SEL2_CAP = 1024;      // listed keys per workgroup (16 KiB of LDS)
+
+struct Sel2Shared {
+  IKey tmin[SEL_BLOCK];
+  IKey bound[SEL_BLOCK / 64];
+  IKey list[SEL2_CAP];
+  int count;
+};
+
+// steps 1-2: `mine` = this thread's smallest key (the sentinel if it has none) -> tau, the same on every thread
+__device__ IKey sel2_threshold(const IKey& mine, int k, Sel2Shared& sh) {
+  const int wave = threadIdx.x >> 6;
+  sh.tmin[threadIdx.x] = mine;
+  if ((threadIdx.x & 63) == 0) sh.bound[wave] = ikey_sentinel();
+  if (threadIdx.x == 0) sh.count = 0;
+  __syncthreads();
+  int rank = 0;
+  for (int j = 0; j < 64; ++j) rank += ikey_less(sh.tmin[wave * 64 + j], mine) ? 1 : 0;
+  if (rank == k - 1 && mine.i != INT64_MAX) sh.bound[wave] = mine;      // real keys are distinct: at most one thread per wave
+  __syncthreads();
+  IKey tau = sh.bound[0];
+  for (int w = 1; w < SEL_BLOCK / 64; ++w) {
+    const IKey o = sh.bound[w];
+    if (ikey_less(o, tau)) tau = o;
+  }
+  return tau;
+}
+
+__device__ __forceinline__ void sel2_list(const IKey& c, const IKey& tau, int cap, Sel2Shared& sh) {
+  if (c.i != INT64_MAX && !ikey_less(tau, c)) {
+    const int pos = atomicAdd(&sh.count, 1);
+    if (pos < cap) sh.list[pos] = c;
+  }
+}
+
+// step 4: out[r] = the listed key of rank r < k (value re-read from ys), the sentinel where the list is shorter than k
+__device__ void sel2_emit(int n_listed, int k, const double* __restrict__ ys, Key* __restrict__ out, Sel2Shared& sh) {
+  for (int j = threadIdx.x; j < n_listed; j += SEL_BLOCK) {
+    const IKey c = sh.list[j];
+    int rank = 0;
+    for (int q = 0; q < n_listed; ++q) rank += ikey_less(sh.list[q], c) ? 1 : 0;
+    if (rank < k) {
+      Key r;
+      r.v = ys[c.i];
+      r.i = c.i;
+      out[rank] = r;
+    }
+  }
+  for (int t = n_listed + threadIdx.x; t < k; t += SEL_BLOCK) {
+    Key r;
+    r.v = std::numeric_limits<double>::quiet_NaN();
+    r.i = INT64_MAX;
+    out[t] = r;
+  }
+}
+
+__global__ __launch_bounds__(SEL_BLOCK) void select_block_topk_v2_kernel(const double* __restrict__ ys, int64_t M, int k, int cap,
+                                                                         Key* __restrict__ partial,
+                                                                         int64_t* __restrict__ nan_partial) {
+  __shared__ Sel2Shared sh;
+  __shared__ Key shk[SEL_BLOCK / 64];
+  __shared__ int64_t shn[SEL_BLOCK / 64];
+  const int64_t base = (int64_t)blockIdx.x * (SEL_BLOCK * SEL_ITEMS) + threadIdx.x;
+  double v[SEL_ITEMS];
+  int64_t fn = INT64_MAX;
+  IKey mine = ikey_sentinel();
+#pragma unroll
+  for (int it = 0; it < SEL_ITEMS; ++it) {
+    const int64_t m = base + (int64_t)it * SEL_BLOCK;
+    v[it] = (m < M) ? ys[m] : 0.0;
+    if (m < M) {
+      if (v[it] != v[it] && m < fn) fn = m;
+      IKey c;
+      c.kv = order_bits(v[it]);
+      c.i = m;
+      if (ikey_less(c, mine)) mine = c;
+    }
+  }
+  const IKey tau = sel2_threshold(mine, k, sh);
+#pragma unroll
+  for (int it = 0; it < SEL_ITEMS; ++it) {
+    const int64_t m = base + (int64_t)it * SEL_BLOCK;
+    IKey c;
+    c.kv = order_bits(v[it]);
+    c.i = (m < M) ? m : INT64_MAX;
+    sel2_list(c, tau, cap, sh);
+  }
+  __syncthreads();
+  const int n_listed = sh.count;
+  Key* out = partial + (int64_t)blockIdx.x * k;
+  if (n_listed <= cap) {
+    sel2_emit(n_listed, k, ys, out, sh);
+  } else {
+    // the k passes of select_block_topk_kernel
+    Key prev;
+    prev.v = 0.0; prev.i = -1;
+    for (int t = 0; t < k; ++t) {
+      Key best;
+      best.v = std::numeric_limits<double>::quiet_NaN();
+      best.i = INT64_MAX;
+#pragma unroll
+      for (int it = 0; it < SEL_ITEMS; ++it) {
+        Key c;
+        c.v = v[it];
+        c.i = base + (int64_t)it * SEL_BLOCK;
+        if (c.i < M && (prev.i < 0 || key_less(prev, c))) best = key_min(best, c);
+      }
+      const Key r = block_reduce_key(best, shk);
+      if (threadIdx.x == 0) out[t] = r;
+      prev = r;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const int64_t o = __shfl_xor(fn, off);
+    fn = o < fn ? o : fn;
+  }
+  if ((threadIdx.x & 63) == 0) shn[threadIdx.x >> 6] = fn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t f = shn[0];
+    for (int w = 1; w < SEL_BLOCK / 64; ++w) f = shn[w] < f ? shn[w] : f;
+    nan_partial[blockIdx.x] = f;
+  }
+}
+
+__global__ __launch_bounds__(SEL_BLOCK) void select_merge_topk_v2_kernel(const double* __restrict__ ys,
+                                                                         const Key* __restrict__ partial,
+                                                                         const int64_t* __restrict__ nan_partial, int nblocks, int k,
+                                                                         int cap, SelState* st, Key* __restrict__ picks) {
+  __shared__ Sel2Shared sh;
+  __shared__ Key shk[SEL_BLOCK / 64];
+  __shared__ int64_t shn[SEL_BLOCK / 64];
+  const int64_t n = (int64_t)nblocks * k;
+  IKey mine = ikey_sentinel();
+  for (int64_t j = threadIdx.x; j < n; j += SEL_BLOCK) {
+    const IKey c = ikey_of(partial[j]);
+    if (ikey_less(c, mine)) mine = c;
+  }
+  const IKey tau = sel2_threshold(mine, k, sh);
+  for (int64_t j = threadIdx.x; j < n; j += SEL_BLOCK) sel2_list(ikey_of(partial[j]), tau, cap, sh);
+  __syncthreads();
+  const int n_listed = sh.count;
+  if (n_listed <= cap) {
+    sel2_emit(n_listed, k, ys, picks, sh);
+  } else {
+    Key prev;
+    prev.v = 0.0; prev.i = -1;
+    for (int t = 0; t < k; ++t) {
+      Key best;
+      best.v = std::numeric_limits<double>::quiet_NaN();
+      best.i = INT64_MAX;
+      for (int64_t j = threadIdx.x; j < n; j += SEL_BLOCK) {
+        const Key c = partial[j];
+        if (c.i != INT64_MAX && (prev.i < 0 || key_less(prev, c))) best = key_min(best, c);
+      }
+      const Key r = block_reduce_key(best, shk);
+      if (threadIdx.x == 0) picks[t] = r;
+      prev = r;
+    }
+  }
+  int64_t fn = INT64_MAX;
+  for (int b = threadIdx.x; b < nblocks; b += SEL_BLOCK) fn = nan_partial[b] < fn ? nan_partial[b] : fn;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const int64_t o = __shfl_xor(fn, off);
+    fn = o < fn ? o : fn;
+  }
+  if ((threadIdx.x & 63) == 0) shn[threadIdx.x >> 6] = fn;
+  __syncthreads();      // also orders this workgroup's picks[] stores before the read below (same workgroup, global memory)
+  if (threadIdx.x == 0) {
+    int64_t f = shn[0];
+    for (int w = 1; w < SEL_BLOCK / 64; ++w) f = shn[w] < f ? shn[w] : f;
+    st->first_nan = f;
+    __threadfence();
+    st->prev = picks[k - 1];
+  }
+}
+
+static int select_v2_cap() {      // read per call: gpbo_debug_select and the tests switch it inside one process
+  const char* e = getenv("GPBO_SELECT_V2_CAP");
+  const int c = e ? atoi(e) : SEL2_CAP;
+  return c < 1 ? 1 : (c > SEL2_CAP ? SEL2_CAP : c);
+}
+static bool select_v2_enabled() {
+  const char* e = getenv("GPBO_SELECT_V2");
+  return e ? atoi(e) != 0 : true;
+}
+
+// the two selection launches over ctx->ys[0..M): SelState and picks[npass] at the head of ctx->red
+static int enqueue_select(gpbo_ctx* ctx, int64_t M, int npass, bool v2, SelState** st_out, Key** picks_out) {
   int rc;
-  if ((rc = ensure(ctx, &ctx->ys, &ctx->cap_ys, M))) return rc;
   const int nblocks = (int)((M + SEL_BLOCK * SEL_ITEMS - 1) / (SEL_BLOCK * SEL_ITEMS));
-  const int npass = k_seeds > 0 ? k_seeds : 1;
   // scratch layout: SelState | picks[npass] | partial[nblocks][npass] | nan_partial[nblocks]
   const int64_t bytes = sizeof(SelState) + sizeof(Key) * (npass + (int64_t)nblocks * npass) + sizeof(int64_t) * nblocks + 64;
   {
@@ -237,17 +455,64 @@ static int enqueue_acq_select(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_
   Key* picks = (Key*)(base + sizeof(SelState));
   Key* partial = picks + npass;
   int64_t* nan_partial = (int64_t*)(partial + (int64_t)nblocks * npass);
+  if (v2) {
+    const int cap = select_v2_cap();
+    select_block_topk_v2_kernel<<<dim3((unsigned)nblocks), dim3(SEL_BLOCK), 0, ctx->stream>>>(ctx->ys, M, npass, cap, partial, nan_partial);
+    select_merge_topk_v2_kernel<<<dim3(1), dim3(SEL_BLOCK), 0, ctx->stream>>>(ctx->ys, partial, nan_partial, nblocks, npass, cap, st, picks);
+  } else {
+    select_block_topk_kernel<<<dim3((unsigned)nblocks), dim3(SEL_BLOCK), 0, ctx->stream>>>(ctx->ys, M, npass, partial, nan_partial);
+    select_merge_topk_kernel<<<dim3(1), dim3(SEL_BLOCK), 0, ctx->stream>>>(partial, nan_partial, nblocks, npass, st, picks);
+  }
+  GPBO_HIP(ctx, hipGetLastError());
+  *st_out = st; *picks_out = picks;
+  return GPBO_OK;
+}
 
+// acq values + the selection enqueued on ctx->stream; SelState and picks[npass] stay in ctx->red
+static int enqueue_acq_select(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, SelState** st_out, Key** picks_out,
+                              int* npass_out) {
+  int rc;
+  if ((rc = ensure(ctx, &ctx->ys, &ctx->cap_ys, M))) return rc;
+  const int npass = k_seeds > 0 ? k_seeds : 1;
   AcqDev d;
   d.acq = a.acq; d.param = a.param; d.y_max = a.y_max; d.n_constraints = a.n_constraints;
   for (int j = 0; j < GPBO_MAX_MODELS; ++j) { d.lb[j] = a.lb[j]; d.ub[j] = a.ub[j]; d.mu[j] = a.mu[j]; d.sd[j] = a.sd[j]; }
   acq_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream>>>(d, M, ctx->ys);
   GPBO_HIP(ctx, hipGetLastError());
+  if ((rc = enqueue_select(ctx, M, npass, select_v2_enabled(), st_out, picks_out))) return rc;
+  *npass_out = npass;
+  return GPBO_OK;
+}
 
-  select_block_topk_kernel<<<dim3((unsigned)nblocks), dim3(SEL_BLOCK), 0, ctx->stream>>>(ctx->ys, M, npass, partial, nan_partial);
-  select_merge_topk_kernel<<<dim3(1), dim3(SEL_BLOCK), 0, ctx->stream>>>(partial, nan_partial, nblocks, npass, st, picks);
-  GPBO_HIP(ctx, hipGetLastError());
-  *st_out = st; *picks_out = picks; *npass_out = npass;
+// gpbo_debug_select: the selection alone over caller-supplied values (both forms, timed) — see include/gpbo.h
+int debug_select(gpbo_ctx* ctx, const double* ys_host, int64_t M, int k, int variant, int iters, int64_t* idx_out, double* val_out,
+                 int64_t* first_nan_out, float* ms_out) {
+  int rc;
+  if ((rc = ensure(ctx, &ctx->ys, &ctx->cap_ys, M))) return rc;
+  GPBO_HIP(ctx, hipMemcpyAsync(ctx->ys, ys_host, (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  SelState* st = nullptr; Key* picks = nullptr;
+  if ((rc = enqueue_select(ctx, M, k, variant == 2, &st, &picks))) return rc;      // warm-up and the answer
+  hipEvent_t e0, e1;
+  GPBO_HIP(ctx, hipEventCreate(&e0));
+  GPBO_HIP(ctx, hipEventCreate(&e1));
+  GPBO_HIP(ctx, hipEventRecord(e0, ctx->stream));
+  for (int t = 0; t < iters; ++t)
+    if ((rc = enqueue_select(ctx, M, k, variant == 2, &st, &picks))) break;
+  (void)hipEventRecord(e1, ctx->stream);
+  std::vector<char> host(sizeof(SelState) + sizeof(Key) * (size_t)k);
+  hipError_t he = hipMemcpyAsync(host.data(), st, host.size(), hipMemcpyDeviceToHost, ctx->stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+  float ms = 0.0f;
+  if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  GPBO_HIP(ctx, he);
+  const SelState* hst = (const SelState*)host.data();
+  const Key* hp = (const Key*)(host.data() + sizeof(SelState));
+  for (int t = 0; t < k; ++t) { idx_out[t] = hp[t].i == INT64_MAX ? -1 : hp[t].i; val_out[t] = hp[t].v; }
+  if (first_nan_out) *first_nan_out = hst->first_nan == INT64_MAX ? -1 : hst->first_nan;
+  if (ms_out) *ms_out = iters > 0 ? ms / (float)iters : 0.0f;
   return GPBO_OK;
 }
 

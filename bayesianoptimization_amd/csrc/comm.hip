@@ -281,6 +281,7 @@ extern "C" int gpbo_comm_allreduce_max(gpbo_ctx* ctx, double* value) {
   if (!ctx || !value) return GPBO_ERR_INVALID;
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
   GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->comm_lost) GPBO_FAIL(ctx, GPBO_ERR_COMM, "comm_allreduce_max: the communicator was aborted after a failed collective");
   if (!ctx->comm) return GPBO_OK;    // one rank: the maximum is the value itself
   char *dsend, *drecv, *hrecv;
   int rc = comm_buffers(ctx, 1, &dsend, &drecv, &hrecv);
@@ -344,6 +345,7 @@ struct gpbo_group {
       std::lock_guard<std::mutex> lk(mu);
       job = std::move(f);
       pending = (int)ctx.size();
+      std::fill(done_flag.begin(), done_flag.end(), 0);     // here, not in the worker: a worker that never picks the job up is late too
       ++generation;
     }
     cv_job.notify_all();
@@ -387,7 +389,6 @@ static void group_worker(gpbo_group* g, int rank) {
       if (g->stop) return;
       seen = g->generation;
       f = g->job;
-      g->done_flag[rank] = 0;
     }
     const int rc = f(rank);
     {

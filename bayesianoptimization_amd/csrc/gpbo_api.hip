@@ -1161,6 +1161,15 @@ int gpbo_debug_gemm_bench(gpbo_ctx* ctx, int m, int n, int k, int b_trans, int a
   return rc;
 }
 
+int gpbo_debug_select(gpbo_ctx* ctx, const double* ys, int64_t M, int k, int variant, int iters, int64_t* idx_out, double* val_out,
+                      int64_t* first_nan_out, float* ms_out) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  if (!ys || !idx_out || !val_out || M < 1 || k < 1 || k > GPBO_MAX_SEEDS || (variant != 1 && variant != 2) || iters < 0)
+    GPBO_FAIL(ctx, GPBO_ERR_INVALID, "debug_select: bad arguments");
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  return debug_select(ctx, ys, M, k, variant, iters, idx_out, val_out, first_nan_out, ms_out);
+}
+
 int gpbo_debug_latency_probe(gpbo_ctx* ctx, long long* out, int n) {
   if (!ctx || !out || n < 1) return GPBO_ERR_INVALID;
   GPBO_HIP(ctx, hipSetDevice(ctx->device));

@@ -317,6 +317,9 @@ int launch_acq_argbest(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, 
 struct BestRecord { double v; int64_t i; };
 // acq + selection enqueued on ctx->stream, the 1 + k_seeds records left ON THE DEVICE at `records_dev`
 int launch_acq_records(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_seeds, int64_t offset, BestRecord* records_dev);
+// gpbo_debug_select: the selection launches alone over caller-supplied values (variant 1: k passes, 2: threshold + ranks), timed
+int debug_select(gpbo_ctx* ctx, const double* ys_host, int64_t M, int k, int variant, int iters, int64_t* idx_out, double* val_out,
+                 int64_t* first_nan_out, float* ms_out);
 // the reference's argmin / min / argsort[:k] over the union of `world` shards from their records (host; identical on every rank)
 void merge_records(const BestRecord* all, int world, int k_seeds, int64_t* best_idx, double* best_val, int64_t* seed_idx,
                    double* seed_val);

@@ -401,6 +401,16 @@ class GpEngine:
                                                   stamps.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(ms), C.byref(info)))
         return np.tril(Lo), dinv, stamps, ms.value, info.value
 
+    def debug_select(self, ys, k, variant=1, iters=0):
+        """The selection launches alone over `ys` (gpbo_debug_select): (idx (k,), vals (k,), first_nan, ms per selection)."""
+        ys = np.ascontiguousarray(ys, dtype=np.float64)
+        idx = np.empty(int(k), dtype=np.int64)
+        vals = np.empty(int(k))
+        first_nan, ms = C.c_int64(-1), C.c_float(0.0)
+        self._check(self._lib.gpbo_debug_select(self._h, dptr(ys), ys.shape[0], int(k), int(variant), int(iters),
+                                                idx.ctypes.data_as(C.POINTER(C.c_int64)), dptr(vals), C.byref(first_nan), C.byref(ms)))
+        return idx, vals, int(first_nan.value), float(ms.value)
+
     def latency_probe(self, n=16):
         out = np.zeros(32, dtype=np.int64)
         self._check(self._lib.gpbo_debug_latency_probe(self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), int(n)))

@@ -208,7 +208,9 @@ int gpbo_predict_grad(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int 
  * box_lo < box_hi (d,).  Outputs per seed: x_out (n_seeds,d) inside the box, f_out, status_out (0: projected gradient
  * below tolerance, 1: relative reduction below tolerance / no further progress, 2: iteration limit or a non-finite start —
  * SciPy's success = False), n_rounds_out (optional) = batched evaluations issued; n_iter_out / n_eval_out (optional, per seed) =
- * accepted steps / objective evaluations, SciPy's nit / nfev. */
+ * accepted steps / objective evaluations, SciPy's nit / nfev.  Like gpbo_predict, the call uses the context's candidate
+ * buffer for its trial points: the resident candidate set is gone afterwards (fetch x_min / the seeds with
+ * gpbo_get_candidate_rows first, as the reference reads x_tries before it starts its local searches, acquisition.py:313-317). */
 int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, double y_max, int n_constraints, const double* lb,
                       const double* ub, const double* y_mean, const double* y_std, const double* seeds, int n_seeds, int d,
                       const double* box_lo, const double* box_hi, int max_iter, double* x_out, double* f_out, int* status_out,
@@ -325,6 +327,14 @@ int gpbo_debug_gemm(gpbo_ctx* ctx, int m, int n, int k, double alpha, const doub
  * the flops); a_trans: A given as (k,m). */
 int gpbo_debug_gemm_bench(gpbo_ctx* ctx, int m, int n, int k, int b_trans, int a_trans, int lower_only, int iters,
                           double* out);
+/* The selection launches of gpbo_acq_argbest alone — ys.argmin(), argsort(ys)[:k] (bayes_opt/acquisition.py:313-317) — over
+ * caller-supplied values ys (M,): idx_out / val_out (k,) = the k smallest keys in order (index -1 = fewer than k values),
+ * first_nan_out = lowest index holding NaN or -1, ms_out = milliseconds per selection over `iters` repeats.  variant 1: k
+ * block-reduction passes (what GPBO_SELECT_V2=0 switches gpbo_acq_argbest back to); variant 2: threshold + rank counting
+ * (the default; GPBO_SELECT_V2_CAP bounds its LDS list, beyond which it falls back to the passes).  Same picks, bit for
+ * bit.  Overwrites the context's acquisition values. */
+int gpbo_debug_select(gpbo_ctx* ctx, const double* ys, int64_t M, int k, int variant, int iters, int64_t* idx_out,
+                      double* val_out, int64_t* first_nan_out, float* ms_out);
 /* Single-wave instruction latency / issue-cost probe: out[t] = shader cycles for 64 copies of pattern t (latency_probe.hip
  * lists the patterns; t = 0 is the empty bracket).  n <= 32. */
 int gpbo_debug_latency_probe(gpbo_ctx* ctx, long long* out, int n);

@@ -16,7 +16,8 @@ MAP = {
     "chol_trace_4096_kernel_stats.txt": "r03_trace_cholesky_4096_kernel_stats.txt",
     "chol_trace_512_kernel_stats.txt": "r03_trace_cholesky_512_kernel_stats.txt",
     "lml_trace_kernel_stats.txt": "r03_trace_lml_4096_kernel_stats.txt",
-    "pytest.log": "r03_pytest_gpu.log",
+    "pytest.log": "r03_pytest_gpu.log", "pytest_select_v1.log": "r03_pytest_gpu_select_v1.log",
+    "r03_select_probe.json": "r03_select_probe.json", "c2_trace_kernel_stats.txt": "r03_trace_C2_kernel_stats.txt",
 }
 for src, dst in MAP.items():
     s = os.path.join(F, src)

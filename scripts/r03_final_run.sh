@@ -2,6 +2,8 @@
 # End-of-round measurement run (on the GPU box through gpurun): the whole -m gpu suite, smoke(), the rocprofv3 passes of the
 # bench command (their summaries are put under profiles/ ON THE BOX first so that the bench line quotes PMC numbers of the
 # very library it runs), the bench lines and the round's timing scripts.  Everything lands in gpurun_out/final3/.
+# The Cholesky / LML traces and the latency probes of the earlier runs are not repeated here: those kernels have not changed
+# since (scripts/r03_chol_run.sh, r03_lml_run.sh reproduce them).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 F=gpurun_out/final3; rm -rf $F; mkdir -p $F
@@ -10,21 +12,6 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 bash scripts/profile_pmc.sh final3/pmc_C3 --config C3 > $F/pmc_C3.log 2>&1
 cp $F/pmc_C3/summary.json profiles/r03_pmc_C3.json; cp $F/pmc_C3/summary.txt profiles/r03_pmc_C3.txt
 timeout 300 python bench.py > $F/bench_default.json 2> $F/bench_default.err
-GPBO_BENCH_DEVICES=0,0 timeout 300 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > $F/bench_C4_group2_virtual.json 2> $F/bench_C4_group2_virtual.err
-timeout 200 python scripts/r03_chol_probe.py > $F/chol_probe.log 2>&1; cp gpurun_out/r03_chol_probe.json $F/ 2>/dev/null
-timeout 100 python scripts/theta_search_timing.py > $F/theta.log 2>&1; cp gpurun_out/theta_search_timing.json $F/ 2>/dev/null
-timeout 100 python scripts/r03_polish_modes.py > $F/polish_modes.log 2>&1; cp gpurun_out/r03_polish_modes.json $F/ 2>/dev/null
-timeout 100 python scripts/r03_la_probe.py 224 > $F/la_probe.log 2>&1; cp gpurun_out/r03_la_probe.json $F/ 2>/dev/null
-timeout 60 python scripts/r03_col_stamps.py 128 512 > $F/col_stamps.log 2>&1
-timeout 60 python scripts/r03_latency_probe.py > $F/latency_probe.log 2>&1
-for n in 4096 512; do
-  timeout 120 rocprofv3 --kernel-trace --stats -d $F/chol_trace_$n -o chol -- python scripts/r03_chol_trace.py $n 3 > $F/chol_trace_$n.log 2>&1
-  f=$(find $F/chol_trace_$n -name '*results.db' | head -1)
-  [ -n "$f" ] && python scripts/rocpd_summary.py "$f" > $F/chol_trace_${n}_kernel_stats.txt
-done
-timeout 120 rocprofv3 --kernel-trace --stats -d $F/lml_trace -o lml -- python scripts/r03_lml_trace.py 4096 > $F/lml_trace.log 2>&1
-f=$(find $F/lml_trace -name '*results.db' | head -1); [ -n "$f" ] && python scripts/rocpd_summary.py "$f" > $F/lml_trace_kernel_stats.txt
-find $F -name '*.db' -delete      # the summaries stay, the databases do not travel back
 python - "$F/bench_default.json" <<'PY'
 import json, sys
 try:
@@ -37,3 +24,14 @@ try:
 except Exception as e:
     print("ERR", e)
 PY
+timeout 100 python scripts/r03_select_probe.py > $F/select_probe.log 2>&1; cp gpurun_out/r03_select_probe.json $F/ 2>/dev/null; cat $F/select_probe.log | tail -9
+timeout 120 rocprofv3 --kernel-trace --stats -d $F/c2_trace -o c2 -- python bench.py --config C2 --steps 20 --warmup 3 --no-cpu-baseline --no-suggest > $F/c2_trace.log 2>&1
+f=$(find $F/c2_trace -name '*results.db' | head -1); [ -n "$f" ] && python scripts/rocpd_summary.py "$f" > $F/c2_trace_kernel_stats.txt
+GPBO_BENCH_DEVICES=0,0 timeout 300 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > $F/bench_C4_group2_virtual.json 2> $F/bench_C4_group2_virtual.err
+# the k-pass selection (GPBO_SELECT_V2=0) keeps the whole suite green too
+GPBO_SELECT_V2=0 timeout 900 python -m pytest tests -x -q -m gpu > $F/pytest_select_v1.log 2>&1; echo "pytest(select v1) rc=$?"; grep -E "passed|failed" $F/pytest_select_v1.log | tail -1
+timeout 100 python scripts/theta_search_timing.py > $F/theta.log 2>&1; cp gpurun_out/theta_search_timing.json $F/ 2>/dev/null
+timeout 100 python scripts/r03_polish_modes.py > $F/polish_modes.log 2>&1; cp gpurun_out/r03_polish_modes.json $F/ 2>/dev/null
+timeout 200 python scripts/r03_chol_probe.py > $F/chol_probe.log 2>&1; cp gpurun_out/r03_chol_probe.json $F/ 2>/dev/null
+find $F -name '*.db' -delete      # the summaries stay, the databases do not travel back
+echo done
