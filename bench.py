@@ -272,11 +272,15 @@ def run_extra_config(eng, name, steps=5, warmup=2):
         else:
             eng.fit(X, yn, w.kernel, w.length_scale, w.noise, slot=0, precision=prec)
         eng.posterior(0, y_mean, y_std, fetch=False)
-        post[0] = eng.last_timings()["posterior_main"]
         if w.constrained:
+            # the two posteriors share one event pair: the first is read (a stream synchronisation) before the second is enqueued
+            post[0] = eng.last_timings()["posterior_main"]
             eng.posterior(1, c_mean, c_std, fetch=False)
             post[0] += eng.last_timings()["posterior_main"]
-        return eng.acq_argbest(w.acq, w.acq_param, 0.0 if y_max is None else y_max, lb_c, ub_c, k_seeds=10)[:4]
+        best = eng.acq_argbest(w.acq, w.acq_param, 0.0 if y_max is None else y_max, lb_c, ub_c, k_seeds=10)[:4]
+        if not w.constrained:
+            post[0] = eng.last_timings()["posterior_main"]     # after the step: the harness puts no synchronisation inside it
+        return best
 
     for _ in range(warmup):
         step()
@@ -460,12 +464,16 @@ def main():
             return argbest()
         eng.fit(X, yn, w.kernel, w.length_scale, w.noise, slot=0, precision=prec)
         eng.posterior(0, y_mean, y_std, fetch=False)
-        post_ms[0] = eng.last_timings()["posterior_main"]
         if w.constrained:   # constraint GP in slot 1 (bayes_opt/constraint.py:132-151, 199-221)
+            # the two posteriors share one event pair: the first is read (a stream synchronisation) before the second is enqueued
+            post_ms[0] = eng.last_timings()["posterior_main"]
             eng.fit(X, cn, W.MATERN25, w.constraint_length_scale, w.noise, slot=1, precision=prec)
             eng.posterior(1, c_mean, c_std, fetch=False)
             post_ms[0] += eng.last_timings()["posterior_main"]
-        return argbest()
+        best = argbest()
+        if not w.constrained:
+            post_ms[0] = eng.last_timings()["posterior_main"]   # after the step: the harness puts no synchronisation inside it
+        return best
 
     for _ in range(args.warmup):
         step()
