@@ -479,7 +479,8 @@ static int enqueue_acq_select(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_
   for (int j = 0; j < GPBO_MAX_MODELS; ++j) { d.lb[j] = a.lb[j]; d.ub[j] = a.ub[j]; d.mu[j] = a.mu[j]; d.sd[j] = a.sd[j]; }
   acq_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream>>>(d, M, ctx->ys);
   GPBO_HIP(ctx, hipGetLastError());
-  if ((rc = enqueue_select(ctx, M, npass, select_v2_enabled(), st_out, picks_out))) return rc;
+  // one or two picks: the passes are the shorter chain (k = 1: 11 us against 16, profiles/r03_select_probe.json)
+  if ((rc = enqueue_select(ctx, M, npass, select_v2_enabled() && npass >= 3, st_out, picks_out))) return rc;
   *npass_out = npass;
   return GPBO_OK;
 }

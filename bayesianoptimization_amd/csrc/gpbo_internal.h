@@ -337,7 +337,7 @@ int launch_lml_terms(gpbo_ctx* ctx, Model& m, double* out2_dev);
 int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, double* partial, double* grad_dev);
 // mt_jump.hip: states_dev[w] = block 1 + poly_idx[w] * stride_blocks of the MT19937 sequence whose block 0 is key_dev
 int mt_jump_states(gpbo_ctx* ctx, const unsigned* key_dev, int64_t stride_blocks, int max_k, const int* poly_idx_dev,
-                   int n_states, unsigned* seq_dev, unsigned* states_dev);
+                   int n_states, unsigned* seq_dev, unsigned* states_dev, unsigned* windows_dev);
 // probe.hip
 int run_mfma_peak(gpbo_ctx* ctx, int iters, double* tflops);
 int run_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);

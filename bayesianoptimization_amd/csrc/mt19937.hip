@@ -273,12 +273,13 @@ static int mt_generate_rows(gpbo_ctx* ctx, int64_t M, int d, int64_t r0, int64_t
   if (M * (int64_t)d >= 1 && chunks.empty()) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "generate_candidates_mt19937: empty plan");
   // when the last double is not generated here, nobody returns the state
   const bool owns_end = (r1 == M);
-  // device work area: [key_out 624 | seq 34 x 624 | states n x 624] words ; descriptors + polynomial indices
+  // device work area: [key_out 624 | seq 34 x 624 | states n x 624 | windows n x 624] words ; descriptors + polynomial indices
   const int n_states = (int)polys.size();
-  if ((rc = ensure(ctx, &ctx->mt_work, &ctx->cap_mt_work, (int64_t)MT_N * (1 + 34 + std::max(1, n_states))))) return rc;
+  if ((rc = ensure(ctx, &ctx->mt_work, &ctx->cap_mt_work, (int64_t)MT_N * (1 + 34 + 2 * std::max(1, n_states))))) return rc;
   unsigned* key_out_dev = ctx->mt_work;
   unsigned* seq_dev = key_out_dev + MT_N;
   unsigned* states_dev = seq_dev + 34 * MT_N;
+  unsigned* windows_dev = states_dev + (int64_t)MT_N * std::max(1, n_states);
   const size_t desc_bytes = chunks.size() * sizeof(MtChunk), idx_bytes = (size_t)std::max(1, n_states) * sizeof(int);
   {
     char* p = (char*)ctx->mt_desc;
@@ -292,7 +293,7 @@ static int mt_generate_rows(gpbo_ctx* ctx, int64_t M, int d, int64_t r0, int64_t
   GPBO_HIP(ctx, hipMemcpyAsync(chunks_dev, chunks.data(), desc_bytes, hipMemcpyHostToDevice, ctx->stream));
   if (n_states > 0) {
     GPBO_HIP(ctx, hipMemcpyAsync(polys_dev, polys.data(), (size_t)n_states * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-    if ((rc = mt_jump_states(ctx, dkey, stride, max_k, polys_dev, n_states, seq_dev, states_dev))) return rc;
+    if ((rc = mt_jump_states(ctx, dkey, stride, max_k, polys_dev, n_states, seq_dev, states_dev, windows_dev))) return rc;
   }
   mt19937_uniform_kernel<<<dim3((unsigned)chunks.size()), dim3(512), 0, ctx->stream>>>(
       dkey, pos, chunks_dev, states_dev, (const double*)ctx->red, ctx->stage, key_out_dev,

@@ -16,7 +16,9 @@ MAP = {
     "chol_trace_4096_kernel_stats.txt": "r03_trace_cholesky_4096_kernel_stats.txt",
     "chol_trace_512_kernel_stats.txt": "r03_trace_cholesky_512_kernel_stats.txt",
     "lml_trace_kernel_stats.txt": "r03_trace_lml_4096_kernel_stats.txt",
-    "pytest.log": "r03_pytest_gpu.log", "pytest_select_v1.log": "r03_pytest_gpu_select_v1.log",
+    "pytest.log": "r03_pytest_gpu.log", "pytest_round2_forms.log": "r03_pytest_gpu_round2_forms.log",
+    "suggest_C2_n_smart_0_reference_kernel_stats.txt": "r03_trace_C2_suggest_kernel_stats.txt",
+    "suggest_C2_n_smart_10_device_kernel_stats.txt": "r03_trace_C2_suggest_device_local_search_kernel_stats.txt",
     "r03_select_probe.json": "r03_select_probe.json", "c2_trace_kernel_stats.txt": "r03_trace_C2_kernel_stats.txt",
 }
 for src, dst in MAP.items():

@@ -1,9 +1,10 @@
 #!/bin/bash
 # End-of-round measurement run (on the GPU box through gpurun): the whole -m gpu suite, smoke(), the rocprofv3 passes of the
 # bench command (their summaries are put under profiles/ ON THE BOX first so that the bench line quotes PMC numbers of the
-# very library it runs), the bench lines and the round's timing scripts.  Everything lands in gpurun_out/final3/.
-# The Cholesky / LML traces and the latency probes of the earlier runs are not repeated here: those kernels have not changed
-# since (scripts/r03_chol_run.sh, r03_lml_run.sh reproduce them).
+# very library it runs), the bench line, kernel traces of whole suggest() calls at C2, and the suite once more on the
+# round-2 forms of the two kernels this round replaced late (selection, MT19937 jump).  Everything lands in gpurun_out/final3/.
+# Not repeated here (those kernels have not changed since their runs, see profiles/README.md): scripts/r03_chol_run.sh,
+# r03_lml_run.sh, r03_select_probe.py, r03_chol_probe.py, theta_search_timing.py, the C2 step trace, the 2-virtual-rank bench.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 F=gpurun_out/final3; rm -rf $F; mkdir -p $F
@@ -24,14 +25,15 @@ try:
 except Exception as e:
     print("ERR", e)
 PY
-timeout 100 python scripts/r03_select_probe.py > $F/select_probe.log 2>&1; cp gpurun_out/r03_select_probe.json $F/ 2>/dev/null; cat $F/select_probe.log | tail -9
-timeout 120 rocprofv3 --kernel-trace --stats -d $F/c2_trace -o c2 -- python bench.py --config C2 --steps 20 --warmup 3 --no-cpu-baseline --no-suggest > $F/c2_trace.log 2>&1
-f=$(find $F/c2_trace -name '*results.db' | head -1); [ -n "$f" ] && python scripts/rocpd_summary.py "$f" > $F/c2_trace_kernel_stats.txt
-GPBO_BENCH_DEVICES=0,0 timeout 300 python bench.py --gpus 2 --steps 3 --warmup 1 --no-cpu-baseline > $F/bench_C4_group2_virtual.json 2> $F/bench_C4_group2_virtual.err
-# the k-pass selection (GPBO_SELECT_V2=0) keeps the whole suite green too
-GPBO_SELECT_V2=0 timeout 900 python -m pytest tests -x -q -m gpu > $F/pytest_select_v1.log 2>&1; echo "pytest(select v1) rc=$?"; grep -E "passed|failed" $F/pytest_select_v1.log | tail -1
-timeout 100 python scripts/theta_search_timing.py > $F/theta.log 2>&1; cp gpurun_out/theta_search_timing.json $F/ 2>/dev/null
+for spec in "0 reference" "10 device"; do
+  set -- $spec
+  tag=suggest_C2_n_smart_$1_$2
+  timeout 100 rocprofv3 --kernel-trace --stats -d $F/$tag -o t -- python scripts/r03_suggest_trace.py C2 $1 $2 20 > $F/$tag.log 2>&1
+  f=$(find $F/$tag -name '*results.db' | head -1); [ -n "$f" ] && python scripts/rocpd_summary.py "$f" > $F/${tag}_kernel_stats.txt
+  grep -E "median" $F/$tag.log
+done
+# the round-2 selection (k passes) and MT19937 jump (one workgroup per window) keep the whole suite green too
+GPBO_SELECT_V2=0 GPBO_MT_JUMP_SPLIT=0 timeout 900 python -m pytest tests -x -q -m gpu > $F/pytest_round2_forms.log 2>&1; echo "pytest(round-2 forms) rc=$?"; grep -E "passed|failed" $F/pytest_round2_forms.log | tail -1
 timeout 100 python scripts/r03_polish_modes.py > $F/polish_modes.log 2>&1; cp gpurun_out/r03_polish_modes.json $F/ 2>/dev/null
-timeout 200 python scripts/r03_chol_probe.py > $F/chol_probe.log 2>&1; cp gpurun_out/r03_chol_probe.json $F/ 2>/dev/null
 find $F -name '*.db' -delete      # the summaries stay, the databases do not travel back
 echo done
