@@ -6,7 +6,7 @@ import warnings
 
 import numpy as np
 import pytest
-from sklearn.gaussian_process.kernels import RBF, Matern
+from sklearn.gaussian_process.kernels import Matern
 
 from bayesianoptimization_amd import fused_acquisition as A
 from bayesianoptimization_amd import workloads as W

@@ -5,7 +5,6 @@ import ctypes as C
 import os
 import subprocess
 import sys
-import time
 
 import pytest
 

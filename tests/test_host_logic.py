@@ -1,7 +1,5 @@
 """CPU: host-side mirror of the reference interface (space, acquisition orchestration, merge rules),
 checked against the reference itself when /root/reference is mounted."""
-import warnings
-
 import numpy as np
 import pytest
 

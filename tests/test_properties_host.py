@@ -4,7 +4,6 @@ NumPy's NaN-first / first-index tie rules included), the finite-difference point
 L-BFGS-B driver (must equal SciPy's approx_derivative steps), and the MT19937 block walk (any stream position, any
 shape)."""
 import numpy as np
-import pytest
 from hypothesis import given, settings
 from hypothesis import strategies as st
 
