@@ -12,13 +12,14 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpbo.so")
+DEBUG_LIB_PATH = os.path.join(_HERE, "libgpbo_dbg.so")     # the same sources built with -DGPBO_DEBUG (tests / scripts only)
 
 GPBO_OK = 0
-ERR_INVALID, ERR_HIP, ERR_NOT_PD, ERR_STATE, ERR_UNSUPPORTED, ERR_COMM = -1, -2, -3, -4, -5, -6
+ERR_INVALID, ERR_HIP, ERR_NOT_PD, ERR_STATE, ERR_UNSUPPORTED, ERR_COMM, ERR_PEER = -1, -2, -3, -4, -5, -6, -7
 MAX_MODELS = 8
 MAX_DIM = 64
 MAX_SEEDS = 64
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_double_p = C.POINTER(C.c_double)
 _c_int64_p = C.POINTER(C.c_int64)
@@ -100,6 +101,13 @@ SIGNATURES = {
     "gpbo_polish_seeds": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_int, _c_double_p, _c_double_p, _c_double_p,
                                     _c_double_p, _c_double_p, C.c_int, C.c_int, _c_double_p, _c_double_p, C.c_int, _c_double_p,
                                     _c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gpbo_mfma_f64_peak": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
+    "gpbo_mfma_f64_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _c_double_p]),
+    "gpbo_hbm_copy_peak": (C.c_int, [C.c_void_p, C.c_int64, _c_double_p]),
+}
+
+# entry points only libgpbo_dbg.so exports (include/gpbo.h, "#ifdef GPBO_DEBUG")
+DEBUG_SIGNATURES = {
     "gpbo_debug_minimize_box": (C.c_int, [C.c_void_p, C.c_void_p, _c_double_p, C.c_int, C.c_int, _c_double_p, _c_double_p, C.c_int,
                                           _c_double_p, _c_double_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                           C.POINTER(C.c_int)]),
@@ -114,17 +122,27 @@ SIGNATURES = {
                                   C.c_int, C.c_double, _c_double_p]),
     "gpbo_debug_gemm_bench": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         _c_double_p]),
-    "gpbo_mfma_f64_peak": (C.c_int, [C.c_void_p, C.c_int, _c_double_p]),
-    "gpbo_mfma_f64_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, _c_double_p]),
     "gpbo_hybrid_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_double_p]),
-    "gpbo_hbm_copy_peak": (C.c_int, [C.c_void_p, C.c_int64, _c_double_p]),
+    "gpbo_debug_fail_next_acq": (C.c_int, [C.c_void_p]),
 }
 
 _lib = None
+_debug_lib = None
 
 
 class GpboError(RuntimeError):
     """HIP / state / communicator failure reported by libgpbo."""
+
+
+def _bind(path: str, signatures: dict):
+    lib = C.CDLL(path)
+    for name, (res, args) in signatures.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gpbo_abi_version() != ABI_VERSION:
+        raise ImportError(f"libgpbo ABI {lib.gpbo_abi_version()} != expected {ABI_VERSION}; rebuild")
+    return lib
 
 
 def load_library(path: str | None = None):
@@ -145,15 +163,25 @@ def load_library(path: str | None = None):
         raise ImportError(
             f"{path} not found: the HIP extension has not been built. Run "
             "`python -m bayesianoptimization_amd.build` (needs hipcc). There is no CPU fallback.")
-    lib = C.CDLL(path)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the .so is stale
-        fn.restype = res
-        fn.argtypes = args
-    if lib.gpbo_abi_version() != ABI_VERSION:
-        raise ImportError(f"libgpbo ABI {lib.gpbo_abi_version()} != expected {ABI_VERSION}; rebuild")
-    _lib = lib
+    lib = _bind(path, SIGNATURES)
+    if not explicit:
+        _lib = lib
     return lib
+
+
+def load_debug_library():
+    """libgpbo_dbg.so: the product's sources + the debug entry points and A/B switches.  For tests and scripts — nothing on
+    the product path (engine defaults, dropin, bench's timed region) loads it."""
+    global _debug_lib
+    if _debug_lib is None:
+        if not os.path.exists(DEBUG_LIB_PATH):
+            try:
+                from .build import build_debug
+                build_debug(verbose=False)
+            except Exception as e:  # noqa: BLE001
+                raise ImportError(f"{DEBUG_LIB_PATH} not found and building it failed ({e})") from e
+        _debug_lib = _bind(DEBUG_LIB_PATH, {**SIGNATURES, **DEBUG_SIGNATURES})
+    return _debug_lib
 
 
 def dptr(a: np.ndarray | None):

@@ -2,8 +2,11 @@
 
     python -m bayesianoptimization_amd.build [--force]
 
-hipcc cross-compiles without a GPU.  The shared library lands next to this file
-(bayesianoptimization_amd/libgpbo.so) so that it travels with the source tree.
+hipcc cross-compiles without a GPU.  Two shared libraries land next to this file so that they travel with the source
+tree:
+  libgpbo.so      the product: the C ABI of include/gpbo.h, no debug entry points, no A/B environment switches
+  libgpbo_dbg.so  the same sources with -DGPBO_DEBUG: + the self-test seams / micro-benchmarks (gpbo_debug_*, probes) and
+                  the kernel A/B switches — what tests/ and scripts/ load when they need those (never the product path)
 """
 from __future__ import annotations
 
@@ -18,6 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libgpbo.so")
+LIB_DEBUG = os.path.join(HERE, "libgpbo_dbg.so")
 OBJDIR = os.path.join(HERE, "build")
 ARCH = "gfx950"
 
@@ -37,9 +41,11 @@ SOURCES = {
     "candidates.hip": [],
     "mt19937.hip": ["-ffp-contract=off"],      # lo + (hi - lo) * u as NumPy computes it
     "mt_jump.hip": [],                         # jump-ahead polynomials (host) + sub-stream start states (device)
-    "probe.hip": [],
-    "latency_probe.hip": [],
+    "probe.hip": [],                           # calibration: MFMA fp64 peak / sustained clock, HBM copy peak (bench.py's roofline keys)
     "comm.hip": [],
+}
+DEBUG_ONLY_SOURCES = {
+    "latency_probe.hip": [],                   # single-wave instruction latency probe (the one scratch-using kernel): debug build only
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result",
           "-I" + INCLUDE, "-I" + CSRC, "-I/opt/rocm/include"] + os.environ.get("GPBO_EXTRA_FLAGS", "").split()   # probe builds: -D switches
@@ -61,24 +67,30 @@ def _fingerprint() -> str:
             h.update(n.encode())
             h.update(open(p, "rb").read())
     h.update(repr(sorted(SOURCES.items())).encode())
+    h.update(repr(sorted(DEBUG_ONLY_SOURCES.items())).encode())
     # flags without the absolute include paths: the same sources must give the same fingerprint wherever the tree lies
     # (the GPU box runs from a scratch copy; profiles/ stamps its PMC summaries with this value)
     h.update(" ".join(f for f in COMMON if not f.startswith("-I")).encode())
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    stamp = LIB + ".fingerprint"   # next to the library, so the pair travels together
-    fp = _fingerprint()
-    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == fp:
-        return LIB
-    os.makedirs(OBJDIR, exist_ok=True)
+def _build_one(lib: str, debug: bool, force: bool, verbose: bool) -> str:
+    stamp = lib + ".fingerprint"   # next to the library, so the pair travels together
+    fp = _fingerprint() + ("-debug" if debug else "")
+    if not force and os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read() == fp:
+        return lib
+    objdir = OBJDIR + ("_dbg" if debug else "")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
+    sources = dict(SOURCES)
+    if debug:
+        sources.update(DEBUG_ONLY_SOURCES)
+    defines = ["-DGPBO_DEBUG"] if debug else []
 
     def compile_one(item):
         src, extra = item
-        obj = os.path.join(OBJDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, *COMMON, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc, *COMMON, *defines, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
@@ -86,16 +98,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
             sys.stderr.write(r.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
-        objs = list(ex.map(compile_one, SOURCES.items()))
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", LIB, "-ldl"]
+    with ThreadPoolExecutor(max_workers=min(8, len(sources))) as ex:
+        objs = list(ex.map(compile_one, sources.items()))
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", *objs, "-o", lib, "-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
     open(stamp, "w").write(fp)
     if verbose:
-        print(f"built {LIB}")
-    return LIB
+        print(f"built {lib}")
+    return lib
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """Build both libraries (each only when its sources / flags changed); returns the PRODUCT library's path."""
+    _build_one(LIB_DEBUG, True, force, verbose)
+    return _build_one(LIB, False, force, verbose)
+
+
+def build_debug(force: bool = False, verbose: bool = True) -> str:
+    return _build_one(LIB_DEBUG, True, force, verbose)
 
 
 if __name__ == "__main__":

@@ -428,12 +428,12 @@ __global__ __launch_bounds__(SEL_BLOCK) void select_merge_topk_v2_kernel(const d
 }
 
 static int select_v2_cap() {      // read per call: gpbo_debug_select and the tests switch it inside one process
-  const char* e = getenv("GPBO_SELECT_V2_CAP");
+  const char* e = dbg_env("GPBO_SELECT_V2_CAP");
   const int c = e ? atoi(e) : SEL2_CAP;
   return c < 1 ? 1 : (c > SEL2_CAP ? SEL2_CAP : c);
 }
 static bool select_v2_enabled() {
-  const char* e = getenv("GPBO_SELECT_V2");
+  const char* e = dbg_env("GPBO_SELECT_V2");
   return e ? atoi(e) != 0 : true;
 }
 

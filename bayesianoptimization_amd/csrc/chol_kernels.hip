@@ -645,9 +645,9 @@ static int launch_step(gpbo_ctx* ctx, Model& m, int kb, int nblk, const GemmArgs
 // the rest free for the chain at any moment.  GPBO_CHOL_LA=0 turns the look-ahead off (A/B runs).
 static int lookahead_min_np() {
   static const int v = [] {
-    const char* e = getenv("GPBO_CHOL_LA");
+    const char* e = dbg_env("GPBO_CHOL_LA");
     if (e && e[0] == '0') return 1 << 30;
-    const char* f = getenv("GPBO_CHOL_LA_MIN_NP");
+    const char* f = dbg_env("GPBO_CHOL_LA_MIN_NP");
     return f ? atoi(f) : 4096;     // measured (scripts/r03_la_probe.py): 2048 0.709 -> 0.721 ms, 4096 1.82 -> 1.75, 8192 6.42 -> 6.17
   }();
   return v;
@@ -660,7 +660,7 @@ static LookAhead* lookahead_for(gpbo_ctx* ctx, int n_events) {
   if (!la) {
     LookAhead l;
     l.main = ctx->stream;
-    static const int cus = getenv("GPBO_CHOL_LA_CUS") ? atoi(getenv("GPBO_CHOL_LA_CUS")) : 0;
+    static const int cus = dbg_env("GPBO_CHOL_LA_CUS") ? atoi(dbg_env("GPBO_CHOL_LA_CUS")) : 0;
     hipError_t e = hipErrorUnknown;
     if (cus > 0) {
       hipDeviceProp_t prop;

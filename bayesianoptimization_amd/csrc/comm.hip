@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <functional>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -125,12 +126,16 @@ static double env_seconds(const char* name, double dflt) {
   return v > 0.0 ? v : dflt;
 }
 
+// The group's main thread (deadline of a job) and the context's own worker (deadline of a collective) may both decide to
+// abort: whoever exchanges the pointer out owns the one ncclCommAbort call; the other finds NULL and does nothing.
 static void abort_comm(gpbo_ctx* ctx) {
-  if (!ctx || !ctx->comm) return;
-  if (g_rccl.CommAbort) (void)g_rccl.CommAbort((ncclComm_t)ctx->comm);
-  ctx->comm = nullptr;       // never used again (not destroyed: ncclCommAbort has released it)
-  ctx->comm_lost = true;
+  if (!ctx) return;
+  void* c = __atomic_exchange_n(&ctx->comm, (void*)nullptr, __ATOMIC_ACQ_REL);   // never used again (not destroyed: the abort releases it)
+  if (!c) return;
+  __atomic_store_n(&ctx->comm_lost, true, __ATOMIC_RELEASE);
+  if (g_rccl.CommAbort) (void)g_rccl.CommAbort((ncclComm_t)c);
 }
+static void* comm_of(gpbo_ctx* ctx) { return __atomic_load_n(&ctx->comm, __ATOMIC_ACQUIRE); }
 
 // hipStreamSynchronize with a deadline; on expiry the communicator is aborted
 static int wait_collective(gpbo_ctx* ctx, const char* what) {
@@ -187,7 +192,8 @@ extern "C" int gpbo_comm_init(gpbo_ctx* ctx, const char id[128], int world_size,
 
 extern "C" int gpbo_comm_allgather_best(gpbo_ctx* ctx, const double* vals, const int64_t* idxs,
                                         int n_records, double* all_vals, int64_t* all_idxs) {
-  if (!ctx || !ctx->comm) GPBO_FAIL(ctx, GPBO_ERR_STATE, "comm_allgather_best: communicator not initialised");
+  if (!ctx || !comm_of(ctx)) GPBO_FAIL(ctx, GPBO_ERR_STATE, "comm_allgather_best: communicator not initialised");
+  void* const comm = comm_of(ctx);
   if (n_records < 1 || n_records > 4096) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "comm_allgather_best: bad n_records");
   if (!vals || !idxs || !all_vals || !all_idxs) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "comm_allgather_best: NULL argument");
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
@@ -198,7 +204,7 @@ extern "C" int gpbo_comm_allgather_best(gpbo_ctx* ctx, const double* vals, const
   std::vector<BestRecord> host((size_t)n_records);
   for (int t = 0; t < n_records; ++t) host[t] = BestRecord{vals[t], idxs[t]};
   GPBO_HIP(ctx, hipMemcpyAsync(dsend, host.data(), send_bytes, hipMemcpyHostToDevice, ctx->stream));
-  GPBO_NCCL(ctx, g_rccl.AllGather(dsend, drecv, send_bytes, ncclChar, (ncclComm_t)ctx->comm, ctx->stream));
+  GPBO_NCCL(ctx, g_rccl.AllGather(dsend, drecv, send_bytes, ncclChar, (ncclComm_t)comm, ctx->stream));
   GPBO_HIP(ctx, hipMemcpyAsync(hrecv, drecv, recv_bytes, hipMemcpyDeviceToHost, ctx->stream));
   if ((rc = wait_collective(ctx, "comm_allgather_best"))) return rc;
   const BestRecord* all = (const BestRecord*)hrecv;
@@ -215,7 +221,8 @@ extern "C" int gpbo_comm_acq_argbest(gpbo_ctx* ctx, int acq, double acq_param, d
                           best_val, seed_idx, seed_val, &a);
   if (rc) return rc;
   if (ctx->comm_lost) GPBO_FAIL(ctx, GPBO_ERR_COMM, "comm_acq_argbest: the communicator was aborted after a failed collective");
-  if (ctx->world > 1 && !ctx->comm) GPBO_FAIL(ctx, GPBO_ERR_STATE, "comm_acq_argbest: communicator not initialised");
+  void* const comm = comm_of(ctx);     // read once: the group's deadline may abort (and clear) it from another thread
+  if (ctx->world > 1 && !comm) GPBO_FAIL(ctx, GPBO_ERR_STATE, "comm_acq_argbest: communicator not initialised");
   char *dsend, *drecv, *hrecv;
   const int n_records = 1 + k_seeds;
   if ((rc = comm_buffers(ctx, n_records, &dsend, &drecv, &hrecv))) {
@@ -225,13 +232,15 @@ extern "C" int gpbo_comm_acq_argbest(gpbo_ctx* ctx, int acq, double acq_param, d
   const size_t send_bytes = sizeof(BestRecord) * (size_t)n_records, recv_bytes = send_bytes * (size_t)ctx->world;
   ev_begin(ctx, T_ACQ);
   int rc_local = launch_acq_records(ctx, a, ctx->M, k_seeds, index_offset, (BestRecord*)dsend);
-  if (const char* inj = getenv("GPBO_TEST_FAIL_ACQ_RANK"))          // tests: this rank pretends its local pass failed
-    if (rc_local == GPBO_OK && atoi(inj) == ctx->rank) {
-      ctx->err = "injected local failure (GPBO_TEST_FAIL_ACQ_RANK)";
-      rc_local = GPBO_ERR_HIP;
-    }
+#ifdef GPBO_DEBUG
+  if (ctx->debug_fail_next_acq && rc_local == GPBO_OK) {     // gpbo_debug_fail_next_acq: this rank pretends its local pass failed
+    ctx->debug_fail_next_acq = false;
+    ctx->err = "injected local failure (gpbo_debug_fail_next_acq)";
+    rc_local = GPBO_ERR_HIP;
+  }
+#endif
   const std::string local_err = ctx->err;
-  if (rc_local != GPBO_OK && ctx->comm) {
+  if (rc_local != GPBO_OK && comm) {
     // rule (1): enter the exchange anyway, with a poisoned record
     std::vector<BestRecord> poison((size_t)n_records, BestRecord{std::numeric_limits<double>::quiet_NaN(), -1});
     poison[0].i = POISON_INDEX;
@@ -248,8 +257,8 @@ extern "C" int gpbo_comm_acq_argbest(gpbo_ctx* ctx, int acq, double acq_param, d
     return rc_local;
   }
   const char* gathered = dsend;    // a single shard is its own union
-  if (ctx->comm) {
-    const ncclResult_t nr = g_rccl.AllGather(dsend, drecv, send_bytes, ncclChar, (ncclComm_t)ctx->comm, ctx->stream);
+  if (comm) {
+    const ncclResult_t nr = g_rccl.AllGather(dsend, drecv, send_bytes, ncclChar, (ncclComm_t)comm, ctx->stream);
     if (nr != ncclSuccess) {
       ev_end(ctx, T_ACQ);
       abort_comm(ctx);
@@ -258,31 +267,42 @@ extern "C" int gpbo_comm_acq_argbest(gpbo_ctx* ctx, int acq, double acq_param, d
     gathered = drecv;
   }
   ev_end(ctx, T_ACQ);
-  GPBO_HIP(ctx, hipMemcpyAsync(hrecv, gathered, ctx->comm ? recv_bytes : send_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  GPBO_HIP(ctx, hipMemcpyAsync(hrecv, gathered, comm ? recv_bytes : send_bytes, hipMemcpyDeviceToHost, ctx->stream));
   if (ys_out && rc_local == GPBO_OK)
     GPBO_HIP(ctx, hipMemcpyAsync(ys_out, ctx->ys, (size_t)ctx->M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  if (ctx->comm) {
+  if (comm) {
     if ((rc = wait_collective(ctx, "comm_acq_argbest"))) return rc;
   } else {
     GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
-  const int world = ctx->comm ? ctx->world : 1;
+  const int world = comm ? ctx->world : 1;
   const BestRecord* all = (const BestRecord*)hrecv;
   for (int r = 0; r < world; ++r)
     if (all[(size_t)r * n_records].i == POISON_INDEX) {
       if (rc_local != GPBO_OK) { ctx->err = local_err; set_global_error(local_err); return rc_local; }
-      GPBO_FAIL(ctx, GPBO_ERR_COMM, "comm_acq_argbest: rank " + std::to_string(r) + " reported a local failure; no result for this step");
+      // the exchange itself completed and the communicator is intact: a distinct code, so that callers (and
+      // gpbo_group::run) can tell "a peer's step failed" from "the communicator is gone"
+      GPBO_FAIL(ctx, GPBO_ERR_PEER, "comm_acq_argbest: rank " + std::to_string(r) + " reported a local failure; no result for this step");
     }
   merge_records(all, world, k_seeds, best_idx, best_val, seed_idx, seed_val);
   return GPBO_OK;
 }
+
+#ifdef GPBO_DEBUG
+extern "C" int gpbo_debug_fail_next_acq(gpbo_ctx* ctx) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  ctx->debug_fail_next_acq = true;
+  return GPBO_OK;
+}
+#endif
 
 extern "C" int gpbo_comm_allreduce_max(gpbo_ctx* ctx, double* value) {
   if (!ctx || !value) return GPBO_ERR_INVALID;
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
   GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->comm_lost) GPBO_FAIL(ctx, GPBO_ERR_COMM, "comm_allreduce_max: the communicator was aborted after a failed collective");
-  if (!ctx->comm) return GPBO_OK;    // one rank: the maximum is the value itself
+  void* const comm = comm_of(ctx);
+  if (!comm) return GPBO_OK;    // one rank: the maximum is the value itself
   char *dsend, *drecv, *hrecv;
   int rc = comm_buffers(ctx, 1, &dsend, &drecv, &hrecv);
   if (rc) return rc;
@@ -290,7 +310,7 @@ extern "C" int gpbo_comm_allreduce_max(gpbo_ctx* ctx, double* value) {
   double* hword = (double*)(hrecv + sizeof(BestRecord) * (size_t)ctx->world);
   *hword = *value;
   GPBO_HIP(ctx, hipMemcpyAsync(dword, hword, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  GPBO_NCCL(ctx, g_rccl.AllReduce(dword, dword, 1, ncclDouble, ncclMax, (ncclComm_t)ctx->comm, ctx->stream));
+  GPBO_NCCL(ctx, g_rccl.AllReduce(dword, dword, 1, ncclDouble, ncclMax, (ncclComm_t)comm, ctx->stream));
   GPBO_HIP(ctx, hipMemcpyAsync(hword, dword, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if ((rc = wait_collective(ctx, "comm_allreduce_max"))) return rc;
   *value = *hword;
@@ -299,8 +319,8 @@ extern "C" int gpbo_comm_allreduce_max(gpbo_ctx* ctx, double* value) {
 
 extern "C" int gpbo_comm_destroy(gpbo_ctx* ctx) {
   if (!ctx) return GPBO_ERR_INVALID;
-  if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)ctx->comm);
-  ctx->comm = nullptr;
+  void* c = __atomic_exchange_n(&ctx->comm, (void*)nullptr, __ATOMIC_ACQ_REL);
+  if (c && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)c);
   ctx->comm_lost = false;
   ctx->world = 1;
   ctx->rank = 0;
@@ -335,6 +355,12 @@ struct gpbo_group {
   // did not enter, a wedged device — turns into GPBO_ERR_COMM for the caller instead of a hung suggest().  The
   // communicators are aborted (which releases workers blocked inside RCCL), the group is marked broken and every later
   // call fails at once; gpbo_group_destroy then detaches whatever is still stuck.
+  // Lifetime rule: a job closure captures BY VALUE — scalars, the caller's array pointers, and a shared_ptr to whatever
+  // per-job state the workers write (info words, records, returned RNG state).  Every worker holds its own copy of the
+  // closure while it runs, so a worker that is released long after run() gave up writes into state it keeps alive
+  // itself, never into a dead stack frame; the results are copied out to the caller only when run() succeeded.
+  // (The caller's own arrays stay the caller's: after GPBO_ERR_COMM from a timed-out call they must outlive the group —
+  // include/gpbo.h; GroupEngine keeps them referenced.)
   int run(std::function<int(int)> f) {
     if (broken) {
       err = "device group is broken (an earlier call missed its deadline or lost its communicator); create a new group";
@@ -350,29 +376,43 @@ struct gpbo_group {
     }
     cv_job.notify_all();
     std::unique_lock<std::mutex> lk(mu);
-    const double limit = env_seconds("GPBO_GROUP_TIMEOUT_S", 300.0);
+    double limit = env_seconds("GPBO_GROUP_TIMEOUT_S", 300.0);
+    if (!no_device && !virtual_ranks) {
+      // a worker's own collective deadline has to fire first (it names the collective and aborts ITS communicator from
+      // its own thread); the job deadline is the backstop for everything that is not a collective
+      const double comm_limit = env_seconds("GPBO_COMM_TIMEOUT_S", 120.0);
+      if (limit < comm_limit + 15.0) limit = comm_limit + 15.0;
+    }
     if (!cv_done.wait_for(lk, std::chrono::duration<double>(limit), [&] { return pending == 0; })) {
       broken = true;
       std::string late;
       for (size_t r = 0; r < ctx.size(); ++r)
         if (!done_flag[r]) late += (late.empty() ? "" : ", ") + std::to_string(r);
-      for (gpbo_ctx* c : ctx) abort_comm(c);
-      // released by the abort, the workers usually come back with an error within moments: give them that long, so that
-      // nothing of this call's stack is referenced afterwards
+      lk.unlock();                               // abort_comm may block inside RCCL: not under the group's mutex
+      for (gpbo_ctx* c : ctx) abort_comm(c);     // (serialised per context against the worker's own abort)
+      lk.lock();
+      // released by the abort, the workers usually come back with an error within moments
       cv_done.wait_for(lk, std::chrono::seconds(5), [&] { return pending == 0; });
       err = "device group: rank(s) " + late + " did not finish within " + std::to_string((int)limit) +
             " s (GPBO_GROUP_TIMEOUT_S); communicators aborted, the group is unusable";
       set_global_error(err);
       return GPBO_ERR_COMM;
     }
+    // the root cause first: a rank that only relays "a peer failed" (GPBO_ERR_PEER) is reported when nobody says more
+    int first = -1;
     for (size_t r = 0; r < ctx.size(); ++r)
-      if (rcs[r] != GPBO_OK) {
-        err = "device " + std::to_string(no_device ? (int)r : devices[r]) + " (rank " + std::to_string(r) + "): " +
-              (ctx[r] ? ctx[r]->err : std::string("injected failure"));
-        set_global_error(err);
-        if (rcs[r] == GPBO_ERR_COMM || (ctx[r] && ctx[r]->comm_lost)) broken = true;   // a lost communicator never comes back
-        return rcs[r];
-      }
+      if (rcs[r] != GPBO_OK && (first < 0 || (rcs[(size_t)first] == GPBO_ERR_PEER && rcs[r] != GPBO_ERR_PEER))) first = (int)r;
+    if (first >= 0) {
+      const size_t r = (size_t)first;
+      err = "device " + std::to_string(no_device ? (int)r : devices[r]) + " (rank " + std::to_string(r) + "): " +
+            (ctx[r] ? ctx[r]->err : std::string("injected failure"));
+      set_global_error(err);
+      // only a LOST communicator breaks the group: a rank's local failure relayed through the (completed) exchange leaves
+      // every communicator intact and the next call may succeed
+      for (size_t q = 0; q < ctx.size(); ++q)
+        if (rcs[q] == GPBO_ERR_COMM || (ctx[q] && ctx[q]->comm_lost)) broken = true;
+      return rcs[r];
+    }
     return GPBO_OK;
   }
   std::vector<char> done_flag;
@@ -474,6 +514,7 @@ extern "C" int gpbo_group_destroy(gpbo_group* g) {
   return GPBO_OK;
 }
 
+#ifdef GPBO_DEBUG
 // Self-test seam (no device needed): a group of `n_ranks` workers without contexts, and a job in which rank `fail_rank`
 // returns `fail_code` and rank `hang_rank` sleeps `hang_ms` before returning — what a failed / wedged device looks like
 // to gpbo_group::run.  Either rank may be -1.
@@ -498,6 +539,7 @@ extern "C" int gpbo_group_debug_run(gpbo_group* g, int fail_rank, int fail_code,
     return r == fail_rank ? fail_code : (int)GPBO_OK;
   });
 }
+#endif  // GPBO_DEBUG
 
 extern "C" int gpbo_group_size(const gpbo_group* g) { return g ? (int)g->ctx.size() : 0; }
 extern "C" gpbo_ctx* gpbo_group_ctx(gpbo_group* g, int rank) {
@@ -515,12 +557,12 @@ extern "C" int gpbo_group_fit(gpbo_group* g, int slot, const double* X, const do
                               const double* length_scale, int n_ls, double noise, int precision, int* info) {
   if (!g) return GPBO_ERR_INVALID;
   if (info) *info = 0;
-  std::vector<int> infos(g->ctx.size(), 0);
+  auto infos = std::make_shared<std::vector<int>>(g->ctx.size(), 0);      // per-job state: owned by the closure copies
   // replicated: every device factorises the same (deterministic) model — cheaper than shipping N^2 doubles
-  int rc = g->run([&](int r) {
-    return gpbo_fit(g->ctx[r], slot, X, y_norm, N, d, kernel, length_scale, n_ls, noise, precision, &infos[r]);
+  int rc = g->run([=](int r) {
+    return gpbo_fit(g->ctx[r], slot, X, y_norm, N, d, kernel, length_scale, n_ls, noise, precision, &(*infos)[r]);
   });
-  if (info) *info = infos[0];
+  if (info && rc != GPBO_ERR_COMM) *info = (*infos)[0];
   return rc;
 }
 
@@ -528,9 +570,9 @@ extern "C" int gpbo_group_fit_append(gpbo_group* g, int slot, const double* x_ne
                                      int64_t n_total, int* info) {
   if (!g) return GPBO_ERR_INVALID;
   if (info) *info = 0;
-  std::vector<int> infos(g->ctx.size(), 0);
-  int rc = g->run([&](int r) { return gpbo_fit_append(g->ctx[r], slot, x_new, n_new, d, y_norm, n_total, &infos[r]); });
-  if (info) *info = infos[0];
+  auto infos = std::make_shared<std::vector<int>>(g->ctx.size(), 0);
+  int rc = g->run([=](int r) { return gpbo_fit_append(g->ctx[r], slot, x_new, n_new, d, y_norm, n_total, &(*infos)[r]); });
+  if (info && rc != GPBO_ERR_COMM) *info = (*infos)[0];
   return rc;
 }
 
@@ -549,7 +591,7 @@ extern "C" int gpbo_group_set_candidates(gpbo_group* g, const double* Xc, int64_
   if (!Xc || d < 1 || d > GPBO_MAX_DIM || M < (int64_t)g->ctx.size())
     return group_fail(g, GPBO_ERR_INVALID, "group_set_candidates: need at least one candidate per device");
   group_partition(g, M, d);
-  return g->run([&](int r) {
+  return g->run([=](int r) {
     const int64_t a = g->row0[r], b = g->row0[r + 1];
     return gpbo_set_candidates(g->ctx[r], Xc + a * d, b - a, d);
   });
@@ -565,18 +607,20 @@ extern "C" int gpbo_group_generate_candidates_mt19937(gpbo_group* g, int64_t M, 
   if (!lo || !hi || !key || !pos || d < 1 || d > GPBO_MAX_DIM || M < (int64_t)g->ctx.size() || *pos < 0 || *pos > 624)
     return group_fail(g, GPBO_ERR_INVALID, "group_generate_candidates_mt19937: bad arguments (need >= one candidate per device)");
   group_partition(g, M, d);
-  uint32_t key_new[624];
-  int pos_new = *pos;
+  struct State { uint32_t key_in[624]; uint32_t key_new[624]; int pos_in; int pos_new; };
+  auto st = std::make_shared<State>();            // per-job state (inputs copied: the workers read them too)
+  memcpy(st->key_in, key, sizeof(st->key_in));
+  st->pos_in = st->pos_new = *pos;
   // every device draws ITS rows of every column straight from the caller's stream (jump-ahead sub-streams): no host
   // sampling, no upload; the device that owns the last row hands the advanced state back
-  int rc = g->run([&](int r) {
+  int rc = g->run([=](int r) {
     const bool last = (r + 1 == (int)g->ctx.size());
-    return gpbo_generate_candidate_rows_mt19937(g->ctx[r], M, d, g->row0[r], g->row0[r + 1], lo, hi, key, *pos,
-                                                last ? key_new : nullptr, last ? &pos_new : nullptr);
+    return gpbo_generate_candidate_rows_mt19937(g->ctx[r], M, d, g->row0[r], g->row0[r + 1], lo, hi, st->key_in, st->pos_in,
+                                                last ? st->key_new : nullptr, last ? &st->pos_new : nullptr);
   });
   if (rc) return rc;
-  memcpy(key, key_new, sizeof(key_new));
-  *pos = pos_new;
+  memcpy(key, st->key_new, sizeof(st->key_new));
+  *pos = st->pos_new;
   return GPBO_OK;
 }
 
@@ -590,7 +634,7 @@ extern "C" int gpbo_group_shard(const gpbo_group* g, int rank, int64_t* row_begi
 extern "C" int gpbo_group_posterior(gpbo_group* g, int slot, double y_mean, double y_std, double* mu, double* sd) {
   if (!g) return GPBO_ERR_INVALID;
   if (g->M < 1) return group_fail(g, GPBO_ERR_STATE, "group_posterior: no candidates resident (call gpbo_group_set_candidates)");
-  return g->run([&](int r) {
+  return g->run([=](int r) {
     const int64_t a = g->row0[r];
     return gpbo_posterior(g->ctx[r], slot, y_mean, y_std, mu ? mu + a : nullptr, sd ? sd + a : nullptr);
   });
@@ -604,8 +648,8 @@ extern "C" int gpbo_group_acq_argbest(gpbo_group* g, int acq, double acq_param, 
   if (k_seeds < 0 || k_seeds > GPBO_MAX_SEEDS || !best_idx || !best_val || (k_seeds > 0 && (!seed_idx || !seed_val)))
     return group_fail(g, GPBO_ERR_INVALID, "group_acq_argbest: bad arguments");
   const int G = (int)g->ctx.size(), stride = 1 + k_seeds;
-  std::vector<BestRecord> rec((size_t)G * stride);     // per rank: [best, seeds...]
-  auto local = [&](int r, bool exchange) {
+  auto recs = std::make_shared<std::vector<BestRecord>>((size_t)G * stride);     // per rank: [best, seeds...]; per-job state
+  auto local = [=](int r, bool exchange) {
     int64_t bi = -1; double bv = 0.0;
     std::vector<int64_t> si((size_t)std::max(k_seeds, 1), -1);
     std::vector<double> sv((size_t)std::max(k_seeds, 1), 0.0);
@@ -616,20 +660,22 @@ extern "C" int gpbo_group_acq_argbest(gpbo_group* g, int acq, double acq_param, 
       : gpbo_acq_argbest(g->ctx[r], acq, acq_param, y_max, n_constraints, lb, ub, k_seeds, g->row0[r], &bi, &bv, si.data(),
                          sv.data(), ys);
     if (rc) return rc;
+    std::vector<BestRecord>& rec = *recs;
     rec[(size_t)r * stride] = BestRecord{bv, bi};
     for (int t = 0; t < k_seeds; ++t) rec[(size_t)r * stride + 1 + t] = BestRecord{sv[t], si[t]};
     return (int)GPBO_OK;
   };
   if (g->virtual_ranks) {
     // shards of one GPU (tests): every rank's local records, merged here exactly as the ranks merge the gathered ones
-    int rc = g->run([&](int r) { return local(r, false); });
+    int rc = g->run([=](int r) { return local(r, false); });
     if (rc) return rc;
-    merge_records(rec.data(), G, k_seeds, best_idx, best_val, seed_idx, seed_val);
+    merge_records(recs->data(), G, k_seeds, best_idx, best_val, seed_idx, seed_val);
     return GPBO_OK;
   }
   // every device: records packed on the device -> ncclAllGather on its stream -> the same merge; all ranks must agree
-  int rc = g->run([&](int r) { return local(r, true); });
+  int rc = g->run([=](int r) { return local(r, true); });
   if (rc) return rc;
+  const std::vector<BestRecord>& rec = *recs;
   for (int r = 1; r < G; ++r)
     for (int t = 0; t < stride; ++t) {
       const BestRecord &a = rec[t], &b = rec[(size_t)r * stride + t];
@@ -650,11 +696,12 @@ extern "C" int gpbo_group_get_candidate_rows(gpbo_group* g, const int64_t* idx, 
   for (int t = 0; t < n; ++t)
     if (idx[t] < 0 || idx[t] >= g->M)
       for (int c = 0; c < d; ++c) out[(size_t)t * d + c] = std::numeric_limits<double>::quiet_NaN();
-  return g->run([&](int r) {
+  const int64_t* const row0 = g->row0.data();      // (group-owned)
+  return g->run([=](int r) {
     std::vector<int64_t> loc;
     std::vector<int> pos;
     for (int t = 0; t < n; ++t)
-      if (idx[t] >= g->row0[r] && idx[t] < g->row0[r + 1]) { loc.push_back(idx[t] - g->row0[r]); pos.push_back(t); }
+      if (idx[t] >= row0[r] && idx[t] < row0[r + 1]) { loc.push_back(idx[t] - row0[r]); pos.push_back(t); }
     if (loc.empty()) return (int)GPBO_OK;
     std::vector<double> rows(loc.size() * (size_t)d);
     int rc = gpbo_get_candidate_rows(g->ctx[r], loc.data(), (int)loc.size(), rows.data());

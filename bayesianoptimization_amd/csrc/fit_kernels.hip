@@ -4,7 +4,7 @@
 // What they replace (SK = sklearn, reference paths relative to /root/reference):
 //   prescale      X / length_scale                         SK/gaussian_process/kernels.py:1711,1556
 //   kmat          Matern(nu=2.5)/RBF __call__(X) + alpha*I  kernels.py:1711-1738, :1556-1565; _gpr.py:346-347
-//   potrf/gemm    cholesky(K, lower=True) -> LAPACK dpotrf  _gpr.py:349
+//   gemm          the products of cholesky(K, lower=True) -> LAPACK dpotrf (_gpr.py:349; the chain itself: chol_kernels.hip)
 //   trtri         W = L^-1: turns the per-candidate solve_triangular (_gpr.py:454-456) into a GEMM
 //   trmv          alpha = cho_solve((L, True), y)           _gpr.py:360-364, as W^T (W y)
 #include <cstdlib>
@@ -135,261 +135,8 @@ int launch_kmat(gpbo_ctx* ctx, Model& m, double noise, double* out) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Cholesky + inverse of one 64x64 diagonal block by one 256-thread workgroup — the serial link of the blocked
-// factorisation (N / 64 of these run one after another; at N = 4096 they are about half of the Cholesky's time).
-//
-// Factorisation (right-looking, one column per step, NO workgroup barrier): thread (row i = tid & 63, quarter
-// q = tid >> 6) keeps A[i][16q .. 16q+15] in registers, so wave q owns 16 whole columns.  A wave first applies the
-// columns left of its own as the owning waves publish them (column-major LDS image + a release/acquire counter it
-// polls), then factors its 16 columns inside the wave — pivot and pivot-row entries by v_readlane — publishing
-// each column the moment it is final.  Every element still receives its rank-1 updates in column order, so the
-// result does not depend on the timing.  All register indices are compile-time (the 16 steps are unrolled).
-// (Measured alternative, round 2: interleaved column ownership — every wave takes a quarter of each rank-1 update,
-// columns handed over through LDS one by one — is SLOWER, 33 vs 25 us per block: the chain is the pivot arithmetic
-// (v_rsq_f64 + two Newton steps, ~12 dependent fp64 operations) plus one LDS hand-off per column instead of one per 16.)
-//
-// Inverse: the four 16x16 diagonal sub-blocks by forward substitution in registers (thread = column), then the two
-// doubling levels  W21 = -W22 (L21 W11)  as v_mfma_f64_16x16x4_f64 products out of LDS (round 1 used scalar LDS matrix
-// products: ~4 of the kernel's 25 us).
-// Writes L_kk in place (upper part zeroed) and L_kk^-1 to dinv[kb].
-constexpr int PD_S = 80;   // LDS row stride (doubles): the two k-rows of a 32-lane ds_read_b64 group fall 32 banks apart
-
-// FUSE (chol_step_kernel below): the block has received the rank-64 updates of every block column but the previous one,
-// whose in-panel update runs in the OTHER workgroups of the same launch.  The workgroup applies that last update to its
-// own block itself: A_kk -= X X^T with X = L[kb][kb-1] (already solved by the panel kernel) — one 64^3 MFMA product out
-// of LDS — and then factors; the update tiles of the launch leave block (kb, kb) alone.
-template <bool FUSE>
-__device__ __forceinline__ void potrf_diag_body(double* L, int64_t ld, int kb, double* __restrict__ dinv, int* info) {
-  extern __shared__ __attribute__((aligned(16))) double pd2_smem[];
-  double* Lc = pd2_smem;                 // [64][PD_S] column-major image of L: Lc[j * PD_S + i] = L[i][j]
-  double* Wr = Lc + 64 * PD_S;           // [64][PD_S] row-major W = L^-1
-  double* Tb = Wr + 64 * PD_S;           // [32][PD_S] product temporaries
-  double* rdiag = Tb + 32 * PD_S;        // [64] 1 / L[j][j]
-  int* flags = reinterpret_cast<int*>(rdiag + 64);   // [0] bad pivot (1-based), [1] columns published, [2] hand-off broken
-  const int tid = threadIdx.x;
-  const int i = tid & 63;
-  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
-  double* A = L + (int64_t)kb * 64 * ld + (int64_t)kb * 64;
-  if (tid < 3) flags[tid] = 0;
-  double a[16];
-  {
-    const double2* src = reinterpret_cast<const double2*>(A + (int64_t)i * ld + 16 * q);
-#pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      const double2 v = src[h];
-      a[2 * h] = v.x;
-      a[2 * h + 1] = v.y;
-    }
-  }
-  if constexpr (FUSE) {
-    const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
-    double* At = Lc;     // [k][i] stride PD_S: X^T
-    {
-      const int row = tid >> 2, seg = (tid & 3) * 16;
-      const double2* xs = reinterpret_cast<const double2*>(A - 64 + (int64_t)row * ld + seg);    // block (kb, kb - 1)
-#pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        const double2 xv = xs[h];
-        At[(seg + 2 * h) * PD_S + row] = xv.x;
-        At[(seg + 2 * h + 1) * PD_S + row] = xv.y;
-      }
-    }
-    __syncthreads();
-    d4 acc[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc[u] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {     // (X X^T)[i][c] = sum_k X[i][k] X[c][k], wave q: rows 16q .. 16q+15
-      const double av = At[(4 * ks + lk) * PD_S + 16 * q + lr];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, At[(4 * ks + lk) * PD_S + 16 * u + lr], acc[u], 0, 0, 0);
-    }
-    double* Ur = Wr;     // [i][c] stride 81 (odd: a thread walks its own row conflict-free); runs over into Tb
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Ur[(16 * q + lk + 4 * r) * 81 + 16 * u + lr] = acc[u][r];
-    __syncthreads();
-#pragma unroll
-    for (int cc = 0; cc < 16; ++cc) a[cc] -= Ur[i * 81 + 16 * q + cc];
-  }
-  __syncthreads();
-  {
-    // consume the columns left of this wave's 16 as they appear, then factor the own 16 inside the wave
-    const int need = 16 * q;
-    int applied = 0, spins = 0;
-    while (applied < need) {
-      int avail = __hip_atomic_load(&flags[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if (avail <= applied) {
-        if (++spins > (1 << 22)) {   // cannot happen while the owner wave runs; never hang the GPU on a bug
-          if (i == 0) flags[2] = 1;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-        continue;
-      }
-      if (avail > need) avail = need;
-      for (int k = applied; k < avail; ++k) {
-        const double li = Lc[k * PD_S + i];
-        const double* prow = Lc + k * PD_S + 16 * q;      // L[16q + cc][k]: the same address for every lane
-#pragma unroll
-        for (int cc = 0; cc < 16; ++cc) a[cc] = fma(-li, prow[cc], a[cc]);
-      }
-      applied = avail;
-    }
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-      const int j = 16 * q + jj;
-      const unsigned long long pv = __double_as_longlong(a[jj]);
-      const unsigned plo = __builtin_amdgcn_readlane((int)(unsigned)pv, j);
-      const unsigned phi = __builtin_amdgcn_readlane((int)(unsigned)(pv >> 32), j);
-      double piv = __longlong_as_double(((unsigned long long)phi << 32) | plo);
-      if (!(piv > 0.0)) {
-        if (i == 0 && flags[0] == 0) flags[0] = j + 1;
-        piv = 1.0;
-      }
-      // 1/sqrt(piv): v_rsq_f64 seed (2^-23) + two Newton steps, then sqrt = piv * rs with one correction;
-      // the column is scaled by the reciprocal (as LAPACK's dpotf2 does) instead of 64 divisions
-      double rs = __builtin_amdgcn_rsq(piv);
-      double e = fma(-piv * rs, rs, 1.0);
-      rs = fma(0.5 * rs, e, rs);
-      e = fma(-piv * rs, rs, 1.0);
-      rs = fma(0.5 * rs, e, rs);
-      double dg = piv * rs;
-      dg = fma(fma(-dg, dg, piv), 0.5 * rs, dg);
-      double l = (i == j) ? dg : a[jj] * rs;
-      l = (i >= j) ? l : 0.0;
-      a[jj] = l;
-      Lc[j * PD_S + i] = l;
-      if (i == 0) {
-        rdiag[j] = rs;    // 1 / L[j][j] for the inverse below (saves its 16 dependent fp64 divisions per thread)
-        __hip_atomic_store(&flags[1], j + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      // this wave's remaining columns: L[16q + cc][j] sits in lane 16q + cc of `l`
-      const unsigned long long lv = __double_as_longlong(l);
-#pragma unroll
-      for (int cc = jj + 1; cc < 16; ++cc) {
-        const unsigned llo = __builtin_amdgcn_readlane((int)(unsigned)lv, 16 * q + cc);
-        const unsigned lhi = __builtin_amdgcn_readlane((int)(unsigned)(lv >> 32), 16 * q + cc);
-        a[cc] = fma(-l, __longlong_as_double(((unsigned long long)lhi << 32) | llo), a[cc]);
-      }
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {
-    if (flags[2] && *info == 0) *info = -1 - kb;                    // broken hand-off (never seen): surfaces as an error
-    else if (flags[0] && *info == 0) *info = kb * 64 + flags[0];
-  }
-  // L -> global (row-major, upper part zero); clear W
-  {
-    const int row = tid >> 2, seg = (tid & 3) * 16;
-    double2* dst = reinterpret_cast<double2*>(A + (int64_t)row * ld + seg);
-#pragma unroll
-    for (int h = 0; h < 8; ++h)
-      dst[h] = make_double2(Lc[(seg + 2 * h) * PD_S + row], Lc[(seg + 2 * h + 1) * PD_S + row]);
-    for (int e = tid; e < 64 * PD_S; e += 256) Wr[e] = 0.0;
-  }
-  __syncthreads();
-  // --- inverse, step A: 16x16 diagonal sub-blocks (thread = sub-block b, column c)
-  if (tid < 64) {
-    const int b = tid >> 4, c = tid & 15;
-    double w[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) w[r] = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const double wk = w[k] * rdiag[16 * b + k];
-      w[k] = wk;
-#pragma unroll
-      for (int r = k + 1; r < 16; ++r) w[r] = fma(-Lc[(16 * b + k) * PD_S + 16 * b + r], wk, w[r]);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Wr[(16 * b + r) * PD_S + 16 * b + c] = w[r];
-  }
-  __syncthreads();
-  const int lane = tid & 63, lr = lane & 15, lk = lane >> 4;
-  // --- step B: 16 -> 32 for the two 32x32 diagonal blocks (wave 0: o = 0, wave 1: o = 32)
-  {
-    const int o = 32 * q;
-    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-    if (q < 2) {   // T = L21 W11
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const double av = Lc[(o + 4 * ks + lk) * PD_S + o + 16 + lr];
-        const double bv = Wr[(o + 4 * ks + lk) * PD_S + o + lr];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Tb[(16 * q + lk + 4 * r) * PD_S + lr] = acc[r];
-    }
-    __syncthreads();
-    if (q < 2) {   // W21 = -W22 T
-      d4 acc2 = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const double av = Wr[(o + 16 + lr) * PD_S + o + 16 + 4 * ks + lk];
-        const double bv = Tb[(16 * q + 4 * ks + lk) * PD_S + lr];
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc2, 0, 0, 0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Wr[(o + 16 + lk + 4 * r) * PD_S + o + lr] = -acc2[r];
-    }
-    __syncthreads();
-  }
-  // --- step C: 32 -> 64, four 16x16 output tiles, one per wave (ti = q >> 1, tj = q & 1)
-  {
-    const int ti = q >> 1, tj = q & 1;
-    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {   // T = L21 W11 over k = 0..31
-      const double av = Lc[(4 * ks + lk) * PD_S + 32 + 16 * ti + lr];
-      const double bv = Wr[(4 * ks + lk) * PD_S + 16 * tj + lr];
-      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Tb[(16 * ti + lk + 4 * r) * PD_S + 16 * tj + lr] = acc[r];
-    __syncthreads();
-    d4 acc2 = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {   // W21 = -W22 T over k = 0..31
-      const double av = Wr[(32 + 16 * ti + lr) * PD_S + 32 + 4 * ks + lk];
-      const double bv = Tb[(4 * ks + lk) * PD_S + 16 * tj + lr];
-      acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc2, 0, 0, 0);
-    }
-    __syncthreads();   // every wave has read W22 / T before the lower-left quadrant is written (it is disjoint, but keep the phases apart)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Wr[(32 + 16 * ti + lk + 4 * r) * PD_S + 16 * tj + lr] = -acc2[r];
-  }
-  __syncthreads();
-  double* D = dinv + (int64_t)kb * 64 * 64;
-  for (int e = tid; e < 4096; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    D[e] = (c <= r) ? Wr[r * PD_S + c] : 0.0;
-  }
-}
-
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* L, int64_t ld, int kb, double* __restrict__ dinv, int* info,
-                                                          int64_t lane_stride) {
-  // lane mode: one workgroup per lane; the info word lives in the lane's slab too (ints: 2 per double)
-  potrf_diag_body<false>(L + (int64_t)blockIdx.x * lane_stride, ld, kb, dinv + (int64_t)blockIdx.x * lane_stride,
-                         info + (int64_t)blockIdx.x * lane_stride * 2);
-}
-
-constexpr size_t PD_LDS_BYTES = (size_t)(64 * PD_S * 2 + 32 * PD_S + 64 + 8) * sizeof(double);
-
-int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb) {
-  if (!(ctx->func_attrs & ATTR_POTRF_DIAG)) {
-    GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_diag_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)PD_LDS_BYTES));
-    ctx->func_attrs |= ATTR_POTRF_DIAG;
-  }
-  potrf_diag_kernel<<<dim3((unsigned)ctx->lanes), dim3(256), PD_LDS_BYTES, ctx->stream>>>(m.L, m.NP, kb, m.dinv, ctx->info_dev,
-                                                                                            ctx->lane_stride);
-  GPBO_HIP(ctx, hipGetLastError());
-  return GPBO_OK;
-}
-
+// (The 64-column Cholesky steps of rounds 1-2 — potrf_diag_kernel / chol_step_kernel — lived here; the factorisation is
+// chol_kernels.hip's 128-column schedule since round 3 and the old kernels were retired in round 4.)
 template <bool BT, bool AT>
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   const int zl = blockIdx.z / g.batch, bz = blockIdx.z - zl * g.batch;   // lane mode: z = lane * batch + b
@@ -401,43 +148,6 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   if (g.b_lower) { bm = (int)blockIdx.x; bn = (int)blockIdx.y; }
   __shared__ __attribute__((aligned(16))) double gt_lds[GT_LDS_DOUBLES];
   gemm_tile_body<BT, AT>(g, bm, bn, zl, bz, gt_lds);
-}
-
-// One step of the blocked Cholesky inside an outer panel, as ONE launch: workgroup 0 factors (and inverts) diagonal
-// block kb after applying the previous block column's update to it itself (potrf_diag_body<FUSE>), the other workgroups
-// are the 64x64 tiles of that previous column's rank-64 update of the rest of the panel (tile (0, 0) = block (kb, kb)
-// excluded).  The two are independent, so the ~10 us update disappears behind the ~25 us diagonal block instead of
-// standing in front of it — per 64 columns the chain is panel solve -> this launch, two launches instead of three.
-// Measured at N = 4096 (scripts/r02_fit_probe.py): three launches per step 3.34 ms, this 2.84 ms.  Two variants were built,
-// validated and dropped: a two-stream schedule of the same dependency graph (the cross-stream event waits cost more than
-// the kernels they hid: 3.51 ms), and folding the panel solve into this launch as well (column-0 tiles waiting for the
-// diagonal workgroup's inverse through an agent-scope release/acquire flag: 2.80 ms — the in-launch hand-off costs what
-// the launch boundary costs, so the simpler form stays).
-__global__ __launch_bounds__(256) void chol_step_kernel(double* L, int64_t ld, int kb, double* __restrict__ dinv, int* info,
-                                                         GemmArgs g, int tiles_n) {
-  if (blockIdx.x == 0) {
-    potrf_diag_body<true>(L, ld, kb, dinv, info);
-    return;
-  }
-  const int b = (int)blockIdx.x - 1;
-  const int bm = b / tiles_n, bn = b - bm * tiles_n;
-  __shared__ __attribute__((aligned(16))) double gt_lds[GT_LDS_DOUBLES];
-  gemm_tile_body<true, false>(g, bm, bn, 0, 0, gt_lds);
-}
-
-int launch_chol_step(gpbo_ctx* ctx, Model& m, int kb, const GemmArgs& g_in) {
-  GemmArgs g = g_in;
-  g.lanes = 1; g.lane_stride = 0; g.batch = 1; g.skip00 = 1;
-  if (!(ctx->func_attrs & ATTR_CHOL_STEP)) {
-    GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(chol_step_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)PD_LDS_BYTES));
-    ctx->func_attrs |= ATTR_CHOL_STEP;
-  }
-  const int tiles_m = g.m / 64, tiles_n = g.n / 64;
-  chol_step_kernel<<<dim3((unsigned)(1 + tiles_m * tiles_n)), dim3(256), PD_LDS_BYTES, ctx->stream>>>(
-      m.L, m.NP, kb, m.dinv, ctx->info_dev, g, tiles_n);
-  GPBO_HIP(ctx, hipGetLastError());
-  return GPBO_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -616,7 +326,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 static bool gemm128_enabled() {
-  static const bool on = !(getenv("GPBO_GEMM128") && getenv("GPBO_GEMM128")[0] == '0');
+  static const bool on = !(dbg_env("GPBO_GEMM128") && dbg_env("GPBO_GEMM128")[0] == '0');
   return on;
 }
 
@@ -638,11 +348,11 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
   // many, each a quarter of the work, handed out longest first).  Measured (r02 fit probe): W = L^-1 at N = 4096
   // 0.93 -> 0.82 ms; with deeper grids (N = 8192: 1024 tiles) the 128x128 kernel wins, 3.91 vs 4.11 ms.
   // GPBO_TRI64=0 turns the rule off (A/B runs).
-  static const bool tri64 = !(getenv("GPBO_TRI64") && getenv("GPBO_TRI64")[0] == '0');
+  static const bool tri64 = !(dbg_env("GPBO_TRI64") && dbg_env("GPBO_TRI64")[0] == '0');
   const bool triangular = g.a_lower || g.b_lower || g.k_from_tile;
   // ... and W^T W (k_from_tile: the first tile's k-loop is the whole N) takes them while one 128x128 tile per slot would make that
   // tile the launch: N = 4096, 528 tiles: 1.04 ms, the longest tile alone 1.05 ms at a 512th of the chip's rate
-  static const int tri64_limit = getenv("GPBO_TRI64_LIMIT") ? atoi(getenv("GPBO_TRI64_LIMIT")) : 600;
+  static const int tri64_limit = dbg_env("GPBO_TRI64_LIMIT") ? atoi(dbg_env("GPBO_TRI64_LIMIT")) : 600;
   const bool prefer64 = tri64 && triangular && (blocks128 < 512 || (g.k_from_tile && blocks128 < tri64_limit));
   if (gemm128_enabled() && !prefer64 && g.m >= 128 && g.n >= 128 && g.k >= 256 && blocks128 >= 192) {
     constexpr size_t lds = (size_t)4 * G2_TILE * sizeof(double);   // 65 536 B

@@ -57,126 +57,24 @@ static int alloc_model(gpbo_ctx* ctx, Model& m, int64_t NP, int DP) {
   return GPBO_OK;
 }
 
-// The three-launch schedule of the blocked Cholesky (see cholesky() below): per 64 columns diagonal block -> panel solve ->
-// in-panel update, one after the other.
-static int cholesky_serial(gpbo_ctx* ctx, Model& m, int outer) {
-  const int nblk = (int)(m.NP / NB);
-  const int per_outer = outer / NB;
-  int rc;
-  for (int ob = 0; ob < nblk; ob += per_outer) {
-    const int oe = (ob + per_outer < nblk) ? ob + per_outer : nblk;      // inner blocks [ob, oe) form this outer panel
-    for (int kb = ob; kb < oe; ++kb) {
-      if ((rc = launch_potrf_diag(ctx, m, kb))) return rc;
-      const int rem = (int)(m.NP - (int64_t)(kb + 1) * NB);               // rows below the diagonal block
-      if (rem == 0) break;
-      double* panel = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)kb * NB;
-      GemmArgs g{};
-      // panel: L21 = A21 * L11^-T  (in place)
-      g.m = rem; g.n = NB; g.k = NB; g.alpha = 1.0; g.beta = 0.0;
-      g.A = panel; g.lda = m.NP; g.strideA = 0;
-      g.B = m.dinv + (int64_t)kb * NB * NB; g.ldb = NB; g.strideB = 0; g.b_trans = 1;
-      g.C = panel; g.ldc = m.NP; g.strideC = 0; g.batch = 1;
-      if ((rc = launch_gemm(ctx, g))) return rc;
-      // rank-64 update of the outer panel's remaining columns [kb + 1, oe): rows below, lower tiles only
-      const int wi = (oe - (kb + 1)) * NB;
-      if (wi > 0) {
-        GemmArgs s{};
-        s.m = rem; s.n = wi; s.k = NB; s.alpha = -1.0; s.beta = 1.0;
-        s.A = panel; s.lda = m.NP; s.B = panel; s.ldb = m.NP; s.b_trans = 1;
-        s.C = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)(kb + 1) * NB; s.ldc = m.NP;
-        s.batch = 1; s.lower_only = 1;
-        if ((rc = launch_gemm(ctx, s))) return rc;
-      }
-    }
-    // rank-(outer) update of everything right of the outer panel: A22 -= P P^T, P = L[oe.., ob..oe)
-    const int rem2 = (int)(m.NP - (int64_t)oe * NB);
-    if (rem2 > 0) {
-      const double* P = m.L + (int64_t)oe * NB * m.NP + (int64_t)ob * NB;
-      GemmArgs t{};
-      t.m = rem2; t.n = rem2; t.k = (oe - ob) * NB; t.alpha = -1.0; t.beta = 1.0;
-      t.A = P; t.lda = m.NP; t.B = P; t.ldb = m.NP; t.b_trans = 1;
-      t.C = m.L + (int64_t)oe * NB * m.NP + (int64_t)oe * NB; t.ldc = m.NP;
-      t.batch = 1; t.lower_only = 1;
-      if ((rc = launch_gemm(ctx, t))) return rc;
-    }
-  }
-  return GPBO_OK;
-}
-
-// The same factorisation with the in-panel update of step k and the diagonal block of step k + 1 in ONE launch
-// (chol_step_kernel, fit_kernels.hip): per 64 columns the dependent chain is  panel solve -> [diagonal block k+1 || update k]
-// instead of  diagonal block -> panel solve -> update.  The diagonal-block workgroup applies step k's update to its own
-// block itself (one extra 64^3 MFMA product), the update tiles skip that block.
-static int cholesky_fused(gpbo_ctx* ctx, Model& m, int outer) {
-  const int nblk = (int)(m.NP / NB);
-  const int per_outer = outer / NB;
-  int rc;
-  for (int ob = 0; ob < nblk; ob += per_outer) {
-    const int oe = (ob + per_outer < nblk) ? ob + per_outer : nblk;
-    if ((rc = launch_potrf_diag(ctx, m, ob))) return rc;          // first block of the panel: everything before it is applied
-    for (int kb = ob; kb < oe; ++kb) {
-      const int rem = (int)(m.NP - (int64_t)(kb + 1) * NB);
-      if (rem == 0) break;
-      double* panel = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)kb * NB;
-      GemmArgs g{};      // panel: L21 = A21 * L11^-T  (in place)
-      g.m = rem; g.n = NB; g.k = NB; g.alpha = 1.0; g.beta = 0.0;
-      g.A = panel; g.lda = m.NP; g.strideA = 0;
-      g.B = m.dinv + (int64_t)kb * NB * NB; g.ldb = NB; g.strideB = 0; g.b_trans = 1;
-      g.C = panel; g.ldc = m.NP; g.strideC = 0; g.batch = 1;
-      if ((rc = launch_gemm(ctx, g))) return rc;
-      const int wi = (oe - (kb + 1)) * NB;
-      if (wi > 0) {
-        GemmArgs s{};    // rank-64 update of the panel's remaining columns, tile (0, 0) left to the diagonal-block workgroup
-        s.m = rem; s.n = wi; s.k = NB; s.alpha = -1.0; s.beta = 1.0;
-        s.A = panel; s.lda = m.NP; s.B = panel; s.ldb = m.NP; s.b_trans = 1;
-        s.C = m.L + (int64_t)(kb + 1) * NB * m.NP + (int64_t)(kb + 1) * NB; s.ldc = m.NP;
-        s.batch = 1; s.lower_only = 1;
-        if ((rc = launch_chol_step(ctx, m, kb + 1, s))) return rc;
-      }
-    }
-    const int rem2 = (int)(m.NP - (int64_t)oe * NB);
-    if (rem2 > 0) {
-      const double* P = m.L + (int64_t)oe * NB * m.NP + (int64_t)ob * NB;
-      GemmArgs t{};
-      t.m = rem2; t.n = rem2; t.k = (oe - ob) * NB; t.alpha = -1.0; t.beta = 1.0;
-      t.A = P; t.lda = m.NP; t.B = P; t.ldb = m.NP; t.b_trans = 1;
-      t.C = m.L + (int64_t)oe * NB * m.NP + (int64_t)oe * NB; t.ldc = m.NP;
-      t.batch = 1; t.lower_only = 1;
-      if ((rc = launch_gemm(ctx, t))) return rc;
-    }
-  }
-  return GPBO_OK;
-}
-
-// Blocked Cholesky of m.L (lower), two levels: 64-wide inner blocks (diagonal block factored and inverted by one
-// workgroup, panel solve = GEMM with the inverted block) inside CHOL_OUTER-wide outer panels.  Inside an outer panel the
-// rank-64 updates touch only the panel's own remaining columns; the rest of the matrix gets ONE rank-CHOL_OUTER update
-// per outer panel, so the trailing matrix is read and written N / CHOL_OUTER times instead of N / 64 times (the rank-64
-// update is HBM-bound on exactly that traffic).  GPBO_CHOL_OUTER=64 restores the one-level algorithm (A/B runs); default
-// 512.  GPBO_CHOL_FUSED=0 selects the three-launch schedule (A/B runs; lane mode — several models per launch, inside
-// gpbo_lml_batch — always uses it).
+// Blocked Cholesky of m.L (lower, in place) + the inverted 64x64 diagonal blocks (chol_kernels.hip): 128-column steps —
+// one workgroup factors and inverts the diagonal block while the rest of the launch applies the previous step's update —
+// inside `outer`-column panels; the matrix right of a panel gets ONE rank-`outer` update per panel, so the trailing
+// matrix is read and written N / outer times instead of N / 128 times.  (Round 2's 64-column schedules — potrf_diag_kernel /
+// chol_step_kernel — were retired in round 4.)
 static int chol_outer_width(int64_t NP) {
-  // Outer panel width by size (scripts/r03_chol_probe.py under GPBO_CHOL_OUTER, round-3 schedule): up to NP = 2048 one
-  // panel — the rank-128 updates of the steps reach the whole trailing matrix, whose traffic is still small, and no
-  // latency-bound rank-`outer` GEMM stands between the steps (NP = 1024: 0.312 -> 0.283 ms, 2048: 0.683 -> 0.618); 1024 up
-  // to NP = 4096 (1.70 -> 1.66-1.68); 512 beyond (8192: 6.0 against 6.36 with 1024), where the trailing matrix no longer fits
-  // the caches and every pass over it counts.
+  // Outer panel width by size (scripts/r03_chol_probe.py, round-3 schedule): up to NP = 2048 one panel — the rank-128
+  // updates of the steps reach the whole trailing matrix, whose traffic is still small, and no latency-bound
+  // rank-`outer` GEMM stands between the steps (NP = 1024: 0.312 -> 0.283 ms, 2048: 0.683 -> 0.618); 1024 up to NP = 4096
+  // (1.70 -> 1.66-1.68); 512 beyond (8192: 6.0 against 6.36 with 1024), where the trailing matrix no longer fits the
+  // caches and every pass over it counts.
   int outer = NP <= 2048 ? (int)round_up(NP, 2 * NB) : (NP <= 4096 ? 1024 : 512);
-  if (const char* e = getenv("GPBO_CHOL_OUTER")) outer = atoi(e);
-  if (outer < NB || outer % NB) outer = NB;
+  if (const char* e = dbg_env("GPBO_CHOL_OUTER")) outer = atoi(e);
+  if (outer < 2 * NB || outer % (2 * NB)) outer = 2 * NB;
   return outer;
 }
 
-static int cholesky(gpbo_ctx* ctx, Model& m, int variant = -1) {
-  const int outer = chol_outer_width(m.NP);
-  // variant 3 (default): 128-column steps, chol_kernels.hip; 2: the round-2 schedules below (GPBO_CHOL=2 for A/B runs)
-  static const int env_variant = getenv("GPBO_CHOL") ? atoi(getenv("GPBO_CHOL")) : 3;
-  if (variant < 0) variant = env_variant;
-  if (variant >= 3 && outer >= 2 * NB && outer % (2 * NB) == 0) return launch_cholesky128(ctx, m, outer, nullptr);
-  static const bool fused_off = getenv("GPBO_CHOL_FUSED") && getenv("GPBO_CHOL_FUSED")[0] == '0';
-  if (fused_off || ctx->lanes != 1 || outer < 2 * NB) return cholesky_serial(ctx, m, outer);
-  return cholesky_fused(ctx, m, outer);
-}
+static int cholesky(gpbo_ctx* ctx, Model& m) { return launch_cholesky128(ctx, m, chol_outer_width(m.NP), nullptr); }
 
 // W = L^-1 by recursive doubling from the inverted 64x64 diagonal blocks:
 //   [[A,0],[C,B]]^-1 = [[A^-1,0],[-B^-1 C A^-1, B^-1]]  — two batched GEMMs per level.
@@ -775,7 +673,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
   const int n_groups = (n_theta + per_group - 1) / per_group;
   for (int g = 0; g < n_groups; ++g)
     if (!ctx->lml_stream[g]) GPBO_HIP(ctx, hipStreamCreateWithFlags(&ctx->lml_stream[g], hipStreamNonBlocking));
-  static const bool graphs_allowed = !(getenv("GPBO_LML_GRAPH") && getenv("GPBO_LML_GRAPH")[0] == '0');
+  static const bool graphs_allowed = !(dbg_env("GPBO_LML_GRAPH") && dbg_env("GPBO_LML_GRAPH")[0] == '0');
   hipStream_t stream0 = ctx->stream;
   void* red0 = ctx->red; int64_t cap_red0 = ctx->cap_red;
   int* info0 = ctx->info_dev;
@@ -806,7 +704,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
     ctx->pinned = window;
     ctx->lanes = gl; ctx->lane_stride = stride;
     ctx->no_timing = true;
-    static const bool la_lanes = getenv("GPBO_CHOL_LA_LANES") && getenv("GPBO_CHOL_LA_LANES")[0] == '1';
+    static const bool la_lanes = dbg_env("GPBO_CHOL_LA_LANES") && dbg_env("GPBO_CHOL_LA_LANES")[0] == '1';
     ctx->no_lookahead = n_groups > 1 && !la_lanes;
     auto enqueue = [&](double** oh, int** ih) {
       int r = enqueue_factor(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, ih);
@@ -1051,9 +949,10 @@ int gpbo_last_timings(gpbo_ctx* ctx, float* ms, int n) {
   return GPBO_OK;
 }
 
+#ifdef GPBO_DEBUG   // self-tests and micro-benchmarks: libgpbo_dbg.so only (include/gpbo.h, "debug build")
 int gpbo_debug_cholesky(gpbo_ctx* ctx, const double* A, int64_t n, int variant, int iters, double* L_out, double* dinv_out,
                         long long* stamps_out, double* ms_out, int* info_out) {
-  if (!ctx || !A || n < 64 || n % 64 || iters < 1) return GPBO_ERR_INVALID;
+  if (!ctx || !A || n < 64 || n % 64 || iters < 1 || variant != 3) return GPBO_ERR_INVALID;   // (variant 2, the round-2 schedule, is retired)
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
   Model m;
   int rc = alloc_model(ctx, m, n, 4);
@@ -1078,8 +977,7 @@ int gpbo_debug_cholesky(gpbo_ctx* ctx, const double* A, int64_t n, int variant, 
     (void)hipMemcpyAsync(m.L, m.K, sq, hipMemcpyDeviceToDevice, ctx->stream);
     (void)hipMemsetAsync(ctx->info_dev, 0, sizeof(int), ctx->stream);
     (void)hipEventRecord(e0, ctx->stream);
-    if (variant >= 3 && it == iters - 1) rc = launch_cholesky128(ctx, m, chol_outer_width(m.NP) % (2 * NB) ? 512 : chol_outer_width(m.NP), stamps_dev);   // stamps: the last (warm) run
-    else rc = cholesky(ctx, m, variant);
+    rc = launch_cholesky128(ctx, m, chol_outer_width(m.NP), it == iters - 1 ? stamps_dev : nullptr);   // stamps: the last (warm) run
     (void)hipEventRecord(e1, ctx->stream);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return done(GPBO_ERR_HIP);
     float ms = 0.f;
@@ -1176,6 +1074,8 @@ int gpbo_debug_latency_probe(gpbo_ctx* ctx, long long* out, int n) {
   return run_latency_probe(ctx, out, n);
 }
 
+#endif  // GPBO_DEBUG
+
 int gpbo_mfma_f64_peak(gpbo_ctx* ctx, int iters, double* tflops) {
   if (!ctx || !tflops || iters < 1) return GPBO_ERR_INVALID;
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
@@ -1188,11 +1088,13 @@ int gpbo_mfma_f64_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, 
   return run_mfma_probe(ctx, iters, waves_per_simd, mode, out);
 }
 
+#ifdef GPBO_DEBUG
 int gpbo_hybrid_probe(gpbo_ctx* ctx, int iters, int cfg, double* out) {
   if (!ctx || !out || iters < 1 || cfg < 0 || cfg > 4) return GPBO_ERR_INVALID;
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
   return run_hybrid_probe(ctx, iters, cfg, out);
 }
+#endif
 
 int gpbo_hbm_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps) {
   if (!ctx || !gbps || bytes < (1 << 20)) return GPBO_ERR_INVALID;

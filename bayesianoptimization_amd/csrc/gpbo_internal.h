@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -145,8 +146,9 @@ struct gpbo_ctx {
   std::vector<gpbo::LookAhead> lookahead;
   gpbo::EventPair ev[gpbo::T_COUNT];
   // RCCL
-  void* comm = nullptr;
+  void* comm = nullptr;          // ncclComm_t; exchanged atomically by whoever aborts it (comm.hip: abort_comm)
   bool comm_lost = false;        // the communicator was aborted after a collective failed or timed out
+  bool debug_fail_next_acq = false;   // debug build: gpbo_debug_fail_next_acq armed (the field exists in both builds: one layout)
   int world = 1, rank = 0;
   void* comm_buf = nullptr;      // device: [send records | gathered records | 8-byte reduction word]
   int64_t cap_comm_buf = 0;
@@ -158,7 +160,7 @@ namespace gpbo {
 
 constexpr size_t SMALL_PIN_IN = 128 * 1024, SMALL_PIN_OUT = 32 * 1024;   // bytes: candidates in; mu, sd out (each)
 constexpr size_t SMALL_PIN_BYTES = SMALL_PIN_IN + 2 * SMALL_PIN_OUT;
-constexpr unsigned ATTR_POTRF_DIAG = 1u, ATTR_CHOL_STEP = 2u, ATTR_GEMM128 = 4u, ATTR_MT_JUMP = 8u, ATTR_CHOL128 = 16u;
+constexpr unsigned ATTR_GEMM128 = 4u, ATTR_CHOL128 = 16u;
 
 // ---- pinned host staging layout -------------------------------------------------------------------------------
 // ONE allocation of PIN_WINDOWS windows of PIN_WINDOW bytes.  Window 0 (ctx->pinned) carries the words of a fit /
@@ -187,6 +189,18 @@ static_assert(PIN_AUX_CAND + PIN_AUX_CAND_BYTES <= PIN_AUX_NEGVAR, "candidate st
 static_assert(PIN_AUX_NEGVAR + sizeof(int) <= PIN_WINDOW, "clipped-variance flag leaves the window");
 
 void set_global_error(const std::string& s);
+
+// Environment policy.  The product library reads exactly four variables, none of which changes a result:
+//   GPBO_KSTAR_GB (k* slab workspace budget), GPBO_COMM_TIMEOUT_S, GPBO_GROUP_TIMEOUT_S (deadlines of the multi-GPU
+//   failure path) and GPBO_GROUP_HOST_MERGE (a device group merges its shards' records on the host instead of over RCCL).
+// Everything else — A/B switches between kernel variants, dispatch thresholds, probes, fault injection — goes through
+// dbg_env(), which is getenv() only in the -DGPBO_DEBUG build (libgpbo_dbg.so: the tests' and scripts' library) and a
+// constant NULL in the product (tests/test_abi.py greps the sources for getenv against that allow-list).
+#ifdef GPBO_DEBUG
+inline const char* dbg_env(const char* name) { return getenv(name); }
+#else
+inline const char* dbg_env(const char*) { return nullptr; }
+#endif
 
 #define GPBO_HIP(ctx, expr)                                                                  \
   do {                                                                                       \
@@ -263,7 +277,6 @@ int64_t kstar_slab_budget_bytes(gpbo_ctx* ctx, int64_t want_bytes_if_unlimited);
 int launch_prescale(gpbo_ctx* ctx, const double* X, int64_t n, int d, int DP, const double* ls,
                     double* out, int64_t n_pad);
 int launch_kmat(gpbo_ctx* ctx, Model& m, double noise, double* out);   // out: m.K, or m.L (factorised in place)
-int launch_potrf_diag(gpbo_ctx* ctx, Model& m, int kb);
 int launch_fill_w_diag(gpbo_ctx* ctx, Model& m);
 int launch_trmv(gpbo_ctx* ctx, Model& m);
 int launch_append_row(gpbo_ctx* ctx, Model& m, int64_t j);   // row j (== current m.N) from the prescaled m.Xs[j]
@@ -286,8 +299,6 @@ struct GemmArgs {
                           // workgroup of the same launch (or an earlier launch) owns them
 };
 int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g);
-// diagonal block kb (with the previous block column's update applied by the workgroup itself) || the 64x64 tiles of update g
-int launch_chol_step(gpbo_ctx* ctx, Model& m, int kb, const GemmArgs& g);
 // chol_kernels.hip: blocked Cholesky of m.L in place + inverted 64x64 diagonal blocks (128-column steps, `outer`-column panels);
 // stamps (device, >= 8 words, may be null): in-kernel clocks of the first diagonal workgroup
 int launch_cholesky128(gpbo_ctx* ctx, Model& m, int outer, long long* stamps);
@@ -341,10 +352,12 @@ int mt_jump_states(gpbo_ctx* ctx, const unsigned* key_dev, int64_t stride_blocks
 // probe.hip
 int run_mfma_peak(gpbo_ctx* ctx, int iters, double* tflops);
 int run_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);
-int run_hybrid_probe(gpbo_ctx* ctx, int iters, int cfg, double* out3);
 int run_mfma_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, double* out4);
-// latency_probe.hip
+#ifdef GPBO_DEBUG
+int run_hybrid_probe(gpbo_ctx* ctx, int iters, int cfg, double* out3);
+// latency_probe.hip (debug build only: the one kernel of the library that uses scratch)
 int run_latency_probe(gpbo_ctx* ctx, long long* out_host, int n);
+#endif
 
 inline void ev_begin(gpbo_ctx* ctx, int slot) {
   if (ctx->no_timing) return;

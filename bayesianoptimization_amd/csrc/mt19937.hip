@@ -234,7 +234,7 @@ static int mt_generate_rows(gpbo_ctx* ctx, int64_t M, int d, int64_t r0, int64_t
 
   // ---- plan: d columns x P pieces --------------------------------------------------------------------------------------
   int want = 64;                                            // sub-streams aimed at (GPBO_MT_STREAMS); at least one per column
-  if (const char* e = getenv("GPBO_MT_STREAMS")) want = atoi(e) > 0 ? atoi(e) : 1;
+  if (const char* e = dbg_env("GPBO_MT_STREAMS")) want = atoi(e) > 0 ? atoi(e) : 1;
   if (want > 1024) want = 1024;
   const int64_t my_blocks = 2 * Mloc * d / MT_N + 1;        // blocks' worth of words generated here
   // a tiny stream: one run per column, each walking from the caller's block (the prefix it re-walks is tiny by definition)
@@ -297,7 +297,7 @@ static int mt_generate_rows(gpbo_ctx* ctx, int64_t M, int d, int64_t r0, int64_t
   }
   mt19937_uniform_kernel<<<dim3((unsigned)chunks.size()), dim3(512), 0, ctx->stream>>>(
       dkey, pos, chunks_dev, states_dev, (const double*)ctx->red, ctx->stage, key_out_dev,
-      getenv("GPBO_MT_PROBE") ? atoi(getenv("GPBO_MT_PROBE")) : 0);
+      dbg_env("GPBO_MT_PROBE") ? atoi(dbg_env("GPBO_MT_PROBE")) : 0);
   GPBO_HIP(ctx, hipGetLastError());
   transpose_stream_kernel<<<dim3((unsigned)((Mloc + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->stage, Mloc, d, ctx->Xc);
   GPBO_HIP(ctx, hipGetLastError());

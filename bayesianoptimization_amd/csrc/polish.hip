@@ -41,7 +41,8 @@ struct Run {
   int hist = 0, head = 0;       // pairs stored, next slot
   int iter = 0, evals = 0, ls = 0;
   int phase = 0;                // 0: first evaluation pending, 1: line search, 2: finished
-  int status = 2;               // 0: projected gradient, 1: relative reduction / no further progress, 2: iteration limit
+  int status = 2;               // 0: projected gradient, 1: relative reduction / no further progress, 2: iteration limit,
+                                // 3: line search exhausted (SciPy: ABNORMAL_TERMINATION_IN_LNSRCH, success = False)
 };
 
 // max_i |P(x - g)_i - x_i|
@@ -144,7 +145,10 @@ void advance(Run& r, double ft, const double* gt, const double* lo, const double
     // two shrinks — the values differ by less than the relative-reduction tolerance, i.e. the test is deciding on rounding
     const bool flat = std::isfinite(ft) && r.ls >= 2 &&
                       std::fabs(ft - r.f) <= FTOL * std::max(std::max(std::fabs(ft), std::fabs(r.f)), 1.0);
-    if (++r.ls >= MAXLS || moved == 0.0 || flat) { r.phase = 2; r.status = 1; return; }
+    // (an exhausted line search is SciPy's "ABNORMAL" termination, success = False: the reference discards such a run,
+    //  acquisition.py:367 — its own status, so that the caller can do the same)
+    if (moved == 0.0 || flat) { r.phase = 2; r.status = 1; return; }
+    if (++r.ls >= MAXLS) { r.phase = 2; r.status = 3; return; }
     // the minimiser of the parabola through f, its slope and f_t, kept inside [0.1, 0.5] of the step that failed
     double shrink = 0.1;
     if (std::isfinite(ft)) {
@@ -236,6 +240,7 @@ int lockstep_minimize(Eval&& eval, const double* seeds, int n_seeds, int d, cons
 
 using namespace gpbo;
 
+#ifdef GPBO_DEBUG
 extern "C" int gpbo_debug_minimize_box(gpbo_fg_callback fg, void* user, const double* seeds, int n_seeds, int d, const double* box_lo,
                                        const double* box_hi, int max_iter, double* x_out, double* f_out, int* status_out,
                                        int* n_rounds_out, int* n_iter_out, int* n_eval_out) {
@@ -248,6 +253,7 @@ extern "C" int gpbo_debug_minimize_box(gpbo_fg_callback fg, void* user, const do
   return lockstep_minimize([&](const double* batch, int live, double* f, double* g) { return fg(batch, live, d, f, g, user); }, seeds,
                            n_seeds, d, box_lo, box_hi, max_iter, x_out, f_out, status_out, n_rounds_out, n_iter_out, n_eval_out);
 }
+#endif  // GPBO_DEBUG
 
 extern "C" int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, double y_max, int n_constraints, const double* lb,
                                  const double* ub, const double* y_mean, const double* y_std, const double* seeds, int n_seeds,
@@ -328,7 +334,7 @@ extern "C" int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, doubl
           for (int side = 0; side < 2; ++side) {
             const double bound = side == 0 ? ub[j] : lb[j];
             const double sign = side == 0 ? 1.0 : -1.0;
-            if (std::isinf(bound)) { if (side == 0 && bound > 0) pv += 1.0; continue; }   // Phi(+inf) = 1, Phi(-inf) = 0
+            if (std::isinf(bound)) { if (bound > 0) pv += sign; continue; }   // Phi(+inf) = 1, Phi(-inf) = 0, for either side (constraint.py:202-207)
             const double z = (bound - cm) / csd;
             pv += sign * norm_cdf(z);
             const double w = sign * norm_pdf(z) / csd;

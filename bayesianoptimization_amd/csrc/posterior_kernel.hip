@@ -106,7 +106,7 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
   if ((rc = launch_prescale(ctx, ctx->Xc, M, m.d, m.DP, m.ls, ctx->Xcs, Mp))) return rc;
   {
     // latency path: a handful of candidates (HipGPR.predict from the host optimiser) -> batched GEMV
-    const char* sm = getenv("GPBO_POST_SMALL");
+    const char* sm = dbg_env("GPBO_POST_SMALL");
     if (M <= small_batch_limit(m.NP) && !(sm && sm[0] == '0')) {
       ev_begin(ctx, T_POST_MAIN);
       rc = launch_posterior_small(ctx, m, (int)M, y_mean, y_std);
@@ -123,7 +123,7 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
   // loop carries no other VALU work (posterior_kernel_v2.hip).  Measured at M = 65 536 (scripts/r02_small_n_posterior_ab.py):
   // NP = 512: v3 0.37-0.39 ms vs v2 0.40-0.42; NP = 256: v2 0.12 vs v3 0.14 (one chunk: nothing is generated twice).
   // GPBO_POST_KERNEL=2|3 forces one of them (A/B runs).
-  const char* kv = getenv("GPBO_POST_KERNEL");
+  const char* kv = dbg_env("GPBO_POST_KERNEL");
   // (two chunks and a small batch — the host optimisers' rounds of ~100 points: the second launch is not worth it)
   const bool use_v2 = kv ? (kv[0] == '2') : (nchunks <= 1 || (nchunks == 2 && Mp < 8192));
   const bool use_f32 = (m.precision == GPBO_F32);   // fp32 slab + f32 MFMA GEMM (posterior_kernel_f32.hip)

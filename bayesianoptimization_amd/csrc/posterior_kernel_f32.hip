@@ -27,8 +27,8 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 // instructions (64 cycles each instead of 32), which leaves the issue slots the LDS reads, the slab / W loads and the
 // barrier need: the 16x16 kernel ran its matrix pipe 81 % busy.  The two forms want W packed differently.
 static bool f32_use_mfma32(int64_t NP) {
-  static const bool off = getenv("GPBO_F32_MFMA") && atoi(getenv("GPBO_F32_MFMA")) == 16;
-  static const bool rt2 = getenv("GPBO_F32_RT") && getenv("GPBO_F32_RT")[0] == '2';
+  static const bool off = dbg_env("GPBO_F32_MFMA") && atoi(dbg_env("GPBO_F32_MFMA")) == 16;
+  static const bool rt2 = dbg_env("GPBO_F32_RT") && dbg_env("GPBO_F32_RT")[0] == '2';
   return !off && !rt2 && NP >= 512;
 }
 
@@ -482,7 +482,7 @@ int launch_posterior_f32(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, int* 
     a.Wp = m.Wp32; a.Kst = kst; a.part = ctx->part; a.NP = (int)m.NP; a.Mp = Mp;
     a.n_ctiles = (int)(ldk / F32_CANDS); a.ldk = ldk; a.m0 = m0;
     // wave tile: 64 rows (chunks of 512 rows) by default; GPBO_F32_RT=2 selects 32 rows (chunks of 256)
-    const char* e = getenv("GPBO_F32_RT");
+    const char* e = dbg_env("GPBO_F32_RT");
     const bool rt2 = (e && e[0] == '2') || m.NP < 512;
     const bool mf32 = f32_use_mfma32(m.NP);     // (the packed W of this fit was laid out for the same choice)
     a.nchunks = rt2 ? nchunks : (int)((m.NP + 511) / 512);

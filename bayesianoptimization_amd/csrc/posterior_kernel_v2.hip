@@ -370,7 +370,7 @@ int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
   // (4e9 B = 121 984 candidates at N = 4096 = 1906 candidate tiles x 16 row chunks per launch); measured at C3: one 34 GB
   // slab 263.7 ms, eight 4 GB slabs 264.4 ms (round 1 A/B) — the big workspace bought nothing.  GPBO_KSTAR_GB overrides.
   // 32 train points per stage: 262.9 vs 264.0 ms per C3 launch (round-2 A/B, same box, same run); GPBO_POST_BK=16 restores 16
-  static const int post_bk = (getenv("GPBO_POST_BK") && atoi(getenv("GPBO_POST_BK")) == 16) ? 16 : 32;
+  static const int post_bk = (dbg_env("GPBO_POST_BK") && atoi(dbg_env("GPBO_POST_BK")) == 16) ? 16 : 32;
   const int64_t budget = kstar_slab_budget_bytes(ctx, Mp * m.NP * 8);
   int64_t ms = budget / (m.NP * 8);
   // the slab kernel addresses a stage's rows as 32-bit buffer offsets: 3 rows of ldk doubles must stay below 2^31 bytes
@@ -406,11 +406,15 @@ int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
 template <int DP, int KERNEL>
 static int launch_v2_t(gpbo_ctx* ctx, const PostArgs2& a, int64_t nblocks) {
   const size_t lds = (size_t)(2 * POST_BK * V2_STRIDE + DP * V2_CANDS) * sizeof(double);
-  const char* ab = getenv("GPBO_POST_ABLATE_GEN");
-  if (ab && ab[0] == '1')
+#ifdef GPBO_DEBUG   // timing-only ablation (k* replaced by a constant: WRONG results) — scripts/ablate_gen.py, debug build only
+  const char* ab = dbg_env("GPBO_POST_ABLATE_GEN");
+  if (ab && ab[0] == '1') {
     posterior_kernel_v2<DP, KERNEL, 0><<<dim3((unsigned)nblocks), dim3(512), lds, ctx->stream>>>(a);
-  else
-    posterior_kernel_v2<DP, KERNEL, 1><<<dim3((unsigned)nblocks), dim3(512), lds, ctx->stream>>>(a);
+    GPBO_HIP(ctx, hipGetLastError());
+    return GPBO_OK;
+  }
+#endif
+  posterior_kernel_v2<DP, KERNEL, 1><<<dim3((unsigned)nblocks), dim3(512), lds, ctx->stream>>>(a);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }

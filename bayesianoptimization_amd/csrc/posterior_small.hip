@@ -22,7 +22,7 @@ constexpr int SMALL_MAX = 1024;   // scratch bound: n_seeds * (d + 1) finite-dif
 // (N <= 512 runs the single fused MFMA kernel, which is why its crossover is low.)  GPBO_SMALL_MAX overrides
 // the rule (A/B runs, and tests that pin one path).
 int small_batch_limit(int64_t NP) {
-  if (const char* e = getenv("GPBO_SMALL_MAX")) {
+  if (const char* e = dbg_env("GPBO_SMALL_MAX")) {
     const long v = atol(e);
     return (int)(v < 0 ? 0 : (v > SMALL_MAX ? SMALL_MAX : v));
   }

@@ -25,15 +25,26 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) 
 
 // Same MFMA stream with in-kernel clocks: s_memtime (shader cycles) and s_memrealtime (100 MHz) bracket
 // the loop, so cycles per MFMA per SIMD and the sustained shader clock can be told apart.
-template <int MODE>  // 0: builtin (compiler picks VGPR accumulators); 1: inline asm with AGPR accumulators
+template <int MODE>  // 0: builtin (compiler picks VGPR accumulators); 1: inline asm with AGPR accumulators;
+                     // 2: the posterior GEMM's register pattern — a 2 x 4 tile grid, every MFMA another (A, B) register pair
 __global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, unsigned long long* clk, int iters) {
   d4 acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
   const double a = 1.0 + threadIdx.x * 1e-6, b = 0.5 - threadIdx.x * 1e-6;
+  double av[2] = {a, a * 1.0000003}, bv[4] = {b, b * 0.9999991, b * 1.0000007, b * 0.9999987};
   const unsigned long long c0 = __builtin_amdgcn_s_memtime();
   const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   for (int i = 0; i < iters; ++i) {
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[u], acc[u], 0, 0, 0);
+        acc[4 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[u], acc[4 + u], 0, 0, 0);
+      }
+      asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));   // keep the six operand registers apart
+      continue;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if constexpr (MODE == 1) {
@@ -67,7 +78,7 @@ int run_mfma_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, doubl
   hipEvent_t e0, e1;
   GPBO_HIP(ctx, hipEventCreate(&e0));
   GPBO_HIP(ctx, hipEventCreate(&e1));
-  auto kern = mode == 1 ? mfma_probe_kernel<1> : mfma_probe_kernel<0>;
+  auto kern = mode == 2 ? mfma_probe_kernel<2> : mode == 1 ? mfma_probe_kernel<1> : mfma_probe_kernel<0>;
   kern<<<dim3(grid), dim3(256), 0, ctx->stream>>>(out, clk, 16);
   GPBO_HIP(ctx, hipEventRecord(e0, ctx->stream));
   kern<<<dim3(grid), dim3(256), 0, ctx->stream>>>(out, clk, iters);
@@ -94,6 +105,7 @@ int run_mfma_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, doubl
   return GPBO_OK;
 }
 
+#ifdef GPBO_DEBUG
 // Hybrid probe: per loop iteration a wave issues NM independent MFMAs and NV v_fma_f64 whose multiplier is a
 // wave-uniform double fetched with scalar loads (the shape of a VALU GEMM row update: acc_r += W[r][k] * k*[k][lane]).
 // Answers: how much fp64 VALU FMA throughput is available NEXT TO a saturated fp64 matrix pipe?
@@ -163,6 +175,7 @@ int run_hybrid_probe(gpbo_ctx* ctx, int iters, int cfg, double* out3) {
   GPBO_HIP(ctx, hipFree(wsc));
   return GPBO_OK;
 }
+#endif  // GPBO_DEBUG
 
 int run_mfma_peak(gpbo_ctx* ctx, int iters, double* tflops) {
   const int grid = 256 * 2;  // 2 workgroups of 4 waves per CU -> 2 waves per SIMD

@@ -26,8 +26,11 @@ class GpEngine:
     candidate matrix.  Calls are synchronous from the host's point of view unless noted (`posterior(fetch=False)` only
     enqueues); a context is not thread-safe — the lockstep helpers keep every device call on the serving thread."""
 
-    def __init__(self, device: int = 0):
-        self._lib = _lib.load_library()
+    def __init__(self, device: int = 0, debug: bool = False):
+        # debug=True: the context lives in libgpbo_dbg.so (same sources + gpbo_debug_* entry points and the kernel A/B
+        # environment switches) — tests and scripts only
+        self._lib = _lib.load_debug_library() if debug else _lib.load_library()
+        self.debug = bool(debug)
         h = C.c_void_p()
         rc = self._lib.gpbo_create(int(device), C.byref(h))
         if rc != _lib.GPBO_OK:
@@ -383,7 +386,16 @@ class GpEngine:
         self._check(rc)
         return best_idx.value, best_val.value, seed_idx[:k_seeds], seed_val[:k_seeds], ys
 
-    # -- timing / probes ---------------------------------------------------------------------------
+    # -- timing / probes (debug_* and the latency / hybrid probes need GpEngine(debug=True)) ----------------------------
+    def _need_debug(self, what: str):
+        if not getattr(self, "debug", False):
+            raise _lib.GpboError(f"{what} is a debug entry point: create the engine with GpEngine(device, debug=True) (libgpbo_dbg.so)")
+
+    def debug_fail_next_acq(self):
+        """Fault injection (debug build): the next comm_acq_argbest behaves as if this rank's local pass had failed."""
+        self._need_debug("gpbo_debug_fail_next_acq")
+        self._check(self._lib.gpbo_debug_fail_next_acq(self._h))
+
     def last_timings(self) -> dict:
         ms = (C.c_float * 8)()
         self._check(self._lib.gpbo_last_timings(self._h, ms, 8))
@@ -391,6 +403,7 @@ class GpEngine:
 
     def debug_cholesky(self, A, variant=3, iters=1):
         """The device Cholesky alone (gpbo_debug_cholesky): returns (L lower n x n, dinv [n/64][64][64], stamps[16], ms, info)."""
+        self._need_debug("gpbo_debug_cholesky")
         A = np.ascontiguousarray(A, dtype=np.float64)
         n = A.shape[0]
         Lo = np.empty((n, n))
@@ -403,6 +416,7 @@ class GpEngine:
 
     def debug_select(self, ys, k, variant=1, iters=0):
         """The selection launches alone over `ys` (gpbo_debug_select): (idx (k,), vals (k,), first_nan, ms per selection)."""
+        self._need_debug("gpbo_debug_select")
         ys = np.ascontiguousarray(ys, dtype=np.float64)
         idx = np.empty(int(k), dtype=np.int64)
         vals = np.empty(int(k))
@@ -412,11 +426,13 @@ class GpEngine:
         return idx, vals, int(first_nan.value), float(ms.value)
 
     def latency_probe(self, n=16):
+        self._need_debug("gpbo_debug_latency_probe")
         out = np.zeros(32, dtype=np.int64)
         self._check(self._lib.gpbo_debug_latency_probe(self._h, out.ctypes.data_as(C.POINTER(C.c_int64)), int(n)))
         return out[:n]
 
     def debug_gemm(self, A, B, C_in=None, alpha=1.0, beta=0.0, b_trans=False):
+        self._need_debug("gpbo_debug_gemm")
         A = np.ascontiguousarray(A, dtype=np.float64)
         B = np.ascontiguousarray(B, dtype=np.float64)
         m, k = A.shape
@@ -427,6 +443,7 @@ class GpEngine:
         return Cm
 
     def gemm_bench(self, m, n, k, b_trans=True, a_trans=False, lower_only=False, iters=10) -> dict:
+        self._need_debug("gpbo_debug_gemm_bench")
         out = np.zeros(2)
         self._check(self._lib.gpbo_debug_gemm_bench(self._h, int(m), int(n), int(k), int(b_trans), int(a_trans),
                                                     int(lower_only), int(iters), dptr(out)))
@@ -443,6 +460,7 @@ class GpEngine:
         return {"tflops": out[0], "cycles_per_mfma": out[1], "shader_mhz": out[2], "ms": out[3]}
 
     def hybrid_probe(self, iters=2000, cfg=2) -> dict:
+        self._need_debug("gpbo_hybrid_probe")
         out = np.zeros(3)
         self._check(self._lib.gpbo_hybrid_probe(self._h, int(iters), int(cfg), dptr(out)))
         return {"ms": out[0], "mfma_tflops": out[1], "valu_tflops": out[2]}

@@ -310,8 +310,8 @@ class AcquisitionFunction(abc.ABC):
                         pj = np.zeros_like(cm)
                         dpj = np.zeros_like(dcm)
                         for bound, sign in ((hi, 1.0), (lo, -1.0)):
-                            if not np.isfinite(bound):
-                                pj = pj + (1.0 if (sign > 0 and bound == np.inf) else 0.0)
+                            if not np.isfinite(bound):       # cdf(+inf) = 1, cdf(-inf) = 0, for either side (constraint.py:202-207)
+                                pj = pj + (sign if bound == np.inf else 0.0)
                                 continue
                             z = (bound - cm) / cs
                             pj = pj + sign * ndtr(z)
@@ -413,7 +413,7 @@ class AcquisitionFunction(abc.ABC):
             xs, fs, status, _ = chain[0]._engine().polish_seeds(
                 self._acq_kind, self._acq_param(), getattr(self, "y_max", None), lb, ub,
                 [float(m._y_train_mean) for m in chain], [float(m._y_train_std) for m in chain], np.asarray(x_seeds), box)
-            ok = np.flatnonzero((status < 2) & np.isfinite(fs))         # SciPy's res.success
+            ok = np.flatnonzero((status < 2) & np.isfinite(fs))         # SciPy's res.success (2: iteration limit, 3: line search exhausted)
             if ok.size == 0:
                 return None
             k = ok[np.argmin(fs[ok])]                                  # the first of equal minima, as the reference's scan

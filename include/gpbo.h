@@ -17,6 +17,14 @@
  *     bayes_opt/target_space.py:95-96); `precision` selects the on-device arithmetic.
  *   - determinism: fixed reduction trees; arg-best ties -> lowest index; NaN -> first NaN wins
  *     (numpy argmin semantics, bayes_opt/acquisition.py:313).
+ *   - environment: the library reads exactly four variables, none of which changes a result —
+ *       GPBO_KSTAR_GB          k* slab workspace budget in GB (default 4)
+ *       GPBO_COMM_TIMEOUT_S    deadline of a wait for a collective (default 120)
+ *       GPBO_GROUP_TIMEOUT_S   deadline of a device-group job (default 300; kept >= the collective deadline + 15 s)
+ *       GPBO_GROUP_HOST_MERGE  1: a device group merges its shards' records on the host instead of over RCCL
+ *     (tests/test_abi.py checks the sources against this list).  Kernel A/B switches, dispatch overrides, probes and
+ *     fault injection exist only in the DEBUG BUILD (-DGPBO_DEBUG, libgpbo_dbg.so), together with the entry points at
+ *     the end of this header.
  */
 #ifndef GPBO_H
 #define GPBO_H
@@ -27,7 +35,7 @@
 extern "C" {
 #endif
 
-#define GPBO_ABI_VERSION 1
+#define GPBO_ABI_VERSION 2
 
 enum gpbo_status {
   GPBO_OK = 0,
@@ -36,7 +44,9 @@ enum gpbo_status {
   GPBO_ERR_NOT_PD = -3,       /* K + noise*I not positive definite (see `info`)      -> LinAlgError  */
   GPBO_ERR_STATE = -4,        /* call order (predict before fit, no candidates ...)  -> RuntimeError */
   GPBO_ERR_UNSUPPORTED = -5,  /* kernel/precision/size outside the HIP path          -> NotImplementedError */
-  GPBO_ERR_COMM = -6          /* RCCL failure                                        -> RuntimeError */
+  GPBO_ERR_COMM = -6,         /* RCCL failure / missed deadline: the communicator is gone -> RuntimeError */
+  GPBO_ERR_PEER = -7          /* multi-GPU: another rank's LOCAL step failed; the exchange completed and the
+                                 communicators are intact — this step has no result, the next one may  -> RuntimeError */
 };
 
 enum gpbo_kernel { GPBO_KERNEL_RBF = 0, GPBO_KERNEL_MATERN25 = 1 };
@@ -216,14 +226,6 @@ int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, double y_max, in
                       const double* box_lo, const double* box_hi, int max_iter, double* x_out, double* f_out, int* status_out,
                       int* n_rounds_out, int* n_iter_out, int* n_eval_out);
 
-/* The optimiser of gpbo_polish_seeds alone, over a host objective (self-test seam: no device, no context): `fg` is called
- * once per lockstep round with the trial points of the runs that are still alive — x (n_live,d) -> f (n_live), g (n_live,d) —
- * and returns 0 or an error code that ends the call.  Same outputs as gpbo_polish_seeds. */
-typedef int (*gpbo_fg_callback)(const double* x, int n_live, int d, double* f, double* g, void* user);
-int gpbo_debug_minimize_box(gpbo_fg_callback fg, void* user, const double* seeds, int n_seeds, int d, const double* box_lo,
-                            const double* box_hi, int max_iter, double* x_out, double* f_out, int* status_out, int* n_rounds_out,
-                            int* n_iter_out, int* n_eval_out);
-
 /* ---- acquisition + arg-best ------------------------------------------------------------- */
 /* Replaces the _get_acq closure + base_acq + argmin/min/argsort[:k]
  * (bayes_opt/acquisition.py:198-217, 485, 660-661, 847-849, 312-317) and, when n_constraints > 0,
@@ -306,18 +308,48 @@ int gpbo_group_get_candidate_rows(gpbo_group* grp, const int64_t* idx, int n, do
  * collective has one (GPBO_COMM_TIMEOUT_S, default 120 s): a device that never comes back, or a peer that never enters
  * the all-gather, turns into GPBO_ERR_COMM (communicators aborted with ncclCommAbort, the group / communicator unusable
  * afterwards) instead of a hung suggest().  A rank whose LOCAL pass failed still enters the all-gather with a poisoned
- * record, so that every rank returns an error from the same step.  Self-test seam, no device needed: a group of workers
- * without contexts, and a job in which rank `fail_rank` returns `fail_code` and rank `hang_rank` sleeps `hang_ms`
- * (either may be -1). */
+ * record, so that every rank returns an error from the same step: the failing rank its own code, the others
+ * GPBO_ERR_PEER (the exchange completed, the communicators are intact, the group stays usable).  Buffers passed to a
+ * gpbo_group_* call that returned GPBO_ERR_COMM because a device missed its deadline must stay allocated until
+ * gpbo_group_destroy: a worker released late may still read them (everything the workers WRITE besides the caller's
+ * output arrays lives in state owned by the job itself). */
+
+/* ---- calibration (bench.py's roofline: measured peak and sustained clock next to the datasheet numbers) ---- */
+/* Sustained v_mfma_f64_16x16x4_f64 rate in TFLOP/s over `iters` dependent-chain-free MFMAs. */
+int gpbo_mfma_f64_peak(gpbo_ctx* ctx, int iters, double* tflops);
+/* The same MFMA stream with in-kernel clocks. out[4] = { TFLOP/s, shader cycles per MFMA per SIMD,
+ * sustained shader clock in MHz (s_memtime / s_memrealtime), kernel milliseconds }.
+ * mode 0: accumulators where the compiler puts them (VGPRs); mode 1: AGPR accumulators (inline asm); mode 2: the
+ * posterior GEMM's register pattern (2 x 4 tiles, six operand registers). */
+int gpbo_mfma_f64_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, double* out);
+/* Streaming copy bandwidth in GB/s (read+write bytes) over a `bytes`-sized buffer. */
+int gpbo_hbm_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);
+
+/* ==== DEBUG BUILD ONLY (-DGPBO_DEBUG: bayesianoptimization_amd/libgpbo_dbg.so) ==========================================
+ * Self-test seams, single-kernel timers and micro-benchmarks the tests and scripts/ use.  The product library
+ * (libgpbo.so) exports none of them, reads none of the A/B environment switches (GPBO_CHOL_*, GPBO_POST_*, GPBO_SMALL_MAX,
+ * GPBO_SELECT_V2*, GPBO_MT_*, GPBO_F32_*, GPBO_GEMM128, GPBO_TRI64*, GPBO_LML_GRAPH) and contains no scratch-using kernel. */
+#ifdef GPBO_DEBUG
+/* The optimiser of gpbo_polish_seeds alone, over a host objective (self-test seam: no device, no context): `fg` is called
+ * once per lockstep round with the trial points of the runs that are still alive — x (n_live,d) -> f (n_live), g (n_live,d) —
+ * and returns 0 or an error code that ends the call.  Same outputs as gpbo_polish_seeds. */
+typedef int (*gpbo_fg_callback)(const double* x, int n_live, int d, double* f, double* g, void* user);
+int gpbo_debug_minimize_box(gpbo_fg_callback fg, void* user, const double* seeds, int n_seeds, int d, const double* box_lo,
+                            const double* box_hi, int max_iter, double* x_out, double* f_out, int* status_out, int* n_rounds_out,
+                            int* n_iter_out, int* n_eval_out);
+
+/* Multi-GPU failure path, self-test seam (no device needed): a group of workers without contexts, and a job in which
+ * rank `fail_rank` returns `fail_code` and rank `hang_rank` sleeps `hang_ms` (either may be -1). */
 int gpbo_group_debug_create(int n_ranks, gpbo_group** out);
 int gpbo_group_debug_run(gpbo_group* grp, int fail_rank, int fail_code, int hang_rank, int hang_ms);
-
-/* ---- device self-tests / micro-benchmarks (used by tests and bench headers) -------------- */
+/* Fault injection: the next gpbo_comm_acq_argbest on `ctx` behaves as if its local pass had failed (it still enters the
+ * exchange, with a poisoned record). */
+int gpbo_debug_fail_next_acq(gpbo_ctx* ctx);
 /* The blocked Cholesky alone on an n x n matrix (n a multiple of 64, lower triangle read; replaces LAPACK dpotrf behind
  * sklearn _gpr.py:349): L_out = the factorised buffer (n x n row-major, lower triangle valid), dinv_out = the inverted
  * 64x64 diagonal blocks [n/64][64][64], stamps_out[16] = shader-clock stamps of the first diagonal workgroup's phases
- * (variant 3), ms_out = best of `iters` device times, info_out = LAPACK-style pivot info.  variant 3: round-3 schedule
- * (128-column steps), 2: round-2 schedule.  Any output pointer may be NULL. */
+ * , ms_out = best of `iters` device times, info_out = LAPACK-style pivot info.  variant must be 3 (the 128-column
+ * schedule; 2, the round-2 schedule, is retired).  Any output pointer may be NULL. */
 int gpbo_debug_cholesky(gpbo_ctx* ctx, const double* A, int64_t n, int variant, int iters, double* L_out, double* dinv_out,
                         long long* stamps_out, double* ms_out, int* info_out);
 /* C = alpha * A(m,k) * op(B) + beta * C on the fit GEMM kernel; b_trans: B given as (n,k). */
@@ -338,18 +370,11 @@ int gpbo_debug_select(gpbo_ctx* ctx, const double* ys, int64_t M, int k, int var
 /* Single-wave instruction latency / issue-cost probe: out[t] = shader cycles for 64 copies of pattern t (latency_probe.hip
  * lists the patterns; t = 0 is the empty bracket).  n <= 32. */
 int gpbo_debug_latency_probe(gpbo_ctx* ctx, long long* out, int n);
-/* Sustained v_mfma_f64_16x16x4_f64 rate in TFLOP/s over `iters` dependent-chain-free MFMAs. */
-int gpbo_mfma_f64_peak(gpbo_ctx* ctx, int iters, double* tflops);
-/* The same MFMA stream with in-kernel clocks. out[4] = { TFLOP/s, shader cycles per MFMA per SIMD,
- * sustained shader clock in MHz (s_memtime / s_memrealtime), kernel milliseconds }.
- * mode 0: accumulators where the compiler puts them (VGPRs); mode 1: AGPR accumulators (inline asm). */
-int gpbo_mfma_f64_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, double* out);
 /* fp64 VALU FMA throughput next to the matrix pipe, 4 waves/SIMD. cfg 0: 16 MFMA per iteration only, 1: 256
  * v_fma_f64 (scalar-operand) only, 2: 16 MFMA + 256 VALU, 3: 16 + 128, 4: 8 + 256.
  * out[3] = { kernel ms, MFMA TFLOP/s, VALU TFLOP/s }. */
 int gpbo_hybrid_probe(gpbo_ctx* ctx, int iters, int cfg, double* out);
-/* Streaming copy bandwidth in GB/s (read+write bytes) over a `bytes`-sized buffer. */
-int gpbo_hbm_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);
+#endif /* GPBO_DEBUG */
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 from bayesianoptimization_amd import workloads as W  # noqa: E402
 from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
 
-eng = GpEngine(0)
+eng = GpEngine(0, debug=True)
 out = {}
 print(out, flush=True)
 for name, M in (("C3", 1 << 20), ("C2", 1 << 16)):

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bayesianoptimization_amd import workloads as W
 from bayesianoptimization_amd.engine import GpEngine
-eng = GpEngine(0)
+eng = GpEngine(0, debug=True)
 w = W.C3
 X, y, c = W.make_observations(w)
 ym, ys = float(np.mean(y)), float(np.std(y)); yn = (y - ym) / ys

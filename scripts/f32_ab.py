@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bayesianoptimization_amd import workloads as W
 from bayesianoptimization_amd.engine import GpEngine, F32
-eng = GpEngine(0)
+eng = GpEngine(0, debug=True)
 for name, M in (("C5", 1 << 18), ("C3", 1 << 20)):
     w = W.ALL[name]
     X, y, c = W.make_observations(w)

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bayesianoptimization_amd.engine import MATERN25, GpEngine  # noqa: E402
 
-eng = GpEngine(0)
+eng = GpEngine(0, debug=True)
 out = {}
 outers = sys.argv[1:] or ["64", "128", "256", "512"]
 for N, d in ((1024, 16), (2048, 16), (4096, 16), (8192, 32)):

@@ -2,7 +2,7 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bayesianoptimization_amd.engine import GpEngine
-eng = GpEngine(0)
+eng = GpEngine(0, debug=True)
 names = {0: "16 MFMA", 1: "256 VALU", 2: "16 MFMA + 256 VALU", 3: "16 MFMA + 128 VALU", 4: "8 MFMA + 256 VALU"}
 out = {}
 for rnd in range(2):

@@ -2,7 +2,7 @@
 import os, sys, time, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from bayesianoptimization_amd.engine import MATERN25, GpEngine
-eng = GpEngine(0)
+eng = GpEngine(0, debug=True)
 for N, d in ((256, 4), (512, 8), (1024, 16), (2048, 16)):
     rng = np.random.RandomState(0); X = rng.uniform(size=(N, d)); y = np.sin(X.sum(1)); yn = (y - y.mean()) / y.std()
     for n in (1, 6, 8):

@@ -8,7 +8,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
 
-eng = GpEngine(0)
+eng = GpEngine(0, debug=True)
 for M, d in ((65536, 8), (1 << 20, 16), (1 << 20, 32)):
     lo, hi = np.zeros(d), np.ones(d)
     t0 = time.perf_counter()

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 def probe():
     from bayesianoptimization_amd.engine import MATERN25, GpEngine
-    eng = GpEngine(0)
+    eng = GpEngine(0, debug=True)
     out = {"gemm128": os.environ.get("GPBO_GEMM128", "1"), "gemm": {}, "fit": {}}
     for (m, n, k, bt, at, lo, tag) in [(4096, 4096, 4096, 1, 0, 0, "NT 4096^3"), (4096, 4096, 4096, 0, 0, 0, "NN 4096^3"),
                                        (4096, 4096, 4096, 0, 1, 0, "TN 4096^3"), (3584, 3584, 512, 1, 0, 1, "SYRK 3584 k512 lower"),

@@ -4,7 +4,7 @@ import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from bayesianoptimization_amd import workloads as W
 from bayesianoptimization_amd.engine import GpEngine
-eng = GpEngine(0)
+eng = GpEngine(0, debug=True)
 for name in ("C2",):
     w = W.ALL[name]
     X, y, c = W.make_observations(w)

@@ -30,7 +30,7 @@ def spd(n, seed=0, kind="kernel"):
 
 def probe():
     from bayesianoptimization_amd.engine import MATERN25, GpEngine
-    eng = GpEngine(0)
+    eng = GpEngine(0, debug=True)
     out = {"chol": {}, "fit": {}, "variant_env": os.environ.get("GPBO_CHOL", "3")}
     for n in (64, 128, 192, 512, 576, 1024, 2048, 4096, 8192):
         for kind in ("random", "kernel"):

@@ -11,7 +11,7 @@ from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-eng = GpEngine(0)
+eng = GpEngine(0, debug=True)
 A = spd(n, 1, "kernel")
 L, dinv, stamps, ms, info = eng.debug_cholesky(A, variant=variant, iters=4)
 print(n, variant, ms, info)

@@ -13,8 +13,8 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
 from r03_chol_probe import spd  # noqa: E402
 
-eng = GpEngine(0)
-eng2 = GpEngine(0)
+eng = GpEngine(0, debug=True)
+eng2 = GpEngine(0, debug=True)
 
 
 def fma_ticks():

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
 from r03_chol_probe import spd  # noqa: E402
 
-eng = GpEngine(0)
+eng = GpEngine(0, debug=True)
 for n in [int(x) for x in (sys.argv[1:] or (64, 128, 512))]:
     A = spd(n, 1, "kernel")
     Lref = np.linalg.cholesky(A)

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 def child():
     from bayesianoptimization_amd.engine import MATERN25, RBF, GpEngine
-    eng = GpEngine(0)
+    eng = GpEngine(0, debug=True)
     out = {}
     for N, d, kern in ((512, 8, MATERN25), (1000, 5, RBF), (4096, 16, MATERN25), (8192, 32, MATERN25)):
         rng = np.random.RandomState(0)

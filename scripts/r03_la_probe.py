@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 def child():
     from bayesianoptimization_amd.engine import MATERN25, GpEngine
-    eng = GpEngine(0)
+    eng = GpEngine(0, debug=True)
     out = {}
     for N, d in ((2048, 16), (4096, 16), (8192, 32)):
         rng = np.random.RandomState(0)

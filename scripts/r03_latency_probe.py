@@ -18,7 +18,7 @@ NAMES = ["empty bracket", "dependent v_fma_f64", "dependent v_mul_f64", "4 indep
          "the same code, SECOND pass (x4 = per column)",
          "16 x column chain without the LDS write (x4 = per column)", "16 x column chain with one ds_write_b64 (x4 = per column)",
          "16 x column chain, v_mul for v_rsq, no LDS write (x4 = per column)"]
-eng = GpEngine(0)
+eng = GpEngine(0, debug=True)
 for _ in range(2):
     out = eng.latency_probe(len(NAMES))
 base = out[0]

@@ -9,7 +9,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
 
-eng = GpEngine(0)
+eng = GpEngine(0, debug=True)
 rng = np.random.RandomState(0)
 out = {}
 for M in (1 << 16, 1 << 20, 1 << 23):

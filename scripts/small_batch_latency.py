@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bayesianoptimization_amd.engine import MATERN25, GpEngine  # noqa: E402
 
-eng = GpEngine(0)
+eng = GpEngine(0, debug=True)
 out = {}
 for N, d in ((512, 8), (1024, 16), (2048, 16), (4096, 16), (8192, 32)):
     rng = np.random.RandomState(0)

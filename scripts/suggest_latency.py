@@ -21,7 +21,7 @@ from bayesianoptimization_amd.gpr import HipGPR  # noqa: E402
 from bayesianoptimization_amd.float_space import FloatSpace  # noqa: E402
 
 warnings.simplefilter("ignore")
-eng = GpEngine(0)
+eng = GpEngine(0, debug=True)
 out = {}
 for name in ("C2", "C3"):
     w = W.ALL[name]

@@ -30,6 +30,17 @@ def engine():
     eng.close()
 
 
+@pytest.fixture(scope="session")
+def debug_engine():
+    """A context in libgpbo_dbg.so (the product's sources built with -DGPBO_DEBUG): for the tests that need a debug entry
+    point (gpbo_debug_*) or one of the kernel A/B environment switches, which the product library does not read."""
+    from bayesianoptimization_amd.engine import GpEngine
+
+    eng = GpEngine(0, debug=True)
+    yield eng
+    eng.close()
+
+
 def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)

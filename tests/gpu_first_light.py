@@ -38,7 +38,7 @@ def section(name):
     return deco
 
 
-eng = GpEngine(0)
+eng = GpEngine(0, debug=True)      # gpbo_debug_gemm: the debug build (same sources as libgpbo.so)
 
 
 @section("device")

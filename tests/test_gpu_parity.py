@@ -26,7 +26,8 @@ def _data(N, d, seed=0):
                                       # the 128x128 double-buffered kernel (m, n >= 128, k >= 32), incl. ragged last blocks
                                       (128, 128, 32, True), (256, 384, 512, True), (320, 192, 80, False),
                                       (448, 704, 144, True), (192, 192, 48, False)])
-def test_mfma_gemm_layout(engine, m, n, k, bt):
+def test_mfma_gemm_layout(debug_engine, m, n, k, bt):
+    engine = debug_engine      # gpbo_debug_gemm: debug build
     """Transpose-detecting check of the f64 MFMA fragment maps (asymmetric random operands)."""
     rng = np.random.RandomState(1)
     A = rng.randn(m, k)
@@ -268,11 +269,13 @@ def test_rccl_single_rank_roundtrip(engine):
         engine.world_size, engine.rank = 1, 0
 
 
-def test_rccl_local_failure_enters_the_exchange_and_surfaces_as_an_error(engine, monkeypatch):
-    """A rank whose local acquisition pass failed (here: injected) still enters ncclAllGather with a poisoned record, so
-    the collective completes on every rank and the call returns an error instead of leaving its peers blocked; the
-    communicator stays usable for the next step."""
+def test_rccl_local_failure_enters_the_exchange_and_surfaces_as_an_error(debug_engine):
+    """A rank whose local acquisition pass failed (here: injected through the debug build's gpbo_debug_fail_next_acq) still
+    enters ncclAllGather with a poisoned record, so the collective completes on every rank and the call returns an error
+    instead of leaving its peers blocked; the communicator stays usable for the next step."""
     from bayesianoptimization_amd.engine import GpEngine
+
+    engine = debug_engine
 
     X, y = _data(120, 3, seed=5)
     yn, ym, ys = O.normalize_targets(y)
@@ -283,10 +286,9 @@ def test_rccl_local_failure_enters_the_exchange_and_surfaces_as_an_error(engine,
     try:
         good = engine.comm_acq_argbest(O.UCB, 2.0, k_seeds=4)
         assert good[:2] == engine.acq_argbest(O.UCB, 2.0, k_seeds=4)[:2]
-        monkeypatch.setenv("GPBO_TEST_FAIL_ACQ_RANK", "0")
+        engine.debug_fail_next_acq()
         with pytest.raises(_lib.GpboError, match="injected local failure"):
             engine.comm_acq_argbest(O.UCB, 2.0, k_seeds=4)
-        monkeypatch.delenv("GPBO_TEST_FAIL_ACQ_RANK")
         again = engine.comm_acq_argbest(O.UCB, 2.0, k_seeds=4)
         assert again[:2] == good[:2] and np.array_equal(again[2], good[2])
     finally:
@@ -327,10 +329,12 @@ def test_lml_not_pd_returns_minus_inf(engine):
 
 @pytest.mark.parametrize("M", [1, 2, 3, 5, 8, 17, 170])
 @pytest.mark.parametrize("N,d,kernel,ls", [(150, 6, O.MATERN25, 0.8), (1030, 16, O.MATERN25, 1.5), (70, 2, O.RBF, 0.5)])
-def test_small_batch_path_equals_oracle_and_big_kernel(engine, M, N, d, kernel, ls):
+def test_small_batch_path_equals_oracle_and_big_kernel(debug_engine, M, N, d, kernel, ls):
     """M <= 8 goes through the batched-GEMV latency path (posterior_small.hip): same results as the oracle
-    and as the MFMA kernel (GPBO_POST_SMALL=0) to rounding."""
+    and as the MFMA kernel (GPBO_POST_SMALL=0, a debug-build switch) to rounding."""
     import os
+
+    engine = debug_engine
 
     X, y = _data(N, d, seed=21)
     gp = O.fit_fixed_theta(kernel, X, y, ls, 1e-6)
@@ -354,11 +358,14 @@ def test_small_batch_path_equals_oracle_and_big_kernel(engine, M, N, d, kernel, 
     assert np.max(np.abs(sd - sd_b)) <= tol * max(np.max(np.abs(sd_o)), 1e-3)
 
 
-def test_small_batch_rows_do_not_depend_on_the_batch(engine):
+def test_small_batch_rows_do_not_depend_on_the_batch(debug_engine):
     """The GEMV path evaluates every candidate with the same instruction sequence whatever batch it arrives in
     (pass width 1/2/4/8/16, pass index): a lockstep round of n_seeds * (d + 1) points returns, row for row, the
-    bits the per-run batches of d + 1 points return — what lets the merged L-BFGS-B runs retrace the separate ones."""
+    bits the per-run batches of d + 1 points return — what lets the merged L-BFGS-B runs retrace the separate ones.
+    (GPBO_SMALL_MAX pins the path: a debug-build switch.)"""
     import os
+
+    engine = debug_engine
 
     N, d = 700, 9
     X, y = _data(N, d, seed=51)

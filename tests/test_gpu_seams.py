@@ -169,11 +169,13 @@ def test_device_theta_search_matches_sklearn_optimum(engine):
     assert rel_err(m2, m1) < 1e-5 and rel_err(s2, s1) < 1e-5
 
 
-def test_batched_fd_smart_stage_is_bitwise_the_per_point_path(engine, monkeypatch):
+def test_batched_fd_smart_stage_is_bitwise_the_per_point_path(debug_engine, monkeypatch):
     """The smart stage in its shapes — all runs in lockstep (one device batch of n_seeds * (d + 1) points per
     round; SciPy's setulb driven directly, or one thread per run around the public minimize), one batched (d + 1)-point call per L-BFGS-B iteration of each run, and the reference-shaped per-point
     path — returns exactly the same point: the GEMV kernel evaluates a candidate identically alone or in any
-    batch (the path is pinned; across the GEMV/MFMA switch the agreement is to rounding, next test)."""
+    batch (the path is pinned — GPBO_SMALL_MAX, a debug-build switch; across the GEMV/MFMA switch the agreement is to
+    rounding, next test)."""
+    engine = debug_engine
     monkeypatch.setenv("GPBO_SMALL_MAX", "1024")
     w = W.P2
     sp = _space(w)
@@ -282,10 +284,11 @@ def test_incremental_refit_in_a_maximize_loop(engine):
 
 
 @pytest.mark.parametrize("streams", [2, 7, 64, 256])
-def test_device_candidate_substreams_by_jump_ahead_are_the_sequential_stream(engine, streams, monkeypatch):
+def test_device_candidate_substreams_by_jump_ahead_are_the_sequential_stream(debug_engine, streams, monkeypatch):
     """The sub-stream generator (csrc/mt_jump.hip: S start states by polynomial jump-ahead, S workgroups) against the
     reference stream, EVERY value, for sub-stream counts that do and do not divide the block count, an odd stream
-    position, doubles that straddle sub-stream boundaries, and the state handed back."""
+    position, doubles that straddle sub-stream boundaries, and the state handed back.  (GPBO_MT_STREAMS: debug build.)"""
+    engine = debug_engine
     monkeypatch.setenv("GPBO_MT_STREAMS", str(streams))
     M, d = 150001, 5
     lo = np.linspace(-1.0, 2.0, d)

@@ -2,7 +2,8 @@
 to produce on demand — ys.argmin() / argsort(ys)[:k] of the reference (bayes_opt/acquisition.py:313-317; NumPy: first NaN wins
 the argmin, NaNs sort last, -0.0 == 0.0, ties keep the lower index).
 
-variant 1 = k block-reduction passes (GPBO_SELECT_V2=0), variant 2 = threshold + rank counting (the default), whose LDS list
+The debug build's entry point gpbo_debug_select runs either form (the product uses the passes for k <= 2 and the threshold form
+beyond): variant 1 = k block-reduction passes (GPBO_SELECT_V2=0), variant 2 = threshold + rank counting (the default), whose LDS list
 is bounded: a tiny GPBO_SELECT_V2_CAP drives it into its fall-back, which must give the same picks."""
 import numpy as np
 import pytest
@@ -43,7 +44,8 @@ def _cases():
 
 
 @pytest.mark.parametrize("name,ys", _cases(), ids=[c[0] for c in _cases()])
-def test_both_selection_forms_equal_numpy(engine, monkeypatch, name, ys):
+def test_both_selection_forms_equal_numpy(debug_engine, monkeypatch, name, ys):
+    engine = debug_engine      # gpbo_debug_select + GPBO_SELECT_V2_CAP: debug build
     for k in (1, 10, 64):
         want_idx, want_nan = _reference(ys, k)
         for variant, cap in ((1, None), (2, None), (2, "16"), (2, "1")):
@@ -60,7 +62,8 @@ def test_both_selection_forms_equal_numpy(engine, monkeypatch, name, ys):
             assert np.all(np.isnan(vals[idx < 0])), tag
 
 
-def test_a_full_size_pass_selects_the_same_seeds_in_both_forms(engine, monkeypatch):
+def test_a_full_size_pass_selects_the_same_seeds_in_both_forms(debug_engine, monkeypatch):
+    engine = debug_engine
     ys = np.random.RandomState(3).standard_normal(1 << 20)
     ys[123456] = ys[654321] = ys.min() - 1.0            # an exact tie for the minimum, blocks apart
     want_idx, _ = _reference(ys, 64)
@@ -70,7 +73,8 @@ def test_a_full_size_pass_selects_the_same_seeds_in_both_forms(engine, monkeypat
     assert list(want_idx[:2]) == [123456, 654321]
 
 
-def test_acq_argbest_gives_the_same_answer_through_either_selection_form(engine, monkeypatch):
+def test_acq_argbest_gives_the_same_answer_through_either_selection_form(debug_engine, monkeypatch):
+    engine = debug_engine      # GPBO_SELECT_V2: debug build
     rng = np.random.RandomState(11)
     X = rng.uniform(size=(200, 3))
     y = np.sin(3 * X.sum(1)) + 0.05 * rng.randn(200)

@@ -1,6 +1,7 @@
 """CPU: the device group's failure path.  gpbo_group::run gives every job a deadline and turns a worker
 that fails or never comes back into an error for the caller; exercised through the self-test seam (a group of worker
-threads without device contexts, include/gpbo.h: gpbo_group_debug_create / gpbo_group_debug_run)."""
+threads without device contexts, include/gpbo.h: gpbo_group_debug_create / gpbo_group_debug_run — entry points of the debug
+build, libgpbo_dbg.so: the same comm.hip as the product's)."""
 import ctypes as C
 import os
 import subprocess
@@ -20,7 +21,7 @@ def _group(lib, n):
 
 
 def test_every_worker_ok_then_one_fails_with_its_code():
-    lib = _lib.load_library()
+    lib = _lib.load_debug_library()
     g = _group(lib, 4)
     assert lib.gpbo_group_size(g) == 4
     assert lib.gpbo_group_debug_run(g, -1, 0, -1, 0) == _lib.GPBO_OK
@@ -36,7 +37,7 @@ def test_a_worker_that_never_returns_becomes_an_error_within_the_deadline():
 import ctypes as C, sys, time
 sys.path.insert(0, %r)
 from bayesianoptimization_amd import _lib
-lib = _lib.load_library()
+lib = _lib.load_debug_library()
 g = C.c_void_p()
 assert lib.gpbo_group_debug_create(3, C.byref(g)) == 0
 t0 = time.time()
@@ -60,7 +61,7 @@ print("RESULT", rc, round(dt, 2), rc2, round(time.time() - t1, 2), msg)
 
 
 def test_python_layer_maps_comm_errors_to_runtime_error():
-    lib = _lib.load_library()
+    lib = _lib.load_debug_library()
     g = _group(lib, 2)
     rc = lib.gpbo_group_debug_run(g, 0, _lib.ERR_COMM, -1, 0)
     with pytest.raises(_lib.GpboError):
@@ -68,3 +69,14 @@ def test_python_layer_maps_comm_errors_to_runtime_error():
     # a communicator error marks the group broken for good
     assert lib.gpbo_group_debug_run(g, -1, 0, -1, 0) == _lib.ERR_COMM
     lib.gpbo_group_destroy(g)
+
+
+def test_a_relayed_peer_failure_does_not_break_the_group_and_the_root_cause_is_reported():
+    """healthy ranks that only relay "a peer's local step failed" (GPBO_ERR_PEER: the exchange completed, the
+    communicators are intact) must not poison the group for good, and the caller must see the failing rank's own code."""
+    lib = _lib.load_debug_library()
+    g = _group(lib, 3)
+    # every rank relays: the group stays usable
+    assert lib.gpbo_group_debug_run(g, 0, _lib.ERR_PEER, -1, 0) == _lib.ERR_PEER
+    assert lib.gpbo_group_debug_run(g, -1, 0, -1, 0) == _lib.GPBO_OK
+    assert lib.gpbo_group_destroy(g) == _lib.GPBO_OK

@@ -14,7 +14,7 @@ FG = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c
 
 
 def _minimize_many(fun_grad, seeds, lo, hi, max_iter=0):
-    lib = _lib.load_library()
+    lib = _lib.load_debug_library()
     seeds = np.ascontiguousarray(seeds, dtype=np.float64)
     S, d = seeds.shape
     calls = []
@@ -103,14 +103,14 @@ def test_iteration_limit_and_bad_arguments():
     seeds = np.array([[-1.2, 1.0, -0.5, 0.7]])
     x, f, status, nit, nfev, rounds, _ = _minimize_many(_rosenbrock, seeds, np.full(4, -2.0), np.full(4, 2.0), max_iter=3)
     assert status[0] == 2 and nit[0] == 3                                 # SciPy's success = False
-    lib = _lib.load_library()
+    lib = _lib.load_debug_library()
     z = np.zeros(2)
     assert lib.gpbo_debug_minimize_box(None, None, _lib.dptr(z), 1, 2, _lib.dptr(z), _lib.dptr(z + 1), 0, _lib.dptr(z), _lib.dptr(z),
                                        None, None, None, None) == _lib.ERR_INVALID
 
 
 def test_a_failing_objective_ends_the_call_with_its_code():
-    lib = _lib.load_library()
+    lib = _lib.load_debug_library()
 
     def cb(xp, n_live, dd, fp, gp, _user):
         return -2
