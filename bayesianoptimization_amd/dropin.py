@@ -50,7 +50,7 @@ def _convert_acquisition(fn):
 
 
 def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=None, precision: str = "f64",
-               devices=None, local_search: str = "reference"):
+               devices=None, local_search: str = "auto"):
     """Swap the GP(s) and the acquisition function of `optimizer` in place; returns `optimizer`.
 
     `devices=[0, 1, ...]`: shard the random stage of every suggest() over these GPUs from this ONE process (GroupEngine:
@@ -62,13 +62,15 @@ def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=N
     `n_random` overrides the number of random candidates per suggest() (reference default 10_000).
     `precision="f32"` keeps the fp64 factorisation but runs the posterior contraction in fp32 (2x matrix rate).
     `engine` lets several optimizers share (or tests inject) a GpEngine; default: one per device.
-    `local_search`: "reference" (default) keeps SciPy's L-BFGS-B over finite differences, iterate for iterate the
-    reference's local searches (bayes_opt/acquisition.py:364-374); "device" runs the stage as one library call
-    (gpbo_polish_seeds: projected L-BFGS, analytic gradient, the same stopping rule) — about half the latency of a
-    small-N suggest(), the same acquisition value at the returned point, not the same iterates.
+    `local_search`: "auto" (default) runs the local-search stage as one library call (gpbo_polish_seeds: projected L-BFGS,
+    analytic gradient, L-BFGS-B's stopping rule — about half the latency of a small-N suggest(), the same or a better
+    acquisition value at the returned point, not the same iterates) wherever it applies: all-float spaces (no input
+    transform) and stock UCB / EI / POI policies; mixed spaces and custom policies keep the reference-shaped stage.
+    "device" asks for the same explicitly; "reference" keeps SciPy's L-BFGS-B over finite differences, iterate for iterate
+    the reference's local searches (bayes_opt/acquisition.py:364-374).
     """
-    if local_search not in ("reference", "device"):
-        raise ValueError("local_search must be 'reference' or 'device'")
+    if local_search not in ("auto", "reference", "device"):
+        raise ValueError("local_search must be 'auto', 'reference' or 'device'")
     if engine is None:
         engine = shared_engine(tuple(devices)) if devices is not None else shared_engine(device)
     space = optimizer._space
@@ -85,9 +87,9 @@ def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=N
     optimizer._acquisition_function = _convert_acquisition(optimizer._acquisition_function)
     if n_random is not None and isinstance(optimizer._acquisition_function, A.AcquisitionFunction):
         optimizer._acquisition_function.default_n_random = int(n_random)
-    if local_search == "device":
+    if local_search != "auto":
         fn = optimizer._acquisition_function
         for f in [fn, getattr(fn, "base_acquisition", None), *getattr(fn, "base_acquisitions", [])]:
             if isinstance(f, A.AcquisitionFunction):
-                f.device_polish = True
+                f.device_polish = (local_search == "device")
     return optimizer

@@ -189,10 +189,15 @@ class AcquisitionFunction(abc.ABC):
     #: are no longer SciPy's finite-difference ones, so parity with the reference is statistical (equal or better
     #: acquisition value), not bit-wise.  Needs engine-backed GPs without input transform and a stock policy.
     analytic_gradient = False
-    # True: the whole local-search stage is ONE library call (gpbo_polish_seeds: projected L-BFGS on the host side of the C
-    # ABI, batched value + analytic gradient on the device, SciPy's stopping rule) — no SciPy, no Python between the
-    # rounds.  Not the reference's iterates: parity is statistical (the acquisition value at the returned point).
-    device_polish = False
+    #: the local-search stage.  "auto" (default since round 4) / True: ONE library call whenever it
+    #: applies — engine-backed GPs without input transform, a stock policy, a non-degenerate box, <= 64 seeds
+    #: (gpbo_polish_seeds: projected L-BFGS on the host side of the C ABI, batched value + analytic gradient on the device,
+    #: SciPy's stopping rule; no SciPy, no Python between the rounds) — otherwise the reference-shaped path below.  Not the
+    #: reference's iterates: parity is statistical, the acquisition value at the returned point (the 66-problem x 10-seed
+    #: sweep of tests/test_gpu_polish.py, profiles/r04_polish_sweep.json, is what the default rests on).
+    #: False: SciPy's L-BFGS-B over (batched) finite differences, iterate for iterate the reference's local searches
+    #: (bayes_opt/acquisition.py:364-374).
+    device_polish = "auto"
     _acq_kind: int | None = None     # engine acquisition id of the stock policies; None = host formula only
 
     def __init__(self, random_state=None) -> None:

@@ -14,13 +14,26 @@ import tempfile
 import time
 
 
+def _parent_start_ticks() -> str:
+    """Start time of the launcher process (clock ticks since boot, /proc/<ppid>/stat field 22): every rank of ONE launch
+    reads the same value, and no other launch can — a pid may be reused, a (pid, start time) pair cannot.  This is the
+    per-launch nonce of the key: a crashed run's leftover file under the same (port, launcher pid) has another name."""
+    try:
+        with open(f"/proc/{os.getppid()}/stat", "rb") as f:
+            stat = f.read().decode(errors="replace")
+        return stat[stat.rindex(")") + 2:].split()[19]      # fields after "pid (comm)": state is #3, starttime #22
+    except (OSError, ValueError, IndexError):
+        return "x"
+
+
 def _path(key: str | None = None) -> str:
     base = os.environ.get("GPBO_RDZV_DIR", tempfile.gettempdir())
     if key is None:
-        # (port, launcher pid) + the launcher's own run id / restart count when it has one: an elastic restart under the
-        # same launcher must not meet the previous attempt's file
-        key = (f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}"
-               f"_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}")
+        # (port, launcher pid, launcher start time) + the launcher's own run id / restart count when it has one: neither an
+        # elastic restart under the same launcher nor a new launcher that happens to get the old one's pid meets the
+        # previous attempt's file
+        key = (f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{_parent_start_ticks()}"
+               f"_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}")
     return os.path.join(base, f"gpbo_rdzv_{key}.id")
 
 
@@ -37,7 +50,7 @@ def share_unique_id(rank: int, make_id, key: str | None = None, timeout: float =
             except OSError:
                 pass
         tmp = f"{path}.{os.getpid()}.tmp"
-        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)     # nobody else's file, nobody else's to read
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)     # nobody else's file, nobody else's to read
         with os.fdopen(fd, "wb") as f:
             f.write(uid)
             f.flush()
@@ -64,8 +77,15 @@ def share_unique_id(rank: int, make_id, key: str | None = None, timeout: float =
 def mark_done(rank: int, key: str | None = None) -> None:
     """Rank 0: tell the peers (host side, no device work) that everything it does alone after the timed region is over."""
     if rank == 0:
+        path = _path(key) + ".done"
         try:
-            fd = os.open(_path(key) + ".done", os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o600)
+            os.unlink(path)            # ours from an earlier call, or a leftover: never written THROUGH
+        except OSError:
+            pass
+        try:
+            # a new file of our own: O_EXCL refuses an existing name, O_NOFOLLOW a symlink planted under it (the id file
+            # gets the same treatment in share_unique_id)
+            fd = os.open(path, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
             os.close(fd)
         except OSError:
             pass

@@ -67,7 +67,8 @@ def cpu_baseline(w, X, y, c, Xc, y_max, gpu_ys, n_chunks=3):
     from oracle import gp_oracle as O
     from oracle.refenv import have_reference
 
-    chunk = 8192 if w.N <= 4096 else 2048
+    chunk = min(8192 if w.N <= 4096 else 2048, Xc.shape[0])
+    n_chunks = max(1, min(n_chunks, Xc.shape[0] // chunk))
     kind = "port"
     acq = None
     if have_reference():
@@ -147,6 +148,7 @@ def suggest_latency(w, X, y, eng, M, reps=3):
     fn = {W.UCB: lambda: A.UpperConfidenceBound(kappa=w.acq_param), W.EI: lambda: A.ExpectedImprovement(xi=w.acq_param),
           W.POI: lambda: A.ProbabilityOfImprovement(xi=w.acq_param)}[w.acq]()
     res = {}
+    fn.device_polish = False          # "n_smart_10" = the reference-shaped local searches (SciPy's iterates, bit parity)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for n_smart in (0, 10):
@@ -172,7 +174,9 @@ def suggest_latency(w, X, y, eng, M, reps=3):
         res["device_local_search_error"] = repr(e)
     finally:
         fn.device_polish = False
-    res["note"] = "median of 3 after one warm-up; fixed theta; candidates = the reference's RandomState stream, generated on the device"
+    res["note"] = ("median of 3 after one warm-up; fixed theta unless the key says otherwise; candidates = the reference's RandomState "
+                   "stream, generated on the device; n_smart_10 = SciPy's L-BFGS-B iterates (local_search='reference'), "
+                   "n_smart_10_device_local_search = gpbo_polish_seeds (the default of accelerate() since round 4)")
     # ... and as BayesianOptimization itself configures its GP (bayesian_optimization.py: Matern(nu=2.5), alpha=1e-6,
     # normalize_y=True, n_restarts_optimizer=5): every suggest() then also runs sklearn's theta search — 1 + 5 L-BFGS-B
     # runs over the log-marginal likelihood, here with the LML and its gradient on the device (gpbo_lml_batch lanes)
@@ -187,9 +191,27 @@ def suggest_latency(w, X, y, eng, M, reps=3):
                 fn.suggest(gp_t, sp, n_random=M, n_smart=10, fit_gp=True, random_state=np.random.RandomState(7 + rep))
                 ts.append((time.perf_counter() - t0) * 1e3)
         res["n_smart_10_with_theta_search"] = float(np.median(ts[1:]))
+        # THE CALL THE REFERENCE MAKES, as accelerate(optimizer) configures it by default: BayesianOptimization's GP (theta
+        # search with 5 restarts in every fit, bayesian_optimization.py:124-130; sklearn _gpr.py:296-338) + 10 local searches
+        # (acquisition.py:116-169, 322-420) on the device path
+        fn.device_polish = "auto"
+        ts = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for rep in range(4):
+                t0 = time.perf_counter()
+                fn.suggest(gp_t, sp, n_random=M, n_smart=10, fit_gp=True, random_state=np.random.RandomState(7 + rep))
+                ts.append((time.perf_counter() - t0) * 1e3)
+        res["default_call"] = float(np.median(ts[1:]))
+        res["default_call_minus_n_smart_0"] = res["default_call"] - res["n_smart_0"]
+        res["default_call_is"] = ("suggest(n_random=M, n_smart=10, fit_gp=True) with GaussianProcessRegressor(Matern(2.5), alpha=1e-6, "
+                                  "normalize_y=True, n_restarts_optimizer=5): theta search (LML + gradient on the device, lockstep "
+                                  "restarts) + refit + M candidates + 10 local searches (gpbo_polish_seeds)")
     except Exception as e:  # noqa: BLE001
-        res["n_smart_10_with_theta_search"] = None
+        res.setdefault("n_smart_10_with_theta_search", None)
         res["theta_search_error"] = repr(e)
+    finally:
+        fn.device_polish = False
     return res
 
 
@@ -223,6 +245,28 @@ def reference_golden(name, n_shards, M_shard):
             "source": f"tests/golden/{name}_s0..s{n_shards - 1}.npz (merged)"}
 
 
+def measured_peak(eng, prec):
+    """the spec peak AND the micro-benchmarked one.  ~0.2 s of device time: v_mfma_f64_16x16x4_f64 streams
+    (gpbo_mfma_f64_probe, in-kernel s_memtime / s_memrealtime clocks) in the posterior GEMM's register pattern at 4 waves
+    per SIMD and in the plain 8-accumulator pattern at 2 — `peak_measured` is the best of them, `sustained_mhz` the shader
+    clock under that load, `peak_at_sustained_clock` = 256 CUs x 4 SIMDs x 32 flop/clk x that clock (what the datasheet's
+    78.6 TFLOP/s becomes at the clock this box holds; the fp32 matrix rate is twice that)."""
+    probes = []
+    for waves, mode in ((4, 2), (2, 0), (4, 0)):
+        r = eng.mfma_f64_probe(iters=6000, waves_per_simd=waves, mode=mode)
+        probes.append({"waves_per_simd": waves, "pattern": {0: "8 accumulators, one operand pair", 2: "2x4 tiles, six operand registers"}[mode],
+                       "tflops": float(r["tflops"]), "cycles_per_mfma": float(r["cycles_per_mfma"]), "shader_mhz": float(r["shader_mhz"]),
+                       "ms": float(r["ms"])})
+    best = max(probes, key=lambda p: p["tflops"])
+    scale = 2.0 if prec else 1.0
+    return {"peak_measured": best["tflops"] * scale, "sustained_mhz": best["shader_mhz"],
+            "peak_at_sustained_clock": 256 * 4 * 32 * best["shader_mhz"] * 1e6 / 1e12 * scale,
+            "peak_measured_note": ("best of the v_mfma_f64_16x16x4_f64 micro-benchmarks below" + (" x 2 (fp32 matrix rate)" if prec else "")
+                                   + "; a register-constant MFMA stream is not a ceiling for a kernel (DESIGN.md §4.1 fact 3): "
+                                     "frac_of_measured may exceed what frac_at_sustained_clock allows"),
+            "mfma_probes": probes}
+
+
 def pmc_summary_for(w):
     """HBM-side bytes per launch of the dominant kernels from the rocprofv3 --pmc passes of THIS command
     (scripts/profile_pmc.sh -> scripts/pmc_summary.py), trusted only when the summary was taken from the very kernel
@@ -243,12 +287,22 @@ def pmc_summary_for(w):
     return pm, f"profiles/{os.path.basename(ppath)} (same kernel sources: fingerprint {_fingerprint()[:12]})"
 
 
-def run_extra_config(eng, name, steps=5, warmup=2):
+def resolved(w):
+    """Workloads whose theta comes from the reference's own fit (C1, F1: length_scale=None) read it from their golden file."""
+    if w.length_scale is not None:
+        return w
+    import dataclasses
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"{w.name}.npz"))
+    return dataclasses.replace(w, length_scale=float(np.atleast_1d(g["length_scale"])[0]))
+
+
+def run_extra_config(eng, name, steps=5, warmup=2, cpu_chunks=0):
     """One more BASELINE.json config on the already-open single engine, after the headline's timed region: the same step
     (fit at fixed theta + posterior + acquisition + arg-best/top-10 over the resident candidates; sharded configs: shard 0
     = one GPU's share of the 8-GPU job), wall-clocked over `steps` steps between stream synchronisations, with the
-    dominant kernels' HIP-event time and the parity block against the reference's golden for exactly this job."""
-    w = W.ALL[name]
+    dominant kernels' HIP-event time and the parity block against the reference's golden for exactly this job.
+    cpu_chunks > 0: the CPU path beside it (cpu_baseline on that many chunks of the same candidates)."""
+    w = resolved(W.ALL[name])
     X, y, c = W.make_observations(w)
     y_mean, y_std = float(np.mean(y)), float(np.std(y))
     yn = (y - y_mean) / y_std
@@ -261,7 +315,8 @@ def run_extra_config(eng, name, steps=5, warmup=2):
         c_mean, c_std = float(np.mean(c)), float(np.std(c))
         cn = (c - c_mean) / c_std
         lb_c, ub_c = [-np.inf], [w.constraint_ub]
-    eng.set_candidates(W.make_candidates(w.bounds_array(), M, 7))
+    Xc = W.make_candidates(w.bounds_array(), M, 7)
+    eng.set_candidates(Xc)
     post = [0.0]
 
     def step():
@@ -309,6 +364,13 @@ def run_extra_config(eng, name, steps=5, warmup=2):
                          "top10_equals_reference": bool(np.array_equal(top10, g["top_idx"][:10])),
                          "min_rel_err": float(abs(best[1] - g["min"]) / abs(g["min"])), "reference": g["source"],
                          "arithmetic": "fp32 posterior vs the fp64 reference" if prec else "fp64"}
+    if cpu_chunks > 0:
+        try:
+            _, _, _, _, gpu_ys = eng.acq_argbest(w.acq, w.acq_param, 0.0 if y_max is None else y_max, lb_c, ub_c, k_seeds=0,
+                                                 return_values=True)
+            out["cpu_baseline"] = cpu_baseline(w, X, y, c, Xc, y_max, gpu_ys, n_chunks=cpu_chunks)
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(e)}
     if name == "C2":      # the small config is where ms/suggest is a latency, not a throughput, number
         try:
             out["suggest_ms"] = suggest_latency(w, X, y, eng, M)
@@ -564,6 +626,14 @@ def main():
             out["step_breakdown_ms"]["fits_overlapped_wall"] = kern_ms_overlapped[0] / steps
             out["roofline_fit"]["note"] = ("stage timings of one fit measured alone (outside the timed region); in the timed steps "
                                            "the two GPs' fits are enqueued side by side: step_breakdown_ms.fits_overlapped_wall")
+        if mode == "single":
+            try:
+                mp = measured_peak(eng, prec)
+                out["roofline"].update(mp)
+                out["roofline"]["frac_of_measured"] = achieved / mp["peak_measured"]
+                out["roofline"]["frac_at_sustained_clock"] = achieved / mp["peak_at_sustained_clock"]
+            except Exception as e:  # noqa: BLE001
+                log(f"[bench] measured peak not available: {e!r}")
         # HBM traffic of the dominant kernels: separate rocprofv3 --pmc passes of this very command, summarised in profiles/
         try:
             pm, note = pmc_summary_for(w)
@@ -601,11 +671,12 @@ def main():
                 log(f"[bench] cpu_baseline failed: {e!r}")
                 out["cpu_baseline"] = None
         if mode == "single" and args.config is None and not args.no_extra_configs:
-            # every other BASELINE.json config that fits one GPU, in the line the driver records (5 steps each, no CPU leg)
+            # every other BASELINE.json config, in the line the driver records (5 steps each, the CPU path beside each on a
+            # bounded sample: C1 / C2 whole or 3 chunks, the two big shards 2 chunks)
             out["configs"] = {}
-            for key, nm in (("C2", "C2"), ("C4_s0", "C4"), ("C5_f32_s0", "C5")):
+            for key, nm, cpu_chunks in (("C1", "C1", 1), ("C2", "C2", 3), ("C4_s0", "C4", 2), ("C5_f32_s0", "C5", 2)):
                 try:
-                    out["configs"][key] = run_extra_config(eng, nm)
+                    out["configs"][key] = run_extra_config(eng, nm, cpu_chunks=cpu_chunks)
                 except Exception as e:  # noqa: BLE001
                     log(f"[bench] extra config {key} failed: {e!r}")
                     out["configs"][key] = {"error": repr(e)}

@@ -151,3 +151,25 @@ def test_suggest_child_failure_costs_only_its_key(monkeypatch):
     monkeypatch.setenv("GPBO_FORCE_NO_DEVICE", "1")
     res = b.suggest_in_child(2, "C4", timeout_s=120)
     assert isinstance(res, dict) and "error" in res
+
+
+def test_rendezvous_files_are_never_written_through_a_symlink_and_the_key_is_per_launch(tmp_path, monkeypatch):
+    """mark_done created its flag with O_CREAT|O_TRUNC — through a planted symlink that truncates somebody else's
+    file; now it is unlink + O_EXCL|O_NOFOLLOW like the id file.  And the default key carries the launcher's START TIME,
+    so a crashed run's leftover under the same (port, launcher pid) cannot feed a stale id to a new launch."""
+    from bayesianoptimization_amd import rendezvous
+
+    monkeypatch.setenv("GPBO_RDZV_DIR", str(tmp_path))
+    victim = tmp_path / "victim.txt"
+    victim.write_text("precious")
+    key = "symlink_case"
+    flag = rendezvous._path(key) + ".done"
+    os.symlink(victim, flag)
+    rendezvous.mark_done(0, key=key)
+    assert victim.read_text() == "precious"                         # not truncated through the link
+    assert os.path.exists(flag) and not os.path.islink(flag)        # the link was replaced by a file of our own
+    assert oct(os.stat(flag).st_mode & 0o777) == "0o600"
+    ticks = rendezvous._parent_start_ticks()
+    assert ticks.isdigit() and ticks in os.path.basename(rendezvous._path())
+    monkeypatch.setenv("MASTER_PORT", "29511")
+    assert f"29511_{os.getppid()}_{ticks}_" in os.path.basename(rendezvous._path())

@@ -4,8 +4,10 @@ bayes_opt/target_space.py:95-96), so this mode is checked against the SAME fp64 
 tolerance stated here: mu keeps fp64 accuracy (its dot product is accumulated in fp64 before rounding); the
 VARIANCE carries the absolute error of an fp32 sum of squares, |sigma^2 - sigma_ref^2| <= 2e-5 * y_std^2 (measured 5e-6 at C3/C5)
 (so sigma itself is only resolved down to ~2e-3 * y_std: the cancellation 1 - |W k*|^2 cannot be repaired after
-the fact); the acquisition 5e-3 of its range; the arg-best index must match wherever the reference's top-2 gap
-is wide."""
+the fact); the acquisition within 1e-4 of its range (10x the 2e-6 .. 9e-6 the full C5 shards measure,
+profiles/r03_f32_shards.json — the bound tests/test_gpu_sharded.py asserts; until round 4 this file asserted a loose 5e-3
+and a conditional arg-best); the arg-best index equals the fp64 reference's, unconditionally: every golden's top-2 gap is
+> 6 % of the range, hundreds of times the error bound (asserted, so that the claim cannot silently turn into a coin flip)."""
 import numpy as np
 import pytest
 
@@ -15,6 +17,8 @@ from conftest import load_golden, rel_err
 from oracle import gp_oracle as O
 
 pytestmark = pytest.mark.gpu
+
+F32_ACQ_TOL = 1e-4      # of the acquisition range (tests/test_gpu_sharded.py uses the same bound on all 8 C5 shards)
 
 
 @pytest.mark.parametrize("N,d,M,kernel,ls", [(200, 3, 4096, O.MATERN25, 0.4), (600, 8, 5000, O.MATERN25, 1.0),
@@ -62,8 +66,14 @@ def test_f32_against_reference_goldens(engine, name):
     y_max = W.feasible_y_max(w, y, c)
     bi, bv, si, sv, ys = engine.acq_argbest(w.acq, w.acq_param, y_max, lb, ub, k_seeds=4, return_values=True)
     rng_ = np.max(g["ys"]) - np.min(g["ys"])
-    assert np.max(np.abs(ys[:S] - g["ys"])) < 5e-3 * rng_
+    e = F32_ACQ_TOL * rng_
+    assert np.max(np.abs(ys[:S] - g["ys"])) <= e
     gap = float(g["topk_val"][1] - g["topk_val"][0])
-    if gap > 0.02 * rng_:                       # C2: 6.7 %, C5S: 8 %, C5: 40 % of |min|
-        assert bi == int(g["argmin"])
-    assert abs(bv - float(g["min"])) < 5e-3 * rng_
+    assert gap > 2 * e                          # C2: 6.7 %, C5S: 8 %, C5: 40 % of |min| against a bound of 0.02 %
+    assert bi == int(g["argmin"])
+    assert abs(bv - float(g["min"])) <= e
+    # the four best in the reference's order wherever its values stand clear of each other by more than twice the bound
+    ref_idx, ref_val = g["topk_idx"].astype(np.int64), g["topk_val"]
+    for p in range(4):
+        if (p == 0 or ref_val[p] - ref_val[p - 1] > 2 * e) and ref_val[p + 1] - ref_val[p] > 2 * e:
+            assert si[p] == ref_idx[p]

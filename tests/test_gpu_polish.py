@@ -69,6 +69,66 @@ def test_polish_is_at_least_as_good_as_scipy_on_the_oracle_objective(engine, acq
     assert close >= 7
 
 
+def test_sweep_of_66_problems_against_scipy_on_the_oracle_objective(engine):
+    """What the default `local_search="auto"` rests on: UCB / EI / POI x unconstrained / constrained x
+    d in {2, 8, 16, 32} x N in {60, 512, 2048} (+ six RBF problems), 10 seeds each, `gpbo_polish_seeds` against
+    `scipy.optimize.minimize(method="L-BFGS-B")` on the oracle's objective from the SAME seeds.  SciPy's half is the
+    committed fixture tests/golden/polish_sweep.npz (oracle/gen_polish_sweep.py: deterministic CPU code); the device's end
+    points are evaluated with the same oracle here.  Asserted: every point in the box; the reported value is the oracle's
+    value at the reported point; no run ends above its seed; per problem the best over the seeds is SciPy's best or better
+    (1e-6 relative); over all 660 runs at least 90 % end within 1e-5 of SciPy's value or below it; fewer than 1 % end
+    without convergence (status 2: iteration limit / 3: line search exhausted).  The table goes to
+    gpurun_out/r04_polish_sweep.json (-> profiles/)."""
+    import json
+    import os
+
+    from oracle import gen_polish_sweep as G
+
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "polish_sweep.npz"))
+    table, n_runs, n_close, n_bad, n_better, n_worse = {}, 0, 0, 0, 0, 0
+    for spec in G.problems():
+        key, acq, param, constrained, two_sided, kernel, d, N = spec
+        p = G.build(*spec)
+        seeds = fx[f"{key}__seeds"]
+        assert np.array_equal(seeds, p["seeds"]), key                 # the fixture was made from these very inputs
+        yn, ym, ys = O.normalize_targets(p["y"])
+        engine.fit(p["X"], yn, kernel, p["ls"], 1e-6, slot=0)
+        y_means, y_stds = [ym], [ys]
+        if constrained:
+            cn, cm, cs = O.normalize_targets(p["c"])
+            engine.fit(p["X"], cn, O.MATERN25, p["cls"], 1e-6, slot=1)
+            y_means.append(cm); y_stds.append(cs)
+        xs, fs, status, rounds = engine.polish_seeds(acq, param, p["y_max"], p["lb"], p["ub"], y_means, y_stds, seeds, p["box"])
+        assert np.all(xs >= 0.0) and np.all(xs <= 1.0), key
+        f_at = p["f_batch"](xs)
+        scale = np.maximum(np.abs(f_at), 1e-12)
+        assert np.all(np.abs(fs - f_at) <= 1e-7 * scale + 1e-12), (key, fs, f_at)
+        assert np.all(fs <= fx[f"{key}__f_seeds"] + 1e-12), key      # never worse than where it started
+        ref_f, ref_ok = fx[f"{key}__scipy_f"], fx[f"{key}__scipy_ok"]
+        ok = (status < 2) & np.isfinite(fs)
+        assert ok.any(), key
+        ref_best = float(ref_f[ref_ok].min()) if ref_ok.any() else float(ref_f.min())
+        mine_best = float(fs[ok].min())
+        tol = 1e-6 * max(abs(ref_best), 1e-6)
+        assert mine_best <= ref_best + tol, (key, mine_best, ref_best)
+        close = (np.abs(fs - ref_f) <= 1e-5 * np.maximum(np.abs(ref_f), 1e-6)) | (fs < ref_f)
+        n_runs += len(fs); n_close += int(close.sum()); n_bad += int((status >= 2).sum())
+        n_better += int(mine_best < ref_best - tol); n_worse += 0
+        table[key] = {"device_best": mine_best, "scipy_best": ref_best, "rel_gap_best": (mine_best - ref_best) / max(abs(ref_best), 1e-300),
+                      "seeds_within_1e-5_or_better": int(close.sum()), "status": np.bincount(status, minlength=4).tolist(),
+                      "rounds": int(rounds), "device_evals_mean": float(np.mean(engine.last_polish["nfev"])),
+                      "device_iters_mean": float(np.mean(engine.last_polish["nit"])),
+                      "scipy_evals_mean": float(np.mean(fx[f"{key}__scipy_nfev"])), "scipy_success": int(ref_ok.sum())}
+    summary = {"problems": len(table), "runs": n_runs, "runs_within_1e-5_or_better": n_close, "frac_close": n_close / n_runs,
+               "runs_status_ge_2": n_bad, "frac_unconverged": n_bad / n_runs, "problems_where_device_best_is_strictly_better": n_better,
+               "problems_where_device_best_is_worse_beyond_1e-6": n_worse}
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump({"summary": summary, "problems": table}, open("gpurun_out/r04_polish_sweep.json", "w"), indent=1)
+    assert len(table) >= 60
+    assert n_close >= 0.90 * n_runs, summary
+    assert n_bad < 0.01 * n_runs, summary
+
+
 def test_suggest_with_device_polish_through_the_seams(engine):
     """FloatSpace + HipGPR + fused EI: suggest(n_smart=10) with the stage on the device returns a point whose acquisition
     value is at least that of the bit-parity path (SciPy's setulb over finite differences) from the same random stage."""

@@ -183,6 +183,7 @@ def test_batched_fd_smart_stage_is_bitwise_the_per_point_path(debug_engine, monk
     for mode in ("lockstep", "threads", "batched", "per_point"):
         gp = HipGPR(kernel=RBF(length_scale=0.6), alpha=w.noise, normalize_y=True, optimizer=None, engine=engine)
         fn = A.ExpectedImprovement(xi=0.01)
+        fn.device_polish = False                 # the reference-shaped stage (SciPy's iterates) is what this test compares
         fn.batched_fd = mode != "per_point"
         fn.lockstep = {"lockstep": True, "threads": "threads"}.get(mode, False)   # True: SciPy's setulb driven directly
         n0 = [0]
@@ -216,6 +217,7 @@ def test_lockstep_rounds_across_the_kernel_switch(engine):
         gp = HipGPR(kernel=Matern(nu=2.5, length_scale=w.length_scale), alpha=w.noise, normalize_y=True,
                     optimizer=None, engine=engine)
         fn = A.UpperConfidenceBound(kappa=2.576)
+        fn.device_polish = False                 # SciPy's L-BFGS-B runs, in lockstep or one after another
         fn.lockstep = lockstep
         xs[lockstep] = fn.suggest(gp, sp, n_random=4096, n_smart=10, random_state=np.random.RandomState(7))
     acq = fn._get_acq(gp)
