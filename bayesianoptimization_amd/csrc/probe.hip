@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double* out, int iters) 
 // the loop, so cycles per MFMA per SIMD and the sustained shader clock can be told apart.
 template <int MODE>  // 0: builtin (compiler picks VGPR accumulators); 1: inline asm with AGPR accumulators;
                      // 2: the posterior GEMM's register pattern — a 2 x 4 tile grid, every MFMA another (A, B) register pair
-__global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, unsigned long long* clk, int iters) {
+__global__ __launch_bounds__(1024) void mfma_probe_kernel(double* out, unsigned long long* clk, int iters) {
   d4 acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
@@ -58,46 +58,59 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, unsigned l
   double s = 0.0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
-  out[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;   // forces completion of the MFMAs before the clocks
+  out[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] = s;   // forces completion of the MFMAs before the clocks
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const unsigned long long c1 = __builtin_amdgcn_s_memtime();
   const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
   if ((threadIdx.x & 63) == 0) {
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    clk[2 * w] = c1 - c0;
-    clk[2 * w + 1] = r1 - r0;
+    const int w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    clk[4 * w] = c1 - c0;
+    clk[4 * w + 1] = r1 - r0;
+    clk[4 * w + 2] = r0;          // absolute 100 MHz stamps: the span first start .. last end is the kernel's own time,
+    clk[4 * w + 3] = r1;          // free of the launch and of the event bracket
   }
 }
 
 int run_mfma_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, double* out4) {
-  const int grid = 256 * (waves_per_simd < 1 ? 1 : waves_per_simd);
+  // ONE workgroup per compute unit (256 of them), 4 * waves_per_simd waves each: the dispatcher has nothing to balance, every
+  // SIMD gets exactly waves_per_simd waves (256-thread workgroups — the first form of this probe — were packed 8 to a CU on
+  // half of the CUs: in-kernel clocks said 62 cycles per MFMA while the event time gave 48 TFLOP/s)
+  const int wps = waves_per_simd < 1 ? 1 : (waves_per_simd > 4 ? 4 : waves_per_simd);
+  const int grid = 256, threads = 256 * wps;
   double* out = nullptr;
   unsigned long long* clk = nullptr;
-  GPBO_HIP(ctx, hipMalloc((void**)&out, (size_t)grid * 256 * sizeof(double)));
-  GPBO_HIP(ctx, hipMalloc((void**)&clk, (size_t)grid * 4 * 2 * sizeof(unsigned long long)));
+  const int nw = grid * 4 * wps;
+  GPBO_HIP(ctx, hipMalloc((void**)&out, (size_t)grid * threads * sizeof(double)));
+  GPBO_HIP(ctx, hipMalloc((void**)&clk, (size_t)nw * 4 * sizeof(unsigned long long)));
   hipEvent_t e0, e1;
   GPBO_HIP(ctx, hipEventCreate(&e0));
   GPBO_HIP(ctx, hipEventCreate(&e1));
   auto kern = mode == 2 ? mfma_probe_kernel<2> : mode == 1 ? mfma_probe_kernel<1> : mfma_probe_kernel<0>;
-  kern<<<dim3(grid), dim3(256), 0, ctx->stream>>>(out, clk, 16);
+  kern<<<dim3(grid), dim3(threads), 0, ctx->stream>>>(out, clk, 16);
   GPBO_HIP(ctx, hipEventRecord(e0, ctx->stream));
-  kern<<<dim3(grid), dim3(256), 0, ctx->stream>>>(out, clk, iters);
+  kern<<<dim3(grid), dim3(threads), 0, ctx->stream>>>(out, clk, iters);
   GPBO_HIP(ctx, hipEventRecord(e1, ctx->stream));
   GPBO_HIP(ctx, hipEventSynchronize(e1));
   float ms = 0.f;
   GPBO_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
-  const int nw = grid * 4;
-  std::string h((size_t)nw * 16, '\0');
+  std::string h((size_t)nw * 32, '\0');
   GPBO_HIP(ctx, hipMemcpy(&h[0], clk, h.size(), hipMemcpyDeviceToHost));
   const unsigned long long* c = (const unsigned long long*)h.data();
   double cyc = 0.0, rt = 0.0;
-  for (int w = 0; w < nw; ++w) { cyc += (double)c[2 * w]; rt += (double)c[2 * w + 1]; }
+  unsigned long long first = ~0ull, last = 0;
+  for (int w = 0; w < nw; ++w) {
+    cyc += (double)c[4 * w]; rt += (double)c[4 * w + 1];
+    if (c[4 * w + 2] < first) first = c[4 * w + 2];
+    if (c[4 * w + 3] > last) last = c[4 * w + 3];
+  }
   cyc /= nw; rt /= nw;
-  const double mfma_per_simd = (double)iters * 8.0 * (waves_per_simd < 1 ? 1 : waves_per_simd);
-  out4[0] = (double)grid * 4.0 * iters * 8.0 * 2048.0 / (ms * 1e-3) / 1e12;   // TFLOP/s
-  out4[1] = cyc / mfma_per_simd;                                               // shader cycles per MFMA per SIMD
-  out4[2] = cyc / (rt / 100.0);                                                // shader MHz (s_memrealtime = 100 MHz)
-  out4[3] = ms;
+  const double mfma_per_simd = (double)iters * 8.0 * wps;
+  const double flops = (double)nw * iters * 8.0 * 2048.0;
+  const double span_s = (double)(last - first) * 1e-8;              // s_memrealtime: 100 MHz
+  out4[0] = span_s > 0.0 ? flops / span_s / 1e12 : 0.0;            // TFLOP/s over the kernel's own span
+  out4[1] = cyc / mfma_per_simd;                                    // shader cycles per MFMA per SIMD
+  out4[2] = cyc / (rt / 100.0);                                     // shader MHz
+  out4[3] = ms;                                                     // event-bracketed milliseconds (launch included)
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   GPBO_HIP(ctx, hipFree(out));

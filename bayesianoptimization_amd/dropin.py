@@ -50,7 +50,7 @@ def _convert_acquisition(fn):
 
 
 def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=None, precision: str = "f64",
-               devices=None, local_search: str = "auto"):
+               devices=None, local_search: str = "auto", lml_on_device="auto"):
     """Swap the GP(s) and the acquisition function of `optimizer` in place; returns `optimizer`.
 
     `devices=[0, 1, ...]`: shard the random stage of every suggest() over these GPUs from this ONE process (GroupEngine:
@@ -62,6 +62,10 @@ def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=N
     `n_random` overrides the number of random candidates per suggest() (reference default 10_000).
     `precision="f32"` keeps the fp64 factorisation but runs the posterior contraction in fp32 (2x matrix rate).
     `engine` lets several optimizers share (or tests inject) a GpEngine; default: one per device.
+    `lml_on_device`: where the theta search of every fit evaluates the log-marginal likelihood and its gradient (sklearn
+    _gpr.py:296-338, 537-652).  "auto" (default) / True: on the device, the restarts advanced in lockstep (gpbo_lml_batch) —
+    the same optimum to rounding, the shared RandomState consumed identically, 2x .. 300x faster than the host at N = 16 ..
+    512 (profiles/r04_lml_crossover.json); False: sklearn's own host arithmetic, theta bit for bit the reference's.
     `local_search`: "auto" (default) runs the local-search stage as one library call (gpbo_polish_seeds: projected L-BFGS,
     analytic gradient, L-BFGS-B's stopping rule — about half the latency of a small-N suggest(), the same or a better
     acquisition value at the returned point, not the same iterates) wherever it applies: all-float spaces (no input
@@ -77,6 +81,7 @@ def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=N
     transform = None if _identity_transform(space) else space.kernel_transform
     describe_kernel(optimizer._gp.kernel)
     optimizer._gp = HipGPR.from_sklearn(optimizer._gp, transform=transform, engine=engine, slot=0, precision=precision)
+    optimizer._gp.lml_on_device = lml_on_device
     constraint = getattr(space, "_constraint", None)
     if constraint is not None:
         if len(constraint._model) > 7:
@@ -84,6 +89,7 @@ def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=N
         for j, m in enumerate(constraint._model):
             describe_kernel(m.kernel)
             constraint._model[j] = HipGPR.from_sklearn(m, transform=transform, engine=engine, slot=j + 1, precision=precision)
+            constraint._model[j].lml_on_device = lml_on_device
     optimizer._acquisition_function = _convert_acquisition(optimizer._acquisition_function)
     if n_random is not None and isinstance(optimizer._acquisition_function, A.AcquisitionFunction):
         optimizer._acquisition_function.default_n_random = int(n_random)

@@ -33,6 +33,7 @@ from .engine import MATERN25, GpEngine
 from .engine import RBF as K_RBF
 
 _shared_engines: dict = {}
+LML_DEVICE_MIN_N = 1      # lml_on_device="auto": device from this many observations (see HipGPR.__init__; measured, round 4)
 
 
 def shared_engine(device=0) -> GpEngine:
@@ -87,8 +88,13 @@ class HipGPR(GaussianProcessRegressor):
         self.transform = transform  # host-side input transform (None = identity, the all-float case)
         self.engine = engine
         self.slot = slot
-        # theta search: evaluate log_marginal_likelihood(theta, eval_gradient=True) on the GPU (True), with
-        # sklearn's host code (False), or on the GPU from N >= 512 observations ("auto")
+        # theta search: evaluate log_marginal_likelihood(theta, eval_gradient=True) on the GPU (True), with sklearn's host
+        # code (False), or "auto" = on the GPU whenever the kernel is one the device evaluates.  Until round 4 "auto" meant
+        # N >= 512, a threshold no measurement backed; scripts/r04_lml_crossover.py (profiles/r04_lml_crossover.json, MI355X
+        # + 256 host threads) finds no crossover to speak of: one value + gradient on the device costs 0.13 ms at N = 16 ..
+        # 64 (host: 0.10 / 0.13 / 0.19 ms), 0.16 vs 0.44 at N = 128, 0.35 vs 10 at N = 512, and the whole default fit (5
+        # restarts, lockstep lanes) is faster on the device at EVERY size: 1.0 vs 2.0 ms at N = 16, 3.2 vs 96 at N = 128,
+        # 6.3 vs 1990 at N = 512.
         self.lml_on_device = lml_on_device
         # "f64" (reference arithmetic) or "f32": fp64 factorisation, fp32 posterior contraction (engine.F32)
         self.precision = precision
@@ -129,7 +135,7 @@ class HipGPR(GaussianProcessRegressor):
     def _device_lml_ok(self, kernel) -> bool:
         if self.lml_on_device is False or not hasattr(self, "X_train_"):
             return False
-        if self.lml_on_device == "auto" and self.X_train_.shape[0] < 512:
+        if self.lml_on_device == "auto" and self.X_train_.shape[0] < LML_DEVICE_MIN_N:
             return False
         if np.iterable(self.alpha):
             return False

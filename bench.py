@@ -183,35 +183,62 @@ def suggest_latency(w, X, y, eng, M, reps=3):
     try:
         gp_t = HipGPR(kernel=Matern(nu=2.5), alpha=1e-6, normalize_y=True, n_restarts_optimizer=5,
                       random_state=np.random.RandomState(1), engine=eng, incremental=False)
-        ts = []
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            for rep in range(3):
-                t0 = time.perf_counter()
-                fn.suggest(gp_t, sp, n_random=M, n_smart=10, fit_gp=True, random_state=np.random.RandomState(7 + rep))
-                ts.append((time.perf_counter() - t0) * 1e3)
-        res["n_smart_10_with_theta_search"] = float(np.median(ts[1:]))
-        # THE CALL THE REFERENCE MAKES, as accelerate(optimizer) configures it by default: BayesianOptimization's GP (theta
-        # search with 5 restarts in every fit, bayesian_optimization.py:124-130; sklearn _gpr.py:296-338) + 10 local searches
-        # (acquisition.py:116-169, 322-420) on the device path
-        fn.device_polish = "auto"
-        ts = []
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            for rep in range(4):
-                t0 = time.perf_counter()
-                fn.suggest(gp_t, sp, n_random=M, n_smart=10, fit_gp=True, random_state=np.random.RandomState(7 + rep))
-                ts.append((time.perf_counter() - t0) * 1e3)
-        res["default_call"] = float(np.median(ts[1:]))
-        res["default_call_minus_n_smart_0"] = res["default_call"] - res["n_smart_0"]
-        res["default_call_is"] = ("suggest(n_random=M, n_smart=10, fit_gp=True) with GaussianProcessRegressor(Matern(2.5), alpha=1e-6, "
-                                  "normalize_y=True, n_restarts_optimizer=5): theta search (LML + gradient on the device, lockstep "
-                                  "restarts) + refit + M candidates + 10 local searches (gpbo_polish_seeds)")
+        stage = {"fit": [], "polish": []}
+        fit0 = gp_t.fit
+
+        def timed_fit(X_, y_):
+            t0 = time.perf_counter()
+            r = fit0(X_, y_)
+            stage["fit"].append((time.perf_counter() - t0) * 1e3)
+            return r
+
+        gp_t.fit = timed_fit
+        polish0 = eng.polish_seeds
+
+        def timed_polish(*a, **k):
+            t0 = time.perf_counter()
+            r = polish0(*a, **k)
+            stage["polish"].append((time.perf_counter() - t0) * 1e3)
+            return r
+
+        eng.polish_seeds = timed_polish
+
+        def timed_calls(n):
+            """n suggest() calls; call r draws its theta-search restarts from RandomState(100 + r) in EVERY mode (the length of
+            a search depends on where its restarts start), candidates from RandomState(7 + r)"""
+            ts = []
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for rep in range(n):
+                    gp_t.random_state = np.random.RandomState(100 + rep)
+                    t0 = time.perf_counter()
+                    fn.suggest(gp_t, sp, n_random=M, n_smart=10, fit_gp=True, random_state=np.random.RandomState(7 + rep))
+                    ts.append((time.perf_counter() - t0) * 1e3)
+            return ts
+
+        try:
+            fn.device_polish = False
+            res["n_smart_10_with_theta_search"] = float(np.median(timed_calls(5)[1:]))
+            # THE CALL THE REFERENCE MAKES, as accelerate(optimizer) configures it by default: BayesianOptimization's GP (theta
+            # search with 5 restarts in every fit, bayesian_optimization.py:124-130; sklearn _gpr.py:296-338) + 10 local
+            # searches (acquisition.py:116-169, 322-420), both on the device path
+            fn.device_polish = "auto"
+            stage["fit"].clear(); stage["polish"].clear()
+            res["default_call"] = float(np.median(timed_calls(5)[1:]))
+            res["default_call_minus_n_smart_0"] = res["default_call"] - res["n_smart_0"]
+            res["default_call_stages_ms"] = {"fit_with_theta_search": float(np.median(stage["fit"][1:])),
+                                             "local_search_gpbo_polish_seeds": float(np.median(stage["polish"][1:])) if stage["polish"] else None,
+                                             "length_scale_found": float(np.exp(gp_t.kernel_.theta[0]))}
+            res["default_call_is"] = ("suggest(n_random=M, n_smart=10, fit_gp=True) with GaussianProcessRegressor(Matern(2.5), alpha=1e-6, "
+                                      "normalize_y=True, n_restarts_optimizer=5): theta search (LML + gradient on the device, lockstep "
+                                      "restarts) + refit + M candidates + 10 local searches (gpbo_polish_seeds); median of 4 calls whose "
+                                      "restarts start from RandomState(101..104), the same in n_smart_10_with_theta_search")
+        finally:
+            del eng.polish_seeds
+            fn.device_polish = False
     except Exception as e:  # noqa: BLE001
         res.setdefault("n_smart_10_with_theta_search", None)
         res["theta_search_error"] = repr(e)
-    finally:
-        fn.device_polish = False
     return res
 
 

@@ -317,8 +317,9 @@ int gpbo_group_get_candidate_rows(gpbo_group* grp, const int64_t* idx, int n, do
 /* ---- calibration (bench.py's roofline: measured peak and sustained clock next to the datasheet numbers) ---- */
 /* Sustained v_mfma_f64_16x16x4_f64 rate in TFLOP/s over `iters` dependent-chain-free MFMAs. */
 int gpbo_mfma_f64_peak(gpbo_ctx* ctx, int iters, double* tflops);
-/* The same MFMA stream with in-kernel clocks. out[4] = { TFLOP/s, shader cycles per MFMA per SIMD,
- * sustained shader clock in MHz (s_memtime / s_memrealtime), kernel milliseconds }.
+/* The same MFMA stream with in-kernel clocks, one workgroup of 4 * waves_per_simd (<= 4) waves per compute unit.
+ * out[4] = { TFLOP/s over the kernel's own span (first wave's start .. last wave's end, s_memrealtime), shader cycles per
+ * MFMA per SIMD, sustained shader clock in MHz (s_memtime / s_memrealtime), event-bracketed kernel milliseconds }.
  * mode 0: accumulators where the compiler puts them (VGPRs); mode 1: AGPR accumulators (inline asm); mode 2: the
  * posterior GEMM's register pattern (2 x 4 tiles, six operand registers). */
 int gpbo_mfma_f64_probe(gpbo_ctx* ctx, int iters, int waves_per_simd, int mode, double* out);

@@ -26,7 +26,8 @@ def main(src, dst):
     for path in glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
             if "kmat_kernel" in r["Kernel_Name"]:
-                dur[int(r["Grid_Size"])].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+                grid = int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1)
+                dur[grid].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     out, lines = {}, [f"# kmat_kernel counters from {src} (per-launch averages)"]
     for grid, cs in sorted(per.items()):
         tiles = grid // 256                     # 256 threads per lower 64x64 tile

@@ -20,7 +20,10 @@ def black_box(x, y):
 PB = {"x": (2, 4), "y": (-3, 3)}
 
 
-def _pair(seed=1, constraint=None, acq=None, acq2=None):
+def _pair(seed=1, constraint=None, acq=None, acq2=None, lml_on_device=False):
+    """(reference optimizer, accelerated twin over a FakeEngine).  The bit-for-bit comparisons of this file need theta
+    bit for bit, i.e. sklearn's own LML arithmetic in the theta search: lml_on_device=False (accelerate()'s default, "auto",
+    evaluates it on the engine, where theta agrees to rounding — test_default_theta_search_runs_on_the_engine_...)."""
     import_reference()
     from bayes_opt import BayesianOptimization
 
@@ -31,7 +34,7 @@ def _pair(seed=1, constraint=None, acq=None, acq2=None):
     mine = BayesianOptimization(f=black_box, pbounds=PB, random_state=seed, verbose=0, constraint=constraint,
                                 acquisition_function=acq2)
     eng = FakeEngine()
-    accelerate(mine, engine=eng)
+    accelerate(mine, engine=eng, lml_on_device=lml_on_device)
     return ref, mine, eng
 
 
@@ -71,6 +74,24 @@ def test_maximize_trajectory_equals_reference_random_stage():
     assert [c[1] for c in eng.calls if c[0] == "generate_candidates_like"] == [3000, 2500]
     kinds = [c[0] for c in eng.calls]
     assert "acq_argbest" in kinds and "posterior" in kinds        # the fused path was taken
+
+
+def test_default_theta_search_runs_on_the_engine_and_agrees_to_rounding():
+    """accelerate()'s default: the theta search's LML evaluations go to the engine at every N (profiles/r04_lml_crossover.json)
+    — lockstep lanes through lml_batch — and land on the reference's optimum to rounding, with the shared RandomState
+    consumed identically (the restarts' starting points are drawn from it, sklearn _gpr.py:325-334)."""
+    ref, mine, eng = _pair(seed=3, lml_on_device="auto")
+    for o in (ref, mine):
+        o.maximize(init_points=4, n_iter=0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        xr = ref._acquisition_function.suggest(ref._gp, ref._space, n_random=2000, n_smart=0, fit_gp=True, random_state=ref._random_state)
+        xm = mine._acquisition_function.suggest(mine._gp, mine._space, n_random=2000, n_smart=0, fit_gp=True, random_state=mine._random_state)
+    assert any(c[0] == "lml_batch" for c in eng.calls)                      # N = 4: the engine, not sklearn's host code
+    assert np.allclose(ref._gp.kernel_.theta, mine._gp.kernel_.theta, rtol=1e-5, atol=1e-6)
+    assert mine._gp.log_marginal_likelihood_value_ == pytest.approx(ref._gp.log_marginal_likelihood_value_, rel=1e-8)
+    assert np.allclose(xr, xm, atol=1e-4)
+    assert ref._random_state.uniform() == mine._random_state.uniform()
 
 
 def test_full_maximize_runs_and_improves():
@@ -127,7 +148,7 @@ def test_predict_and_state_roundtrip(tmp_path):
         mine.save_state(path)
         nxt = mine.suggest()
         fresh = BayesianOptimization(f=black_box, pbounds=PB, random_state=11, verbose=0)
-        accelerate(fresh, engine=FakeEngine())
+        accelerate(fresh, engine=FakeEngine(), lml_on_device=False)     # as `mine` (_pair)
         fresh.load_state(path)
         nxt2 = fresh.suggest()
     assert nxt == nxt2
@@ -171,8 +192,13 @@ def test_hipgpr_device_lml_override_semantics():
     n_lml = sum(c[0] == "lml" for c in eng.calls)
     gp3.log_marginal_likelihood(th, eval_gradient=True)
     assert sum(c[0] == "lml" for c in eng.calls) == n_lml
+    # "auto": the device at every N since round 4 (the measured crossover: profiles/r04_lml_crossover.json) ...
+    assert HipGPR(kernel=Matern(nu=2.5), engine=eng, lml_on_device="auto", alpha=1e-6,
+                  optimizer=None).fit(X, y)._device_lml_ok(Matern(nu=2.5))
+    # ... for the kernels the device evaluates: anything else keeps sklearn's host code
+    from sklearn.gaussian_process.kernels import WhiteKernel
     assert not HipGPR(kernel=Matern(nu=2.5), engine=eng, lml_on_device="auto", alpha=1e-6,
-                      optimizer=None).fit(X, y)._device_lml_ok(Matern(nu=2.5))   # auto: N < 512 stays on the host
+                      optimizer=None).fit(X, y)._device_lml_ok(Matern(nu=2.5) + WhiteKernel())
 
 
 def test_meta_acquisitions_run_through_the_seams():
@@ -192,7 +218,7 @@ def test_meta_acquisitions_run_through_the_seams():
         ref = BayesianOptimization(f=black_box, pbounds=PB, random_state=4, verbose=0, acquisition_function=make())
         opt = BayesianOptimization(f=black_box, pbounds=PB, random_state=4, verbose=0, acquisition_function=make())
         eng = FakeEngine()
-        accelerate(opt, engine=eng)
+        accelerate(opt, engine=eng, lml_on_device=False)      # bit-for-bit trajectories: sklearn's LML arithmetic
         assert isinstance(opt._gp, HipGPR)
         meta = opt._acquisition_function
         assert type(meta).__module__.startswith("bayes_opt")                         # meta policy untouched
@@ -226,7 +252,7 @@ def test_integer_parameters_use_the_host_transform():
     ref = BayesianOptimization(f=f, pbounds=pb, random_state=9, verbose=0)
     mine = BayesianOptimization(f=f, pbounds=pb, random_state=9, verbose=0)
     eng = FakeEngine()
-    accelerate(mine, engine=eng)
+    accelerate(mine, engine=eng, lml_on_device=False)
     assert mine._gp.transform is not None
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -331,7 +357,7 @@ def test_fused_gphedge_is_the_reference_gphedge_and_can_share_one_posterior_pass
     fused = A.GPHedge([A.UpperConfidenceBound(kappa=2.0), A.ExpectedImprovement(xi=0.01), A.ProbabilityOfImprovement(xi=0.02)])
     opt = BayesianOptimization(f=black_box, pbounds=PB, random_state=6, verbose=0, acquisition_function=fused)
     eng = FakeEngine()
-    accelerate(opt, engine=eng)
+    accelerate(opt, engine=eng, lml_on_device=False)
     assert opt._acquisition_function is fused
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -353,7 +379,7 @@ def test_fused_gphedge_is_the_reference_gphedge_and_can_share_one_posterior_pass
                        share_candidates=True)
     opt2 = BayesianOptimization(f=black_box, pbounds=PB, random_state=6, verbose=0, acquisition_function=shared)
     eng2 = FakeEngine()
-    accelerate(opt2, engine=eng2)
+    accelerate(opt2, engine=eng2, lml_on_device=False)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         opt2.maximize(init_points=2, n_iter=1)
