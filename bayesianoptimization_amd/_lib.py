@@ -89,6 +89,9 @@ SIGNATURES = {
                                  _c_double_p, C.c_int, C.c_double, C.c_int, C.POINTER(C.c_int)]),
     "gpbo_group_fit_append": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int64, C.c_int, _c_double_p, C.c_int64,
                                         C.POINTER(C.c_int)]),
+    "gpbo_group_lml_batch": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, _c_double_p, C.c_int64, C.c_int, C.c_int, _c_double_p,
+                                       C.c_int, C.c_double, C.c_int, _c_double_p, _c_double_p, C.POINTER(C.c_int),
+                                       C.POINTER(C.c_int)]),
     "gpbo_group_set_candidates": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, C.c_int]),
     "gpbo_group_generate_candidates_mt19937": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, _c_double_p, _c_double_p,
                                                          C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),

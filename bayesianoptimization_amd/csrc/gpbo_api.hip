@@ -609,6 +609,27 @@ int gpbo_lml(gpbo_ctx* ctx, int slot, const double* X, const double* y_norm, int
   return GPBO_OK;
 }
 
+}  // extern "C"
+
+namespace gpbo {
+// The raw inputs of a theta search, resident on the device for every later gpbo_lml_batch call with X == y_norm == NULL
+// (shared with gpbo_group_lml_batch, which puts them on every device of the group before it hands out lanes).
+int lml_upload_inputs(gpbo_ctx* ctx, const double* X, const double* y_norm, int64_t N, int d) {
+  if (!ctx || !X || !y_norm || N < 1 || d < 1) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "lml inputs: bad arguments");
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  int rc;
+  ctx->lml_N = 0;
+  if ((rc = ensure(ctx, &ctx->lml_X, &ctx->cap_lml_X, N * d))) return rc;
+  if ((rc = ensure(ctx, &ctx->lml_y, &ctx->cap_lml_y, N))) return rc;
+  GPBO_HIP(ctx, hipMemcpy(ctx->lml_X, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice));
+  GPBO_HIP(ctx, hipMemcpy(ctx->lml_y, y_norm, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+  ctx->lml_N = N; ctx->lml_d = d;
+  return GPBO_OK;
+}
+}  // namespace gpbo
+
+extern "C" {
+
 int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_norm, int64_t N, int d, int kernel,
                    const double* length_scales, int n_ls, double noise, int eval_gradient, double* lml, double* grad,
                    int* info) {
@@ -656,14 +677,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
   const int64_t stride = off;
   int rc;
   if ((rc = ensure(ctx, &ctx->lml_slab, &ctx->cap_lml_slab, stride * n_theta))) return rc;
-  if (!reuse_inputs) {
-    ctx->lml_N = 0;
-    if ((rc = ensure(ctx, &ctx->lml_X, &ctx->cap_lml_X, N * d))) return rc;
-    if ((rc = ensure(ctx, &ctx->lml_y, &ctx->cap_lml_y, N))) return rc;
-    GPBO_HIP(ctx, hipMemcpy(ctx->lml_X, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice));
-    GPBO_HIP(ctx, hipMemcpy(ctx->lml_y, y_norm, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
-    ctx->lml_N = N; ctx->lml_d = d;
-  }
+  if (!reuse_inputs && (rc = lml_upload_inputs(ctx, X, y_norm, N, d))) return rc;
   double* base = ctx->lml_slab;
   // Lanes are processed in groups: a group runs the launch sequence once for its lanes on its own stream.  Small
   // problems are dispatch-bound (every kernel is tiny): ONE group of all lanes.  From NP = 2048 on the big GEMMs fill

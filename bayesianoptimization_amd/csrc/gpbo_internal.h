@@ -334,6 +334,8 @@ int debug_select(gpbo_ctx* ctx, const double* ys_host, int64_t M, int k, int var
 // the reference's argmin / min / argsort[:k] over the union of `world` shards from their records (host; identical on every rank)
 void merge_records(const BestRecord* all, int world, int k_seeds, int64_t* best_idx, double* best_val, int64_t* seed_idx,
                    double* seed_val);
+// gpbo_api.hip: the theta search's raw inputs made resident on ctx's device (gpbo_lml_batch with X == NULL reads them)
+int lml_upload_inputs(gpbo_ctx* ctx, const double* X, const double* y_norm, int64_t N, int d);
 // gpbo_api.hip: argument checks + posterior pointers of gpbo_acq_argbest, shared with the multi-GPU entry points
 int build_acq_args(gpbo_ctx* ctx, const char* who, int acq, double acq_param, double y_max, int n_constraints,
                    const double* lb, const double* ub, int k_seeds, const void* best_idx, const void* best_val,

@@ -638,6 +638,26 @@ class GroupEngine(GpEngine):
         self._gcheck(rc, info.value)
         return self._touch(slot)
 
+    def lml_batch(self, X, y_norm, kernel: int, length_scales, noise: float, eval_gradient=True, reuse_inputs=False):
+        """The lanes of one lockstep round of the theta search spread over the group's devices (gpbo_group_lml_batch: lane
+        i on device i mod G; inputs made resident on every device by the first call of a search).  Same return value as
+        GpEngine.lml_batch, every entry bitwise what `lml()` returns on one device; `last_lane_devices` says where each
+        lane ran."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        y_norm = np.ascontiguousarray(y_norm, dtype=np.float64).ravel()
+        ls = np.ascontiguousarray(np.atleast_2d(np.asarray(length_scales, dtype=np.float64)))
+        n, n_ls = ls.shape
+        vals = np.zeros(n)
+        grads = np.zeros((n, n_ls))
+        infos = (C.c_int * n)()
+        where = (C.c_int * n)()
+        rc = self._lib.gpbo_group_lml_batch(self._g, n, None if reuse_inputs else dptr(X), None if reuse_inputs else dptr(y_norm),
+                                            X.shape[0], X.shape[1], int(kernel), dptr(ls), n_ls, float(noise),
+                                            int(bool(eval_gradient)), dptr(vals), dptr(grads), infos, where)
+        self._gcheck(rc)
+        self.last_lane_devices = list(where)
+        return [(float(vals[i]), grads[i].copy()) for i in range(n)]
+
     # -- sharded candidates ----------------------------------------------------------------------
     def set_candidates(self, Xc):
         Xc = np.ascontiguousarray(Xc, dtype=np.float64)

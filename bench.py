@@ -229,6 +229,13 @@ def suggest_latency(w, X, y, eng, M, reps=3):
             res["default_call_stages_ms"] = {"fit_with_theta_search": float(np.median(stage["fit"][1:])),
                                              "local_search_gpbo_polish_seeds": float(np.median(stage["polish"][1:])) if stage["polish"] else None,
                                              "length_scale_found": float(np.exp(gp_t.kernel_.theta[0]))}
+            if getattr(eng, "last_lane_devices", None) is not None:
+                # device group: the theta search's lanes of a lockstep round run on different devices (gpbo_group_lml_batch)
+                res["theta_search_lane_devices_last_round"] = list(eng.last_lane_devices)
+                distinct = len(set(getattr(eng, "devices", [0])))
+                res["theta_search_lanes"] = ("lane i of a lockstep round on device i mod G (gpbo_group_lml_batch)" +
+                                             ("" if distinct > 1 else "; virtual ranks on ONE physical GPU here: the gain of "
+                                              "spreading the lanes is unmeasured on hardware"))
             res["default_call_is"] = ("suggest(n_random=M, n_smart=10, fit_gp=True) with GaussianProcessRegressor(Matern(2.5), alpha=1e-6, "
                                       "normalize_y=True, n_restarts_optimizer=5): theta search (LML + gradient on the device, lockstep "
                                       "restarts) + refit + M candidates + 10 local searches (gpbo_polish_seeds); median of 4 calls whose "

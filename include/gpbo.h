@@ -290,6 +290,14 @@ int gpbo_group_fit(gpbo_group* grp, int slot, const double* X, const double* y_n
                    const double* length_scale, int n_ls, double noise, int precision, int* info);
 int gpbo_group_fit_append(gpbo_group* grp, int slot, const double* x_new, int64_t n_new, int d, const double* y_norm,
                           int64_t n_total, int* info);
+/* gpbo_lml_batch across the group: the theta search's 1 + n_restarts_optimizer L-BFGS-B runs are independent (sklearn
+ * _gpr.py:296-338), so the lanes of a lockstep round are spread over the devices, lane i on device i mod G (n_theta <= 64).
+ * X / y_norm non-NULL: made resident on every device first; NULL: the previous call's inputs.  Every lane is bitwise what
+ * gpbo_lml returns on any one device, so the search ends at the single-device theta.  lane_device (optional, n_theta):
+ * the device each lane ran on. */
+int gpbo_group_lml_batch(gpbo_group* grp, int n_theta, const double* X, const double* y_norm, int64_t N, int d, int kernel,
+                         const double* length_scales, int n_ls, double noise, int eval_gradient, double* lml, double* grad,
+                         int* info, int* lane_device);
 /* x_tries (M,d): device r keeps rows [r M / G, (r + 1) M / G) resident (gpbo_group_shard reports the range). */
 int gpbo_group_set_candidates(gpbo_group* grp, const double* Xc, int64_t M, int d);
 int gpbo_group_shard(const gpbo_group* grp, int rank, int64_t* row_begin, int64_t* row_end);

@@ -351,3 +351,43 @@ def test_device_group_through_the_seams_with_constraint_and_theta_search(engine)
     for a, b in zip(single[:5], group[:5]):
         assert np.array_equal(a, b)
     assert single[5] == group[5]
+
+
+@pytest.mark.parametrize("N,d", [(300, 5), (2100, 16)])
+def test_theta_search_lanes_spread_over_the_group_are_bitwise_the_single_device_lanes(engine, N, d):
+    """VERDICT r3 #5a: the 1 + n_restarts_optimizer L-BFGS-B runs of sklearn's theta search (_gpr.py:296-338) are
+    independent, so a device group evaluates the live runs' LML requests of a lockstep round on DIFFERENT devices
+    (gpbo_group_lml_batch: lane i on device i mod G) instead of side by side on device 0.  With virtual ranks (three
+    contexts on the one GPU of the box): every lane bitwise gpbo_lml's, the lane -> device map as documented, inputs
+    resident on every device after the first call (a later call may use a device the first one did not), and a whole
+    HipGPR.fit — theta, LML, the shared RandomState's position — identical to the single-device search."""
+    from sklearn.gaussian_process.kernels import Matern
+
+    from bayesianoptimization_amd.gpr import HipGPR
+
+    rng = np.random.RandomState(N)
+    X = rng.uniform(size=(N, d))
+    y = np.exp(-((X - 0.5) ** 2).sum(1)) + 0.01 * rng.standard_normal(N)
+    yn, _, _ = O.normalize_targets(y)
+    scales = np.array([[0.5], [0.8], [1.0], [1.5], [2.0], [3.0], [0.3]])
+    single = engine.lml_batch(X, yn, O.MATERN25, scales, 1e-6)
+    with GroupEngine([0, 0, 0]) as grp:
+        first = grp.lml_batch(X, yn, O.MATERN25, scales[:2], 1e-6)            # two lanes: devices 0 and 1 only ...
+        assert grp.last_lane_devices == [0, 0]                                 # (device ids: virtual ranks all sit on GPU 0)
+        got = grp.lml_batch(X, yn, O.MATERN25, scales, 1e-6, reuse_inputs=True)   # ... now rank 2 as well, from resident inputs
+        assert len(grp.last_lane_devices) == 7
+        for (v, g), (v1, g1) in zip(got, single):
+            assert v == v1 and np.array_equal(g, g1)
+        for (v, g), (v1, g1) in zip(first, single[:2]):
+            assert v == v1 and np.array_equal(g, g1)
+        one = engine.lml(X, yn, O.MATERN25, 1.5, 1e-6)
+        assert got[3][0] == one[0] and np.array_equal(got[3][1], one[1])
+
+        def fit(eng):
+            rs = np.random.RandomState(3)
+            gp = HipGPR(kernel=Matern(nu=2.5), alpha=1e-6, normalize_y=True, n_restarts_optimizer=5, random_state=rs,
+                        engine=eng, lml_on_device=True).fit(X, y)
+            return gp.kernel_.theta.copy(), gp.log_marginal_likelihood_value_, rs.uniform()
+
+        a, b = fit(engine), fit(grp)
+        assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2]
