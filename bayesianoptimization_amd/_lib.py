@@ -56,6 +56,10 @@ SIGNATURES = {
                                                        _c_double_p, C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_uint32),
                                                        C.POINTER(C.c_int)]),
     "gpbo_mt19937_jump_blocks": (C.c_int, [C.POINTER(C.c_uint32), C.c_int64, C.POINTER(C.c_uint32)]),
+    "gpbo_generate_candidate_columns_mt19937": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, _c_double_p, _c_double_p,
+                                                          C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
+    "gpbo_set_candidate_columns": (C.c_int, [C.c_void_p, _c_double_p, C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "gpbo_transform_candidates": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gpbo_get_candidate_rows": (C.c_int, [C.c_void_p, _c_int64_p, C.c_int, _c_double_p]),
     "gpbo_posterior": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, _c_double_p, _c_double_p]),
     "gpbo_predict": (C.c_int, [C.c_void_p, C.c_int, _c_double_p, C.c_int64, C.c_int, C.c_double, C.c_double,

@@ -226,7 +226,7 @@ int gpbo_destroy(gpbo_ctx* ctx) {
   if (ctx->lml_slab) (void)hipFree(ctx->lml_slab);
   if (ctx->lml_X) (void)hipFree(ctx->lml_X);
   if (ctx->lml_y) (void)hipFree(ctx->lml_y);
-  void* ptrs[] = {ctx->Xc, ctx->Xcs, ctx->part, ctx->mu_part, ctx->ys, ctx->red, ctx->info_dev, ctx->comm_buf, ctx->kst, ctx->stage};
+  void* ptrs[] = {ctx->Xc, ctx->Xc_raw, ctx->Xcs, ctx->part, ctx->mu_part, ctx->ys, ctx->red, ctx->info_dev, ctx->comm_buf, ctx->kst, ctx->stage};
   if (ctx->comm_host) (void)hipHostFree(ctx->comm_host);
   if (ctx->mt_work) (void)hipFree(ctx->mt_work);
   if (ctx->mt_bits) (void)hipFree(ctx->mt_bits);
@@ -829,6 +829,7 @@ int gpbo_set_candidates(gpbo_ctx* ctx, const double* Xc, int64_t M, int d) {
   if (!Xc || M < 1 || d < 1 || d > GPBO_MAX_DIM) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "set_candidates: bad arguments");
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
+  ctx->raw_valid = false;
   if ((rc = ensure(ctx, &ctx->Xc, &ctx->cap_Xc, M * d))) return rc;
   const size_t bytes = (size_t)M * d * sizeof(double);
   if (bytes <= SMALL_PIN_IN) {

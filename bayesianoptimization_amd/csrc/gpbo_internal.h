@@ -106,6 +106,9 @@ struct gpbo_ctx {
   int64_t cap_Xc = 0;      // capacity in doubles
   int64_t M = 0;
   int d_c = 0;
+  double* Xc_raw = nullptr;   // [M][d] the candidates BEFORE gpbo_transform_candidates (what gpbo_get_candidate_rows returns then)
+  int64_t cap_Xc_raw = 0;
+  bool raw_valid = false;     // Xc holds kernel_transform(Xc_raw); cleared by everything that rewrites Xc
   double* stage = nullptr; // [d][M] stream-order image of device-generated candidates (mt19937.hip)
   int64_t cap_stage = 0;
   unsigned* mt_work = nullptr;   // MT19937 jump-ahead work area: returned state | 34-block stretch | sub-stream states
@@ -309,6 +312,7 @@ int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, dou
 // posterior_kernel_v2.hip
 int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
 int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
+int launch_posterior_v4(gpbo_ctx* ctx, Model& m, int64_t Mp, int* part_chunks);   // fused, 512-row chunks (NP <= 1024)
 int launch_kstar_slab(gpbo_ctx* ctx, Model& m, double* Kst, int64_t ldk, int64_t Mp, int64_t m0, int nchunks);
 // posterior_cov.hip
 int launch_posterior_cov(gpbo_ctx* ctx, Model& m, int64_t M, double y_std, double** cov_dev, int64_t* ld_cov);

@@ -191,11 +191,12 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(const unsigned* __
 }
 
 // stream image S[c][r] (d x M) -> candidate matrix Xc[r][c] (M x d)
+// (columns [col0, col0 + d) of a d_total-wide matrix: a mixed space assembles its matrix from several column groups)
 __global__ __launch_bounds__(256) void transpose_stream_kernel(const double* __restrict__ S, int64_t M, int d,
-                                                               double* __restrict__ Xc) {
+                                                               double* __restrict__ Xc, int d_total, int col0) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= M) return;
-  for (int c = 0; c < d; ++c) Xc[r * d + c] = S[(int64_t)c * M + r];
+  for (int c = 0; c < d; ++c) Xc[r * d_total + col0 + c] = S[(int64_t)c * M + r];
 }
 
 }  // namespace gpbo
@@ -208,12 +209,18 @@ using namespace gpbo;
 // from (M, d, pieces) only, so the polynomial table is built once per process) and walks at most `stride` blocks before
 // its first word.  key_out / pos_out (may be NULL): the state after the WHOLE matrix — available only when the last row
 // is generated here (r1 == M); *has_state says so.
+// d_total / col0: the d generated columns are columns [col0, col0 + d) of a d_total-wide resident matrix (a space with
+// non-float parameters is assembled group by group, gpbo_generate_candidate_columns_mt19937); d_total = d, col0 = 0
+// otherwise.
 static int mt_generate_rows(gpbo_ctx* ctx, int64_t M, int d, int64_t r0, int64_t r1, const double* lo, const double* hi,
-                            const uint32_t* key, int pos, uint32_t* key_out, int* pos_out, int* has_state) {
+                            const uint32_t* key, int pos, uint32_t* key_out, int* pos_out, int* has_state, int d_total = 0,
+                            int col0 = 0) {
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  if (d_total <= 0) d_total = d;
   const int64_t Mloc = r1 - r0;
   int rc;
-  if ((rc = ensure(ctx, &ctx->Xc, &ctx->cap_Xc, Mloc * d))) return rc;
+  ctx->raw_valid = false;
+  if ((rc = ensure(ctx, &ctx->Xc, &ctx->cap_Xc, Mloc * d_total))) return rc;
   if ((rc = ensure(ctx, &ctx->stage, &ctx->cap_stage, Mloc * d))) return rc;
   {
     char* p = (char*)ctx->red;
@@ -299,7 +306,7 @@ static int mt_generate_rows(gpbo_ctx* ctx, int64_t M, int d, int64_t r0, int64_t
       dkey, pos, chunks_dev, states_dev, (const double*)ctx->red, ctx->stage, key_out_dev,
       dbg_env("GPBO_MT_PROBE") ? atoi(dbg_env("GPBO_MT_PROBE")) : 0);
   GPBO_HIP(ctx, hipGetLastError());
-  transpose_stream_kernel<<<dim3((unsigned)((Mloc + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->stage, Mloc, d, ctx->Xc);
+  transpose_stream_kernel<<<dim3((unsigned)((Mloc + 255) / 256)), dim3(256), 0, ctx->stream>>>(ctx->stage, Mloc, d, ctx->Xc, d_total, col0);
   GPBO_HIP(ctx, hipGetLastError());
   if (owns_end) GPBO_HIP(ctx, hipMemcpyAsync(hkey, key_out_dev, MT_N * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
   GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -311,8 +318,23 @@ static int mt_generate_rows(gpbo_ctx* ctx, int64_t M, int d, int64_t r0, int64_t
   }
   (void)n_blocks;
   ctx->M = Mloc;
-  ctx->d_c = d;
+  ctx->d_c = d_total;
   for (auto& m : ctx->models) m.M_post = -1;
+  return GPBO_OK;
+}
+
+extern "C" int gpbo_generate_candidate_columns_mt19937(gpbo_ctx* ctx, int64_t M, int d_total, int col0, int ncols, const double* lo,
+                                                       const double* hi, uint32_t* key, int* pos) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  if (!lo || !hi || !key || !pos || M < 1 || d_total < 1 || d_total > GPBO_MAX_DIM || ncols < 1 || col0 < 0 ||
+      col0 + ncols > d_total || *pos < 0 || *pos > MT_N)
+    GPBO_FAIL(ctx, GPBO_ERR_INVALID, "generate_candidate_columns_mt19937: bad arguments");
+  uint32_t key_new[MT_N];
+  int pos_new = 0, has = 0;
+  int rc = mt_generate_rows(ctx, M, ncols, 0, M, lo, hi, key, *pos, key_new, &pos_new, &has, d_total, col0);
+  if (rc) return rc;
+  memcpy(key, key_new, sizeof(key_new));
+  *pos = pos_new;
   return GPBO_OK;
 }
 

@@ -118,20 +118,26 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
       return GPBO_OK;
     }
   }
-  // v2 = fused generation (one kernel); v3 = k* slab + GEMM.  Default: v3 as soon as k* would be generated twice (two row
-  // chunks, NP > 256): the fp64 VALU work of the generation runs instead of MFMAs, not beside them, and the slab GEMM's
-  // loop carries no other VALU work (posterior_kernel_v2.hip).  Measured at M = 65 536 (scripts/r02_small_n_posterior_ab.py):
-  // NP = 512: v3 0.37-0.39 ms vs v2 0.40-0.42; NP = 256: v2 0.12 vs v3 0.14 (one chunk: nothing is generated twice).
-  // GPBO_POST_KERNEL=2|3 forces one of them (A/B runs).
+  // v2 = fused generation (one kernel, 256-row chunks); v3 = k* slab + GEMM; v4 = fused generation with 512-row chunks.
+  // v3 as soon as k* would be generated more than twice: the fp64 VALU work of the generation runs instead of MFMAs, not
+  // beside them, and the slab GEMM's loop carries no other VALU work (posterior_kernel_v2.hip).  Up to NP = 1024 and for
+  // batches that fill the chip, v4 (round 4): one 16-wave workgroup covers 512 rows, so k* is generated once (NP <= 512)
+  // or 1.5 times and never crosses HBM — the slab route pays a 268 MB round trip and a second launch for a two-chunk
+  // problem (C2: 0.09 + 0.29 ms).  Small batches (the host optimisers' rounds of ~100 points) keep v2: two 256-row
+  // workgroups side by side are the shorter chain there.  Round-2 measurements at M = 65 536 (scripts/
+  // r02_small_n_posterior_ab.py): NP = 512: v3 0.37-0.39 ms vs v2 0.40-0.42; NP = 256: v2 0.12 vs v3 0.14.
+  // GPBO_POST_KERNEL=2|3|4 forces one of them (debug build: A/B runs).
   const char* kv = dbg_env("GPBO_POST_KERNEL");
-  // (two chunks and a small batch — the host optimisers' rounds of ~100 points: the second launch is not worth it)
-  const bool use_v2 = kv ? (kv[0] == '2') : (nchunks <= 1 || (nchunks == 2 && Mp < 8192));
   const bool use_f32 = (m.precision == GPBO_F32);   // fp32 slab + f32 MFMA GEMM (posterior_kernel_f32.hip)
-  const int n_mu = (use_f32 || !use_v2) ? nchunks : 1;
+  int path = (nchunks <= 1 || (nchunks == 2 && Mp < 8192)) ? 2 : ((m.NP >= 384 && m.NP <= 1024 && Mp >= 8192) ? 4 : 3);
+  if (kv && (kv[0] == '2' || kv[0] == '3' || (kv[0] == '4' && m.NP <= 1024))) path = kv[0] - '0';
+  const bool use_v2 = path == 2, use_v4 = path == 4;
+  const int n_mu = (use_f32 || path == 3) ? nchunks : 1;
   ev_begin(ctx, T_POST_MAIN);
-  int part_chunks = nchunks;   // row chunks the sum-of-squares partials are split into (fp32 path: 512-row chunks)
+  int part_chunks = nchunks;   // row chunks the sum-of-squares partials are split into (fp32 path, v4: 512-row chunks)
   if (use_f32) rc = launch_posterior_f32(ctx, m, Mp, nchunks, &part_chunks);
   else if (use_v2) rc = launch_posterior_v2(ctx, m, Mp, nchunks);
+  else if (use_v4) rc = launch_posterior_v4(ctx, m, Mp, &part_chunks);
   else rc = launch_posterior_v3(ctx, m, Mp, nchunks);
   ev_end(ctx, T_POST_MAIN);
   if (rc) return rc;

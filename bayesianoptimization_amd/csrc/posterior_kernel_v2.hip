@@ -56,10 +56,18 @@ constexpr int BUF_FLAGS = 0x00020000;   // gfx9 buffer descriptor word 3: raw bu
 // BK = train points per LDS stage (one s_barrier per stage): 16, or 32 for the slab kernel (half the barriers; the
 // triangular cut-off of a 16-row tile then rounds up to 32 columns — zeros of the packed W, a few per cent more MFMAs
 // in the diagonal chunk only).
-template <int DP, int KERNEL, int GEN, int BK = POST_BK>
-__global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
-  static_assert(BK == 16 || (BK == 32 && GEN == 2), "32-point stages are built for the slab kernel only");
-  constexpr int E = BK / 8;                        // stage elements per thread (lane = candidate, wave = E train points)
+// WAVES = 8: 256-row chunks, two workgroups per CU.  WAVES = 16 (round 4, GEN = 1 only, "v4"): 512-row chunks, ONE 1024-thread
+// workgroup per CU — for NP <= 1024 a candidate tile's k* is then generated once (NP <= 512) or 1.5 times (NP <= 1024)
+// instead of once per 256-row chunk (1.5 / 2.5 times) and never crosses HBM: the slab route generates it once too, but pays a
+// 268 MB round trip at N = 512, M = 65 536 and a second launch (C2: 0.09 + 0.29 ms).
+template <int DP, int KERNEL, int GEN, int BK = POST_BK, int WAVES = 8>
+__global__ __launch_bounds__(WAVES * 64, 4) void posterior_kernel_v2(PostArgs2 p) {
+  static_assert(BK == 16 || BK == 32, "stages of 16 or 32 train points");
+  static_assert(WAVES == 8 || (WAVES == 16 && GEN == 1 && BK == 32), "the 16-wave form is the fused kernel with 32-point stages");
+  constexpr int NT = WAVES * 64;                   // threads
+  constexpr int ROWS = WAVES * 32;                 // rows of W per workgroup (wave = two 16-row tiles)
+  constexpr int E = BK / WAVES;                    // stage elements per thread (lane = candidate, wave = E train points)
+  static_assert(GEN == 2 || E == 2, "the in-kernel generation computes two train points per thread and stage");
   constexpr int KP = BK / 8;                       // k-pairs (8 columns of W) per stage
   extern __shared__ __attribute__((aligned(16))) double smem2[];
   double* Ks = smem2;                              // [2][BK][V2_STRIDE]
@@ -77,13 +85,13 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   const int ct = bid - (bid / p.n_ctiles) * p.n_ctiles;
   const bool last = (r == p.nchunks - 1);
   const int NP = p.NP;
-  const int k_end = min(NP, (r + 1) * POST_ROWS);
+  const int k_end = min(NP, (r + 1) * ROWS);
   const int n_stages = k_end / BK;
 
   // candidate tile -> LDS (thread t loads candidate t>>3, dims (t&7)*DP/8 ...)
   if constexpr (GEN != 2) {
     const double* src = p.Xcs + (int64_t)ct * V2_CANDS * DP;
-    for (int e = tid; e < V2_CANDS * DP; e += 512) {
+    for (int e = tid; e < V2_CANDS * DP; e += NT) {
       const int cnd = e / DP, t = e - cnd * DP;
       Xl[t * V2_CANDS + cnd] = src[e];
     }
@@ -92,8 +100,8 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   // MFMA role.  A chunk holds 16 tiles of 16 rows; wave w owns tiles w and 15 - w (not two adjacent ones):
   // in the chunk's diagonal block a tile t only needs the stages up to its own rows, so the pairing gives
   // every wave the same (t+1) + (16-t) = 17 tile-stages of work instead of 3 ... 31.
-  const int tileA = r * (POST_ROWS / 16) + wave;            // global 16-row tile index (the earlier one)
-  const int tileB = r * (POST_ROWS / 16) + 15 - wave;       // the later one
+  const int tileA = r * (ROWS / 16) + wave;                     // global 16-row tile index (the earlier one)
+  const int tileB = r * (ROWS / 16) + (2 * WAVES - 1) - wave;   // the later one
   const int rowA0 = tileA * 16, rowB0 = tileB * 16;
   const bool activeA = rowA0 < NP, activeB = rowB0 < NP;    // false only in a ragged last chunk
   const int64_t pairs = NP / 8;
@@ -242,8 +250,9 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   for (; s <= last_stage; ++s) stage(s, std::integral_constant<int, 0>{});
 
   // epilogue: per-candidate sum of squares over this chunk's rows, fixed order
-  double* red = Ks;                       // [8][64]
-  double* mured = Ks + 8 * V2_CANDS;      // [8][64]
+  static_assert(2 * WAVES * V2_CANDS <= 2 * BK * V2_STRIDE, "the epilogue's exchange area aliases the stage tiles");
+  double* red = Ks;                           // [WAVES][64]
+  double* mured = Ks + WAVES * V2_CANDS;      // [WAVES][64]
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) {
     double v = 0.0;
@@ -263,13 +272,13 @@ __global__ __launch_bounds__(512, 4) void posterior_kernel_v2(PostArgs2 p) {
   if (tid < V2_CANDS) {
     double v = 0.0;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) v += red[w * V2_CANDS + tid];
+    for (int w = 0; w < WAVES; ++w) v += red[w * V2_CANDS + tid];
     const int64_t m = p.m0 + (int64_t)ct * V2_CANDS + tid;
     p.part[(int64_t)r * p.Mp + m] = v;
     if (GEN != 2 && last) {
       double u = 0.0;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) u += mured[w * V2_CANDS + tid];
+      for (int w = 0; w < WAVES; ++w) u += mured[w * V2_CANDS + tid];
       p.mu_part[m] = u;
     }
   }
@@ -429,6 +438,40 @@ static int launch_v2_k(gpbo_ctx* ctx, int DP, const PostArgs2& a, int64_t nblock
     case 64: return launch_v2_t<64, KERNEL>(ctx, a, nblocks);
   }
   GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: unsupported padded dimension");
+}
+
+// "v4": the fused kernel in its 16-wave form, 512-row chunks (NP <= 1024: at most two).  *part_chunks = the number of row
+// chunks the sum-of-squares partials are split into (what posterior_finalize_kernel sums over).
+template <int DP, int KERNEL>
+static int launch_v4_t(gpbo_ctx* ctx, const PostArgs2& a, int64_t nblocks) {
+  const size_t lds = (size_t)(2 * 32 * V2_STRIDE + DP * V2_CANDS) * sizeof(double);
+  posterior_kernel_v2<DP, KERNEL, 1, 32, 16><<<dim3((unsigned)nblocks), dim3(1024), lds, ctx->stream>>>(a);
+  GPBO_HIP(ctx, hipGetLastError());
+  return GPBO_OK;
+}
+template <int KERNEL>
+static int launch_v4_k(gpbo_ctx* ctx, int DP, const PostArgs2& a, int64_t nblocks) {
+  switch (DP) {
+    case 4: return launch_v4_t<4, KERNEL>(ctx, a, nblocks);
+    case 8: return launch_v4_t<8, KERNEL>(ctx, a, nblocks);
+    case 16: return launch_v4_t<16, KERNEL>(ctx, a, nblocks);
+    case 32: return launch_v4_t<32, KERNEL>(ctx, a, nblocks);
+    case 64: return launch_v4_t<64, KERNEL>(ctx, a, nblocks);
+  }
+  GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: unsupported padded dimension");
+}
+int launch_posterior_v4(gpbo_ctx* ctx, Model& m, int64_t Mp, int* part_chunks) {
+  const int nch = (int)((m.NP + 511) / 512);
+  PostArgs2 a;
+  a.Wp = m.Wp; a.Xs = m.Xs; a.alpha = m.alpha; a.Xcs = ctx->Xcs; a.part = ctx->part;
+  a.mu_part = ctx->mu_part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nch;
+  a.n_ctiles = (int)(Mp / V2_CANDS);
+  a.Kst = nullptr; a.ldk = 0; a.m0 = 0;
+  const int64_t nblocks = (int64_t)a.n_ctiles * nch;
+  if (nblocks > 0x7fffffffLL) GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: grid too large; shard the candidates");
+  *part_chunks = nch;
+  if (m.kernel == GPBO_KERNEL_MATERN25) return launch_v4_k<GPBO_KERNEL_MATERN25>(ctx, m.DP, a, nblocks);
+  return launch_v4_k<GPBO_KERNEL_RBF>(ctx, m.DP, a, nblocks);
 }
 
 // Mp must be a multiple of 128 (the v1 tile) — also a multiple of 64.

@@ -291,6 +291,61 @@ class GpEngine:
         self._check(self._lib.gpbo_get_candidate_rows(self._h, iptr(idx), idx.shape[0], dptr(out)))
         return out
 
+    #: the column-group assembly below exists on a single device only (a device group samples mixed spaces on the host)
+    mixed_device_sampling = True
+
+    def generate_candidates_mixed(self, M: int, groups, random_state):
+        """`space.random_sample(M, random_state)` of a space with float AND integer / categorical parameters, resident on
+        the device: `groups` = [(kind, col0, ncols, lo, hi, param)] in key order (kind 0 float, 1 int, 2 categorical).
+        Runs of float groups are generated on the device from the caller's MT19937 state (gpbo_generate_candidate_columns_
+        mt19937; the state comes back advanced); an int / categorical parameter is drawn by ITS OWN `random_sample` on the
+        host from exactly that position (RandomState.randint: masked rejection sampling, its word consumption depends on
+        the values) and uploaded as its columns (gpbo_set_candidate_columns).  Matrix and RandomState end up bit for bit
+        where the reference's loop (target_space.py:593-600) leaves them."""
+        name, key, pos, has_gauss, cached = random_state.get_state(legacy=True)
+        if name != "MT19937":
+            raise TypeError("generate_candidates_mixed needs an MT19937 RandomState")
+        M = max(1, int(M))
+        d_total = sum(g[2] for g in groups)
+        key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+        cpos = C.c_int(int(pos))
+        i = 0
+        while i < len(groups):
+            kind, col0, ncols, lo, hi, param = groups[i]
+            if kind == 0:
+                j = i
+                while j + 1 < len(groups) and groups[j + 1][0] == 0:      # a run of float parameters: one device call
+                    j += 1
+                lo_v = np.ascontiguousarray(np.concatenate([np.atleast_1d(g[3]) for g in groups[i:j + 1]]), dtype=np.float64)
+                hi_v = np.ascontiguousarray(np.concatenate([np.atleast_1d(g[4]) for g in groups[i:j + 1]]), dtype=np.float64)
+                if not np.all(np.isfinite(hi_v - lo_v)):
+                    raise OverflowError("Range exceeds valid bounds")
+                self._check(self._lib.gpbo_generate_candidate_columns_mt19937(
+                    self._h, M, d_total, int(col0), int(lo_v.shape[0]), dptr(lo_v), dptr(hi_v),
+                    key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cpos)))
+                i = j + 1
+                continue
+            random_state.set_state((name, key, cpos.value, has_gauss, cached))
+            vals = np.ascontiguousarray(np.asarray(param.random_sample(M, random_state), dtype=np.float64).reshape(M, ncols))
+            self._check(self._lib.gpbo_set_candidate_columns(self._h, dptr(vals), M, d_total, int(col0), int(ncols)))
+            _, key, p2, has_gauss, cached = random_state.get_state(legacy=True)
+            key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+            cpos = C.c_int(int(p2))
+            i += 1
+        random_state.set_state((name, key, cpos.value, has_gauss, cached))
+        self.n_candidates = M
+        self._cand_dim = d_total
+
+    def transform_candidates(self, groups):
+        """TargetSpace.kernel_transform over the resident candidates, on the device (gpbo_transform_candidates): the
+        posterior sees round()ed integer columns and the reference's one-hot categorical columns; get_candidate_rows keeps
+        returning the rows as drawn."""
+        n = len(groups)
+        kinds = (C.c_int * n)(*[int(g[0]) for g in groups])
+        col0 = (C.c_int * n)(*[int(g[1]) for g in groups])
+        ncols = (C.c_int * n)(*[int(g[2]) for g in groups])
+        self._check(self._lib.gpbo_transform_candidates(self._h, n, kinds, col0, ncols))
+
     def posterior(self, slot=0, y_mean=0.0, y_std=1.0, fetch=True):
         """mu, sd for the resident candidates (sklearn _gpr.py:443-494). fetch=False keeps them on device."""
         self._settle(slot)
@@ -674,6 +729,8 @@ class GroupEngine(GpEngine):
         self._M_pad = Xc.shape[0]
         self._cand_dim = Xc.shape[1]
         self._resident = True
+
+    mixed_device_sampling = False      # a device group samples spaces with int / categorical parameters on the host
 
     def generate_candidates(self, M: int, lo, hi, seed: int):
         raise NotImplementedError("the Philox throughput generator is per device; a device group draws the reference's "

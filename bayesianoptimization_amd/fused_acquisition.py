@@ -145,6 +145,49 @@ def _reference_stream_on_device(chain, space, random_state, n_random) -> bool:
     return getattr(sampler, "__module__", None) in ("bayes_opt.target_space", "bayesianoptimization_amd.float_space")
 
 
+_PARAM_KINDS = {"FloatParameter": 0, "IntParameter": 1, "CategoricalParameter": 2}
+
+
+def _mixed_groups_on_device(chain, space, random_state, n_random):
+    """Column groups [(kind, col0, ncols, lo, hi, param)] if the device may assemble `space.random_sample(n_random,
+    random_state)` AND apply `space.kernel_transform` itself (second half), else None.  Yes when: the space
+    is the reference's TargetSpace (or this package's stand-in) holding only the reference's three parameter kinds with at
+    least one non-float among them, sampled by the stock per-parameter loop (target_space.py:593-600) on an MT19937
+    RandomState; every GP's input transform IS this space's kernel_transform (what accelerate() installs); the engine is a
+    single device; and the batch is worth a launch."""
+    eng = chain[0]._engine()
+    if not getattr(eng, "mixed_device_sampling", False) or not hasattr(eng, "generate_candidates_mixed"):
+        return None
+    config = getattr(space, "_params_config", None)
+    masks = getattr(space, "masks", None)
+    if config is None or masks is None or n_random * space.bounds.shape[0] < 4096:
+        return None
+    if not isinstance(random_state, np.random.RandomState) or random_state.get_state()[0] != "MT19937":
+        return None
+    if getattr(getattr(type(space), "random_sample", None), "__module__", None) not in ("bayes_opt.target_space",
+                                                                                         "bayesianoptimization_amd.float_space"):
+        return None
+    for model in chain:
+        t = model.transform
+        if t is None or getattr(t, "__self__", None) is not space or getattr(t, "__name__", "") != "kernel_transform":
+            return None
+    groups, col = [], 0
+    for key in getattr(space, "_keys", list(config)):
+        p = config[key]
+        kind = _PARAM_KINDS.get(type(p).__name__)
+        if kind is None or type(p).__module__ not in ("bayes_opt.parameter", "bayesianoptimization_amd.float_space"):
+            return None
+        dim = int(p.dim)
+        if not np.array_equal(np.flatnonzero(masks[key]), np.arange(col, col + dim)):
+            return None
+        b = np.atleast_2d(np.asarray(p.bounds, dtype=np.float64))
+        groups.append((kind, col, dim, b[:, 0].copy(), b[:, 1].copy(), p))
+        col += dim
+    if col != space.bounds.shape[0] or all(g[0] == 0 for g in groups) or col > 64:
+        return None
+    return groups
+
+
 def _fused_models(gp, constraint):
     """[target, constraint GPs...] if all are HipGPRs on one engine in slots 0..n, else None."""
     if not isinstance(gp, HipGPR) or gp.slot != 0:
@@ -358,6 +401,10 @@ class AcquisitionFunction(abc.ABC):
         if chain is not None and self.device_sampling == "auto" and _reference_stream_on_device(chain, space,
                                                                                                random_state, n_random):
             return self._device_minimize(chain, space, None, n_x_seeds, n_random=n_random, stream=random_state)
+        if chain is not None and self.device_sampling == "auto":
+            groups = _mixed_groups_on_device(chain, space, random_state, n_random)
+            if groups is not None:      # float + int / categorical parameters: assembled and transformed on the device
+                return self._device_minimize(chain, space, None, n_x_seeds, n_random=n_random, stream=random_state, groups=groups)
         x_tries = space.random_sample(n_random, random_state=random_state)
         if chain is not None:
             return self._device_minimize(chain, space, x_tries, n_x_seeds)
@@ -365,13 +412,19 @@ class AcquisitionFunction(abc.ABC):
         seeds = x_tries[np.argsort(values)[:n_x_seeds]] if n_x_seeds != 0 else []
         return x_tries[values.argmin()], values.min(), seeds
 
-    def _device_minimize(self, models, space, x_tries, n_x_seeds, n_random=None, seed=None, stream=None):
+    def _device_minimize(self, models, space, x_tries, n_x_seeds, n_random=None, seed=None, stream=None, groups=None):
         """The body of the random stage after sampling, on the GPU (kernels K5-K8 of SURVEY.md §2.1).
         x_tries=None: the candidates are generated on the device too — from `stream`'s MT19937 state (the
         reference's candidates) or, with `seed`, by the Philox throughput generator."""
         target = models[0]
         eng = target._engine()
-        if x_tries is None and stream is not None:
+        if x_tries is None and stream is not None and groups is not None:
+            # a mixed space: float columns from the device generator, int / categorical columns drawn on the host at the
+            # right position of the same stream, then space.kernel_transform on the device (the GPs' own host transform
+            # is skipped: nothing M-sized crosses PCIe but the 8 B per candidate of each non-float column)
+            eng.generate_candidates_mixed(n_random, groups, stream)
+            eng.transform_candidates(groups)
+        elif x_tries is None and stream is not None:
             eng.generate_candidates_like(n_random, space.bounds[:, 0], space.bounds[:, 1], stream)
         elif x_tries is None:
             eng.generate_candidates(n_random, space.bounds[:, 0], space.bounds[:, 1], seed)

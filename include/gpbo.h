@@ -173,6 +173,24 @@ int gpbo_mt19937_jump_blocks(const uint32_t key_in[624], int64_t n_blocks, uint3
  * bayes_opt/acquisition.py:313-317); out is (n, d) row-major; out-of-range indices give NaN rows. */
 int gpbo_get_candidate_rows(gpbo_ctx* ctx, const int64_t* idx, int n, double* out);
 
+/* ---- spaces with Int / Categorical parameters (second half) -------------------------------------------
+ * TargetSpace.random_sample (bayes_opt/target_space.py:593-600) draws parameter by parameter from ONE RandomState:
+ * FloatParameter -> uniform (parameter.py:86-87), IntParameter / CategoricalParameter -> randint (:280-284, :360-377), whose
+ * word consumption depends on the values drawn.  The matrix is therefore assembled group by group in key order, the float
+ * groups on the device, the others on the host at the position the device hands back:
+ *   gpbo_generate_candidate_columns_mt19937  columns [col0, col0 + ncols) = uniform(lo_t, hi_t, M) per column from (key, pos),
+ *                                            which come back advanced past these 2 M ncols words;
+ *   gpbo_set_candidate_columns               columns [col0, col0 + ncols) from a host array (M, ncols).
+ * Every group of one matrix is written with the same (M, d_total).  gpbo_transform_candidates then applies
+ * TargetSpace.kernel_transform (target_space.py:340-347) in place — kind 0: identity, 1: np.round (IntParameter,
+ * parameter.py:308-320), 2: CategoricalParameter's one-hot (parameter.py:434-449, including its batch behaviour: a column
+ * is set in ALL rows as soon as it is the argmax of any row) — and keeps the untransformed matrix aside:
+ * gpbo_get_candidate_rows keeps returning the rows as drawn, gpbo_posterior sees the transformed ones. */
+int gpbo_generate_candidate_columns_mt19937(gpbo_ctx* ctx, int64_t M, int d_total, int col0, int ncols, const double* lo,
+                                            const double* hi, uint32_t* key, int* pos);
+int gpbo_set_candidate_columns(gpbo_ctx* ctx, const double* values, int64_t M, int d_total, int col0, int ncols);
+int gpbo_transform_candidates(gpbo_ctx* ctx, int n_groups, const int* kind, const int* col0, const int* ncols);
+
 /* ---- posterior -------------------------------------------------------------------------- */
 /* Replaces GaussianProcessRegressor.predict(X, return_std=True) (_gpr.py:443-494; called from
  * bayes_opt/acquisition.py:205,216 and bayes_opt/constraint.py:200,213) for the resident

@@ -397,3 +397,70 @@ def test_predict_warns_on_negative_variances_only_like_sklearn(engine):
         warnings.simplefilter("always")
         gp.predict(X[:3], return_std=True)
     assert not rec
+
+
+MIXED_PB = {"a": (0.0, 2.0), "n": (-3, 7, int), "b": (1.0, 4.0), "c": ("x", "y", "z"), "e": (5.0, 6.0), "f": (0.0, 1.0), "k": (0, 1, int)}
+
+
+@pytest.mark.parametrize("M", [4099, 150001])
+def test_mixed_space_candidates_and_kernel_transform_on_the_device(engine, M):
+    """SURVEY.md §8 f3, second half: a space with Float + Int + Categorical parameters.  The float columns come
+    from the device generator, the int / categorical ones are drawn on the host at the right position of the SAME MT19937
+    stream, `TargetSpace.kernel_transform` (np.round, the reference's one-hot with its batch behaviour) runs as device
+    kernels.  Checked bit for bit: the resident matrix == space.random_sample(M, rs) on EVERY row, the RandomState ends
+    where the reference's loop leaves it (target_space.py:593-600), and the posterior over the device-transformed
+    candidates == the posterior over space.kernel_transform(x) uploaded from the host (same kernels, so equal inputs give
+    equal bits)."""
+    from bayesianoptimization_amd.float_space import MixedSpace
+
+    sp = MixedSpace(MIXED_PB)
+    rng = np.random.RandomState(4)
+    Xobs = sp.random_sample(200, rng)
+    y = np.sin(Xobs[:, 0] + 0.3 * Xobs[:, 1]) + 0.1 * Xobs[:, 2] + Xobs[:, 4]
+    gp = HipGPR(kernel=Matern(nu=2.5, length_scale=1.3), alpha=1e-6, normalize_y=True, optimizer=None, engine=engine,
+                transform=sp.kernel_transform).fit(Xobs, y)
+    groups = A._mixed_groups_on_device([gp], sp, np.random.RandomState(0), M)
+    assert groups is not None
+    ref, dev = np.random.RandomState(77), np.random.RandomState(77)
+    for r in (ref, dev):
+        r.randint(0, 2**31 - 1, size=333)
+    want = sp.random_sample(M, ref)
+    engine.generate_candidates_mixed(M, groups, dev)
+    got = np.vstack([engine.get_candidate_rows(np.arange(s0, min(M, s0 + 4096)), sp.dim) for s0 in range(0, M, 4096)])
+    assert np.array_equal(got, want)
+    assert np.array_equal(dev.get_state()[1], ref.get_state()[1]) and dev.get_state()[2] == ref.get_state()[2]
+    assert dev.uniform() == ref.uniform()
+    engine.transform_candidates(groups)
+    assert np.array_equal(engine.get_candidate_rows(np.arange(50), sp.dim), want[:50])     # still the rows as drawn
+    gp._ensure_resident()
+    mu_d, sd_d = engine.posterior(0, float(gp._y_train_mean), float(gp._y_train_std))
+    mu_h, sd_h = engine.predict(sp.kernel_transform(want), y_mean=float(gp._y_train_mean), y_std=float(gp._y_train_std))
+    assert np.array_equal(mu_d, mu_h) and np.array_equal(sd_d, sd_h)
+
+
+def test_suggest_over_a_mixed_space_is_the_host_sampling_suggest(engine):
+    """The fused random stage over a mixed space with the candidates assembled on the device (device_sampling="auto") and
+    with host sampling + host kernel_transform + upload (False): the same suggestion, the same RandomState afterwards."""
+    from bayesianoptimization_amd.float_space import MixedSpace
+
+    sp = MixedSpace(MIXED_PB)
+    rng = np.random.RandomState(4)
+    Xobs = sp.random_sample(300, rng)
+    sp.register_bulk(Xobs, np.sin(Xobs[:, 0] + 0.3 * Xobs[:, 1]) + 0.1 * Xobs[:, 2] + Xobs[:, 4])
+    out = {}
+    for mode in ("auto", False):
+        gp = HipGPR(kernel=Matern(nu=2.5, length_scale=1.3), alpha=1e-6, normalize_y=True, optimizer=None, engine=engine,
+                    transform=sp.kernel_transform)
+        fn = A.UpperConfidenceBound(kappa=2.576)
+        fn.device_sampling = mode
+        used = []
+        orig = engine.generate_candidates_mixed
+        engine.generate_candidates_mixed = lambda *a, _o=orig, **k: (used.append(1), _o(*a, **k))[1]
+        try:
+            rs = np.random.RandomState(21)
+            x = fn.suggest(gp, sp, n_random=60000, n_smart=0, random_state=rs)
+        finally:
+            del engine.generate_candidates_mixed
+        out[mode] = (x, rs.uniform(), len(used))
+    assert out["auto"][2] == 1 and out[False][2] == 0
+    assert np.array_equal(out["auto"][0], out[False][0]) and out["auto"][1] == out[False][1]
