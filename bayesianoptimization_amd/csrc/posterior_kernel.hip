@@ -119,17 +119,24 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
     }
   }
   // v2 = fused generation (one kernel, 256-row chunks); v3 = k* slab + GEMM; v4 = fused generation with 512-row chunks.
-  // v3 as soon as k* would be generated more than twice: the fp64 VALU work of the generation runs instead of MFMAs, not
-  // beside them, and the slab GEMM's loop carries no other VALU work (posterior_kernel_v2.hip).  Up to NP = 1024 and for
-  // batches that fill the chip, v4 (round 4): one 16-wave workgroup covers 512 rows, so k* is generated once (NP <= 512)
-  // or 1.5 times and never crosses HBM — the slab route pays a 268 MB round trip and a second launch for a two-chunk
-  // problem (C2: 0.09 + 0.29 ms).  Small batches (the host optimisers' rounds of ~100 points) keep v2: two 256-row
-  // workgroups side by side are the shorter chain there.  Round-2 measurements at M = 65 536 (scripts/
-  // r02_small_n_posterior_ab.py): NP = 512: v3 0.37-0.39 ms vs v2 0.40-0.42; NP = 256: v2 0.12 vs v3 0.14.
-  // GPBO_POST_KERNEL=2|3|4 forces one of them (debug build: A/B runs).
+  // v3 as soon as k* would be generated more than once: the fp64 VALU work of the generation runs instead of MFMAs, not
+  // beside them, and the slab GEMM's loop carries no other VALU work (posterior_kernel_v2.hip).  For 384 <= NP <= 512 and a
+  // batch that fills the chip, v4 (round 4): ONE 16-wave workgroup covers all rows, so k* is generated once and never
+  // crosses HBM (the slab route: a 268 MB round trip and a second launch at C2).  Measured at M = 65 536 (scripts/
+  // r04_post_small_np_ab.py, profiles/r04_post_small_np_ab.json; round 2: scripts/r02_small_n_posterior_ab.py):
+  //   NP = 512, d = 8 : v2 0.406  v3 0.374  v4 0.352 ms (0.58 / 0.62 / 0.66 of the fp64 matrix peak)      -> v4
+  //   NP = 448, d = 8 : v2 0.357  v3 0.332  v4 0.327                                                      -> v4
+  //   NP = 1024, d = 16: v2 1.48   v3 1.19   v4 1.31 (two 512-row chunks: k* generated 1.5 times)          -> v3
+  //   NP = 768, d = 16, M = 2^18: v3 2.87, v4 4.72 (a ragged second chunk of 16 waves, half of them idle)  -> v3
+  //   NP = 512, M = 8192: v2 0.073, v3 0.115, v4 0.087 (a grid of 128 workgroups does not fill the chip)   -> v2
+  //   NP = 256: v2 0.12 vs v3 0.14 (one chunk: nothing is generated twice).
+  // Why v4 gains only 6 % where the slab traffic and a launch go away: its floor is the GEMM at the matrix pipe's 0.95
+  // (0.25 ms) + one generation of k* on the same datapath (~0.09 ms); one 1024-thread workgroup per CU also means every
+  // s_barrier stalls the whole CU (the 16-wave slab kernel measured 3 % slower at C3 for the same reason).
+  // GPBO_POST_KERNEL=2|3|4 forces a path (debug build: A/B runs; 4 only up to NP = 1024).
   const char* kv = dbg_env("GPBO_POST_KERNEL");
   const bool use_f32 = (m.precision == GPBO_F32);   // fp32 slab + f32 MFMA GEMM (posterior_kernel_f32.hip)
-  int path = (nchunks <= 1 || (nchunks == 2 && Mp < 8192)) ? 2 : ((m.NP >= 384 && m.NP <= 1024 && Mp >= 8192) ? 4 : 3);
+  int path = (nchunks <= 1 || (nchunks == 2 && Mp < 8192)) ? 2 : ((m.NP >= 384 && m.NP <= 512 && Mp >= 16384) ? 4 : 3);
   if (kv && (kv[0] == '2' || kv[0] == '3' || (kv[0] == '4' && m.NP <= 1024))) path = kv[0] - '0';
   const bool use_v2 = path == 2, use_v4 = path == 4;
   const int n_mu = (use_f32 || path == 3) ? nchunks : 1;

@@ -1,7 +1,8 @@
 """GPU (-m gpu): the parity matrix of the LARGE-BATCH posterior paths — k* slab + triangular MFMA GEMM, the pipeline
 `gpbo_posterior` switches to beyond NP = 1024 (csrc/posterior_kernel.hip) and the one every BASELINE headline config runs on
-(here: N = 2111), and the fused 512-row-chunk kernel that serves 384 <= NP <= 1024 since round 4 (here: N = 1000; in fp32
-mode both sizes take the fp32 slab pipeline).  Until round 4 every test that reached it used an isotropic Matern-2.5 kernel with d in {6, 8, 16, 32}
+(here: N = 1000, NP = 1024: four 256-row chunks, and N = 2111: eight chunks + a ragged one; in fp32 mode the fp32 slab
+pipeline).  (384 <= NP <= 512 runs a fused 16-wave kernel since round 4: tests/test_gpu_parity.py::test_the_three_large_
+batch_posterior_kernels_agree and the C2 golden cover it.)  Until round 4 every test that reached it used an isotropic Matern-2.5 kernel with d in {6, 8, 16, 32}
 (VERDICT r3, weak #1); north_star names "Matern/RBF" and BASELINE C1 is RBF.  Here: kernel in {RBF, Matern-2.5} x length
 scale in {scalar, per-dimension} x d in {5, 17, 33} (none a padded width: DP = 8, 32, 64) x N in {1000, 2111} (NP = 1024:
 4 full chunks; NP = 2112: 8 chunks + a ragged one) x M = 70 001 (Mp = 70 016, a ragged last candidate tile), through

@@ -361,12 +361,13 @@ def test_small_batch_path_equals_oracle_and_big_kernel(debug_engine, M, N, d, ke
 @pytest.mark.parametrize("N,d,kernel,ls", [(400, 6, O.MATERN25, 0.9), (512, 8, O.MATERN25, 1.0), (700, 3, O.RBF, 0.25),
                                               (1000, 17, O.MATERN25, [0.7 + 0.05 * t for t in range(17)]), (1024, 33, O.RBF, 1.4)])
 def test_the_three_large_batch_posterior_kernels_agree(debug_engine, N, d, kernel, ls):
-    """For 384 <= NP <= 1024 and a batch that fills the chip the posterior runs on the fused 16-wave kernel with 512-row
-    chunks ("v4", round 4: k* generated once per candidate tile, never through HBM); the fused 256-row-chunk kernel (v2)
-    and the k* slab + GEMM pipeline (v3) compute the same quantities from the same packed W.  The debug build's
-    GPBO_POST_KERNEL forces each in turn: all three agree with each other to summation order (1e-12) and with the oracle
-    (1e-9) on every candidate, ragged last chunk (N = 400, 700), a ragged candidate tile and per-dimension length scales
-    included — what sklearn's predict(return_std=True) gives (_gpr.py:443-494)."""
+    """For 384 <= NP <= 512 and a batch that fills the chip the posterior runs on the fused 16-wave kernel with 512-row
+    chunks ("v4", round 4: k* generated once per candidate tile, never through HBM; instantiated up to NP = 1024); the
+    fused 256-row-chunk kernel (v2) and the k* slab + GEMM pipeline (v3) compute the same quantities from the same packed
+    W.  The debug build's GPBO_POST_KERNEL forces each in turn: all three agree with each other to summation order (1e-12)
+    and with the oracle (1e-9; 1e-8 for the RBF cases, kappa(K) ~ 1e8: two CPU algorithms differ by as much there) on every
+    candidate, ragged last chunk (N = 400, 700), a ragged candidate tile and per-dimension length scales included — what
+    sklearn's predict(return_std=True) gives (_gpr.py:443-494)."""
     import os
 
     engine = debug_engine
@@ -374,7 +375,7 @@ def test_the_three_large_batch_posterior_kernels_agree(debug_engine, N, d, kerne
     gp = O.fit_fixed_theta(kernel, X, y, ls, 1e-6)
     yn, ym, ys = O.normalize_targets(y)
     engine.fit(X, yn, kernel, ls, 1e-6)
-    Xc = np.random.RandomState(62).uniform(size=(9001, d))
+    Xc = np.random.RandomState(62).uniform(size=(17001, d))
     Xc[7] = X[3]
     engine.set_candidates(Xc)
     out = {}
@@ -388,11 +389,13 @@ def test_the_three_large_batch_posterior_kernels_agree(debug_engine, N, d, kerne
         finally:
             os.environ.pop("GPBO_POST_KERNEL", None)
     mu_o, sd_o = O.predict(gp, Xc)
+    tol = 1e-8 if kernel == O.RBF else 1e-9
     for path, (mu, sd) in out.items():
-        assert rel_err(mu, mu_o) <= 1e-9 and rel_err(sd, sd_o) <= 1e-9, path
+        assert rel_err(mu, mu_o) <= tol and rel_err(sd, sd_o) <= tol, path
     for path in ("3", "2"):
         assert rel_err(out[path][0], out["4"][0]) <= 1e-12 and rel_err(out[path][1], out["4"][1]) <= 1e-11, path
-    assert np.array_equal(out[None][0], out["4"][0]) and np.array_equal(out[None][1], out["4"][1])     # the default dispatch here IS v4
+    want = "4" if 384 <= (N + 63) // 64 * 64 <= 512 else "3"        # the default dispatch for a batch of this size
+    assert np.array_equal(out[None][0], out[want][0]) and np.array_equal(out[None][1], out[want][1])
 
 
 def test_small_batch_rows_do_not_depend_on_the_batch(debug_engine):
