@@ -459,6 +459,15 @@ class AcquisitionFunction(abc.ABC):
         x_best, f_best = winner
         return np.clip(x_best, space.bounds[:, 0], space.bounds[:, 1]), f_best
 
+    @staticmethod
+    def _objective_on_device(chain) -> bool:
+        """True when every evaluation of the local searches' objective is a device call (a real engine behind the fused
+        models): L-BFGS-B's own tiny BLAS calls may then stay off the host's thread pool (lbfgsb_lockstep.blas_single_thread)."""
+        try:
+            return chain is not None and type(chain[0]._engine()).__module__.startswith("bayesianoptimization_amd.")
+        except Exception:  # noqa: BLE001
+            return False
+
     def _polish_seeds(self, acq, x_seeds, box):
         chain = getattr(self, "_fused", None)
         if (self.device_polish and chain is not None and len(x_seeds) > 0 and chain[0].transform is None
@@ -482,7 +491,7 @@ class AcquisitionFunction(abc.ABC):
             fg = self._value_and_grad(chain, cons)
             winner = None
             if lbfgsb_lockstep.driver_available():
-                outcomes = lbfgsb_lockstep.minimize_many_with_grad(fg, x_seeds, box)       # one device call per round
+                outcomes = lbfgsb_lockstep.minimize_many_with_grad(fg, x_seeds, box, single_thread_blas=self._objective_on_device(chain))       # one device call per round
             else:
                 outcomes = (minimize(lambda x: tuple(v[0] for v in fg(x[None])), s0, jac=True, bounds=box, method="L-BFGS-B")
                             for s0 in x_seeds)
@@ -495,7 +504,7 @@ class AcquisitionFunction(abc.ABC):
         winner = None
         if batched and self.lockstep and len(x_seeds) > 1:
             if self.lockstep != "threads" and lbfgsb_lockstep.driver_available() and not np.any(box[:, 0] == box[:, 1]):
-                outcomes = lbfgsb_lockstep.minimize_many(acq, x_seeds, box)     # SciPy's setulb driven directly
+                outcomes = lbfgsb_lockstep.minimize_many(acq, x_seeds, box, single_thread_blas=self._objective_on_device(getattr(self, "_fused", None)))     # SciPy's setulb driven directly
             else:
                 outcomes = _polish_in_lockstep(acq, x_seeds, box)               # public API only: one thread per run
         elif batched:

@@ -279,7 +279,7 @@ class HipGPR(GaussianProcessRegressor):
                     starts.append(self._rng.uniform(bounds[:, 0], bounds[:, 1]))
             # (each lockstep lane holds its own K, L, W: ~40 N^2 bytes per lane -> sequential beyond N = 16384)
             if (self.theta_lockstep and len(starts) > 1 and self.optimizer == "fmin_l_bfgs_b"
-                    and self._device_lml_ok(self.kernel_) and self.X_train_.shape[0] <= 16384):
+                    and self.X_train_.shape[0] <= 16384 and self._device_lml_ok(self.kernel_)):
                 optima = self._theta_search_lockstep(starts, bounds)
             else:
                 optima = [self._constrained_optimization(obj_func, start, bounds) for start in starts]
@@ -312,9 +312,10 @@ class HipGPR(GaussianProcessRegressor):
         n_dims = len(starts[0])
 
         # theta = log(length scale(s)) for the kernels _device_lml_ok admits (one free length-scale hyper-parameter,
-        # kernels.py:Hyperparameter/theta); checked once here instead of cloning the kernel for every evaluation
-        kind, ls0 = describe_kernel(self.kernel_.clone_with_theta(starts[0]))
-        if not np.array_equal(ls0, np.exp(starts[0])):
+        # kernels.py:Hyperparameter/theta); checked once here — starts[0] IS kernel_.theta — instead of cloning the kernel
+        # for every evaluation (a clone costs ~0.1 ms of sklearn's get_params / signature machinery)
+        kind, ls0 = describe_kernel(self.kernel_)
+        if not np.allclose(ls0, np.exp(starts[0]), rtol=1e-12, atol=0.0):
             raise RuntimeError("theta does not map to the length scale as expected")    # pragma: no cover
         uploaded = [False]
 
@@ -341,7 +342,9 @@ class HipGPR(GaussianProcessRegressor):
                 return -rows[:, 0], -rows[:, 1:]
 
             optima = []
-            for res in lbfgsb_lockstep.minimize_many_with_grad(value_and_grad, starts, bounds):
+            # (the objective runs on the device: L-BFGS-B's own tiny BLAS calls stay off the host's thread pool)
+            on_device = type(eng).__module__.startswith("bayesianoptimization_amd.")
+            for res in lbfgsb_lockstep.minimize_many_with_grad(value_and_grad, starts, bounds, single_thread_blas=on_device):
                 _check_optimize_result("lbfgs", res)
                 optima.append((res.x, res.fun))
             return optima

@@ -18,6 +18,8 @@ tests/test_host_logic.py::test_lbfgsb_driver_equals_scipy_minimize pins the equi
 """
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
 from scipy.optimize import OptimizeResult
 
@@ -42,6 +44,29 @@ def _setulb():
 
 
 _SELF_CHECK: bool | None = None
+_BLAS_CONTROLLER = None
+
+
+def blas_single_thread():
+    """Context manager: the process's BLAS pools limited to one thread while L-BFGS-B's bookkeeping runs.
+
+    `setulb` does its linear algebra — Cholesky factors and triangular solves of 2m x 2m matrices, m = 10 — through
+    BLAS / LAPACK.  With OpenBLAS's default pool (one thread per host core: 256 on the GPU box) every such call pays the
+    pool's wake-up and hand-off for a few hundred flops: measured here (8 threads) 4.9-7.4 ms per theta search against
+    2.8-3.0 ms with the pool limited to one thread, the objective memoised in both (the GPU box's host LML fit took 96 ms
+    at N = 128 for 13 ms of LML evaluations, profiles/r04_lml_crossover.json).  Only for drivers whose objective does not
+    itself need the host's BLAS (device evaluations): the limit is process-wide while it lasts.  Same bits either way —
+    operands this small never reach a threaded kernel's split (tests/test_host_logic.py pins the driver against
+    scipy.optimize.minimize run WITHOUT the limit)."""
+    global _BLAS_CONTROLLER
+    try:
+        from threadpoolctl import ThreadpoolController
+
+        if _BLAS_CONTROLLER is None:
+            _BLAS_CONTROLLER = ThreadpoolController()
+        return _BLAS_CONTROLLER.limit(limits=1, user_api="blas")
+    except Exception:   # noqa: BLE001  (threadpoolctl is a scikit-learn dependency; without it nothing changes)
+        return contextlib.nullcontext()
 
 
 def _self_check() -> bool:
@@ -140,9 +165,13 @@ def _messages():
         return {}, {}
 
 
-def _drive(evaluate, evals_per_request, starts, box, maxcor, ftol, gtol, maxfun, maxiter, maxls):
+def _drive(evaluate, evals_per_request, starts, box, maxcor, ftol, gtol, maxfun, maxiter, maxls, single_thread_blas=False):
     """The loop of `_minimize_lbfgsb` for all starts at once.  evaluate(X (S, n)) -> (f (S,), g (S, n)) for the S runs
-    that asked this round; evals_per_request = what ScalarFunction adds to nfev per evaluated point."""
+    that asked this round; evals_per_request = what ScalarFunction adds to nfev per evaluated point.
+    single_thread_blas: see blas_single_thread() — for objectives evaluated on the device."""
+    if single_thread_blas:
+        with blas_single_thread():
+            return _drive(evaluate, evals_per_request, starts, box, maxcor, ftol, gtol, maxfun, maxiter, maxls)
     setulb = _setulb()
     if setulb is None:
         raise RuntimeError("scipy's L-BFGS-B reverse-communication routine is not available in the expected form")
@@ -212,7 +241,7 @@ def _drive(evaluate, evals_per_request, starts, box, maxcor, ftol, gtol, maxfun,
 
 
 def minimize_many(acq, starts, box, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5, maxfun=15000, maxiter=15000,
-                  maxls=20):
+                  maxls=20, single_thread_blas=False):
     """[OptimizeResult(x, fun, jac, nit, nfev, status, message, success)] of
     `scipy.optimize.minimize(acq_single, start, bounds=box, method="L-BFGS-B")` (no `jac`: forward differences) for
     every start, where `acq` maps a batch of points (P, d) to their P values and `acq_single(x) = acq(x[None])[0]`."""
@@ -226,11 +255,11 @@ def minimize_many(acq, starts, box, maxcor=10, ftol=2.2204460492503131e-09, gtol
         return vals[:, 0], (vals[:, 1:] - vals[:, :1]) / steps
 
     # ScalarFunction counts the point and its d finite-difference neighbours
-    return _drive(evaluate, n + 1, starts, box, maxcor, ftol, gtol, maxfun, maxiter, maxls)
+    return _drive(evaluate, n + 1, starts, box, maxcor, ftol, gtol, maxfun, maxiter, maxls, single_thread_blas)
 
 
 def minimize_many_with_grad(value_and_grad, starts, box, maxcor=10, ftol=2.2204460492503131e-09, gtol=1e-5,
-                            maxfun=15000, maxiter=15000, maxls=20):
+                            maxfun=15000, maxiter=15000, maxls=20, single_thread_blas=False):
     """The same for an objective that returns its gradient: [OptimizeResult] of
     `scipy.optimize.minimize(fg_single, start, jac=True, bounds=box, method="L-BFGS-B")` for every start, where
     `value_and_grad` maps a batch X (S, n) to (f (S,), g (S, n)) — scikit-learn's theta search with restarts
@@ -239,4 +268,4 @@ def minimize_many_with_grad(value_and_grad, starts, box, maxcor=10, ftol=2.22044
         f, g = value_and_grad(X)
         return np.asarray(f, dtype=np.float64), np.asarray(g, dtype=np.float64).reshape(len(X), -1)
 
-    return _drive(evaluate, 1, starts, box, maxcor, ftol, gtol, maxfun, maxiter, maxls)
+    return _drive(evaluate, 1, starts, box, maxcor, ftol, gtol, maxfun, maxiter, maxls, single_thread_blas)
