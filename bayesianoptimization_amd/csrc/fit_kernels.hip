@@ -77,10 +77,14 @@ __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ Xs
   double* XiT = kmat_smem;            // [DP][64]
   double* XjT = kmat_smem + DP * 64;  // [DP][64]
   const int tid = threadIdx.x;
+  // (consecutive threads = consecutive points of one dimension: the dimension-major LDS image is written 512 contiguous
+  // bytes per wave.  Until round 4 consecutive threads walked the dimensions of one point — LDS addresses 512 B apart, a
+  // DP-way bank conflict on every staging store: SQ_LDS_BANK_CONFLICT 5.1e6 cycles per launch at N = 4096,
+  // profiles/r04_pmc_kmat.txt)
   for (int e = tid; e < 64 * DP; e += 256) {
-    int r = e / DP, t = e - r * DP;
-    XiT[t * 64 + r] = Xs[((int64_t)bi * 64 + r) * DP + t];
-    XjT[t * 64 + r] = Xs[((int64_t)bj * 64 + r) * DP + t];
+    const int t = e >> 6, r = e & 63;
+    XiT[e] = Xs[((int64_t)bi * 64 + r) * DP + t];
+    XjT[e] = Xs[((int64_t)bj * 64 + r) * DP + t];
   }
   __syncthreads();
   const int ty = tid >> 4, tx = tid & 15;

@@ -364,7 +364,7 @@ def test_the_three_large_batch_posterior_kernels_agree(debug_engine, N, d, kerne
     """For 384 <= NP <= 512 and a batch that fills the chip the posterior runs on the fused 16-wave kernel with 512-row
     chunks ("v4", round 4: k* generated once per candidate tile, never through HBM; instantiated up to NP = 1024); the
     fused 256-row-chunk kernel (v2) and the k* slab + GEMM pipeline (v3) compute the same quantities from the same packed
-    W.  The debug build's GPBO_POST_KERNEL forces each in turn: all three agree with each other to summation order (1e-12)
+    W.  The debug build's GPBO_POST_KERNEL forces each in turn: all three agree with each other to summation order (1e-12; RBF: 1e-9)
     and with the oracle (1e-9; 1e-8 for the RBF cases, kappa(K) ~ 1e8: two CPU algorithms differ by as much there) on every
     candidate, ragged last chunk (N = 400, 700), a ragged candidate tile and per-dimension length scales included — what
     sklearn's predict(return_std=True) gives (_gpr.py:443-494)."""
@@ -392,8 +392,9 @@ def test_the_three_large_batch_posterior_kernels_agree(debug_engine, N, d, kerne
     tol = 1e-8 if kernel == O.RBF else 1e-9
     for path, (mu, sd) in out.items():
         assert rel_err(mu, mu_o) <= tol and rel_err(sd, sd_o) <= tol, path
+    xtol = 1e-9 if kernel == O.RBF else 1e-12      # (RBF, kappa ~ 1e8: |alpha| ~ 1e5, so the order of the k*.alpha sum shows at 1e-10)
     for path in ("3", "2"):
-        assert rel_err(out[path][0], out["4"][0]) <= 1e-12 and rel_err(out[path][1], out["4"][1]) <= 1e-11, path
+        assert rel_err(out[path][0], out["4"][0]) <= xtol and rel_err(out[path][1], out["4"][1]) <= 10 * xtol, path
     want = "4" if 384 <= (N + 63) // 64 * 64 <= 512 else "3"        # the default dispatch for a batch of this size
     assert np.array_equal(out[None][0], out[want][0]) and np.array_equal(out[None][1], out[want][1])
 
