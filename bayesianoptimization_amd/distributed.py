@@ -69,6 +69,15 @@ class ShardedAcquisition:
         self.offset = s
         self.engine.set_candidates(Xc_global[s:e])
 
+    def generate_candidates_like(self, M_global: int, lo, hi, random_state):
+        """This rank's block of `space.random_sample(M_global, random_state)` for an all-float space, generated on this rank's
+        GPU from the ONE reference stream (`GpEngine.generate_candidate_rows_like`): every rank calls this with a RandomState
+        in the same state, nobody draws on the host, nothing is uploaded, and every rank's RandomState ends where the
+        reference's would — the one-process-per-GPU counterpart of `GroupEngine.generate_candidates_like`."""
+        s, e = shard_range(int(M_global), self.world_size, self.rank)
+        self.offset = s
+        self.engine.generate_candidate_rows_like(int(M_global), lo, hi, random_state, s, e)
+
     def set_candidates_local(self, Xc_local: np.ndarray, offset: int):
         self.offset = int(offset)
         self.engine.set_candidates(Xc_local)

@@ -21,6 +21,31 @@ F64, F32 = 0, 1
 TIMING_NAMES = ("fit", "posterior_main", "posterior_finalize", "acq_argbest", "kmat", "cholesky", "trtri")
 
 
+def advance_mt19937(random_state, n_words: int, lib=None):
+    """Advance a legacy MT19937 `RandomState` by `n_words` 32-bit outputs WITHOUT generating them: whole 624-word blocks by
+    the polynomial jump the device generator uses (gpbo_mt19937_jump_blocks, host code: x^J mod phi applied to the state),
+    the rest by position.  What `n_words // 2` calls of `random_sample()` would leave behind, bit for bit — a rank that
+    generated only ITS rows of a candidate matrix on its GPU uses it to leave its RandomState where the reference's
+    `space.random_sample(M, random_state)` would (tests/test_mt_jump_host.py checks it against NumPy, no GPU needed)."""
+    lib = lib or _lib.load_library()
+    name, key, pos, has_gauss, cached = random_state.get_state(legacy=True)
+    if name != "MT19937":
+        raise TypeError("advance_mt19937 needs an MT19937 RandomState")
+    n_words = int(n_words)
+    avail = 624 - int(pos)
+    if n_words <= avail:
+        random_state.set_state((name, key, int(pos) + n_words, has_gauss, cached))
+        return
+    n_blocks = (n_words - avail + 623) // 624
+    key_in = np.ascontiguousarray(key, dtype=np.uint32)
+    key_out = np.empty(624, dtype=np.uint32)
+    rc = lib.gpbo_mt19937_jump_blocks(key_in.ctypes.data_as(C.POINTER(C.c_uint32)), n_blocks,
+                                      key_out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if rc != _lib.GPBO_OK:
+        _lib.raise_for_status(lib, None, rc)
+    random_state.set_state((name, key_out, (n_words - avail - 1) % 624 + 1, has_gauss, cached))
+
+
 class GpEngine:
     """One engine context = one GPU, one HIP stream, 8 model slots (0 = target GP, 1.. = constraint GPs) and one resident
     candidate matrix.  Calls are synchronous from the host's point of view unless noted (`posterior(fetch=False)` only
@@ -283,6 +308,29 @@ class GpEngine:
             self._h, int(M), lo.shape[0], dptr(lo), dptr(hi), key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cpos)))
         random_state.set_state((name, key, cpos.value, has_gauss, cached))
         self.n_candidates = int(M)
+        self._cand_dim = lo.shape[0]
+
+    def generate_candidate_rows_like(self, M: int, lo, hi, random_state, row_begin: int, row_end: int):
+        """Rows [row_begin, row_end) of the matrix `generate_candidates_like(M, lo, hi, random_state)` would leave resident
+        — this rank's block of ONE reference stream in the one-process-per-GPU mode (gpbo_generate_candidate_rows_mt19937:
+        every column's run of rows starts at a jump-ahead state, nothing is generated twice, nothing crosses PCIe).  Every
+        rank passes a RandomState in the same state; every rank's is advanced past the WHOLE matrix — on the host, by the
+        same polynomial jump (advance_mt19937) — so the ranks' streams stay in step without exchanging anything."""
+        lo = np.ascontiguousarray(lo, dtype=np.float64).ravel()
+        hi = np.ascontiguousarray(hi, dtype=np.float64).ravel()
+        if lo.shape != hi.shape:
+            raise ValueError("lo and hi must have the same length")
+        if not np.all(np.isfinite(hi - lo)):
+            raise OverflowError("Range exceeds valid bounds")
+        name, key, pos, has_gauss, cached = random_state.get_state(legacy=True)
+        if name != "MT19937":
+            raise TypeError("generate_candidate_rows_like needs an MT19937 RandomState")
+        key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+        self._check(self._lib.gpbo_generate_candidate_rows_mt19937(
+            self._h, int(M), lo.shape[0], int(row_begin), int(row_end), dptr(lo), dptr(hi),
+            key.ctypes.data_as(C.POINTER(C.c_uint32)), int(pos), None, None))
+        advance_mt19937(random_state, 2 * int(M) * lo.shape[0], self._lib)
+        self.n_candidates = int(row_end) - int(row_begin)
         self._cand_dim = lo.shape[0]
 
     def get_candidate_rows(self, idx, d: int):

@@ -391,3 +391,32 @@ def test_theta_search_lanes_spread_over_the_group_are_bitwise_the_single_device_
 
         a, b = fit(engine), fit(grp)
         assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2]
+
+
+def test_one_process_per_gpu_ranks_draw_their_rows_of_the_one_reference_stream(engine):
+    """`ShardedAcquisition.generate_candidates_like` (one-process-per-GPU mode): each of three "ranks" — here three turns of the
+    one engine — generates ITS contiguous block of `space.random_sample(M, rs)` on the device from a RandomState in the same
+    state (gpbo_generate_candidate_rows_mt19937, the single-stream entry point the group uses per device), and every rank's
+    RandomState is advanced on the host past the whole matrix (engine.advance_mt19937).  The blocks concatenate to the
+    reference matrix bit for bit and all RandomStates end where the reference's does — no rank drew on the host, nothing
+    was exchanged."""
+    from bayesianoptimization_amd.distributed import ShardedAcquisition, shard_range
+
+    M, d, world = 100003, 7, 3
+    lo = np.linspace(-1.0, 1.0, d)
+    hi = lo + np.linspace(0.5, 2.5, d)
+    ref = np.random.RandomState(31)
+    ref.randint(0, 2**31 - 1, size=17)
+    start = ref.get_state()
+    want = np.column_stack([ref.uniform(lo[t], hi[t], M) for t in range(d)])
+    for rank in range(world):
+        rs = np.random.RandomState()
+        rs.set_state(start)
+        sh = ShardedAcquisition(engine, world, rank)
+        sh.generate_candidates_like(M, lo, hi, rs)
+        s, e = shard_range(M, world, rank)
+        assert sh.offset == s and engine.n_candidates == e - s
+        got = np.vstack([engine.get_candidate_rows(np.arange(a, min(e - s, a + 4096)), d) for a in range(0, e - s, 4096)])
+        assert np.array_equal(got, want[s:e]), rank
+        a, b = rs.get_state(), ref.get_state()
+        assert np.array_equal(a[1], b[1]) and a[2] == b[2]

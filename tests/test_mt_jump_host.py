@@ -42,3 +42,23 @@ def test_jumps_compose_and_reject_bad_arguments():
     p = out.ctypes.data_as(C.POINTER(C.c_uint32))
     assert lib.gpbo_mt19937_jump_blocks(p, 0, p) == _lib.ERR_INVALID
     assert lib.gpbo_mt19937_jump_blocks(None, 5, p) == _lib.ERR_INVALID
+
+
+@pytest.mark.parametrize("burn,n_words", [(0, 2), (0, 624), (1, 622), (1, 624), (2, 620), (5, 10 ** 4), (311, 2 * 70001 * 5), (624, 1248),
+                                          (333, 2 * (1 << 20) * 16)])
+def test_advance_mt19937_leaves_a_randomstate_where_drawing_would(burn, n_words):
+    """engine.advance_mt19937: what a rank that generated only ITS rows of a candidate matrix on its GPU does to its
+    RandomState — position arithmetic inside a block, the polynomial jump across blocks — against NumPy drawing the
+    doubles (two words each), from any position, a pending gaussian carried over."""
+    from bayesianoptimization_amd.engine import advance_mt19937
+
+    ref, mine = np.random.RandomState(12), np.random.RandomState(12)
+    for r in (ref, mine):
+        if burn:
+            r.randint(0, 2**31 - 1, size=burn)      # one word each on this range: an arbitrary position inside the block
+        r.standard_normal()                          # leaves a cached gaussian behind
+    ref.random_sample(n_words // 2)
+    advance_mt19937(mine, n_words)
+    a, b = ref.get_state(), mine.get_state()
+    assert np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+    assert ref.standard_normal() == mine.standard_normal() and ref.uniform() == mine.uniform()
