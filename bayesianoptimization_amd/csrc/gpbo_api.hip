@@ -3,6 +3,7 @@
 // on the context's stream.
 #include <cmath>
 #include <mutex>
+#include <shared_mutex>
 #include <vector>
 
 #include "gpbo_internal.h"
@@ -10,6 +11,22 @@
 namespace gpbo {
 
 static std::mutex g_err_mu;
+// hipGraph captures are taken one at a time, process-wide, and not while another context of the process allocates or uploads
+// theta-search inputs (shared side): see gpbo_lml_batch.
+static std::shared_mutex g_capture_mu;
+#ifndef GPBO_CAPTURE_MODE
+#define GPBO_CAPTURE_MODE hipStreamCaptureModeThreadLocal
+#endif
+#ifdef GPBO_CAPTURE_NOLOCK           // experiment builds (scripts/r04_capture_stress.sh)
+#define CAPTURE_LOCK
+#else
+#define CAPTURE_LOCK std::unique_lock<std::shared_mutex> capture_lock(g_capture_mu)
+#endif
+#ifdef GPBO_CAPTURE_TRACE
+#define CAPTURE_TRACE(...) fprintf(stderr, __VA_ARGS__)
+#else
+#define CAPTURE_TRACE(...) ((void)0)
+#endif
 static std::string g_err;
 
 void set_global_error(const std::string& s) {
@@ -268,6 +285,16 @@ int gpbo_device_info(gpbo_ctx* ctx, char* buf, int buflen) {
 // stream; the potrf info word is copied to pinned memory (valid after the next stream sync).
 // Copies/fills that act on one buffer of EVERY lane (lane mode: the buffers of lane l sit l * lane_stride doubles
 // behind lane 0's; host staging areas are arrays with `host_pitch` bytes per lane).
+// The look-ahead side stream + events that belong to `main` (a stream about to be destroyed).
+static void drop_lookahead(gpbo_ctx* ctx, hipStream_t main) {
+  for (size_t i = 0; i < ctx->lookahead.size();) {
+    if (ctx->lookahead[i].main != main) { ++i; continue; }
+    for (auto ev : ctx->lookahead[i].ev) (void)hipEventDestroy(ev);
+    if (ctx->lookahead[i].bulk) (void)hipStreamDestroy(ctx->lookahead[i].bulk);
+    ctx->lookahead.erase(ctx->lookahead.begin() + (long)i);
+  }
+}
+
 static hipError_t lane_memset(gpbo_ctx* ctx, void* p, size_t bytes) {
   if (ctx->lanes == 1) return hipMemsetAsync(p, 0, bytes, ctx->stream);
   return hipMemset2DAsync(p, (size_t)ctx->lane_stride * sizeof(double), 0, bytes, (size_t)ctx->lanes, ctx->stream);
@@ -619,10 +646,22 @@ int lml_upload_inputs(gpbo_ctx* ctx, const double* X, const double* y_norm, int6
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
   int rc;
   ctx->lml_N = 0;
+  // On the context's own (non-blocking) stream, never the legacy stream: a synchronous hipMemcpy on one thread while another
+  // thread's context captures its evaluation graph invalidates that capture on this runtime ("would make the legacy stream
+  // depend on a capturing blocking stream"; seen with the lanes of a device group, one thread per device).
+#ifndef GPBO_CAPTURE_NOLOCK
+  std::shared_lock<std::shared_mutex> not_while_capturing(g_capture_mu);
+#endif
   if ((rc = ensure(ctx, &ctx->lml_X, &ctx->cap_lml_X, N * d))) return rc;
   if ((rc = ensure(ctx, &ctx->lml_y, &ctx->cap_lml_y, N))) return rc;
+#ifdef GPBO_LML_SYNC_UPLOAD          // experiment builds (scripts/r04_capture_stress.sh): the legacy-stream copies of rounds 2-3
   GPBO_HIP(ctx, hipMemcpy(ctx->lml_X, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice));
   GPBO_HIP(ctx, hipMemcpy(ctx->lml_y, y_norm, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
+#else
+  GPBO_HIP(ctx, hipMemcpyAsync(ctx->lml_X, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  GPBO_HIP(ctx, hipMemcpyAsync(ctx->lml_y, y_norm, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
+#endif
   ctx->lml_N = N; ctx->lml_d = d;
   return GPBO_OK;
 }
@@ -676,7 +715,10 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
   const int64_t o_info = off;  off += 32;
   const int64_t stride = off;
   int rc;
-  if ((rc = ensure(ctx, &ctx->lml_slab, &ctx->cap_lml_slab, stride * n_theta))) return rc;
+  {
+    std::shared_lock<std::shared_mutex> not_while_capturing(g_capture_mu);      // (hipMalloc / hipFree when the slab grows)
+    if ((rc = ensure(ctx, &ctx->lml_slab, &ctx->cap_lml_slab, stride * n_theta))) return rc;
+  }
   if (!reuse_inputs && (rc = lml_upload_inputs(ctx, X, y_norm, N, d))) return rc;
   double* base = ctx->lml_slab;
   // Lanes are processed in groups: a group runs the launch sequence once for its lanes on its own stream.  Small
@@ -741,14 +783,23 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
       if (same && graphs_allowed && !ctx->lml_graph_off) {
         hipGraph_t graph = nullptr;
         double* oh = nullptr; int* ih = nullptr;
-        hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal);
+        hipError_t e;
         int crc = GPBO_ERR_HIP;
-        if (e == hipSuccess) {
-          crc = enqueue(&oh, &ih);
-          e = hipStreamEndCapture(ctx->stream, &graph);
+        bool instantiated = false;
+        {
+          // Captures of different contexts (the lanes of a device group run on one thread per device) are taken one at a
+          // time, process-wide: concurrent captures were seen to invalidate each other on this runtime
+          // (tests/test_gpu_sharded.py, three virtual ranks).  A capture is ~1 ms of host work once per problem shape.
+          CAPTURE_LOCK;
+          e = hipStreamBeginCapture(ctx->stream, GPBO_CAPTURE_MODE);
+          if (e == hipSuccess) {
+            crc = enqueue(&oh, &ih);
+            e = hipStreamEndCapture(ctx->stream, &graph);
+          }
+          instantiated = e == hipSuccess && crc == GPBO_OK && graph &&
+                         hipGraphInstantiate(&key.exec, graph, nullptr, nullptr, 0) == hipSuccess && key.exec;
         }
-        if (e == hipSuccess && crc == GPBO_OK && graph &&
-            hipGraphInstantiate(&key.exec, graph, nullptr, nullptr, 0) == hipSuccess && key.exec) {
+        if (instantiated) {
           (void)hipGraphDestroy(graph);
           e = hipGraphLaunch(key.exec, ctx->stream);
           if (e != hipSuccess) { restore(); GPBO_HIP(ctx, e); }
@@ -758,6 +809,20 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
           if (key.exec) { (void)hipGraphExecDestroy(key.exec); key.exec = nullptr; }
           (void)hipGetLastError();
           ctx->lml_graph_off = true;
+          CAPTURE_TRACE("gpbo: lml graph capture failed on device %d (hip %d, rc %d): direct launches from now on\n", ctx->device, (int)e, crc);
+          // an invalidated capture can outlive hipStreamEndCapture on this runtime: the direct launches below need a live stream
+          hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+          if (hipStreamIsCapturing(ctx->stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            hipStream_t fresh = nullptr;
+            if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) {
+              drop_lookahead(ctx, ctx->lml_stream[g]);
+              (void)hipStreamDestroy(ctx->lml_stream[g]);
+              ctx->lml_stream[g] = fresh;
+              ctx->stream = fresh;
+              CAPTURE_TRACE("gpbo: replaced the stream the dead capture sat on (device %d)\n", ctx->device);
+            }
+          }
         }
       }
     }

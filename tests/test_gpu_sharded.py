@@ -420,3 +420,24 @@ def test_one_process_per_gpu_ranks_draw_their_rows_of_the_one_reference_stream(e
         assert np.array_equal(got, want[s:e]), rank
         a, b = rs.get_state(), ref.get_state()
         assert np.array_equal(a[1], b[1]) and a[2] == b[2]
+
+
+def test_graph_capture_on_one_rank_while_the_others_upload(engine):
+    """The failure the round-4 GPU run caught (profiles/r04_capture_stress.json): the LML evaluation sequence is captured into a
+    hipGraph the second time a shape comes by, and a synchronous legacy-stream hipMemcpy on ANOTHER thread (a neighbour rank still
+    uploading the theta-search inputs) invalidated that capture — 34 of 200 iterations with the round-3 upload.  Now the upload
+    runs on the context's own stream and captures are taken under a process-wide lock; this is the sharp loop of
+    scripts/r04_capture_stress.py, shortened: switch the kernel (cached graphs no longer fit), evaluate directly, evaluate again
+    WITH the inputs handed over (upload + capture on three threads at once), replay — every lane bitwise the first answer."""
+    rng = np.random.RandomState(5)
+    X = rng.uniform(size=(2100, 16))
+    yn = rng.standard_normal(2100)
+    scales = np.array([[0.5], [0.8], [1.0], [1.5], [2.0], [3.0]])
+    want = {k: engine.lml_batch(X, yn, k, scales, 1e-6) for k in (O.MATERN25, O.RBF)}
+    with GroupEngine([0, 0, 0]) as grp:
+        for i in range(40):
+            kind = (O.MATERN25, O.RBF)[i & 1]
+            for got in (grp.lml_batch(X, yn, kind, scales, 1e-6), grp.lml_batch(X, yn, kind, scales, 1e-6),
+                        grp.lml_batch(X, yn, kind, scales, 1e-6, reuse_inputs=True)):
+                for (v, g), (v1, g1) in zip(got, want[kind]):
+                    assert v == v1 and np.array_equal(g, g1)
