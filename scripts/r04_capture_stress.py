@@ -47,7 +47,7 @@ for N, d in ((2100, 16), (300, 5)):
 # Phase 2, the sharp case: every iteration switches the kernel (the cached graphs no longer fit), evaluates once directly and
 # then AGAIN with the inputs handed over (upload on every rank) — the call that captures, on three threads at once, while the
 # other ranks may still be uploading.
-from oracle import gp_oracle as O  # noqa: E402  (kernel ids only)
+from bayesianoptimization_amd import engine as O  # noqa: E402  (kernel ids)
 
 rng = np.random.RandomState(5)
 X = rng.uniform(size=(2100, 16))
