@@ -586,6 +586,7 @@ static int lml_tail(gpbo_ctx* ctx, Model& m, int n_ls, int eval_gradient, double
     g.A = m.W; g.lda = m.NP; g.a_trans = 1;
     g.B = m.W; g.ldb = m.NP;
     g.C = m.K; g.ldc = m.NP; g.batch = 1; g.lower_only = 1; g.k_from_tile = 1;
+    g.P = m.L;      // split-k workspace (launch_gemm decides by shape): L is dead from here on — its diagonal went into the sum of logs above
     if ((rc = launch_gemm(ctx, g))) return rc;
     if ((rc = launch_lml_grad(ctx, m, n_ls, m.K, m.tmp, scal + 2))) return rc;
   }
@@ -725,7 +726,8 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
   // problems are dispatch-bound (every kernel is tiny): ONE group of all lanes.  From NP = 2048 on the big GEMMs fill
   // the chip by themselves and what is left to win is hiding one lane's latency-bound steps (the diagonal-block
   // kernels) behind another lane's GEMMs: one lane per group, i.e. one stream per lane.
-  const int per_group = (NP >= 2048) ? 1 : n_theta;
+  int per_group = (NP >= 2048) ? 1 : n_theta;
+  if (const char* e = dbg_env("GPBO_LML_PER_GROUP")) per_group = std::max(1, std::min(atoi(e), n_theta));   // A/B runs (debug build)
   const int n_groups = (n_theta + per_group - 1) / per_group;
   for (int g = 0; g < n_groups; ++g)
     if (!ctx->lml_stream[g]) GPBO_HIP(ctx, hipStreamCreateWithFlags(&ctx->lml_stream[g], hipStreamNonBlocking));
