@@ -192,10 +192,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if (g.a_lower) bm = (int)(gridDim.y - 1 - blockIdx.y);
   if (g.b_lower) { bm = (int)blockIdx.x; bn = (int)blockIdx.y; }
   if (g.lower_only && bn > bm) return;
-  // split-k (W^T W): z = (lane * batch + b) * nch + chunk, the chunk fastest so that a tile's chunks start together
-  const int nch = g.kchunk ? (g.k + g.kchunk - 1) / g.kchunk : 1;
-  const int zc = (int)blockIdx.z / nch, chunk = (int)blockIdx.z - zc * nch;
-  const int zl = zc / g.batch, bz = zc - zl * g.batch;                   // lane mode: z = lane * batch + b
+  const int zl = blockIdx.z / g.batch, bz = blockIdx.z - zl * g.batch;   // lane mode: z = lane * batch + b
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t lo = (int64_t)zl * g.lane_stride;
@@ -206,11 +203,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   if (g.a_lower) kend = min(kend, (bm + 1) * G2_B);
   if (g.b_lower) kbeg = bn * G2_B;
   if (g.k_from_tile) kbeg = max(bm, bn) * G2_B;   // both operands vanish above their diagonal tiles
-  if (g.kchunk) {
-    kbeg += chunk * g.kchunk;
-    if (kbeg >= kend) return;
-    kend = min(kend, kbeg + g.kchunk);
-  }
   const int nst = (kend - kbeg) / G2_BK;
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
   const bool idle = g.lower_only && bm == bn && wn >= wm + 32;   // wave tile strictly above the diagonal
@@ -320,17 +312,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
   }
   if (idle) return;
-  if (chunk > 0) {   // a partial product: alpha * acc into the tile's own 128 x 128 block of P
-    double* Pt = g.P + lo + (int64_t)splitk_partial_index(g.m / G2_B, g.kchunk / G2_B, bm, bn, chunk) * (G2_B * G2_B);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          Pt[(wm + 16 * t + (lane >> 4) + 4 * r) * G2_B + wn + 16 * u + (lane & 15)] = g.alpha * acc[t][u][r];
-    return;
-  }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -346,42 +327,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
           *cp = v;
         }
       }
-}
-
-// C tile (bm, bn <= bm) += its partial tiles in chunk order (split-k, see GemmArgs::kchunk).  One 256-thread workgroup per tile;
-// a thread owns 4 consecutive columns of 16 rows.  The quadrant of a diagonal tile that lies above the diagonal 64-blocks was
-// not computed by any chunk (gemm128_f64_kernel: `idle` waves) and is left alone.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
-  const int bn = blockIdx.x, bm = blockIdx.y;
-  if (bn > bm) return;
-  const int nb = g.m / G2_B, kc = g.kchunk / G2_B;
-  const int nch = splitk_chunks(nb, kc, bm);
-  if (nch <= 1) return;
-  const int64_t lo = (int64_t)blockIdx.z * g.lane_stride;
-  const double* P0 = g.P + lo + (int64_t)splitk_partial_index(nb, kc, bm, bn, 1) * (G2_B * G2_B);
-  double* C = g.C + lo + (int64_t)bm * G2_B * g.ldc + (int64_t)bn * G2_B;
-  const int c4 = (threadIdx.x & 31) * 4, r0 = threadIdx.x >> 5;
-  if (bm == bn && c4 >= 64) {       // rows < 64 of these columns are the uncomputed quadrant
-    for (int r = 64 + r0; r < G2_B; r += 8) {
-      d2v v0 = *reinterpret_cast<const d2v*>(C + (int64_t)r * g.ldc + c4), v1 = *reinterpret_cast<const d2v*>(C + (int64_t)r * g.ldc + c4 + 2);
-      for (int c = 0; c < nch - 1; ++c) {
-        v0 += *reinterpret_cast<const d2v*>(P0 + (int64_t)c * (G2_B * G2_B) + r * G2_B + c4);
-        v1 += *reinterpret_cast<const d2v*>(P0 + (int64_t)c * (G2_B * G2_B) + r * G2_B + c4 + 2);
-      }
-      *reinterpret_cast<d2v*>(C + (int64_t)r * g.ldc + c4) = v0;
-      *reinterpret_cast<d2v*>(C + (int64_t)r * g.ldc + c4 + 2) = v1;
-    }
-    return;
-  }
-  for (int r = r0; r < G2_B; r += 8) {
-    d2v v0 = *reinterpret_cast<const d2v*>(C + (int64_t)r * g.ldc + c4), v1 = *reinterpret_cast<const d2v*>(C + (int64_t)r * g.ldc + c4 + 2);
-    for (int c = 0; c < nch - 1; ++c) {
-      v0 += *reinterpret_cast<const d2v*>(P0 + (int64_t)c * (G2_B * G2_B) + r * G2_B + c4);
-      v1 += *reinterpret_cast<const d2v*>(P0 + (int64_t)c * (G2_B * G2_B) + r * G2_B + c4 + 2);
-    }
-    *reinterpret_cast<d2v*>(C + (int64_t)r * g.ldc + c4) = v0;
-    *reinterpret_cast<d2v*>(C + (int64_t)r * g.ldc + c4 + 2) = v1;
-  }
 }
 
 static bool gemm128_enabled() {
@@ -412,15 +357,8 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
   // ... and W^T W (k_from_tile: the first tile's k-loop is the whole N) takes them while one 128x128 tile per slot would make that
   // tile the launch: N = 4096, 528 tiles: 1.04 ms, the longest tile alone 1.05 ms at a 512th of the chip's rate
   static const int tri64_limit = dbg_env("GPBO_TRI64_LIMIT") ? atoi(dbg_env("GPBO_TRI64_LIMIT")) : 600;
-  // ... unless its k-range can be split (the caller offers a workspace): W^T W at N = 4096 is then ~1000 work items of k <= 1024
-  // on 128x128 tiles instead of 2080 64x64 tiles the longest of which (k = 4096, 0.56 ms) is the launch — a rule of the SHAPE
-  // only (never of the lane count: every lane must add its products in the same order).
-  static const bool splitk_on = !(dbg_env("GPBO_SPLITK") && dbg_env("GPBO_SPLITK")[0] == '0');
-  const bool splitk = splitk_on && g.P && g.k_from_tile && g.lower_only && g.a_trans && g.batch == 1 && g.beta == 0.0 && g.m == g.n &&
-                      g.m == g.k && g.m % G2_B == 0 && g.m >= 2048 && g.m <= 4096;
-  if (splitk) g.kchunk = (int)round_up(g.m / 4, G2_B);
-  const bool prefer64 = !splitk && tri64 && triangular && (blocks128 < 512 || (g.k_from_tile && blocks128 < tri64_limit));
-  if (gemm128_enabled() && !prefer64 && g.m >= 128 && g.n >= 128 && g.k >= 256 && (blocks128 >= 192 || splitk)) {
+  const bool prefer64 = tri64 && triangular && (blocks128 < 512 || (g.k_from_tile && blocks128 < tri64_limit));
+  if (gemm128_enabled() && !prefer64 && g.m >= 128 && g.n >= 128 && g.k >= 256 && blocks128 >= 192) {
     constexpr size_t lds = (size_t)4 * G2_TILE * sizeof(double);   // 65 536 B
     if (!(ctx->func_attrs & ATTR_GEMM128)) {
       GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm128_f64_kernel<true, false>),
@@ -431,8 +369,7 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       ctx->func_attrs |= ATTR_GEMM128;
     }
-    const int nch = g.kchunk ? (g.k + g.kchunk - 1) / g.kchunk : 1;
-    dim3 grid((unsigned)((g.n + 127) / 128), (unsigned)((g.m + 127) / 128), (unsigned)(g.batch * g.lanes * nch));
+    dim3 grid((unsigned)((g.n + 127) / 128), (unsigned)((g.m + 127) / 128), (unsigned)(g.batch * g.lanes));
     if (g.b_lower) std::swap(grid.x, grid.y);
     if (g.b_trans)
       gemm128_f64_kernel<true, false><<<grid, dim3(512), lds, ctx->stream>>>(g);
@@ -440,7 +377,6 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
       gemm128_f64_kernel<false, true><<<grid, dim3(512), lds, ctx->stream>>>(g);
     else
       gemm128_f64_kernel<false, false><<<grid, dim3(512), lds, ctx->stream>>>(g);
-    if (g.kchunk) splitk_reduce_kernel<<<dim3(grid.x, grid.y, (unsigned)g.lanes), dim3(256), 0, ctx->stream>>>(g);
     GPBO_HIP(ctx, hipGetLastError());
     return GPBO_OK;
   }

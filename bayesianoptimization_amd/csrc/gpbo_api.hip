@@ -586,7 +586,6 @@ static int lml_tail(gpbo_ctx* ctx, Model& m, int n_ls, int eval_gradient, double
     g.A = m.W; g.lda = m.NP; g.a_trans = 1;
     g.B = m.W; g.ldb = m.NP;
     g.C = m.K; g.ldc = m.NP; g.batch = 1; g.lower_only = 1; g.k_from_tile = 1;
-    g.P = m.L;      // split-k workspace (launch_gemm decides by shape): L is dead from here on — its diagonal went into the sum of logs above
     if ((rc = launch_gemm(ctx, g))) return rc;
     if ((rc = launch_lml_grad(ctx, m, n_ls, m.K, m.tmp, scal + 2))) return rc;
   }

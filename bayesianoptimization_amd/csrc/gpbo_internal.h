@@ -300,21 +300,7 @@ struct GemmArgs {
   int k_from_tile;        // k-loop starts at max(row tile, column tile): W^T W with W lower triangular
   int skip00;             // leave the leading skip00 x skip00 output tiles alone (64x64-tile kernel only): the diagonal-block
                           // workgroup of the same launch (or an earlier launch) owns them
-  // Split-k (128x128-tile kernel, k_from_tile + lower_only + m == n == k, i.e. W^T W): a tile's k-range [128 bm, k) is cut into
-  // chunks of `kchunk` (a multiple of 128); chunk 0 lands in C, chunk c >= 1 in its own compact 128x128 tile of P
-  // (splitk_partial_index), and splitk_reduce_kernel adds them to C in chunk order.  0 = off.
-  int kchunk = 0;
-  double* P = nullptr;    // >= splitk_partial_tiles(m / 128, kchunk / 128) * 16384 doubles (per lane: + lane_stride)
 };
-// number of 128-blocks of k a chunk covers -> chunks of tile row bm (nb = m / 128 tile rows), and the compact index of the
-// partial tile (bm, bn <= bm, chunk c >= 1): rows in order, inside a row the tiles in order, inside a tile the chunks in order
-__host__ __device__ inline int splitk_chunks(int nb, int kc, int bm) { return (nb - bm + kc - 1) / kc; }
-__host__ __device__ inline int splitk_partial_index(int nb, int kc, int bm, int bn, int c) {
-  int pre = 0;
-  for (int q = 0; q < bm; ++q) pre += (q + 1) * (splitk_chunks(nb, kc, q) - 1);
-  return pre + bn * (splitk_chunks(nb, kc, bm) - 1) + (c - 1);
-}
-inline int splitk_partial_tiles(int nb, int kc) { return splitk_partial_index(nb, kc, nb, 0, 1); }
 int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g);
 // chol_kernels.hip: blocked Cholesky of m.L in place + inverted 64x64 diagonal blocks (128-column steps, `outer`-column panels);
 // stamps (device, >= 8 words, may be null): in-kernel clocks of the first diagonal workgroup
