@@ -169,7 +169,11 @@ __device__ __forceinline__ void bcast_fma_from(double* a, double* a2, const doub
 // pivot gives a non-finite reciprocal (v_rsq_f64 of <= 0) that spreads to everything behind it; the caller finds the
 // first one afterwards (LAPACK's info) — no test on the chain.
 template <bool FOLLOW>
-__device__ __forceinline__ void factor_block8(double (&a)[8], double (&a2)[8], double* __restrict__ Lc, double* __restrict__ Lc2,
+// (No __restrict__ on the images, nor on the shared-memory base they are carved from: other waves write what this one reads, and
+// the compiler barriers (GPBO_LDS_ORDER) only bind accesses the optimiser cannot prove private.  With restrict-qualified images the
+// marker poll was, in one inlining context of round 4, taken for loop-invariant: the loop became bare s_sleep.  A `volatile` poll
+// through the generic pointer is no alternative: it compiles to flat_load ... sc0 sc1.)
+__device__ __forceinline__ void factor_block8(double (&a)[8], double (&a2)[8], double* Lc, double* Lc2,
                                               int* broken, const int i, const int w, long long* stamp = nullptr) {
   {
     // Catch-up, two columns per turn (columns are published in order: the marker of column k + 1 vouches for k and
@@ -185,7 +189,7 @@ __device__ __forceinline__ void factor_block8(double (&a)[8], double (&a2)[8], d
     for (int k = 0; k < 8 * w; k += 2) {
       int spins = 0;
       while (Lc[(k + 1) * DS + 64] == 0.0) {
-        if (++spins > (1 << 22)) {   // cannot happen while the owner wave runs; never hang the GPU on a bug
+        if (++spins > (1 << 16)) {   // (x 512 cycles = 14 ms) cannot happen while the owner wave runs; never hang the GPU on a bug
           if (i == 0) *broken = 1;
           break;
         }
@@ -324,8 +328,9 @@ __device__ __forceinline__ void inverse_colblock(const double* __restrict__ Lc, 
     for (int rr = 0; rr < 4; ++rr) Wout[(16 * r + lk + 4 * rr) * 64 + 16 * C + lr] = X[r][rr];
 }
 
-__device__ __forceinline__ void inverse_wave(const double* Lc, double* Dk, double* Wout, const int q, const int lane) {
+__device__ __forceinline__ void inverse_wave(const double* Lc, double* Dk, double* Wout, const int q, const int lane, long long* stamp = nullptr) {
   diag16_inverses(Lc, Dk, lane);
+  if (stamp && lane == 0) *stamp = clock64();
   GPBO_LDS_ORDER();   // the wave reads back its own tiles: same-wave LDS accesses are performed in order
   switch (q) {
     case 0: inverse_colblock<0>(Lc, Dk, Wout, lane); break;
@@ -341,9 +346,9 @@ __device__ __forceinline__ void inverse_wave(const double* Lc, double* Dk, doubl
 //   columns 8w .. 8w+7 of A00 with the same columns of A10 (row 64 + i) riding along  ->  L00, L10
 //   SYRK  A11 -= L10 L10^T  (MFMA out of the L10 image)
 //   columns 8w .. 8w+7 of A11  ->  L11
-//   waves 0-3: inv(L00), waves 4-7: inv(L11), one 16-column block each.
+//   waves 0-3: inv(L00), waves 4-7: inv(L11), one 16-column block each (the second in reverse order: SIMD balance).
 __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64_t ld, const int kb, const int nblk,
-                                             double* __restrict__ dinv, int* __restrict__ info, double* __restrict__ smem,
+                                             double* __restrict__ dinv, int* __restrict__ info, double* smem,
                                              long long* __restrict__ stamps) {
   double* Lc0 = smem + C128_LC0;
   double* LcX = smem + C128_LCX;
@@ -439,8 +444,10 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
     if (stamps && tid == 0) stamps[4] = clock64();
     __syncthreads();
     if (stamps && tid == 0) stamps[5] = clock64();
-    if (w < 4) inverse_wave(Lc0, Wr + w * 4 * 272, dinv + (int64_t)kb * 4096, w, lane);
-    else inverse_wave(LcX, Wr + w * 4 * 272, dinv + (int64_t)(kb + 1) * 4096, w - 4, lane);
+    // waves w and w + 4 share a SIMD and column block C costs 36 / 20 / 8 / 0 MFMAs for C = 0..3: the second inverse hands its
+    // blocks out in reverse, so every SIMD carries 36 or 28 of the 128 instead of 72 / 40 / 16 / 0 (round 4: 11 000 -> 8 000 cycles)
+    if (w < 4) inverse_wave(Lc0, Wr + w * 4 * 272, dinv + (int64_t)kb * 4096, w, lane, (stamps && w == 0) ? stamps + 15 : nullptr);
+    else inverse_wave(LcX, Wr + w * 4 * 272, dinv + (int64_t)(kb + 1) * 4096, 7 - w, lane);
   } else {
     if (w < 4) inverse_wave(Lc0, Wr + w * 4 * 272, dinv + (int64_t)kb * 4096, w, lane);
   }
@@ -463,7 +470,8 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
 // One launch = diagonal block(s) kb (workgroup 0) || the 64x64 tiles of the previous column block's in-panel update, two per
 // 512-thread workgroup (every tile but the leading skip00 x skip00 ones, which chol128_diag_update_kernel has already
 // brought up to date).
-__global__ __launch_bounds__(512) void chol128_step_kernel(double* L, int64_t ld, int kb, int nblk, double* dinv, int* info,
+// (waves_per_eu(2, 2): the launch's dynamic LDS gives every workgroup a CU to itself, so 256 VGPRs are there for the taking — 156 used)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void chol128_step_kernel(double* L, int64_t ld, int kb, int nblk, double* dinv, int* info,
                                                             GemmArgs g, int tiles_n, int tiles, int64_t lane_stride, long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) double c128_smem[];
   const int zl = (int)blockIdx.y;
