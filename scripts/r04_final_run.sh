@@ -32,6 +32,7 @@ PY
 tail -c 1500 $F/bench_C4_group2_virtual.json; tail -2 $F/bench_C4_group2_virtual.err
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $F/c2_trace -o t -- python bench.py --config C2 --steps 20 --warmup 3 --no-cpu-baseline --no-suggest > $F/c2_trace.json 2> $F/c2_trace.err
 timeout 200 python scripts/theta_search_timing.py > $F/theta_search_timing.log 2>&1; cp gpurun_out/theta_search_timing.json $F/ 2>/dev/null
+timeout 100 python scripts/r04_chol_chain.py 128 512 2048 4096 > $F/chol_chain.log 2>&1; cp gpurun_out/r04_chol_chain.json $F/ 2>/dev/null
 find $F -name '*.db' -delete
 ls $F
 echo done
