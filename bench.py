@@ -378,9 +378,18 @@ def run_extra_config(eng, name, steps=5, warmup=2, cpu_chunks=0):
             post[0] = eng.last_timings()["posterior_main"]     # after the step: the harness puts no synchronisation inside it
         return best
 
-    for _ in range(warmup):
+    # Warm-up by TIME as well as by count: this block follows a CPU leg (seconds of host work with the GPU idle), and the first
+    # milliseconds of GPU work after an idle spell run at ramping clocks — a 0.8 ms step timed over five steps right behind it was
+    # once quoted at 4.9 ms (posterior kernel 4.4 instead of 0.37 ms; profiles/r04_bench_default_C3_with_configs.json's first run).
+    # Short steps are also timed over more of them (>= 40 ms of work, at most 200 steps).
+    t_w, n_w, t_last = time.perf_counter(), 0, 0.0
+    while n_w < warmup or time.perf_counter() - t_w < 0.06:
+        t1 = time.perf_counter()
         step()
-    eng.synchronize()
+        eng.synchronize()
+        t_last = time.perf_counter() - t1
+        n_w += 1
+    steps = max(steps, min(200, int(np.ceil(0.04 / max(t_last, 1e-5)))))
     main_ms, fit_ms = 0.0, 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
