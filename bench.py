@@ -340,7 +340,7 @@ def resolved(w):
 def run_extra_config(eng, name, steps=5, warmup=2, cpu_chunks=0):
     """One more BASELINE.json config on the already-open single engine, after the headline's timed region: the same step
     (fit at fixed theta + posterior + acquisition + arg-best/top-10 over the resident candidates; sharded configs: shard 0
-    = one GPU's share of the 8-GPU job), wall-clocked over `steps` steps between stream synchronisations, with the
+    = one GPU's share of the 8-GPU job), every step wall-clocked by itself (median quoted, mean and max beside it), with the
     dominant kernels' HIP-event time and the parity block against the reference's golden for exactly this job.
     cpu_chunks > 0: the CPU path beside it (cpu_baseline on that many chunks of the same candidates)."""
     w = resolved(W.ALL[name])
@@ -390,19 +390,26 @@ def run_extra_config(eng, name, steps=5, warmup=2, cpu_chunks=0):
         t_last = time.perf_counter() - t1
         n_w += 1
     steps = max(steps, min(200, int(np.ceil(0.04 / max(t_last, 1e-5)))))
-    main_ms, fit_ms = 0.0, 0.0
-    t0 = time.perf_counter()
+    # every step is clocked by itself (it ends in the read-back of the arg-best records, a stream synchronisation) and the MEDIAN
+    # is quoted beside the mean: over ~50-200 sub-millisecond steps one stall of tens of milliseconds (seen twice behind the CPU legs
+    # on the GPU box: once inside a posterior kernel, once outside) would otherwise be the number
+    per_step, per_post, per_fit = [], [], []
     for _ in range(steps):
+        t1 = time.perf_counter()
         best = step()
-        main_ms += post[0]
-        fit_ms += eng.last_timings()["fit"]
-    eng.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    main_ms /= steps
+        eng.synchronize()
+        per_step.append((time.perf_counter() - t1) * 1e3)
+        per_post.append(post[0])
+        per_fit.append(eng.last_timings()["fit"])
+    ms = float(np.median(per_step))
+    main_ms = float(np.median(per_post))
+    fit_ms = float(np.median(per_fit)) * steps
     fl = flops_per_candidate(w.N, w.d, n_gp) * M
     peak = FP32_MFMA_PEAK_TFLOPS if prec else FP64_MFMA_PEAK_TFLOPS
     out = {"workload": f"{w.name}{' shard 0 of 8' if w.name in SHARDED else ''}: d={w.d} N={w.N} {W.ACQ_NAMES[w.acq]} M={M}, {n_gp} GP(s)",
-           "dtype": "f32" if prec else "f64", "steps": steps, "ms_per_step": ms, "value": M / (ms * 1e-3), "unit": "candidates/s",
+           "dtype": "f32" if prec else "f64", "steps": steps, "ms_per_step": ms, "ms_per_step_is": "median of the steps, each clocked by itself",
+           "ms_per_step_mean": float(np.mean(per_step)), "ms_per_step_max": float(np.max(per_step)),
+           "value": M / (ms * 1e-3), "unit": "candidates/s",
            "roofline": {"bound": "mfma", "posterior_ms": main_ms, "achieved": fl / (main_ms * 1e-3) / 1e12, "peak": peak,
                         "unit": "TFLOP/s", "frac": fl / (main_ms * 1e-3) / 1e12 / peak,
                         "frac_of_whole_step": fl / (ms * 1e-3) / 1e12 / peak},
