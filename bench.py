@@ -382,14 +382,13 @@ def run_extra_config(eng, name, steps=5, warmup=2, cpu_chunks=0):
     # milliseconds of GPU work after an idle spell run at ramping clocks — a 0.8 ms step timed over five steps right behind it was
     # once quoted at 4.9 ms (posterior kernel 4.4 instead of 0.37 ms; profiles/r04_bench_default_C3_with_configs.json's first run).
     # Short steps are also timed over more of them (>= 40 ms of work, at most 200 steps).
-    t_w, n_w, t_last = time.perf_counter(), 0, 0.0
-    while n_w < warmup or time.perf_counter() - t_w < 0.06:
+    t_w, warm = time.perf_counter(), []
+    while len(warm) < warmup or time.perf_counter() - t_w < 0.06:
         t1 = time.perf_counter()
         step()
         eng.synchronize()
-        t_last = time.perf_counter() - t1
-        n_w += 1
-    steps = max(steps, min(200, int(np.ceil(0.04 / max(t_last, 1e-5)))))
+        warm.append(time.perf_counter() - t1)
+    steps = max(steps, min(200, int(np.ceil(0.04 / max(float(np.median(warm)), 1e-5)))))
     # every step is clocked by itself (it ends in the read-back of the arg-best records, a stream synchronisation) and the MEDIAN
     # is quoted beside the mean: over ~50-200 sub-millisecond steps one stall of tens of milliseconds (seen twice behind the CPU legs
     # on the GPU box: once inside a posterior kernel, once outside) would otherwise be the number

@@ -60,6 +60,38 @@ def test_fit_parity(engine, N, d, kernel, ls):
     assert rel_err(Lg @ Lg.T, K) < 1e-13
 
 
+@pytest.mark.parametrize("kernel", [O.MATERN25, O.RBF])
+def test_kernel_value_exp_against_numpy(engine, kernel):
+    """gpbo_kernel_value's own exp (gpbo_exp_nonpos: Cody-Waite reduction + degree-13 polynomial + v_ldexp_f64, round 4) over the whole
+    range a kernel matrix can reach: points on a line give exponents from 0 down to below the subnormals.  Against NumPy's exp of
+    the same argument: relative error <= 4e-16 (1 + |argument|) wherever the value is a normal number (the argument itself carries
+    one rounding, which exp magnifies by |argument| — for any implementation), absolute error <= one subnormal step below, exactly
+    1 + noise on the diagonal, exactly 0 where NumPy underflows to 0, and never a NaN."""
+    N = 320
+    rng = np.random.RandomState(9)
+    pos = np.sort(np.concatenate([[0.0], rng.uniform(0, 1, 99), rng.uniform(1, 30, 120), rng.uniform(30, 420, 100)]))
+    X = pos[:, None]
+    yn = rng.standard_normal(N)
+    engine.fit(X, yn, kernel, 1.0, 1e-6)
+    K = engine.get_K(N)
+    r = np.abs(pos[:, None] - pos[None, :])
+    if kernel == O.MATERN25:
+        k = np.sqrt(5.0) * r
+        arg, ref = -k, (1.0 + k + k * k / 3.0) * np.exp(-k)
+    else:
+        arg = -0.5 * r * r
+        ref = np.exp(arg)
+    ref[np.diag_indices(N)] += 1e-6
+    assert np.all(np.isfinite(K))
+    assert np.array_equal(np.diag(K), np.full(N, 1.0 + 1e-6))
+    normal = ref > 2.3e-308
+    assert arg.min() < -760 and np.sum(~normal) > 100          # the sample reaches the subnormals and exact zero
+    rel = np.abs(K - ref)[normal] / ref[normal]
+    assert np.max(rel / (1.0 + np.abs(arg[normal]))) < 4e-16
+    assert np.max(np.abs(K - ref)[~normal]) <= 1e-307 * 4e-16 + 5e-324 * 2 ** 12
+    assert np.all(K[ref == 0.0] == 0.0)
+
+
 @pytest.mark.parametrize("M", [1, 2, 127, 128, 129, 1000, 4097])
 def test_posterior_parity_ragged_candidate_counts(engine, M):
     X, y = _data(150, 6, seed=2)
