@@ -98,9 +98,9 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(const double* __restrict_
         double g;
         if (KERNEL == GPBO_KERNEL_MATERN25) {
           const double tmp = sqrt(5.0 * d2[a][b]);
-          g = 5.0 / 3.0 * (tmp + 1.0) * exp(-tmp);
+          g = 5.0 / 3.0 * (tmp + 1.0) * gpbo_exp_nonpos(-tmp);
         } else {
-          g = exp(-0.5 * d2[a][b]);
+          g = gpbo_exp_nonpos(-0.5 * d2[a][b]);
         }
         c = wgt * (ai * aj - kin) * g;
       }

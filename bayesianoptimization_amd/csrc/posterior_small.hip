@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void kstar_grad_small_kernel(const double* __r
     double f;
     if (KERNEL == GPBO_KERNEL_MATERN25) {
       const double s = gpbo_sqrt_pos(d2) * 2.23606797749978969641;      // sqrt(5) r
-      f = -1.66666666666666666667 * (1.0 + s) * exp(-s);
+      f = -1.66666666666666666667 * (1.0 + s) * gpbo_exp_nonpos(-s);
     } else {
       f = -kv;
     }
