@@ -661,6 +661,7 @@ class GroupEngine(GpEngine):
         self._pending_fits = set()  # (never filled: the inherited accessors only look at it)
         self._resident = False      # the group's candidate shards are in place (a small predict on device 0 clobbers them)
         self.collective = self._lib.gpbo_group_collective(g).decode()
+        self._orphans = []          # arrays of failed calls (see _gcheck)
 
     def close(self):
         if getattr(self, "_g", None):
@@ -668,8 +669,13 @@ class GroupEngine(GpEngine):
             self._g = None
             self._h = None
 
-    def _gcheck(self, rc, info=0):
+    def _gcheck(self, rc, info=0, borrowed=()):
+        """`borrowed`: the host arrays the call handed to the group's worker threads.  After a failed call — above all one that
+        missed its deadline, where a worker may still be inside the job (include/gpbo.h: the caller's arrays must outlive the
+        group then) — they stay referenced until close()."""
         if rc != _lib.GPBO_OK:
+            if borrowed:
+                self._orphans.append(borrowed)
             _lib.raise_for_status(self._lib, None, rc, info, group=self._g)
 
     def per_device_timings(self) -> list:
@@ -726,7 +732,7 @@ class GroupEngine(GpEngine):
         self._touch(slot)
         rc = self._lib.gpbo_group_fit(self._g, int(slot), dptr(X), dptr(y_norm), X.shape[0], X.shape[1], int(kernel),
                                       dptr(ls), int(ls.shape[0]), float(noise), int(precision), C.byref(info))
-        self._gcheck(rc, info.value)
+        self._gcheck(rc, info.value, borrowed=(X, y_norm, ls, info))
         return self._touch(slot)
 
     def fit_append(self, x_new, y_norm, slot: int = 0):
@@ -738,7 +744,7 @@ class GroupEngine(GpEngine):
         self._touch(slot)
         rc = self._lib.gpbo_group_fit_append(self._g, int(slot), dptr(x_new) if x_new.shape[0] else None, x_new.shape[0],
                                              x_new.shape[1], dptr(y_norm), y_norm.shape[0], C.byref(info))
-        self._gcheck(rc, info.value)
+        self._gcheck(rc, info.value, borrowed=(x_new, y_norm, info))
         return self._touch(slot)
 
     def lml_batch(self, X, y_norm, kernel: int, length_scales, noise: float, eval_gradient=True, reuse_inputs=False):
@@ -757,7 +763,7 @@ class GroupEngine(GpEngine):
         rc = self._lib.gpbo_group_lml_batch(self._g, n, None if reuse_inputs else dptr(X), None if reuse_inputs else dptr(y_norm),
                                             X.shape[0], X.shape[1], int(kernel), dptr(ls), n_ls, float(noise),
                                             int(bool(eval_gradient)), dptr(vals), dptr(grads), infos, where)
-        self._gcheck(rc)
+        self._gcheck(rc, borrowed=(X, y_norm, ls, vals, grads, infos, where))
         self.last_lane_devices = list(where)
         return [(float(vals[i]), grads[i].copy()) for i in range(n)]
 
@@ -772,7 +778,7 @@ class GroupEngine(GpEngine):
             # the copies are dropped from every result)
             pad = np.repeat(Xc[-1:], self.world_size - n_real, axis=0)
             Xc = np.ascontiguousarray(np.vstack([Xc, pad]))
-        self._gcheck(self._lib.gpbo_group_set_candidates(self._g, dptr(Xc), Xc.shape[0], Xc.shape[1]))
+        self._gcheck(self._lib.gpbo_group_set_candidates(self._g, dptr(Xc), Xc.shape[0], Xc.shape[1]), borrowed=(Xc,))
         self.n_candidates = n_real
         self._M_pad = Xc.shape[0]
         self._cand_dim = Xc.shape[1]
@@ -807,7 +813,8 @@ class GroupEngine(GpEngine):
         key = np.ascontiguousarray(key, dtype=np.uint32).copy()
         cpos = C.c_int(int(pos))
         self._gcheck(self._lib.gpbo_group_generate_candidates_mt19937(
-            self._g, n, lo.shape[0], dptr(lo), dptr(hi), key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cpos)))
+            self._g, n, lo.shape[0], dptr(lo), dptr(hi), key.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(cpos)),
+            borrowed=(lo, hi, key, cpos))
         random_state.set_state((name, key, cpos.value, has_gauss, cached))
         self.n_candidates = n
         self._M_pad = n
@@ -867,7 +874,7 @@ class GroupEngine(GpEngine):
         rc = self._lib.gpbo_group_acq_argbest(self._g, int(acq), float(param), float(y_max if y_max is not None else 0.0),
                                               n_c, dptr(lb), dptr(ub), int(k_seeds), iptr(best_idx), dptr(best_val),
                                               iptr(seed_idx), dptr(seed_val), dptr(ys))
-        self._gcheck(rc)
+        self._gcheck(rc, borrowed=(lb, ub, best_idx, best_val, seed_idx, seed_val, ys))
         seed_idx, seed_val = seed_idx[:k_seeds], seed_val[:k_seeds]
         if self._M_pad != self.n_candidates:      # drop the padding copies of the last row
             keep = seed_idx < self.n_candidates
