@@ -273,17 +273,38 @@ __device__ __forceinline__ int first_bad_column(const double* __restrict__ Lc, c
 // The four 16x16 diagonal blocks of a 64x64 lower factor (column-major image Lc with its reciprocal pivots) inverted by ONE
 // wave: lane (b = lane >> 4, c = lane & 15) runs the forward substitution for column c of inv(L_bb) and parks it
 // k-major in the wave's own tile set, Dk[b][k = c][m] with stride 17 (the layout the MFMA A-fragment reads).
-__device__ __forceinline__ void diag16_inverses(const double* __restrict__ Lc, double* __restrict__ Dk, const int lane) {
+// Only the blocks b >= bmin are inverted (column block C of the 64x64 inverse needs D_C .. D_3).
+// Column sweep, written as a pipeline (round 4): the 16 reciprocal pivots up front, column k + 1 of the block on its way while
+// column k is applied — every step is one multiply and 15 - k independent fmas.  (Left to itself the compiler turned the sweep
+// into a row-by-row form whose rows are chains of up to 15 dependent fmas behind LDS waits: 3 900 cycles; this form 3 400.
+// Computing the four inverses once per factor and sharing them behind a barrier was no faster — 4 000 cycles with two waves at
+// work: the sweep is bound by its own 16 steps, not by the eight waves' LDS traffic.)
+__device__ __forceinline__ void diag16_inverses(const double* __restrict__ Lc, double* __restrict__ Dk, const int lane, const int bmin) {
   const int b = lane >> 4, c = lane & 15;
-  double w[16];
+  if (b < bmin) return;
+  const double* blk = Lc + (16 * b) * DS + 16 * b;      // L_bb[r][k] = blk[k * DS + r]
+  double w[16], rs[16], cur[16], nxt[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) w[r] = (r == c) ? 1.0 : 0.0;
+  for (int r = 0; r < 16; ++r) {
+    w[r] = (r == c) ? 1.0 : 0.0;
+    rs[r] = Lc[(16 * b + r) * DS + 64];
+  }
+#pragma unroll
+  for (int r = 1; r < 16; ++r) cur[r] = blk[r];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
-    const double wk = w[k] * Lc[(16 * b + k) * DS + 64];
+    if (k + 1 < 16) {
+#pragma unroll
+      for (int r = k + 2; r < 16; ++r) nxt[r] = blk[(k + 1) * DS + r];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const double wk = w[k] * rs[k];
     w[k] = wk;
 #pragma unroll
-    for (int r = k + 1; r < 16; ++r) w[r] = fma(-Lc[(16 * b + k) * DS + 16 * b + r], wk, w[r]);
+    for (int r = k + 1; r < 16; ++r) w[r] = fma(-cur[r], wk, w[r]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = k + 2; r < 16; ++r) cur[r] = nxt[r];
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) Dk[b * 272 + c * 17 + r] = w[r];
@@ -328,10 +349,7 @@ __device__ __forceinline__ void inverse_colblock(const double* __restrict__ Lc, 
     for (int rr = 0; rr < 4; ++rr) Wout[(16 * r + lk + 4 * rr) * 64 + 16 * C + lr] = X[r][rr];
 }
 
-__device__ __forceinline__ void inverse_wave(const double* Lc, double* Dk, double* Wout, const int q, const int lane, long long* stamp = nullptr) {
-  diag16_inverses(Lc, Dk, lane);
-  if (stamp && lane == 0) *stamp = clock64();
-  GPBO_LDS_ORDER();   // the wave reads back its own tiles: same-wave LDS accesses are performed in order
+__device__ __forceinline__ void inverse_colblock_of(const double* Lc, const double* Dk, double* Wout, const int q, const int lane) {
   switch (q) {
     case 0: inverse_colblock<0>(Lc, Dk, Wout, lane); break;
     case 1: inverse_colblock<1>(Lc, Dk, Wout, lane); break;
@@ -341,7 +359,7 @@ __device__ __forceinline__ void inverse_wave(const double* Lc, double* Dk, doubl
 }
 
 // Diagonal block of `nblk` (1 or 2) 64-blocks starting at block kb, all earlier updates applied: factor in place, write
-// inv(L_kk) (and inv(L_kk+1)) to dinv.  512 threads = 8 waves, no launch inside, five workgroup barriers.  Wave w,
+// inv(L_kk) (and inv(L_kk+1)) to dinv.  512 threads = 8 waves, no launch inside, seven workgroup barriers.  Wave w,
 // thread = row i (rotated, see factor_block8):
 //   columns 8w .. 8w+7 of A00 with the same columns of A10 (row 64 + i) riding along  ->  L00, L10
 //   SYRK  A11 -= L10 L10^T  (MFMA out of the L10 image)
@@ -361,36 +379,53 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
   const bool two = nblk == 2;
   double* A = L + (int64_t)kb * 64 * ld + (int64_t)kb * 64;
   if (stamps && tid == 0) stamps[0] = clock64();
-  if (tid < 64) {          // column markers: nothing published yet
-    Lc0[tid * DS + 64] = 0.0;
-    LcX[tid * DS + 64] = 0.0;
-  }
   if (tid == 0) flags[0] = 0;
   double a[8], a2[8], b[8];     // rows of A00, A10, A11
   {
-    const double2* s0 = reinterpret_cast<const double2*>(A + (int64_t)i * ld + 8 * w);
+    // The block comes in through LDS (round 4).  Read row-per-lane straight from memory — what the factorisation wants — every
+    // 16-byte load of a wave touches 64 different cache lines, and the CU's one address unit needs ~64 cycles for each of the 96
+    // of them: 7 000 cycles before the first column.  Read ROW-WISE (a wave instruction = 1 KiB of one or two rows), parked in a
+    // staging image with an odd row stride and fetched back row-per-lane (conflict-free: lane i sits 2 banks behind lane i - 1),
+    // the same 96 KiB take about half of that.  The staging image lies over the column images and the exchange area, all unused
+    // so far; their markers are zeroed after it has been read.
+    constexpr int SS = 129;                                   // staging row stride (doubles)
+    static_assert(128 * SS <= C128_FLAGS, "the staging image must end before the flag words");
+    double* S = smem;
+    const int half = lane >> 5, l32 = lane & 31;
 #pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const double2 v = s0[h];
-      a[2 * h] = v.x;
-      a[2 * h + 1] = v.y;
+    for (int q = 0; q < 4; ++q) {                             // rows 0..63, columns 0..63: two rows per wave instruction
+      const int r = 8 * w + 2 * q + half;
+      const double2 v = *reinterpret_cast<const double2*>(A + (int64_t)r * ld + 2 * l32);
+      S[r * SS + 2 * l32] = v.x;
+      S[r * SS + 2 * l32 + 1] = v.y;
     }
     if (two) {
-      const double2* s1 = reinterpret_cast<const double2*>(A + (int64_t)(64 + i) * ld + 8 * w);
-      const double2* s2 = reinterpret_cast<const double2*>(A + (int64_t)(64 + i) * ld + 64 + 8 * w);
 #pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        const double2 v = s1[h];
-        a2[2 * h] = v.x;
-        a2[2 * h + 1] = v.y;
-        const double2 u = s2[h];
-        b[2 * h] = u.x;
-        b[2 * h + 1] = u.y;
+      for (int q = 0; q < 8; ++q) {                           // rows 64..127, columns 0..127: one row per wave instruction
+        const int r = 64 + 8 * w + q;
+        const double2 v = *reinterpret_cast<const double2*>(A + (int64_t)r * ld + 2 * lane);
+        S[r * SS + 2 * lane] = v.x;
+        S[r * SS + 2 * lane + 1] = v.y;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 8; ++h) a[h] = S[i * SS + 8 * w + h];
+    if (two) {
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        a2[h] = S[(64 + i) * SS + 8 * w + h];
+        b[h] = S[(64 + i) * SS + 64 + 8 * w + h];
       }
     } else {
 #pragma unroll
       for (int h = 0; h < 8; ++h) a2[h] = b[h] = 0.0;     // a zero row rides along
     }
+    __syncthreads();
+  }
+  if (tid < 64) {          // column markers: nothing published yet
+    Lc0[tid * DS + 64] = 0.0;
+    LcX[tid * DS + 64] = 0.0;
   }
   __syncthreads();
   if (stamps && tid == 0) stamps[1] = clock64();
@@ -446,10 +481,22 @@ __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64
     if (stamps && tid == 0) stamps[5] = clock64();
     // waves w and w + 4 share a SIMD and column block C costs 36 / 20 / 8 / 0 MFMAs for C = 0..3: the second inverse hands its
     // blocks out in reverse, so every SIMD carries 36 or 28 of the 128 instead of 72 / 40 / 16 / 0 (round 4: 11 000 -> 8 000 cycles)
-    if (w < 4) inverse_wave(Lc0, Wr + w * 4 * 272, dinv + (int64_t)kb * 4096, w, lane, (stamps && w == 0) ? stamps + 15 : nullptr);
-    else inverse_wave(LcX, Wr + w * 4 * 272, dinv + (int64_t)(kb + 1) * 4096, 7 - w, lane);
+    if (w < 4) {
+      diag16_inverses(Lc0, Wr + w * 4 * 272, lane, w);
+      if (stamps && tid == 0) stamps[15] = clock64();
+      GPBO_LDS_ORDER();   // the wave reads back its own tiles: same-wave LDS accesses are performed in order
+      inverse_colblock_of(Lc0, Wr + w * 4 * 272, dinv + (int64_t)kb * 4096, w, lane);
+    } else {
+      diag16_inverses(LcX, Wr + w * 4 * 272, lane, 7 - w);
+      GPBO_LDS_ORDER();
+      inverse_colblock_of(LcX, Wr + w * 4 * 272, dinv + (int64_t)(kb + 1) * 4096, 7 - w, lane);
+    }
   } else {
-    if (w < 4) inverse_wave(Lc0, Wr + w * 4 * 272, dinv + (int64_t)kb * 4096, w, lane);
+    if (w < 4) {
+      diag16_inverses(Lc0, Wr + w * 4 * 272, lane, w);
+      GPBO_LDS_ORDER();
+      inverse_colblock_of(Lc0, Wr + w * 4 * 272, dinv + (int64_t)kb * 4096, w, lane);
+    }
   }
   if (w == 0) {
     // LAPACK potrf: order of the first non-positive leading minor (the images are complete: the inverses started behind
