@@ -51,6 +51,9 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 #ifndef GPBO_CHOL_POLL_SLEEP
 #define GPBO_CHOL_POLL_SLEEP 8      // x 64 cycles between two looks at a marker, cut short by the owner's s_wakeup
 #endif
+#ifndef GPBO_CHOL_WAKE_MASK
+#define GPBO_CHOL_WAKE_MASK 1       // the owner wakes the sleepers behind every column jj with (jj & mask) == mask: every second one
+#endif
 
 // a[c] -= l * m_c and (the riding row) a2[c] -= l2 * m_c for N of the wave's own columns, m_c = the value of l in lane
 // C0 + c (the rows of the wave's diagonal 8x8 block sit in lanes 0..7): v_readlane_b32 into FIXED scalar registers,
@@ -243,7 +246,7 @@ __device__ __forceinline__ void factor_block8(double (&a)[8], double (&a2)[8], d
     GPBO_LDS_ORDER();
     col[jj * DS + 64] = rs;
     GPBO_LDS_ORDER();
-    if (jj & 1) asm volatile("s_wakeup" ::: "memory");      // the store is in the LDS queue before any reader woken by this can queue its read
+    if ((jj & GPBO_CHOL_WAKE_MASK) == GPBO_CHOL_WAKE_MASK) asm volatile("s_wakeup" ::: "memory");      // the store is in the LDS queue before any reader woken by this can queue its read
     GPBO_SCHED_FENCE();
     switch (jj) {     // jj is a compile-time constant of the unrolled loop: only its own case survives
       case 0: bcast_fma_from<1, FOLLOW>(a, a2, l, l2); break;

@@ -13,6 +13,9 @@ from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
 from r03_chol_probe import spd  # noqa: E402
 
 PHASES = ["load", "factor 0..63 (+L10)", "syrk", "exchange + wave 0 of factor 64..127", "rest of factor 64..127", "inverses"]
+if os.environ.get("GPBO_CHAIN_LIB"):      # an experiment build of the debug library (scripts/r04_chol_wake_ab.sh)
+    from bayesianoptimization_amd import _lib
+    _lib._debug_lib = _lib._bind(os.environ["GPBO_CHAIN_LIB"], {**_lib.SIGNATURES, **_lib.DEBUG_SIGNATURES})
 eng = GpEngine(0, debug=True)
 out = {}
 for n in [int(x) for x in (sys.argv[1:] or (128, 512, 2048, 4096))]:
