@@ -51,6 +51,9 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 #ifndef GPBO_CHOL_POLL_SLEEP
 #define GPBO_CHOL_POLL_SLEEP 8      // x 64 cycles between two looks at a marker, cut short by the owner's s_wakeup
 #endif
+#ifndef GPBO_CHOL_DEFER_MATE
+#define GPBO_CHOL_DEFER_MATE 1
+#endif
 #ifndef GPBO_CHOL_WAKE_MASK
 #define GPBO_CHOL_WAKE_MASK 1       // the owner wakes the sleepers behind every column jj with (jj & mask) == mask: every second one
 #endif
@@ -191,7 +194,11 @@ __device__ __forceinline__ void factor_block8(double (&a)[8], double (&a2)[8], d
     const double* prow0 = Lc + 8 * w;      // L[8w + cc][k] = prow0[k * DS + cc]: the same address for every lane
     for (int k = 0; k < 8 * w; k += 2) {
       int spins = 0;
-      while (Lc[(k + 1) * DS + 64] == 0.0) {
+      // Waves w and w - 4 share a SIMD: while w - 4 owns the chain this wave stays asleep (its fmas would take the fp64 pipe
+      // from under the chain) and applies that block's eight columns in one go once the block is complete — it owns the chain
+      // four blocks later, there is time.  (GPBO_CHOL_DEFER_MATE=0: experiment builds without it.)
+      const int kw = (GPBO_CHOL_DEFER_MATE && w >= 4 && (k >> 3) == w - 4) ? 8 * (w - 4) + 7 : k + 1;
+      while (Lc[kw * DS + 64] == 0.0) {
         if (++spins > (1 << 16)) {   // (x 512 cycles = 14 ms) cannot happen while the owner wave runs; never hang the GPU on a bug
           if (i == 0) *broken = 1;
           break;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# How often the owner of a column block wakes the waiting waves (s_wakeup behind every 2nd / 4th / 8th column / never) and how long
+# Whether a wave defers its catch-up while its SIMD-mate owns the chain (GPBO_CHOL_DEFER_MATE), how often the owner of a column block wakes the waiting waves (s_wakeup behind every 2nd / 4th / 8th column / never) and how long
 # they sleep between two looks at a marker: builds of chol_kernels.hip with -DGPBO_CHOL_WAKE_MASK / -DGPBO_CHOL_POLL_SLEEP linked
 # with the tree's other debug objects, each run through scripts/r04_chol_chain.py.
 set -u
@@ -8,7 +8,7 @@ O=gpurun_out/r04_wake; mkdir -p $O
 B=bayesianoptimization_amd/build_dbg
 COMMON="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Iinclude -Ibayesianoptimization_amd/csrc -I/opt/rocm/include -DGPBO_DEBUG"
 OTHERS=$(ls $B/*.o | grep -v chol_kernels.o)
-for v in "wake2_sleep8:" "wake4_sleep8:-DGPBO_CHOL_WAKE_MASK=3" "wake8_sleep8:-DGPBO_CHOL_WAKE_MASK=7" "wake8_sleep32:-DGPBO_CHOL_WAKE_MASK=7 -DGPBO_CHOL_POLL_SLEEP=32" "never_sleep2:-DGPBO_CHOL_WAKE_MASK=8 -DGPBO_CHOL_POLL_SLEEP=2" "wake1_sleep8:-DGPBO_CHOL_WAKE_MASK=0" "wake2_sleep64:-DGPBO_CHOL_POLL_SLEEP=64"; do
+for v in "product:" "no_defer_mate:-DGPBO_CHOL_DEFER_MATE=0" "defer_never_sleep2:-DGPBO_CHOL_WAKE_MASK=8 -DGPBO_CHOL_POLL_SLEEP=2" "nodefer_never_sleep2:-DGPBO_CHOL_DEFER_MATE=0 -DGPBO_CHOL_WAKE_MASK=8 -DGPBO_CHOL_POLL_SLEEP=2" "wake4_sleep8:-DGPBO_CHOL_WAKE_MASK=3" "wake8_sleep8:-DGPBO_CHOL_WAKE_MASK=7" "wake1_sleep8:-DGPBO_CHOL_WAKE_MASK=0" "wake2_sleep64:-DGPBO_CHOL_POLL_SLEEP=64"; do
   label=${v%%:*}; flags=${v#*:}
   mkdir -p /tmp/exp/$label
   hipcc $COMMON $flags -c bayesianoptimization_amd/csrc/chol_kernels.hip -o /tmp/exp/$label/chol_kernels.o || exit 1
