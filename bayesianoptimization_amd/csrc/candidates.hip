@@ -131,6 +131,12 @@ extern "C" int gpbo_transform_candidates(gpbo_ctx* ctx, int n_groups, const int*
     if (kind[g] < 0 || kind[g] > 2 || ncols[g] < 1 || col0[g] < 0 || col0[g] + ncols[g] > d)
       GPBO_FAIL(ctx, GPBO_ERR_INVALID, "transform_candidates: bad group");
     any = any || kind[g] != 0;
+    // The reference's categorical one-hot has BATCH behaviour (a column is set in ALL rows as soon as it is any row's argmax): the
+    // flags are a reduction over the whole (M, d) batch.  A context that holds one shard of a sharded job (gpbo_comm_init with
+    // world > 1, a member of a gpbo_group) would reduce over its rows only and silently transform differently from the reference.
+    if (kind[g] == 2 && ctx->world > 1)
+      GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "transform_candidates: a categorical group needs the WHOLE reference batch resident on "
+                                           "one context (this context is a shard of a multi-device job)");
   }
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
   if (!any) return GPBO_OK;

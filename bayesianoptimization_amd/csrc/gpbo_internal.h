@@ -245,9 +245,13 @@ __device__ __forceinline__ double gpbo_sqrt_pos(double x) {
 // exp(x) for x <= 0 (the only arguments a stationary kernel has): n = rint(x / ln 2), r = x - n ln 2 in two pieces (the high one
 // has 32 significant bits, so n * ln2_hi and the first difference are exact for |n| < 2^11), exp(r) by the degree-13 Taylor
 // polynomial (|r| <= 0.347: truncation 4e-18), result = ldexp(p, n) — v_ldexp_f64 rounds into the subnormals and to 0 by itself,
-// x = 0 gives exactly 1, NaN stays NaN.  20 instructions against ~40 for the library's exp (which also serves x > 0, overflow
+// x = 0 gives exactly 1, NaN stays NaN.  22 instructions against ~40 for the library's exp (which also serves x > 0, overflow
 // and the errno-style cases); < 1 ulp (tests/test_gpu_parity.py::test_kernel_value_exp_against_numpy).  Round 4.
+// Round 5: arguments below -800 are taken as -800 first (the result is an exact 0 from -745.2 on): for x = -inf the
+// reduction was inf - inf = NaN (an RBF entry of points 1e160 apart: NumPy gives 0), and beyond |x| ~ 1e40 the reduced argument
+// was garbage and the polynomial overflowed.  The comparison is false for NaN, which therefore still propagates.
 __device__ __forceinline__ double gpbo_exp_nonpos(double x) {
+  x = (x < -800.0) ? -800.0 : x;
   const double n = __builtin_rint(x * 1.44269504088896338700e+00);
   double r = fma(-n, 6.93147180369123816490e-01, x);       // ln2_hi = 0x3FE62E42FEE00000
   r = fma(-n, 1.90821492927058770002e-10, r);              // ln2_lo

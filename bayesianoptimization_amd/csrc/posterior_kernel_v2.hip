@@ -166,6 +166,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void posterior_kernel_v2(PostArgs2 p
     // (16 waves = 128 VGPRs: with DP = 4 the two inlined evaluations, interleaved, spilled 15-29 registers; one after the other fits)
     if constexpr (WAVES == 16 && DP <= 4) __builtin_amdgcn_sched_barrier(0);
     kv[1] = gpbo_kernel_value<KERNEL>(d2b);
+    if constexpr (WAVES == 16 && DP <= 4) __builtin_amdgcn_sched_barrier(0);
     // mu_weight = 0 for the clamped (repeated) look-ahead of the last stage: it must not be counted twice
     mu_acc = fma(kv[0] * mu_weight, p.alpha[j0], mu_acc);
     mu_acc = fma(kv[1] * mu_weight, p.alpha[j0 + 1], mu_acc);

@@ -9,8 +9,22 @@ Everything else in the optimizer (space, queue, logging, state I/O) is untouched
 """
 from __future__ import annotations
 
+import warnings
+
 from . import fused_acquisition as A
 from .gpr import HipGPR, describe_kernel, shared_engine
+
+
+def _note_unsupported(kernel, what: str) -> str | None:
+    """One UserWarning when a model's kernel is outside the device path: the model is swapped all the same (so that a later
+    `set_gp_params(kernel=...)` with a supported kernel puts it on the GPU) and runs scikit-learn's code until then."""
+    try:
+        describe_kernel(kernel)
+    except NotImplementedError as exc:
+        warnings.warn(f"accelerate(): {what}: {exc}; it keeps running scikit-learn's GaussianProcessRegressor on the host "
+                      "(the reference's path) until its kernel is one the HIP engine evaluates", UserWarning, stacklevel=3)
+        return str(exc)
+    return None
 
 
 def _identity_transform(space) -> bool:
@@ -57,8 +71,11 @@ def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=N
     replicated fit, contiguous candidate blocks, one RCCL all-gather of the per-device arg-best records); the suggestion
     is bit for bit the single-GPU one.
 
-    Raises NotImplementedError for kernels outside the HIP path (see gpr.describe_kernel) and
-    RuntimeError/ImportError when no GPU or no built library is available: there is no CPU fallback.
+    A model whose kernel is outside the HIP path (anything but Matern(nu=2.5) / RBF, see gpr.describe_kernel) — now, or after
+    a later `optimizer.set_gp_params(kernel=...)` (bayes_opt/bayesian_optimization.py:403-407) — degrades instead of raising:
+    that model runs scikit-learn's own fit / predict (the reference's trajectory, bit for bit) with one UserWarning, the
+    fused acquisition classes run over its `predict`.  Supported models have NO CPU fallback: RuntimeError / ImportError
+    when no GPU or no built library is available.
     `n_random` overrides the number of random candidates per suggest() (reference default 10_000).
     `precision="f32"` keeps the fp64 factorisation but runs the posterior contraction in fp32 (2x matrix rate).
     `engine` lets several optimizers share (or tests inject) a GpEngine; default: one per device.
@@ -79,17 +96,21 @@ def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=N
         engine = shared_engine(tuple(devices)) if devices is not None else shared_engine(device)
     space = optimizer._space
     transform = None if _identity_transform(space) else space.kernel_transform
-    describe_kernel(optimizer._gp.kernel)
+    noted = _note_unsupported(optimizer._gp.kernel, "the target GP")
     optimizer._gp = HipGPR.from_sklearn(optimizer._gp, transform=transform, engine=engine, slot=0, precision=precision)
     optimizer._gp.lml_on_device = lml_on_device
+    if noted:
+        optimizer._gp._host_warned = noted          # said once, here
     constraint = getattr(space, "_constraint", None)
     if constraint is not None:
         if len(constraint._model) > 7:
             raise NotImplementedError("at most 7 constraint GPs fit the engine's model slots")
         for j, m in enumerate(constraint._model):
-            describe_kernel(m.kernel)
+            noted = _note_unsupported(m.kernel, f"constraint GP {j}")
             constraint._model[j] = HipGPR.from_sklearn(m, transform=transform, engine=engine, slot=j + 1, precision=precision)
             constraint._model[j].lml_on_device = lml_on_device
+            if noted:
+                constraint._model[j]._host_warned = noted
     optimizer._acquisition_function = _convert_acquisition(optimizer._acquisition_function)
     if n_random is not None and isinstance(optimizer._acquisition_function, A.AcquisitionFunction):
         optimizer._acquisition_function.default_n_random = int(n_random)

@@ -189,15 +189,16 @@ def _mixed_groups_on_device(chain, space, random_state, n_random):
 
 
 def _fused_models(gp, constraint):
-    """[target, constraint GPs...] if all are HipGPRs on one engine in slots 0..n, else None."""
-    if not isinstance(gp, HipGPR) or gp.slot != 0:
+    """[target, constraint GPs...] if all are HipGPRs on one engine in slots 0..n — and on the device path (a model whose
+    kernel the engine does not evaluate runs scikit-learn's code, HipGPR._fit_on_host) — else None."""
+    if not isinstance(gp, HipGPR) or gp.slot != 0 or gp._host_mode:
         return None
     chain = [gp]
     members = [] if constraint is None else getattr(constraint, "_model", None)
     if members is None or len(members) + 1 > 8:
         return None
     for slot, model in enumerate(members, start=1):
-        if not isinstance(model, HipGPR) or model.slot != slot or model._engine() is not gp._engine():
+        if not isinstance(model, HipGPR) or model.slot != slot or model._host_mode or model._engine() is not gp._engine():
             return None
         chain.append(model)
     return chain

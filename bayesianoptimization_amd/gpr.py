@@ -15,7 +15,12 @@ estimator so all of that keeps its meaning, and replaces the two numeric stages:
 
 Supported on the HIP path: Matern(nu=2.5) and RBF (optionally wrapped by bayes_opt's `wrap_kernel`,
 optionally scaled by a fixed-at-1 ConstantKernel as in sklearn's default), scalar `alpha`, 1-D targets.
-Anything else raises NotImplementedError — there is no CPU fallback in this class.
+Anything else — `set_gp_params(kernel=Matern(nu=1.5))` on an accelerated optimizer
+(bayes_opt/bayesian_optimization.py:403-407), a per-sample `alpha`, several targets — is outside the device path: the
+estimator then IS its base class for that fit (scikit-learn's own `fit` / `predict`, the reference's arithmetic and
+RandomState consumption bit for bit) and says so with one UserWarning per estimator (SURVEY.md §2 "Third-party
+kernels": degrade, do not raise).  That is the caller's own configuration running the reference's code, not a CPU
+implementation of the device path: a supported model never leaves the GPU, and fails loudly without one.
 """
 from __future__ import annotations
 
@@ -105,6 +110,48 @@ class HipGPR(GaussianProcessRegressor):
         # side on the device (gpbo_lml_batch); same iterates and same RandomState draws as one run after another
         self.theta_lockstep = theta_lockstep
 
+    # -- outside the device path ------------------------------------------------------------------
+    #: True after a fit that the device path does not cover: every numeric method is then the base class's
+    _host_mode = False
+
+    def _unsupported_reason(self, kernel, y=None):
+        """Why this configuration is outside the device path (None when it is inside)."""
+        try:
+            describe_kernel(kernel)
+        except NotImplementedError as exc:
+            return str(exc)
+        if np.iterable(self.alpha):
+            return "HIP path supports a scalar alpha only"
+        if y is not None and np.ndim(y) == 2 and np.shape(y)[1] != 1:
+            return "HIP path supports a single target"
+        return None
+
+    def _warn_host(self, reason, stacklevel=3):
+        if self.__dict__.get("_host_warned") != reason:
+            warnings.warn(f"{reason}: this model runs scikit-learn's GaussianProcessRegressor on the host "
+                          "(the reference's path), not the HIP engine", UserWarning, stacklevel=stacklevel)
+            self._host_warned = reason
+
+    def set_params(self, **params):
+        """sklearn's set_params; a kernel outside the device path is announced HERE — `BayesianOptimization.set_gp_params`
+        (bayes_opt/bayesian_optimization.py:403-407) ends in this call, whereas the fits run inside suggest() with every
+        warning silenced (acquisition.py:79-86)."""
+        out = super().set_params(**params)
+        if "kernel" in params and self.kernel is not None:
+            reason = self._unsupported_reason(self.kernel)
+            if reason is not None:
+                self._warn_host(reason)
+        return out
+
+    def _fit_on_host(self, X, y, reason):
+        """scikit-learn's own fit for a model the device path does not cover (one warning per estimator and reason)."""
+        self._warn_host(reason, stacklevel=4)
+        self._host_mode = True
+        self._held = None
+        for k in ("_kind", "_ls", "_L_cache", "_alpha_cache", "log_marginal_likelihood_value_", "_lml_lazy"):
+            self.__dict__.pop(k, None)
+        return GaussianProcessRegressor.fit(self, X, y)
+
     # -- plumbing ------------------------------------------------------------------------------
     def _engine(self) -> GpEngine:
         if self.engine is None:
@@ -133,7 +180,7 @@ class HipGPR(GaussianProcessRegressor):
 
     # -- log marginal likelihood ---------------------------------------------------------------------
     def _device_lml_ok(self, kernel) -> bool:
-        if self.lml_on_device is False or not hasattr(self, "X_train_"):
+        if self.lml_on_device is False or not hasattr(self, "X_train_") or self._host_mode:
             return False
         if self.lml_on_device == "auto" and self.X_train_.shape[0] < LML_DEVICE_MIN_N:
             return False
@@ -230,9 +277,10 @@ class HipGPR(GaussianProcessRegressor):
             self.kernel_ = ConstantKernel(1.0, constant_value_bounds="fixed") * RBF(1.0, length_scale_bounds="fixed")
         else:
             self.kernel_ = clone(self.kernel)
-        if np.iterable(self.alpha):
-            raise NotImplementedError("HIP path supports a scalar alpha only")
-        describe_kernel(self.kernel_)  # fail before any work on unsupported kernels
+        reason = self._unsupported_reason(self.kernel_, y)
+        if reason is not None:       # before any work, and before the RandomState is touched: the base class does all of it
+            return self._fit_on_host(X, y, reason)
+        self._host_mode = False
         self._rng = check_random_state(self.random_state)
 
         # sklearn's own input validation (_gpr.py:254-262): same ValueErrors for NaN/inf, wrong rank, length
@@ -242,8 +290,6 @@ class HipGPR(GaussianProcessRegressor):
         y = np.asarray(y, dtype=np.float64)
         self._y_2d = y.ndim == 2
         if self._y_2d:
-            if y.shape[1] != 1:
-                raise NotImplementedError("HIP path supports a single target")
             y = y[:, 0]
 
         if self.normalize_y:  # _gpr.py:272-277 + preprocessing/_data.py:107-110
@@ -410,8 +456,9 @@ class HipGPR(GaussianProcessRegressor):
     def predict(self, X, return_std=False, return_cov=False):
         if return_std and return_cov:
             raise RuntimeError("At most one of return_std or return_cov can be requested.")
-        if not hasattr(self, "X_train_"):
-            # prior (unfitted) predictions are not on the hot path: sklearn's own code handles them
+        if not hasattr(self, "X_train_") or self._host_mode:
+            # prior (unfitted) predictions are not on the hot path: sklearn's own code handles them; so it does for a model
+            # outside the device path (_fit_on_host)
             return super().predict(X, return_std=return_std, return_cov=return_cov)
         X = np.asarray(validate_data(self, X, ensure_2d=True, dtype="numeric", reset=False), dtype=np.float64)  # _gpr.py:412
         self._ensure_resident()
@@ -438,6 +485,10 @@ class HipGPR(GaussianProcessRegressor):
         """(mean, std) for points this package generated itself (finite, right shape): predict(return_std=True)
         without sklearn's input validation and without the clipped-variance warning — the objective of the host
         optimisers calls this hundreds of times per suggest()."""
+        if self._host_mode:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                return GaussianProcessRegressor.predict(self, X, return_std=True)
         self._ensure_resident()
         return self._engine().predict(self._tx(X), slot=self.slot, y_mean=float(self._y_train_mean),
                                       y_std=float(self._y_train_std))
@@ -445,8 +496,8 @@ class HipGPR(GaussianProcessRegressor):
     def _posterior_grad_trusted(self, X):
         """(mean, std, d mean / d x, d std / d x) for a small batch of points this package generated itself
         (gpbo_predict_grad; identity input transform only — the chain rule through a host transform is not formed)."""
-        if self.transform is not None:
-            raise NotImplementedError("input gradients need the identity input transform")
+        if self.transform is not None or self._host_mode:
+            raise NotImplementedError("input gradients need the identity input transform and a model on the device path")
         self._ensure_resident()
         return self._engine().predict_grad(np.ascontiguousarray(X, dtype=np.float64), slot=self.slot,
                                            y_mean=float(self._y_train_mean), y_std=float(self._y_train_std))

@@ -19,6 +19,7 @@ tests/test_host_logic.py::test_lbfgsb_driver_equals_scipy_minimize pins the equi
 from __future__ import annotations
 
 import contextlib
+import threading
 
 import numpy as np
 from scipy.optimize import OptimizeResult
@@ -47,6 +48,42 @@ _SELF_CHECK: bool | None = None
 _BLAS_CONTROLLER = None
 
 
+_BLAS_LOCK = threading.Lock()
+_BLAS_USERS = 0
+_BLAS_LIMIT = None
+
+
+class _BlasSingleThread:
+    """Re-entrant and thread-safe: the limit is set by the first user to enter and lifted by the last one to leave (a module
+    lock + a count).  Without that, two optimizers in two threads could interleave — A saves 256 and sets 1, B saves 1, A
+    restores 256, B restores 1 — and leave the process's BLAS at one thread for good."""
+
+    def __enter__(self):
+        global _BLAS_USERS, _BLAS_LIMIT, _BLAS_CONTROLLER
+        with _BLAS_LOCK:
+            _BLAS_USERS += 1
+            if _BLAS_USERS == 1:
+                try:
+                    from threadpoolctl import ThreadpoolController
+
+                    if _BLAS_CONTROLLER is None:
+                        _BLAS_CONTROLLER = ThreadpoolController()
+                    _BLAS_LIMIT = _BLAS_CONTROLLER.limit(limits=1, user_api="blas")
+                    _BLAS_LIMIT.__enter__()
+                except Exception:   # noqa: BLE001  (threadpoolctl is a scikit-learn dependency; without it nothing changes)
+                    _BLAS_LIMIT = None
+        return self
+
+    def __exit__(self, *exc):
+        global _BLAS_USERS, _BLAS_LIMIT
+        with _BLAS_LOCK:
+            _BLAS_USERS -= 1
+            if _BLAS_USERS == 0 and _BLAS_LIMIT is not None:
+                limit, _BLAS_LIMIT = _BLAS_LIMIT, None
+                limit.__exit__(None, None, None)
+        return False
+
+
 def blas_single_thread():
     """Context manager: the process's BLAS pools limited to one thread while L-BFGS-B's bookkeeping runs.
 
@@ -55,18 +92,11 @@ def blas_single_thread():
     pool's wake-up and hand-off for a few hundred flops: measured here (8 threads) 4.9-7.4 ms per theta search against
     2.8-3.0 ms with the pool limited to one thread, the objective memoised in both (the GPU box's host LML fit took 96 ms
     at N = 128 for 13 ms of LML evaluations, profiles/r04_lml_crossover.json).  Only for drivers whose objective does not
-    itself need the host's BLAS (device evaluations): the limit is process-wide while it lasts.  Same bits either way —
+    itself need the host's BLAS (device evaluations): the limit is process-wide while ANY such driver runs (other threads'
+    host BLAS is throttled meanwhile) and is restored when the last one leaves.  Same bits either way —
     operands this small never reach a threaded kernel's split (tests/test_host_logic.py pins the driver against
     scipy.optimize.minimize run WITHOUT the limit)."""
-    global _BLAS_CONTROLLER
-    try:
-        from threadpoolctl import ThreadpoolController
-
-        if _BLAS_CONTROLLER is None:
-            _BLAS_CONTROLLER = ThreadpoolController()
-        return _BLAS_CONTROLLER.limit(limits=1, user_api="blas")
-    except Exception:   # noqa: BLE001  (threadpoolctl is a scikit-learn dependency; without it nothing changes)
-        return contextlib.nullcontext()
+    return _BlasSingleThread()
 
 
 def _self_check() -> bool:

@@ -185,7 +185,11 @@ int gpbo_get_candidate_rows(gpbo_ctx* ctx, const int64_t* idx, int n, double* ou
  * TargetSpace.kernel_transform (target_space.py:340-347) in place — kind 0: identity, 1: np.round (IntParameter,
  * parameter.py:308-320), 2: CategoricalParameter's one-hot (parameter.py:434-449, including its batch behaviour: a column
  * is set in ALL rows as soon as it is the argmax of any row) — and keeps the untransformed matrix aside:
- * gpbo_get_candidate_rows keeps returning the rows as drawn, gpbo_posterior sees the transformed ones. */
+ * gpbo_get_candidate_rows keeps returning the rows as drawn, gpbo_posterior sees the transformed ones.
+ * Because of that batch behaviour a categorical group (kind 2) is a reduction over ALL M rows: the context must hold the whole
+ * reference batch.  On a context that is one shard of a multi-device job (gpbo_comm_init with world_size > 1, a member of a
+ * gpbo_group) a kind-2 group returns GPBO_ERR_UNSUPPORTED instead of transforming its rows differently from the reference
+ * (sharded callers transform on the host, as GroupEngine does). */
 int gpbo_generate_candidate_columns_mt19937(gpbo_ctx* ctx, int64_t M, int d_total, int col0, int ncols, const double* lo,
                                             const double* hi, uint32_t* key, int* pos);
 int gpbo_set_candidate_columns(gpbo_ctx* ctx, const double* values, int64_t M, int d_total, int col0, int ncols);

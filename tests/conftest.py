@@ -45,3 +45,14 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+def elementwise_err(sd, sd_ref, mu, mu_ref, s_y):
+    """north_star's tolerance as written — "within 1e-5 relative" — per candidate: max |sd - sd_ref| / sd_ref over the candidates
+    with sd_ref > 0, and max |mu - mu_ref| / max(|mu_ref|, s_y).  (rel_err above is a max-norm: a sigma a thousand times below the
+    batch's largest is checked three decades looser by it.)"""
+    sd, sd_ref, mu, mu_ref = (np.asarray(v, dtype=np.float64) for v in (sd, sd_ref, mu, mu_ref))
+    pos = sd_ref > 0
+    e_sd = float(np.max(np.abs(sd - sd_ref)[pos] / sd_ref[pos])) if pos.any() else 0.0
+    e_mu = float(np.max(np.abs(mu - mu_ref) / np.maximum(np.abs(mu_ref), s_y)))
+    return e_sd, e_mu

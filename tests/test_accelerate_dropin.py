@@ -394,3 +394,58 @@ def test_fused_gphedge_is_the_reference_gphedge_and_can_share_one_posterior_pass
     assert stage.count("posterior") == 1 and stage.count("acq_argbest") == 3      # ONE pass, three selections
     assert all(PB[k][0] <= v <= PB[k][1] for k, v in x.items())
     assert shared.previous_candidates.shape == (3, 2) and [b.i for b in shared.base_acquisitions] == [2, 2, 2]
+
+
+def test_unsupported_kernel_degrades_to_the_reference_trajectory():
+    """`set_gp_params(kernel=Matern(nu=1.5))` on an accelerated optimizer (bayes_opt/bayesian_optimization.py:403-407) is a slower
+    step, not an exception (SURVEY.md §2 "Third-party kernels"): the model runs scikit-learn's own fit / predict — one
+    UserWarning — the fused acquisition runs over its `predict`, and the whole maximize() trajectory is the reference's bit for
+    bit, RandomState position included.  Setting a supported kernel afterwards puts the model back on the engine."""
+    from sklearn.gaussian_process.kernels import Matern
+
+    ref, mine, eng = _pair(seed=11)
+    ref.set_gp_params(kernel=Matern(nu=1.5), n_restarts_optimizer=2)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        mine.set_gp_params(kernel=Matern(nu=1.5), n_restarts_optimizer=2)          # said here: the fits run with warnings silenced
+        mine.maximize(init_points=3, n_iter=3)
+    said = [w for w in seen if issubclass(w.category, UserWarning) and "HIP path supports Matern(nu=2.5) only" in str(w.message)]
+    assert len(said) == 1, [str(w.message) for w in seen]                      # once per estimator, not once per fit
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref.maximize(init_points=3, n_iter=3)
+    assert mine._gp._host_mode and not [c for c in eng.calls if c[0] in ("fit", "posterior", "lml", "lml_batch")]
+    assert np.array_equal(mine.space.params, ref.space.params)
+    assert np.array_equal(mine.space.target, ref.space.target)
+    assert np.array_equal(mine._gp.kernel_.theta, ref._gp.kernel_.theta)
+    assert ref._random_state.uniform() == mine._random_state.uniform()
+    # back on the engine with a kernel it evaluates
+    mine.set_gp_params(kernel=Matern(nu=2.5))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mine.maximize(init_points=0, n_iter=1)
+    assert not mine._gp._host_mode and any(c[0] == "fit" for c in eng.calls)
+
+
+def test_accelerate_with_an_unsupported_kernel_warns_once_and_keeps_the_optimizer_usable():
+    import_reference()
+    from bayes_opt import BayesianOptimization
+    from sklearn.gaussian_process.kernels import RationalQuadratic
+
+    from bayesianoptimization_amd import accelerate
+
+    ref = BayesianOptimization(f=black_box, pbounds=PB, random_state=4, verbose=0)
+    mine = BayesianOptimization(f=black_box, pbounds=PB, random_state=4, verbose=0)
+    for o in (ref, mine):
+        o.set_gp_params(kernel=RationalQuadratic())
+    eng = FakeEngine()
+    with pytest.warns(UserWarning, match="the target GP"):
+        accelerate(mine, engine=eng)
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter("always")
+        mine.maximize(init_points=2, n_iter=2)
+    assert not [w for w in seen if "HIP path" in str(w.message)]               # accelerate() said it already
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref.maximize(init_points=2, n_iter=2)
+    assert np.array_equal(mine.space.params, ref.space.params)

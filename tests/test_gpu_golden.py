@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from bayesianoptimization_amd import workloads as W
-from conftest import load_golden, rel_err
+from conftest import elementwise_err, load_golden, rel_err
 from oracle import gp_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -37,6 +37,7 @@ def _run_case(engine, name, M=None):
     mu, sd = engine.posterior(0, ym, ys_)
     S = len(g["mu"])
     assert rel_err(mu[:S], g["mu"]) < TOL and rel_err(sd[:S], g["sd"]) < TOL
+    assert max(elementwise_err(sd[:S], g["sd"], mu[:S], g["mu"], ys_)) <= 1e-5          # north_star's bound, per candidate
     lb = ub = None
     if w.constrained:
         cn, cm, cs = O.normalize_targets(c)
@@ -44,6 +45,7 @@ def _run_case(engine, name, M=None):
         assert rel_err(engine.get_alpha(w.N, slot=1), g["c_alpha"]) < TOL
         cmu, csd = engine.posterior(1, cm, cs)
         assert rel_err(cmu[:S], g["c_mu"]) < TOL and rel_err(csd[:S], g["c_sd"]) < TOL
+        assert max(elementwise_err(csd[:S], g["c_sd"], cmu[:S], g["c_mu"], cs)) <= 1e-5
         lb, ub = [-np.inf], [w.constraint_ub]
     y_max = W.feasible_y_max(w, y, c)
     bi, bv, si, sv, ys = engine.acq_argbest(w.acq, w.acq_param, y_max, lb, ub, k_seeds=16, return_values=True)

@@ -21,7 +21,7 @@ import numpy as np
 import pytest
 
 from bayesianoptimization_amd.engine import F32, F64
-from conftest import rel_err
+from conftest import elementwise_err, rel_err
 from oracle import gp_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -84,6 +84,7 @@ def test_slab_gemm_pipeline_against_the_oracle_on_every_candidate(engine, kernel
         rng_ = float(np.max(ys_o) - np.min(ys_o))
         if precision == F64:
             assert rel_err(mu, mu_o) <= 1e-9 and rel_err(sd, sd_o) <= 1e-9
+            assert max(elementwise_err(sd, sd_o, mu, mu_o, ys_)) <= 1e-5          # north_star's bound, per candidate
             assert rel_err(ys, ys_o) <= 1e-8
             assert bi == int(order[0]) and bv == ys[bi]
             assert np.array_equal(si, order[:K_SEEDS]), (si, order[:K_SEEDS])

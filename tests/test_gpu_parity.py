@@ -92,6 +92,25 @@ def test_kernel_value_exp_against_numpy(engine, kernel):
     assert np.all(K[ref == 0.0] == 0.0)
 
 
+def test_kernel_value_exp_extreme_arguments(engine):
+    """gpbo_exp_nonpos beyond the range a sane kernel matrix reaches.  RBF entries of points 1e150 (squared distance
+    1e300) and 1e200 apart (squared distance overflows to +inf): NumPy's exp gives exactly 0 for both; the device's reduction
+    used to give NaN for -inf (inf - inf) and garbage beyond |x| ~ 1e40."""
+    X = np.array([[0.0], [1.0], [1e150], [1e200], [-1e200]])
+    yn = np.array([0.3, -0.2, 0.1, 0.5, -0.4])
+    engine.fit(X, yn, O.RBF, 1.0, 1e-6)
+    K = engine.get_K(5)
+    with np.errstate(over="ignore"):
+        ref = np.exp(-0.5 * (X - X.T) ** 2)
+    ref[np.diag_indices(5)] = 1.0 + 1e-6
+    assert np.all(np.isfinite(K))
+    assert np.array_equal(K[2:, :2], np.zeros((3, 2))) and K[3, 2] == 0.0 and K[4, 3] == 0.0
+    assert np.allclose(K, ref, rtol=1e-15, atol=0.0)
+    mu, sd = engine.predict(np.array([[0.5], [1e180], [np.inf]]))        # k* rows of zeros: the prior
+    assert np.isfinite(mu[:2]).all() and mu[1] == 0.0 and sd[1] == 1.0
+    assert np.isnan(mu[2]) or mu[2] == 0.0                                 # inf - inf inside the distance: NaN, as NumPy's cdist
+
+
 @pytest.mark.parametrize("M", [1, 2, 127, 128, 129, 1000, 4097])
 def test_posterior_parity_ragged_candidate_counts(engine, M):
     X, y = _data(150, 6, seed=2)

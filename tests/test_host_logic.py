@@ -382,3 +382,45 @@ def test_engine_is_shared_by_copies_and_not_picklable():
     assert copy.deepcopy(gp).engine is eng
     with pytest.raises(TypeError):
         pickle.dumps(eng)
+
+
+def test_blas_single_thread_is_reentrant_and_thread_safe():
+    """the limit the lockstep drivers put on the host BLAS pools is set by the first user and lifted by the last —
+    interleaved enters / exits from several threads (two optimizers, one context each) must leave the pools as they were."""
+    import threading
+
+    from threadpoolctl import threadpool_info
+
+    from bayesianoptimization_amd import lbfgsb_lockstep as D
+
+    def blas_threads():
+        return [m["num_threads"] for m in threadpool_info() if m.get("user_api") == "blas"]
+
+    before = blas_threads()
+    with D.blas_single_thread():
+        with D.blas_single_thread():
+            assert all(n == 1 for n in blas_threads())
+        assert all(n == 1 for n in blas_threads())          # the inner exit must not lift the outer limit
+    assert blas_threads() == before
+    # A enters, B enters, A leaves, B leaves (the order that used to leave the pools at 1)
+    a_in, b_in, a_out = threading.Event(), threading.Event(), threading.Event()
+
+    def a():
+        with D.blas_single_thread():
+            a_in.set()
+            b_in.wait(10)
+        a_out.set()
+
+    def b():
+        a_in.wait(10)
+        with D.blas_single_thread():
+            b_in.set()
+            a_out.wait(10)
+            assert all(n == 1 for n in blas_threads())
+
+    ts = [threading.Thread(target=f) for f in (a, b)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(20)
+    assert blas_threads() == before and D._BLAS_USERS == 0
