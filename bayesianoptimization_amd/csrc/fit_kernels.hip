@@ -13,11 +13,12 @@
 
 #include "gpbo_internal.h"
 #include "gemm_tile.h"
+#include "fit_bodies.h"
 
 namespace gpbo {
 
 // ------------------------------------------------------------------------------------------------
-// X / length_scale into a zero-padded [n_pad][DP] image (true division, as numpy does).
+// X / length_scale into a zero-padded [n_pad][DP] image (true division, as numpy does): prescale_elem (fit_bodies.h).
 __global__ void prescale_kernel(const double* __restrict__ X, int64_t n, int d, int DP,
                                 const double* __restrict__ ls, double* __restrict__ out,
                                 int64_t total, int64_t lane_stride) {
@@ -25,11 +26,7 @@ __global__ void prescale_kernel(const double* __restrict__ X, int64_t n, int d, 
   if (idx >= total) return;
   ls += (int64_t)blockIdx.y * lane_stride;     // lane mode: X is shared, length scales and output are per lane
   out += (int64_t)blockIdx.y * lane_stride;
-  int64_t row = idx / DP;
-  int t = (int)(idx - row * DP);
-  double v = 0.0;
-  if (row < n && t < d) v = X[row * d + t] / ls[t];
-  out[idx] = v;
+  prescale_elem(X, n, d, DP, ls, out, idx);
 }
 
 int launch_prescale(gpbo_ctx* ctx, const double* X, int64_t n, int d, int DP, const double* ls,
@@ -44,14 +41,7 @@ int launch_prescale(gpbo_ctx* ctx, const double* X, int64_t n, int d, int DP, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// Kernel value from a squared scaled distance: ONE arithmetic for both sides of the GP (gpbo_kernel_value in
-// gpbo_internal.h: v_rsq-seeded sqrt, K^2 * (1/3)) — the fit-side K and the posterior-side k* agree bit for bit
-// for equal distances, and both stay within ~1 ulp of sklearn's expression (kernels.py:1722-1724, 1559-1560).
-template <int KERNEL>
-__device__ __forceinline__ double kernel_value(double d2) {
-  return gpbo_kernel_value<KERNEL>(d2);
-}
-
+// (kernel_value and the tile body: fit_bodies.h)
 // K (lower block triangle, 64x64 tiles): one workgroup per LOWER tile (linear block id -> (bi, bj), no idle
 // workgroups), 4x4 outputs per thread, the two point tiles staged k-major in LDS.  HBM-write bound: N^2/2 * 8 B.
 // `out` is K, or directly the buffer the Cholesky factorises in place (no K -> L copy on the fit path).
@@ -66,64 +56,12 @@ __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ Xs
                                                    int64_t NP, double noise, double* __restrict__ K,
                                                    int64_t lane_stride) {
   // blockIdx.x = bi (bi + 1) / 2 + bj, bj <= bi
-  const int b = blockIdx.x;
-  int bi = (int)((sqrt(8.0 * (double)b + 1.0) - 1.0) * 0.5);
-  while ((bi + 1) * (bi + 2) / 2 <= b) ++bi;
-  while (bi * (bi + 1) / 2 > b) --bi;
-  const int bj = b - bi * (bi + 1) / 2;
+  int bi, bj;
+  lower_tile_of((int)blockIdx.x, bi, bj);
   Xs += (int64_t)blockIdx.z * lane_stride;
   K += (int64_t)blockIdx.z * lane_stride;
   extern __shared__ __attribute__((aligned(16))) double kmat_smem[];
-  double* XiT = kmat_smem;            // [DP][64]
-  double* XjT = kmat_smem + DP * 64;  // [DP][64]
-  const int tid = threadIdx.x;
-  // (consecutive threads = consecutive points of one dimension: the dimension-major LDS image is written 512 contiguous
-  // bytes per wave.  Until round 4 consecutive threads walked the dimensions of one point — LDS addresses 512 B apart, a
-  // DP-way bank conflict on every staging store: SQ_LDS_BANK_CONFLICT 5.1e6 cycles per launch at N = 4096,
-  // profiles/r04_pmc_kmat.txt)
-  for (int e = tid; e < 64 * DP; e += 256) {
-    const int t = e >> 6, r = e & 63;
-    XiT[e] = Xs[((int64_t)bi * 64 + r) * DP + t];
-    XjT[e] = Xs[((int64_t)bj * 64 + r) * DP + t];
-  }
-  __syncthreads();
-  const int ty = tid >> 4, tx = tid & 15;
-  double acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b2 = 0; b2 < 4; ++b2) acc[a][b2] = 0.0;
-  for (int t = 0; t < DP; ++t) {
-    double xi[4], xj[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) xi[a] = XiT[t * 64 + ty * 4 + a];
-#pragma unroll
-    for (int b2 = 0; b2 < 4; ++b2) xj[b2] = XjT[t * 64 + tx * 4 + b2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b2 = 0; b2 < 4; ++b2) {
-        double df = xi[a] - xj[b2];
-        acc[a][b2] = fma(df, df, acc[a][b2]);
-      }
-  }
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int64_t i = (int64_t)bi * 64 + ty * 4 + a;
-    double out[4];
-#pragma unroll
-    for (int b2 = 0; b2 < 4; ++b2) {
-      const int64_t j = (int64_t)bj * 64 + tx * 4 + b2;
-      double v;
-      if (i >= N || j >= N) v = (i == j) ? 1.0 : 0.0;       // identity padding
-      else if (i == j) v = 1.0 + noise;                       // unit diagonal (+ alpha, _gpr.py:347)
-      else v = kernel_value<KERNEL>(acc[a][b2]);
-      out[b2] = v;
-    }
-    double2* dst = reinterpret_cast<double2*>(K + i * NP + (int64_t)bj * 64 + tx * 4);
-    dst[0] = make_double2(out[0], out[1]);
-    dst[1] = make_double2(out[2], out[3]);
-  }
+  kmat_tile_body<KERNEL>(Xs, DP, N, NP, noise, K, bi, bj, kmat_smem, (int)threadIdx.x);
 }
 
 int launch_kmat(gpbo_ctx* ctx, Model& m, double noise, double* out) {
@@ -396,14 +334,8 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
 // W := blockdiag(dinv) (W has been zero-filled).
 __global__ __launch_bounds__(256) void fill_w_diag_kernel(const double* __restrict__ dinv,
                                                           double* __restrict__ W, int64_t NP, int64_t lane_stride) {
-  const int kb = blockIdx.x;
-  dinv += (int64_t)blockIdx.y * lane_stride;
-  W += (int64_t)blockIdx.y * lane_stride;
-  const double* D = dinv + (int64_t)kb * 4096;
-  for (int e = threadIdx.x; e < 4096; e += 256) {
-    int r = e >> 6, c = e & 63;
-    W[((int64_t)kb * 64 + r) * NP + (int64_t)kb * 64 + c] = D[e];
-  }
+  fill_w_diag_body(dinv + (int64_t)blockIdx.y * lane_stride, W + (int64_t)blockIdx.y * lane_stride, NP, (int)blockIdx.x,
+                   (int)threadIdx.x);
 }
 
 int launch_fill_w_diag(gpbo_ctx* ctx, Model& m) {
@@ -419,7 +351,7 @@ int launch_fill_w_diag(gpbo_ctx* ctx, Model& m) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// t = W y (one wave per row, fixed shuffle tree) and alpha = W^T t (64 columns per workgroup).
+// t = W y (one wave per row, fixed shuffle tree) and alpha = W^T t (64 columns per workgroup): bodies in fit_bodies.h.
 __global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restrict__ W,
                                                          const double* __restrict__ y,
                                                          double* __restrict__ t, int64_t NP, int64_t lane_stride) {
@@ -429,37 +361,20 @@ __global__ __launch_bounds__(256) void trmv_lower_kernel(const double* __restric
   W += (int64_t)blockIdx.y * lane_stride;
   y += (int64_t)blockIdx.y * lane_stride;
   t += (int64_t)blockIdx.y * lane_stride;
-  const double* row = W + i * NP;
-  double s = 0.0;
-  for (int64_t j = lane; j <= i; j += 64) s = fma(row[j], y[j], s);
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-  if (lane == 0) t[i] = s;
+  trmv_lower_row(W, y, t, NP, i, lane);
 }
 
 // alpha = W^T t in two deterministic passes: (column block of 64) x (row split) partial sums, then a
 // fixed-order reduction over the row splits.
-constexpr int TRMV_SPLITS = 16;
-
 __global__ __launch_bounds__(256) void trmv_lower_t_kernel(const double* __restrict__ W,
                                                            const double* __restrict__ t,
                                                            double* __restrict__ partial, int64_t NP,
                                                            int64_t lane_stride) {
-  __shared__ double red[4][64];
+  __shared__ double red[4 * 64];
   W += (int64_t)blockIdx.z * lane_stride;
   t += (int64_t)blockIdx.z * lane_stride;
   partial += (int64_t)blockIdx.z * lane_stride;
-  const int ig = threadIdx.x >> 6, jl = threadIdx.x & 63;
-  const int64_t j0 = (int64_t)blockIdx.x * 64;
-  const int64_t rows = NP - j0;                                   // rows j0 .. NP-1 hold non-zeros
-  const int64_t chunk = (rows + TRMV_SPLITS - 1) / TRMV_SPLITS;
-  const int64_t r0 = j0 + (int64_t)blockIdx.y * chunk;
-  const int64_t r1 = min(NP, r0 + chunk);
-  double s = 0.0;
-  for (int64_t i = r0 + ig; i < r1; i += 4) s = fma(W[i * NP + j0 + jl], t[i], s);
-  red[ig][jl] = s;
-  __syncthreads();
-  if (ig == 0) partial[(int64_t)blockIdx.y * NP + j0 + jl] = ((red[0][jl] + red[1][jl]) + red[2][jl]) + red[3][jl];
+  trmv_lower_t_body(W, t, partial, NP, (int)blockIdx.x, (int)blockIdx.y, red, (int)threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void trmv_reduce_kernel(const double* __restrict__ partial,
@@ -469,10 +384,7 @@ __global__ __launch_bounds__(256) void trmv_reduce_kernel(const double* __restri
   if (j >= NP) return;
   partial += (int64_t)blockIdx.y * lane_stride;
   alpha += (int64_t)blockIdx.y * lane_stride;
-  double s = 0.0;
-#pragma unroll
-  for (int r = 0; r < TRMV_SPLITS; ++r) s += partial[(int64_t)r * NP + j];
-  alpha[j] = s;
+  trmv_reduce_elem(partial, alpha, NP, j);
 }
 
 int launch_trmv(gpbo_ctx* ctx, Model& m) {
@@ -573,25 +485,12 @@ int launch_append_row(gpbo_ctx* ctx, Model& m, int64_t j) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pack W into the order the posterior kernel's waves consume it: for row slab s (32 rows), k-pair p
-// (8 columns) and 16-row tile t, 64 lanes x 2 doubles contiguous (1 KiB): lane l, element e holds
-// W[32 s + 16 t + (l & 15)][8 p + 4 e + (l >> 4)] — the A fragment of v_mfma_f64_16x16x4_f64 for
-// k-steps 2p and 2p+1.  Entries outside the N x N lower triangle are zero.
+// Pack W into the order the posterior kernel's waves consume it (pack_w_elem, fit_bodies.h).
 __global__ __launch_bounds__(256) void pack_w_kernel(const double* __restrict__ W,
                                                      double* __restrict__ Wp, int64_t N, int64_t NP) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= NP * NP) return;
-  const int e = (int)(idx & 1);
-  const int lane = (int)((idx >> 1) & 63);
-  const int t = (int)((idx >> 7) & 1);
-  const int64_t sp = idx >> 8;
-  const int64_t pairs = NP / 8;
-  const int64_t s = sp / pairs, p = sp - s * pairs;
-  const int64_t row = 32 * s + 16 * t + (lane & 15);
-  const int64_t colx = 8 * p + 4 * e + (lane >> 4);
-  double v = 0.0;
-  if (row < N && colx < N && colx <= row) v = W[row * NP + colx];
-  Wp[idx] = v;
+  pack_w_elem(W, Wp, N, NP, idx);
 }
 
 int launch_pack_w(gpbo_ctx* ctx, Model& m) {

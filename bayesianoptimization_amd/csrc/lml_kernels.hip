@@ -8,39 +8,17 @@
 // (kernels.py:1764-1766, 1567-1582; D = squared scaled coordinate differences, summed for an isotropic
 // length scale).  K^-1 = W^T W comes from the MFMA GEMM; this file holds the reductions.
 #include "gpbo_internal.h"
+#include "lml_bodies.h"
 
 namespace gpbo {
-
-__device__ __forceinline__ double block_sum_256(double v, double* sh) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __syncthreads();
-  if (lane == 0) sh[wave] = v;
-  __syncthreads();
-  return ((sh[0] + sh[1]) + sh[2]) + sh[3];
-}
 
 // out[0] = y . alpha ; out[1] = sum_i log L_ii
 __global__ __launch_bounds__(256) void lml_terms_kernel(const double* __restrict__ y, const double* __restrict__ alpha,
                                                         const double* __restrict__ L, int64_t N, int64_t NP,
                                                         double* __restrict__ out, int64_t lane_stride) {
   __shared__ double sh[4];
-  y += (int64_t)blockIdx.x * lane_stride;
-  alpha += (int64_t)blockIdx.x * lane_stride;
-  L += (int64_t)blockIdx.x * lane_stride;
-  out += (int64_t)blockIdx.x * lane_stride;
-  double a = 0.0, b = 0.0;
-  for (int64_t i = threadIdx.x; i < N; i += 256) {
-    a = fma(y[i], alpha[i], a);
-    b += log(L[i * NP + i]);
-  }
-  const double sa = block_sum_256(a, sh);
-  const double sb = block_sum_256(b, sh);
-  if (threadIdx.x == 0) {
-    out[0] = sa;
-    out[1] = sb;
-  }
+  const int64_t lo = (int64_t)blockIdx.x * lane_stride;
+  lml_terms_body(y + lo, alpha + lo, L + lo, N, NP, out + lo, sh, (int)threadIdx.x, true);
 }
 
 // One workgroup per lower 64x64 tile: sum over the tile of (alpha_i alpha_j - Kinv_ij) * dK_ij/dtheta_t.
@@ -51,94 +29,17 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(const double* __restrict_
                                                        int64_t lane_stride) {
   const int bj = blockIdx.x, bi = blockIdx.y;
   if (bj > bi) return;
-  Xs += (int64_t)blockIdx.z * lane_stride;
-  alpha += (int64_t)blockIdx.z * lane_stride;
-  Kinv += (int64_t)blockIdx.z * lane_stride;
-  partial += (int64_t)blockIdx.z * lane_stride;
+  const int64_t lo = (int64_t)blockIdx.z * lane_stride;
   extern __shared__ __attribute__((aligned(16))) double lg_smem[];
-  double* XiT = lg_smem;             // [DP][64]
-  double* XjT = lg_smem + DP * 64;   // [DP][64]
-  double* sh = XjT + DP * 64;        // [4]
-  const int tid = threadIdx.x;
-  for (int e = tid; e < 64 * DP; e += 256) {
-    int r = e / DP, t = e - r * DP;
-    XiT[t * 64 + r] = Xs[((int64_t)bi * 64 + r) * DP + t];
-    XjT[t * 64 + r] = Xs[((int64_t)bj * 64 + r) * DP + t];
-  }
-  __syncthreads();
-  const int ty = tid >> 4, tx = tid & 15;
-  double d2[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) d2[a][b] = 0.0;
-  for (int t = 0; t < DP; ++t) {
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const double df = XiT[t * 64 + ty * 4 + a] - XjT[t * 64 + tx * 4 + b];
-        d2[a][b] = fma(df, df, d2[a][b]);
-      }
-  }
-  const double wgt = (bi == bj) ? 1.0 : 2.0;   // off-diagonal tiles stand for their mirror image too
-  double coef[4][4];
-  double s_iso = 0.0;
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int64_t i = (int64_t)bi * 64 + ty * 4 + a;
-    const double ai = (i < N) ? alpha[i] : 0.0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int64_t j = (int64_t)bj * 64 + tx * 4 + b;
-      double c = 0.0;
-      if (i < N && j < N && i != j) {
-        const double aj = alpha[j];
-        const double kin = Kinv[i * NP + j];
-        double g;
-        if (KERNEL == GPBO_KERNEL_MATERN25) {
-          const double tmp = sqrt(5.0 * d2[a][b]);
-          g = 5.0 / 3.0 * (tmp + 1.0) * gpbo_exp_nonpos(-tmp);
-        } else {
-          g = gpbo_exp_nonpos(-0.5 * d2[a][b]);
-        }
-        c = wgt * (ai * aj - kin) * g;
-      }
-      coef[a][b] = c;
-      s_iso = fma(c, d2[a][b], s_iso);
-    }
-  }
-  const int64_t tile = (int64_t)bi * (bi + 1) / 2 + bj;
-  if (n_ls == 1) {
-    const double tot = block_sum_256(s_iso, sh);
-    if (tid == 0) partial[tile] = tot;
-  } else {
-    for (int t = 0; t < n_ls; ++t) {
-      double s = 0.0;
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const double df = XiT[t * 64 + ty * 4 + a] - XjT[t * 64 + tx * 4 + b];
-          s = fma(coef[a][b], df * df, s);
-        }
-      const double tot = block_sum_256(s, sh);
-      if (tid == 0) partial[tile * n_ls + t] = tot;
-    }
-  }
+  lml_grad_tile_body<KERNEL>(Xs + lo, DP, n_ls, N, NP, alpha + lo, Kinv + lo, partial + lo, bi, bj, lg_smem, (int)threadIdx.x, true);
 }
 
 // out[t] = 0.5 * sum over tiles (fixed order) of partial[tile][t]
 __global__ __launch_bounds__(256) void lml_grad_final_kernel(const double* __restrict__ partial, int64_t ntiles,
                                                              int n_ls, double* __restrict__ out, int64_t lane_stride) {
   __shared__ double sh[4];
-  const int t = blockIdx.x;
-  partial += (int64_t)blockIdx.y * lane_stride;
-  out += (int64_t)blockIdx.y * lane_stride;
-  double s = 0.0;
-  for (int64_t k = threadIdx.x; k < ntiles; k += 256) s += partial[k * n_ls + t];
-  const double tot = block_sum_256(s, sh);
-  if (threadIdx.x == 0) out[t] = 0.5 * tot;
+  const int64_t lo = (int64_t)blockIdx.y * lane_stride;
+  lml_grad_final_body(partial + lo, ntiles, n_ls, out + lo, (int)blockIdx.x, sh, (int)threadIdx.x, true);
 }
 
 int launch_lml_terms(gpbo_ctx* ctx, Model& m, double* out2_dev) {
