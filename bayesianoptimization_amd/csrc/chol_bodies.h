@@ -363,12 +363,11 @@ __device__ __forceinline__ void inverse_colblock_of(const double* Lc, const doub
 //   waves 0-3: inv(L00), waves 4-7: inv(L11), one 16-column block each (the second in reverse order: SIMD balance).
 __device__ __forceinline__ void diag128_body(double* __restrict__ L, const int64_t ld, const int kb, const int nblk,
                                              double* __restrict__ dinv, int* __restrict__ info, double* smem,
-                                             long long* __restrict__ stamps) {
+                                             long long* __restrict__ stamps, const int tid) {
   double* Lc0 = smem + C128_LC0;
   double* LcX = smem + C128_LCX;
   double* Wr = smem + C128_WR;
   int* flags = reinterpret_cast<int*>(smem + C128_FLAGS);
-  const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i = (lane + 8 * w) & 63;        // the wave's diagonal 8x8 block in lanes 0..7; rows are what every address is computed from

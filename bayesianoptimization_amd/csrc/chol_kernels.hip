@@ -31,7 +31,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int zl = (int)blockIdx.y;
   if (blockIdx.x == 0) {
     diag128_body(L + (int64_t)zl * lane_stride, ld, kb, nblk, dinv + (int64_t)zl * lane_stride, info + (int64_t)zl * lane_stride * 2,
-                 c128_smem, stamps);
+                 c128_smem, stamps, (int)threadIdx.x);
     return;
   }
   const int half = (int)(threadIdx.x >> 8);

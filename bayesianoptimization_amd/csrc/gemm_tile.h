@@ -18,6 +18,19 @@ constexpr int GT_LDS_DOUBLES = 2 * 2 * 16 * 68;   // two stages x (A | B) x [16]
 // D lane l, reg r = D[(l>>4) + 4r][l&15].
 typedef double d2v __attribute__((ext_vector_type(2)));
 
+// How many workgroup barriers gemm_tile_body executes for tile (bm, bn): 0 for a tile it skips, else one after the prologue and one
+// per 16-deep stage.  (fused_small.hip runs two tiles side by side in one 512-thread workgroup and evens the counts out.)
+__device__ __forceinline__ int gemm_tile_barriers(const GemmArgs& g, const int bm, const int bn) {
+  if (g.lower_only && bn > bm) return 0;
+  if (bn < g.skip00 && bm < g.skip00) return 0;
+  int kbeg = 0, kend = g.k;
+  if (g.a_lower) kend = min(kend, (bm + 1) * 64);
+  if (g.b_lower) kbeg = bn * 64;
+  if (g.k_from_tile) kbeg = max(bm, bn) * 64;
+  const int nst = (kend - kbeg) / 16;
+  return nst > 0 ? 1 + nst : 0;
+}
+
 template <bool BT, bool AT>
 // `tid` = the thread's index inside the 256 threads working on this tile (a 512-thread workgroup runs two tiles side by
 // side, each with its own LDS area and the same number of barriers); `write` false = go through the motions on a valid

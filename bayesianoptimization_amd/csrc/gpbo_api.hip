@@ -206,6 +206,10 @@ int gpbo_create(int device, gpbo_ctx** out) {
   if (e == hipSuccess) e = hipMalloc((void**)&ctx->info_dev, sizeof(int));
   if (e == hipSuccess) e = hipHostMalloc(&ctx->pinned, PIN_WINDOWS * PIN_WINDOW, hipHostMallocDefault);
   if (e == hipSuccess) ctx->pinned_aux = (char*)ctx->pinned + (PIN_WINDOWS - 1) * PIN_WINDOW;
+  if (e == hipSuccess) {
+    ctx->pinned_base = ctx->pinned;
+    e = hipHostGetDevicePointer((void**)&ctx->pinned_base_dev, ctx->pinned_base, 0);
+  }
   if (e == hipSuccess) e = hipHostMalloc(&ctx->small_pinned, SMALL_PIN_BYTES, hipHostMallocDefault);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->small_ev, hipEventDisableTiming);
   if (e == hipSuccess) {
@@ -238,6 +242,7 @@ int gpbo_destroy(gpbo_ctx* ctx) {
   if (ctx->small_ev) (void)hipEventDestroy(ctx->small_ev);
   if (ctx->small_pinned) (void)hipHostFree(ctx->small_pinned);
   if (ctx->polish_pinned) (void)hipHostFree(ctx->polish_pinned);
+  if (ctx->fused_stage) (void)hipHostFree(ctx->fused_stage);
   if (ctx->info_slots) (void)hipFree(ctx->info_slots);
   for (auto& ln : ctx->lml_lane) if (ln.exec) (void)hipGraphExecDestroy(ln.exec);
   if (ctx->lml_slab) (void)hipFree(ctx->lml_slab);
@@ -252,7 +257,7 @@ int gpbo_destroy(gpbo_ctx* ctx) {
 
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->pinned_base) (void)hipHostFree(ctx->pinned_base);
   for (auto& e : ctx->ev) {
     if (e.a) (void)hipEventDestroy(e.a);
     if (e.b) (void)hipEventDestroy(e.b);
@@ -321,9 +326,60 @@ static_assert(GPBO_LML_BATCH_MAX * PIN_LS_PITCH <= PIN_LANE_INFO, "lane length s
 static_assert(PIN_LANE_INFO + GPBO_LML_BATCH_MAX * PIN_INFO_PITCH <= PIN_LANE_OUT, "lane info words overlap the lane LML scalars");
 static_assert(PIN_LANE_OUT + GPBO_LML_BATCH_MAX * PIN_OUT_PITCH <= PIN_WINDOW, "lane LML scalars leave the window");
 
+// Small problems (NP <= fused_max_np()): the whole fit — or LML evaluation — as ONE launch of one workgroup per model
+// (fused_small.hip; bitwise the multi-launch sequence below).  mode 0: fit incl. the packed W; 1 / 2: LML value / value + gradient.
+// src 0: raw inputs (host arrays staged through pinned memory the kernel reads directly, or device arrays X_dev / y_dev) and the
+// length scales of the pinned window; src 1: the model's resident Xs / yn / ls.  The pivot word and the LML scalars land in the
+// pinned words *info_host / *out_host (valid after the stream has drained) without copy nodes.
+static bool use_fused(const Model& m) { return m.NP <= fused_max_np(); }
+
+static int enqueue_fused(gpbo_ctx* ctx, Model& m, const double* X, const double* y_norm, const double* X_dev, const double* y_dev,
+                         double noise, int mode, int n_ls, int src, int** info_host, double** out_host) {
+  int rc;
+  m.noise = noise;
+  const double *Xd = X_dev, *yd = y_dev;
+  if (src == 0 && !X_dev) {
+    if (!ctx->fused_stage) {
+      GPBO_HIP(ctx, hipHostMalloc(&ctx->fused_stage, PIN_WINDOWS * FUSED_STAGE_BYTES, hipHostMallocDefault));
+      GPBO_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->fused_stage_dev, ctx->fused_stage, 0));
+    }
+    // window 0: the context's own stream (every such call ends with a stream synchronisation); 1 + slot: a gpbo_fit_begin in flight
+    const size_t w = (size_t)((char*)ctx->pinned - (char*)ctx->pinned_base) / PIN_WINDOW;
+    double* h = (double*)((char*)ctx->fused_stage + w * FUSED_STAGE_BYTES);
+    memcpy(h, X, (size_t)m.N * m.d * sizeof(double));
+    memcpy(h + (size_t)FUSED_NP_CAP * GPBO_MAX_DIM, y_norm, (size_t)m.N * sizeof(double));
+    Xd = (const double*)(ctx->fused_stage_dev + w * FUSED_STAGE_BYTES);
+    yd = Xd + (size_t)FUSED_NP_CAP * GPBO_MAX_DIM;
+  }
+  double* scal = m.tmp;
+  if (mode != 0) {
+    char* p = (char*)ctx->red;
+    int64_t cap = ctx->cap_red;
+    if ((rc = ensure(ctx, &p, &cap, (int64_t)(8 + GPBO_MAX_DIM) * 8))) return rc;
+    ctx->red = p;
+    ctx->cap_red = cap;
+    scal = (double*)ctx->red;
+  }
+  auto dev_of = [&](void* host) { return ctx->pinned_base_dev + ((char*)host - (char*)ctx->pinned_base); };
+  int* info_h = (int*)((char*)ctx->pinned + (ctx->lanes == 1 ? PIN_INFO : PIN_LANE_INFO));
+  double* out_h = (double*)((char*)ctx->pinned + (ctx->lanes == 1 ? PIN_LML_OUT : PIN_LANE_OUT));
+  ev_begin(ctx, T_FIT);
+  if (!ctx->no_timing) ctx->ev[T_KMAT].used = ctx->ev[T_CHOL].used = ctx->ev[T_TRTRI].used = false;   // one kernel: no phase events
+  if ((rc = launch_fused_small(ctx, m, mode, src, n_ls, Xd, yd, (const double*)dev_of(ctx->pinned), scal, (int*)dev_of(info_h),
+                               (int64_t)(PIN_INFO_PITCH / sizeof(int)), mode ? (double*)dev_of(out_h) : nullptr,
+                               (int64_t)(PIN_OUT_PITCH / sizeof(double)))))
+    return rc;
+  if (mode == 0) m.wp_packed = true;
+  else ev_end(ctx, T_FIT);
+  *info_host = info_h;
+  if (out_host) *out_host = out_h;
+  return GPBO_OK;
+}
+
 // K, L, W = L^-1 and alpha from the device-resident scaled inputs m.Xs / targets m.yn (m.N, m.NP, m.kernel set).
 static int factor_resident(gpbo_ctx* ctx, Model& m, double noise, int** info_host) {
   int rc;
+  if (use_fused(m)) return enqueue_fused(ctx, m, nullptr, nullptr, nullptr, nullptr, noise, 0, 0, 1, info_host, nullptr);   // (gpbo_fit_append's rebuild)
   m.noise = noise;
   GPBO_HIP(ctx, lane_memset(ctx, ctx->info_dev, sizeof(int)));
   ev_begin(ctx, T_KMAT);
@@ -379,6 +435,7 @@ static int enqueue_factor(gpbo_ctx* ctx, Model& m, const double* X, const double
                           const double* y_dev, double noise, int** info_host) {
   int rc;
   const int64_t N = m.N, NP = m.NP;
+  if (use_fused(m)) return enqueue_fused(ctx, m, X, y_norm, X_dev, y_dev, noise, 0, 0, 0, info_host, nullptr);
   ev_begin(ctx, T_FIT);
   GPBO_HIP(ctx, lane_h2d(ctx, m.ls, ctx->pinned, PIN_LS_PITCH, GPBO_MAX_DIM * sizeof(double)));
   GPBO_HIP(ctx, lane_memset(ctx, m.yn, (size_t)NP * sizeof(double)));
@@ -406,7 +463,8 @@ static int factorize(gpbo_ctx* ctx, Model& m, const char* who, const double* X, 
 // Tail shared by the fit entry points: pack W for the posterior kernels (enqueue), then wait and resolve the pivot check.
 static int finish_enqueue(gpbo_ctx* ctx, Model& m) {
   int rc;
-  if ((rc = launch_pack_w(ctx, m))) return rc;
+  if (!m.wp_packed && (rc = launch_pack_w(ctx, m))) return rc;
+  m.wp_packed = false;
   if (m.precision == GPBO_F32) {   // fp32 posterior: W rounded to fp32 in f32-MFMA fragment order (fit itself is fp64)
     if ((rc = ensure(ctx, &m.Wp32, &m.cap_Wp32, m.NP * m.NP))) return rc;
     if ((rc = launch_pack_w32(ctx, m))) return rc;
@@ -601,8 +659,10 @@ static int lml_tail(gpbo_ctx* ctx, Model& m, int n_ls, int eval_gradient, double
 static int lml_enqueue(gpbo_ctx* ctx, Model& m, const double* X, const double* y_norm, int64_t N, int d, int kernel,
                        const double* length_scale, int n_ls, double noise, int eval_gradient, double** out_host,
                        int** info_host) {
-  int rc = factorize(ctx, m, "gpbo_lml", X, y_norm, N, d, kernel, length_scale, n_ls, noise, GPBO_F64, info_host);
+  int rc = prepare_model(ctx, m, "gpbo_lml", X && y_norm, N, d, kernel, length_scale, n_ls, noise, GPBO_F64);
   if (rc) return rc;
+  if (use_fused(m)) return enqueue_fused(ctx, m, X, y_norm, nullptr, nullptr, noise, eval_gradient ? 2 : 1, n_ls, 0, info_host, out_host);
+  if ((rc = enqueue_factor(ctx, m, X, y_norm, nullptr, nullptr, noise, info_host))) return rc;
   return lml_tail(ctx, m, n_ls, eval_gradient, out_host);
 }
 
@@ -763,7 +823,9 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
     ctx->no_timing = true;
     static const bool la_lanes = dbg_env("GPBO_CHOL_LA_LANES") && dbg_env("GPBO_CHOL_LA_LANES")[0] == '1';
     ctx->no_lookahead = n_groups > 1 && !la_lanes;
+    const bool fused = use_fused(m);     // one launch for the whole group: nothing to capture
     auto enqueue = [&](double** oh, int** ih) {
+      if (fused) return enqueue_fused(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, eval_gradient ? 2 : 1, n_ls, 0, ih, oh);
       int r = enqueue_factor(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, ih);
       if (r == GPBO_OK) r = lml_tail(ctx, m, n_ls, eval_gradient, oh);
       return r;
@@ -775,13 +837,13 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
                       key.eval_gradient == eval_gradient && key.noise == noise && key.lanes == gl &&
                       key.X == ctx->lml_X && key.y == ctx->lml_y && key.K == gbase;
     bool launched = false;
-    if (same && key.exec) {
+    if (same && key.exec && !fused) {
       hipError_t e = hipGraphLaunch(key.exec, ctx->stream);
       if (e != hipSuccess) { restore(); GPBO_HIP(ctx, e); }
       launched = true;
     } else {
       if (key.exec) { (void)hipGraphExecDestroy(key.exec); key.exec = nullptr; }
-      if (same && graphs_allowed && !ctx->lml_graph_off) {
+      if (same && graphs_allowed && !ctx->lml_graph_off && !fused) {
         hipGraph_t graph = nullptr;
         double* oh = nullptr; int* ih = nullptr;
         hipError_t e;

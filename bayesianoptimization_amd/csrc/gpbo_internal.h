@@ -25,6 +25,7 @@ enum TimingSlot {
 
 struct Model {
   bool fitted = false;
+  bool wp_packed = false;  // the fused small-problem fit has already written Wp (finish_enqueue skips pack_w_kernel)
   int64_t N = 0, NP = 0;   // observations, padded to a multiple of NB
   int d = 0, DP = 0;       // input dimension, padded to {4,8,16,32,64}
   int kernel = 0;
@@ -133,6 +134,10 @@ struct gpbo_ctx {
   int64_t cap_red = 0;
   int* info_dev = nullptr; // potrf info word
   void* pinned = nullptr;  // pinned host staging: window 0 = fit/LML words (PIN_* below), windows 1..8 = gpbo_lml_batch groups
+  void* pinned_base = nullptr;      // the allocation `pinned` points into (never re-pointed) and the address the device sees it at:
+  char* pinned_base_dev = nullptr;  // fused_small.hip reads length scales from it and writes pivot word / LML scalars into it
+  void* fused_stage = nullptr;      // pinned: X / y of a small host-side fit per window (FUSED_STAGE_BYTES each), read by the fused kernel
+  char* fused_stage_dev = nullptr;
   void* pinned_aux = nullptr;   // last window of the same allocation: selection / candidate staging (PIN_AUX_*); never re-pointed
   int* negvar = nullptr;        // device-visible address of the PIN_AUX_NEGVAR word
   // small batches (the host optimisers' rounds: tens to hundreds of points per call, hundreds of calls per suggest):
@@ -163,7 +168,10 @@ namespace gpbo {
 
 constexpr size_t SMALL_PIN_IN = 128 * 1024, SMALL_PIN_OUT = 32 * 1024;   // bytes: candidates in; mu, sd out (each)
 constexpr size_t SMALL_PIN_BYTES = SMALL_PIN_IN + 2 * SMALL_PIN_OUT;
-constexpr unsigned ATTR_GEMM128 = 4u, ATTR_CHOL128 = 16u;
+constexpr unsigned ATTR_GEMM128 = 4u, ATTR_CHOL128 = 16u, ATTR_FUSED = 32u;
+// fused_small.hip: the whole fit / LML evaluation of a problem of NP <= fused_max_np() as one launch of one workgroup per model
+constexpr int FUSED_NP_DEFAULT = 128, FUSED_NP_CAP = 512;
+constexpr size_t FUSED_STAGE_BYTES = ((size_t)FUSED_NP_CAP * GPBO_MAX_DIM + FUSED_NP_CAP) * sizeof(double);   // X (N, d) | y (N)
 
 // ---- pinned host staging layout -------------------------------------------------------------------------------
 // ONE allocation of PIN_WINDOWS windows of PIN_WINDOW bytes.  Window 0 (ctx->pinned) carries the words of a fit /
@@ -335,6 +343,12 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g);
 // chol_kernels.hip: blocked Cholesky of m.L in place + inverted 64x64 diagonal blocks (128-column steps, `outer`-column panels);
 // stamps (device, >= 8 words, may be null): in-kernel clocks of the first diagonal workgroup
 int launch_cholesky128(gpbo_ctx* ctx, Model& m, int outer, long long* stamps);
+// fused_small.hip: the fit (mode 0: ... + packed W) or an LML evaluation (1: value, 2: value + gradient) of m (and, in lane mode, of
+// ctx->lanes models) as ONE launch; src 0: raw X / y / ls_in given (device-visible), 1: m.Xs / m.yn / m.ls resident.  The pivot word
+// and the LML scalars land in the device-visible host words info_out / out (pitches per lane, in ints / doubles).
+int fused_max_np();
+int launch_fused_small(gpbo_ctx* ctx, Model& m, int mode, int src, int n_ls, const double* X, const double* y, const double* ls_in,
+                       double* scal, int* info_out, int64_t info_pitch, double* out, int64_t out_pitch);
 // posterior_kernel.hip
 int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std);
 int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std, double** dmu_dev, double** dsd_dev,
