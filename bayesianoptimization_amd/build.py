@@ -37,7 +37,8 @@ SOURCES = {
     "posterior_kernel_f32.hip": [],
     "posterior_cov.hip": [],
     "lml_kernels.hip": [],
-    "fused_small.hip": [],                     # fit / LML evaluation of a small problem (NP <= 128) as ONE launch of ONE workgroup
+    "fused_small.hip": [],                     # fit / LML evaluation of a small problem (NP <= 64) as ONE launch of ONE workgroup
+    "mid_fit.hip": [],                         # 64 < NP <= 512: inputs, quarter-tile K, W = L^-1 by column strips, alpha (~15 launches per fit)
     "acq_kernels.hip": ["-ffp-contract=off"],  # elementwise formulas follow NumPy op by op
     "candidates.hip": [],
     "mt19937.hip": ["-ffp-contract=off"],      # lo + (hi - lo) * u as NumPy computes it

@@ -272,7 +272,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (fs_tid() == 0) a.info_out[(int64_t)zl * a.info_pitch] = a.info[lo * 2];
 }
 
-// Largest padded size the fused kernel serves.  Up to 128 the problem is one diagonal workgroup plus a handful of tiles.  (Debug
+// Largest padded size the fused kernel serves: 64 in the product.  (At NP = 128 — still one diagonal workgroup plus a handful of
+// tiles — the strip path of mid_fit.hip is faster, 50 against 79 us per fit and 94 against 118 per LML + gradient; at NP = 64 the
+// one launch wins the LML evaluation, 67 against 74 us, and loses 5 us on the fit: profiles/r05_small_fit_timing.json.  Debug
 // build: GPBO_FUSED_MAX_NP = 0 / 64 / 128 / ... up to FUSED_NP_CAP, read per call, for the bitwise A/B tests and the crossover
 // measurement.)
 int fused_max_np() {

@@ -332,25 +332,35 @@ static_assert(PIN_LANE_OUT + GPBO_LML_BATCH_MAX * PIN_OUT_PITCH <= PIN_WINDOW, "
 // length scales of the pinned window; src 1: the model's resident Xs / yn / ls.  The pivot word and the LML scalars land in the
 // pinned words *info_host / *out_host (valid after the stream has drained) without copy nodes.
 static bool use_fused(const Model& m) { return m.NP <= fused_max_np(); }
+// fused_max_np() < NP <= mid_max_np(): the strip path (mid_fit.hip)
+static bool use_mid(const Model& m) { return !use_fused(m) && m.NP <= mid_max_np(); }
+
+// the address the device sees a word of the pinned window allocation at
+static char* pinned_dev(gpbo_ctx* ctx, void* host) { return ctx->pinned_base_dev + ((char*)host - (char*)ctx->pinned_base); }
+
+// X (N, d) | y (N) of a small host-side fit copied into the pinned staging window that belongs to ctx->pinned's window (0: the
+// context's own stream, every such call ends with a stream synchronisation; 1 + slot: a gpbo_fit_begin in flight); the first
+// kernel of the fit reads them there.
+static int stage_small_inputs(gpbo_ctx* ctx, const Model& m, const double* X, const double* y_norm, const double** Xd, const double** yd) {
+  if (!ctx->fused_stage) {
+    GPBO_HIP(ctx, hipHostMalloc(&ctx->fused_stage, PIN_WINDOWS * FUSED_STAGE_BYTES, hipHostMallocDefault));
+    GPBO_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->fused_stage_dev, ctx->fused_stage, 0));
+  }
+  const size_t w = (size_t)((char*)ctx->pinned - (char*)ctx->pinned_base) / PIN_WINDOW;
+  double* h = (double*)((char*)ctx->fused_stage + w * FUSED_STAGE_BYTES);
+  memcpy(h, X, (size_t)m.N * m.d * sizeof(double));
+  memcpy(h + (size_t)STAGE_NP_CAP * GPBO_MAX_DIM, y_norm, (size_t)m.N * sizeof(double));
+  *Xd = (const double*)(ctx->fused_stage_dev + w * FUSED_STAGE_BYTES);
+  *yd = *Xd + (size_t)STAGE_NP_CAP * GPBO_MAX_DIM;
+  return GPBO_OK;
+}
 
 static int enqueue_fused(gpbo_ctx* ctx, Model& m, const double* X, const double* y_norm, const double* X_dev, const double* y_dev,
                          double noise, int mode, int n_ls, int src, int** info_host, double** out_host) {
   int rc;
   m.noise = noise;
   const double *Xd = X_dev, *yd = y_dev;
-  if (src == 0 && !X_dev) {
-    if (!ctx->fused_stage) {
-      GPBO_HIP(ctx, hipHostMalloc(&ctx->fused_stage, PIN_WINDOWS * FUSED_STAGE_BYTES, hipHostMallocDefault));
-      GPBO_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->fused_stage_dev, ctx->fused_stage, 0));
-    }
-    // window 0: the context's own stream (every such call ends with a stream synchronisation); 1 + slot: a gpbo_fit_begin in flight
-    const size_t w = (size_t)((char*)ctx->pinned - (char*)ctx->pinned_base) / PIN_WINDOW;
-    double* h = (double*)((char*)ctx->fused_stage + w * FUSED_STAGE_BYTES);
-    memcpy(h, X, (size_t)m.N * m.d * sizeof(double));
-    memcpy(h + (size_t)FUSED_NP_CAP * GPBO_MAX_DIM, y_norm, (size_t)m.N * sizeof(double));
-    Xd = (const double*)(ctx->fused_stage_dev + w * FUSED_STAGE_BYTES);
-    yd = Xd + (size_t)FUSED_NP_CAP * GPBO_MAX_DIM;
-  }
+  if (src == 0 && !X_dev && (rc = stage_small_inputs(ctx, m, X, y_norm, &Xd, &yd))) return rc;
   double* scal = m.tmp;
   if (mode != 0) {
     char* p = (char*)ctx->red;
@@ -360,14 +370,13 @@ static int enqueue_fused(gpbo_ctx* ctx, Model& m, const double* X, const double*
     ctx->cap_red = cap;
     scal = (double*)ctx->red;
   }
-  auto dev_of = [&](void* host) { return ctx->pinned_base_dev + ((char*)host - (char*)ctx->pinned_base); };
   int* info_h = (int*)((char*)ctx->pinned + (ctx->lanes == 1 ? PIN_INFO : PIN_LANE_INFO));
   double* out_h = (double*)((char*)ctx->pinned + (ctx->lanes == 1 ? PIN_LML_OUT : PIN_LANE_OUT));
   ev_begin(ctx, T_FIT);
   if (!ctx->no_timing) ctx->ev[T_KMAT].used = ctx->ev[T_CHOL].used = ctx->ev[T_TRTRI].used = false;   // one kernel: no phase events
-  if ((rc = launch_fused_small(ctx, m, mode, src, n_ls, Xd, yd, (const double*)dev_of(ctx->pinned), scal, (int*)dev_of(info_h),
-                               (int64_t)(PIN_INFO_PITCH / sizeof(int)), mode ? (double*)dev_of(out_h) : nullptr,
-                               (int64_t)(PIN_OUT_PITCH / sizeof(double)))))
+  if ((rc = launch_fused_small(ctx, m, mode, src, n_ls, Xd, yd, (const double*)pinned_dev(ctx, ctx->pinned), scal,
+                               (int*)pinned_dev(ctx, info_h), (int64_t)(PIN_INFO_PITCH / sizeof(int)),
+                               mode ? (double*)pinned_dev(ctx, out_h) : nullptr, (int64_t)(PIN_OUT_PITCH / sizeof(double)))))
     return rc;
   if (mode == 0) m.wp_packed = true;
   else ev_end(ctx, T_FIT);
@@ -376,12 +385,29 @@ static int enqueue_fused(gpbo_ctx* ctx, Model& m, const double* X, const double*
   return GPBO_OK;
 }
 
+// The strip path behind its inputs: K (quarter tiles) -> Cholesky -> W by column strips (+ the packed W of a fit) -> alpha; the
+// pivot word reaches its pinned word from the last kernel.
+static int factor_mid(gpbo_ctx* ctx, Model& m, double noise, bool pack, int** info_host) {
+  int rc;
+  m.noise = noise;
+  if (!ctx->no_timing) ctx->ev[T_KMAT].used = ctx->ev[T_CHOL].used = ctx->ev[T_TRTRI].used = false;   // no phase events on this path
+  if ((rc = launch_kmat_q(ctx, m, noise, m.L))) return rc;
+  if ((rc = cholesky(ctx, m))) return rc;
+  if ((rc = launch_w_strip(ctx, m, pack))) return rc;
+  int* info_h = (int*)((char*)ctx->pinned + (ctx->lanes == 1 ? PIN_INFO : PIN_LANE_INFO));
+  if ((rc = launch_alpha_strip(ctx, m, (int*)pinned_dev(ctx, info_h), (int64_t)(PIN_INFO_PITCH / sizeof(int))))) return rc;
+  if (pack && m.Wp) m.wp_packed = true;
+  *info_host = info_h;
+  return GPBO_OK;
+}
+
 // K, L, W = L^-1 and alpha from the device-resident scaled inputs m.Xs / targets m.yn (m.N, m.NP, m.kernel set).
-static int factor_resident(gpbo_ctx* ctx, Model& m, double noise, int** info_host) {
+static int factor_resident(gpbo_ctx* ctx, Model& m, double noise, int** info_host, bool pack = true) {
   int rc;
   if (use_fused(m)) return enqueue_fused(ctx, m, nullptr, nullptr, nullptr, nullptr, noise, 0, 0, 1, info_host, nullptr);   // (gpbo_fit_append's rebuild)
   m.noise = noise;
   GPBO_HIP(ctx, lane_memset(ctx, ctx->info_dev, sizeof(int)));
+  if (use_mid(m)) return factor_mid(ctx, m, noise, pack, info_host);
   ev_begin(ctx, T_KMAT);
   if ((rc = launch_kmat(ctx, m, noise, m.L))) return rc;   // straight into the buffer the Cholesky factorises in place
   ev_end(ctx, T_KMAT);
@@ -432,10 +458,17 @@ static int prepare_model(gpbo_ctx* ctx, Model& m, const char* who, bool have_inp
 // The fit enqueued on ctx->stream: inputs from the host (X, y_norm) or already on the device (X_dev raw (N, d), y_dev),
 // then K, L, W, alpha.  With device inputs every operation is capturable into a hipGraph.
 static int enqueue_factor(gpbo_ctx* ctx, Model& m, const double* X, const double* y_norm, const double* X_dev,
-                          const double* y_dev, double noise, int** info_host) {
+                          const double* y_dev, double noise, int** info_host, bool pack = true) {
   int rc;
   const int64_t N = m.N, NP = m.NP;
   if (use_fused(m)) return enqueue_fused(ctx, m, X, y_norm, X_dev, y_dev, noise, 0, 0, 0, info_host, nullptr);
+  if (use_mid(m)) {      // inputs straight from pinned host memory (or the resident device copies): no copy / fill nodes
+    const double *Xd = X_dev, *yd = y_dev;
+    if (!X_dev && (rc = stage_small_inputs(ctx, m, X, y_norm, &Xd, &yd))) return rc;
+    ev_begin(ctx, T_FIT);
+    if ((rc = launch_mid_inputs(ctx, m, Xd, yd, (const double*)pinned_dev(ctx, ctx->pinned)))) return rc;
+    return factor_mid(ctx, m, noise, pack, info_host);
+  }
   ev_begin(ctx, T_FIT);
   GPBO_HIP(ctx, lane_h2d(ctx, m.ls, ctx->pinned, PIN_LS_PITCH, GPBO_MAX_DIM * sizeof(double)));
   GPBO_HIP(ctx, lane_memset(ctx, m.yn, (size_t)NP * sizeof(double)));
@@ -449,7 +482,7 @@ static int enqueue_factor(gpbo_ctx* ctx, Model& m, const double* X, const double
     GPBO_HIP(ctx, hipMemcpyAsync(m.yn, y_norm, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if ((rc = launch_prescale(ctx, m.tmp, N, m.d, m.DP, m.ls, m.Xs, NP))) return rc;
   }
-  return factor_resident(ctx, m, noise, info_host);
+  return factor_resident(ctx, m, noise, info_host, pack);
 }
 
 static int factorize(gpbo_ctx* ctx, Model& m, const char* who, const double* X, const double* y_norm, int64_t N,
@@ -627,16 +660,11 @@ int gpbo_fit_append(gpbo_ctx* ctx, int slot, const double* x_new, int64_t n_new,
 // terms, K^-1 = W^T W and the gradient reduction, and the copy of the results to the pinned words *out_host.
 static int lml_tail(gpbo_ctx* ctx, Model& m, int n_ls, int eval_gradient, double** out_host) {
   int rc;
-  // device scratch for the scalars: red buffer (>= 2 + n_ls doubles)
-  {
-    char* p = (char*)ctx->red;
-    int64_t cap = ctx->cap_red;
-    if ((rc = ensure(ctx, &p, &cap, (int64_t)(8 + GPBO_MAX_DIM) * 8))) return rc;
-    ctx->red = p;
-    ctx->cap_red = cap;
-  }
-  double* scal = (double*)ctx->red;
-  if ((rc = launch_lml_terms(ctx, m, scal))) return rc;
+  // the kernels write the scalars into the pinned words themselves (lane mode: PIN_OUT_PITCH bytes per lane): no copy node
+  double* out_h = (double*)((char*)ctx->pinned + (ctx->lanes == 1 ? PIN_LML_OUT : PIN_LANE_OUT));
+  double* out_d = (double*)pinned_dev(ctx, out_h);
+  const int64_t pitch = (int64_t)(PIN_OUT_PITCH / sizeof(double));
+  if ((rc = launch_lml_terms(ctx, m, out_d, pitch))) return rc;
   if (eval_gradient) {
     // K^-1 = W^T W (lower tiles) into the K buffer, then the trace reduction; partials go to m.tmp
     GemmArgs g{};
@@ -645,11 +673,9 @@ static int lml_tail(gpbo_ctx* ctx, Model& m, int n_ls, int eval_gradient, double
     g.B = m.W; g.ldb = m.NP;
     g.C = m.K; g.ldc = m.NP; g.batch = 1; g.lower_only = 1; g.k_from_tile = 1;
     if ((rc = launch_gemm(ctx, g))) return rc;
-    if ((rc = launch_lml_grad(ctx, m, n_ls, m.K, m.tmp, scal + 2))) return rc;
+    if ((rc = launch_lml_grad(ctx, m, n_ls, m.K, m.tmp, out_d + 2, pitch))) return rc;
   }
   ev_end(ctx, T_FIT);
-  double* out_h = (double*)((char*)ctx->pinned + (ctx->lanes == 1 ? PIN_LML_OUT : PIN_LANE_OUT));   // lane mode: PIN_OUT_PITCH bytes per lane
-  GPBO_HIP(ctx, lane_d2h(ctx, out_h, PIN_OUT_PITCH, scal, (size_t)(2 + (eval_gradient ? n_ls : 0)) * sizeof(double)));
   *out_host = out_h;
   return GPBO_OK;
 }
@@ -662,7 +688,7 @@ static int lml_enqueue(gpbo_ctx* ctx, Model& m, const double* X, const double* y
   int rc = prepare_model(ctx, m, "gpbo_lml", X && y_norm, N, d, kernel, length_scale, n_ls, noise, GPBO_F64);
   if (rc) return rc;
   if (use_fused(m)) return enqueue_fused(ctx, m, X, y_norm, nullptr, nullptr, noise, eval_gradient ? 2 : 1, n_ls, 0, info_host, out_host);
-  if ((rc = enqueue_factor(ctx, m, X, y_norm, nullptr, nullptr, noise, info_host))) return rc;
+  if ((rc = enqueue_factor(ctx, m, X, y_norm, nullptr, nullptr, noise, info_host, false))) return rc;
   return lml_tail(ctx, m, n_ls, eval_gradient, out_host);
 }
 
@@ -826,7 +852,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
     const bool fused = use_fused(m);     // one launch for the whole group: nothing to capture
     auto enqueue = [&](double** oh, int** ih) {
       if (fused) return enqueue_fused(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, eval_gradient ? 2 : 1, n_ls, 0, ih, oh);
-      int r = enqueue_factor(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, ih);
+      int r = enqueue_factor(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, ih, false);
       if (r == GPBO_OK) r = lml_tail(ctx, m, n_ls, eval_gradient, oh);
       return r;
     };
@@ -930,7 +956,7 @@ int gpbo_get_K(gpbo_ctx* ctx, int slot, double* out) {
   // the fit assembles K directly into the buffer it factorises; the parity accessor re-assembles it from the
   // device-resident scaled inputs (same kernel, same bits)
   Model& m = ctx->models[slot];
-  if ((rc = launch_kmat(ctx, m, m.noise, m.K))) return rc;
+  if ((rc = use_mid(m) ? launch_kmat_q(ctx, m, m.noise, m.K) : launch_kmat(ctx, m, m.noise, m.K))) return rc;   // the fit's own kernel
   return copy_square(ctx, m, m.K, out, 0);
 }
 int gpbo_get_L(gpbo_ctx* ctx, int slot, double* out) {

@@ -168,10 +168,15 @@ namespace gpbo {
 
 constexpr size_t SMALL_PIN_IN = 128 * 1024, SMALL_PIN_OUT = 32 * 1024;   // bytes: candidates in; mu, sd out (each)
 constexpr size_t SMALL_PIN_BYTES = SMALL_PIN_IN + 2 * SMALL_PIN_OUT;
-constexpr unsigned ATTR_GEMM128 = 4u, ATTR_CHOL128 = 16u, ATTR_FUSED = 32u;
+constexpr unsigned ATTR_GEMM128 = 4u, ATTR_CHOL128 = 16u, ATTR_FUSED = 32u, ATTR_MID = 64u;
 // fused_small.hip: the whole fit / LML evaluation of a problem of NP <= fused_max_np() as one launch of one workgroup per model
-constexpr int FUSED_NP_DEFAULT = 128, FUSED_NP_CAP = 512;
-constexpr size_t FUSED_STAGE_BYTES = ((size_t)FUSED_NP_CAP * GPBO_MAX_DIM + FUSED_NP_CAP) * sizeof(double);   // X (N, d) | y (N)
+constexpr int FUSED_NP_DEFAULT = 64, FUSED_NP_CAP = 512;
+// mid_fit.hip: fused_max_np() < NP <= mid_max_np(): the strip algorithms, ~15 launches
+constexpr int MID_NP_DEFAULT = 512, MID_NP_CAP = 1024;
+// pinned staging of a small host-side fit's X (N, d) | y (N), read by the first kernel directly (one window per PIN window)
+constexpr int STAGE_NP_CAP = MID_NP_CAP;
+static_assert(STAGE_NP_CAP >= FUSED_NP_CAP, "the staging window serves both small paths");
+constexpr size_t FUSED_STAGE_BYTES = ((size_t)STAGE_NP_CAP * GPBO_MAX_DIM + STAGE_NP_CAP) * sizeof(double);
 
 // ---- pinned host staging layout -------------------------------------------------------------------------------
 // ONE allocation of PIN_WINDOWS windows of PIN_WINDOW bytes.  Window 0 (ctx->pinned) carries the words of a fit /
@@ -349,6 +354,12 @@ int launch_cholesky128(gpbo_ctx* ctx, Model& m, int outer, long long* stamps);
 int fused_max_np();
 int launch_fused_small(gpbo_ctx* ctx, Model& m, int mode, int src, int n_ls, const double* X, const double* y, const double* ls_in,
                        double* scal, int* info_out, int64_t info_pitch, double* out, int64_t out_pitch);
+// mid_fit.hip: the strip path's launches (lane-aware through ctx->lanes / lane_stride)
+int mid_max_np();
+int launch_mid_inputs(gpbo_ctx* ctx, Model& m, const double* X, const double* y, const double* ls_in);
+int launch_kmat_q(gpbo_ctx* ctx, Model& m, double noise, double* out);
+int launch_w_strip(gpbo_ctx* ctx, Model& m, bool pack);                                   // W, the strips' share of W y (m.tmp), Wp if pack
+int launch_alpha_strip(gpbo_ctx* ctx, Model& m, int* info_out, int64_t info_pitch);     // alpha; pivot word -> info_out (device-visible host word)
 // posterior_kernel.hip
 int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std);
 int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std, double** dmu_dev, double** dsd_dev,
@@ -394,8 +405,9 @@ int small_batch_limit(int64_t NP);   // largest M the GEMV path takes (posterior
 int launch_posterior_grad_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double y_std, double* dmu_dev, double* dsd_dev,
                                 double* mu_out, double* sd_out);
 // lml_kernels.hip
-int launch_lml_terms(gpbo_ctx* ctx, Model& m, double* out2_dev);
-int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, double* partial, double* grad_dev);
+// (out / grad: lane l's words l * out_pitch doubles behind lane 0's — device memory or device-visible pinned host words)
+int launch_lml_terms(gpbo_ctx* ctx, Model& m, double* out2, int64_t out_pitch);
+int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, double* partial, double* grad, int64_t out_pitch);
 // mt_jump.hip: states_dev[w] = block 1 + poly_idx[w] * stride_blocks of the MT19937 sequence whose block 0 is key_dev
 int mt_jump_states(gpbo_ctx* ctx, const unsigned* key_dev, int64_t stride_blocks, int max_k, const int* poly_idx_dev,
                    int n_states, unsigned* seq_dev, unsigned* states_dev, unsigned* windows_dev);

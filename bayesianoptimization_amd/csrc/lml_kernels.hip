@@ -15,10 +15,10 @@ namespace gpbo {
 // out[0] = y . alpha ; out[1] = sum_i log L_ii
 __global__ __launch_bounds__(256) void lml_terms_kernel(const double* __restrict__ y, const double* __restrict__ alpha,
                                                         const double* __restrict__ L, int64_t N, int64_t NP,
-                                                        double* __restrict__ out, int64_t lane_stride) {
+                                                        double* __restrict__ out, int64_t lane_stride, int64_t out_pitch) {
   __shared__ double sh[4];
   const int64_t lo = (int64_t)blockIdx.x * lane_stride;
-  lml_terms_body(y + lo, alpha + lo, L + lo, N, NP, out + lo, sh, (int)threadIdx.x, true);
+  lml_terms_body(y + lo, alpha + lo, L + lo, N, NP, out + (int64_t)blockIdx.x * out_pitch, sh, (int)threadIdx.x, true);
 }
 
 // One workgroup per lower 64x64 tile: sum over the tile of (alpha_i alpha_j - Kinv_ij) * dK_ij/dtheta_t.
@@ -36,21 +36,22 @@ __global__ __launch_bounds__(256) void lml_grad_kernel(const double* __restrict_
 
 // out[t] = 0.5 * sum over tiles (fixed order) of partial[tile][t]
 __global__ __launch_bounds__(256) void lml_grad_final_kernel(const double* __restrict__ partial, int64_t ntiles,
-                                                             int n_ls, double* __restrict__ out, int64_t lane_stride) {
+                                                             int n_ls, double* __restrict__ out, int64_t lane_stride,
+                                                             int64_t out_pitch) {
   __shared__ double sh[4];
   const int64_t lo = (int64_t)blockIdx.y * lane_stride;
-  lml_grad_final_body(partial + lo, ntiles, n_ls, out + lo, (int)blockIdx.x, sh, (int)threadIdx.x, true);
+  lml_grad_final_body(partial + lo, ntiles, n_ls, out + (int64_t)blockIdx.y * out_pitch, (int)blockIdx.x, sh, (int)threadIdx.x, true);
 }
 
-int launch_lml_terms(gpbo_ctx* ctx, Model& m, double* out2_dev) {
-  lml_terms_kernel<<<dim3((unsigned)ctx->lanes), dim3(256), 0, ctx->stream>>>(m.yn, m.alpha, m.L, m.N, m.NP, out2_dev,
-                                                                                ctx->lane_stride);
+int launch_lml_terms(gpbo_ctx* ctx, Model& m, double* out2, int64_t out_pitch) {
+  lml_terms_kernel<<<dim3((unsigned)ctx->lanes), dim3(256), 0, ctx->stream>>>(m.yn, m.alpha, m.L, m.N, m.NP, out2,
+                                                                                ctx->lane_stride, out_pitch);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
 
 // Kinv must hold K^-1 (lower 64x64 tiles incl. full diagonal tiles); partial needs ntiles*n_ls doubles.
-int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, double* partial, double* grad_dev) {
+int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, double* partial, double* grad, int64_t out_pitch) {
   const unsigned nb = (unsigned)(m.NP / 64);
   const int64_t ntiles = (int64_t)nb * (nb + 1) / 2;
   const size_t lds = (size_t)(2 * m.DP * 64 + 8) * sizeof(double);
@@ -61,7 +62,7 @@ int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, doubl
   else
     lml_grad_kernel<GPBO_KERNEL_RBF><<<grid, dim3(256), lds, ctx->stream>>>(m.Xs, m.DP, n_ls, m.N, m.NP, m.alpha, Kinv, partial, ls);
   GPBO_HIP(ctx, hipGetLastError());
-  lml_grad_final_kernel<<<dim3((unsigned)n_ls, (unsigned)ctx->lanes), dim3(256), 0, ctx->stream>>>(partial, ntiles, n_ls, grad_dev, ls);
+  lml_grad_final_kernel<<<dim3((unsigned)n_ls, (unsigned)ctx->lanes), dim3(256), 0, ctx->stream>>>(partial, ntiles, n_ls, grad, ls, out_pitch);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }

@@ -1,10 +1,11 @@
-"""One-launch fit / LML evaluation (csrc/fused_small.hip) against the multi-launch sequence, per problem size (MI355X).
+"""Fit / LML evaluation per problem size on the three fit paths (MI355X): the multi-launch sequence, the one-workgroup kernel
+(csrc/fused_small.hip, NP <= 128) and the strip path (csrc/mid_fit.hip, NP <= 1024).
 
-    python scripts/r05_fused_small_timing.py > profiles/r05_fused_small_timing.json
+    python scripts/r05_small_fit_timing.py > profiles/r05_small_fit_timing.json
 
-Debug build (GPBO_FUSED_MAX_NP is read per call): every size is run with the fused kernel (limit 512) and without it (limit 0).
-Reported per N: the fit's device time between its HIP events, the fit's wall time as the caller sees it (gpbo_fit returns after the
-stream has drained), one LML value + gradient (gpbo_lml, wall) and six lanes of gpbo_lml_batch (wall; inputs resident).  Medians.
+Debug build (GPBO_FUSED_MAX_NP / GPBO_MID_MAX_NP are read per call).  Per N and path: the fit's device time between its HIP events,
+the fit's wall time as the caller sees it (gpbo_fit returns after the stream has drained), one LML value + gradient (gpbo_lml, wall),
+six lanes and one lane of gpbo_lml_batch (wall; inputs resident).  Medians of 40 calls after 5 warm-ups.
 """
 import json
 import os
@@ -34,16 +35,20 @@ def main():
     eng = GpEngine(0, debug=True)
     out = {"what": __doc__.strip().split("\n")[0], "d": 8, "kernel": "matern25", "rows": []}
     rng = np.random.RandomState(0)
-    for N in (16, 25, 64, 100, 128, 160, 192, 256, 320, 384, 448, 512):
-        d = 2 if N == 25 else 8
+    for N in (16, 64, 128, 160, 192, 256, 320, 384, 448, 512, 640, 768, 1024):
+        d = 8
         X = rng.uniform(0, 1, size=(N, d))
         y = np.sin(3 * X.sum(1)) + 0.05 * rng.standard_normal(N)
         yn = (y - y.mean()) / y.std()
         ls = np.array([0.7])
         th6 = np.array([[0.3], [0.5], [0.7], [0.9], [1.3], [2.0]])
         row = {"N": N, "d": d}
-        for name, limit in (("multi_launch", 0), ("fused", 512)):
-            os.environ["GPBO_FUSED_MAX_NP"] = str(limit)
+        paths = [("multi_launch", 0, 0), ("strip", 0, 1024)]
+        if N <= 128:
+            paths.append(("one_workgroup", 128, 0))
+        for name, fused, mid in paths:
+            os.environ["GPBO_FUSED_MAX_NP"] = str(fused)
+            os.environ["GPBO_MID_MAX_NP"] = str(mid)
             dev = []
 
             def fit():
@@ -60,6 +65,7 @@ def main():
         out["rows"].append(row)
         print(N, row, file=sys.stderr, flush=True)
     os.environ.pop("GPBO_FUSED_MAX_NP", None)
+    os.environ.pop("GPBO_MID_MAX_NP", None)
     print(json.dumps(out, indent=1))
 
 

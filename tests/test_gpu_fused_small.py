@@ -1,34 +1,25 @@
 """The one-launch fit / LML evaluation of small problems (csrc/fused_small.hip) against the multi-launch sequence it replaces:
 BITWISE — the fused kernel runs the same device bodies in the same order (fit_bodies.h, chol_bodies.h, gemm_tile.h, lml_bodies.h).
 
-The debug build reads GPBO_FUSED_MAX_NP per call: 0 = the multi-launch path, 128 = the product's rule, 512 = the fused kernel's
-general schedule (several diagonal blocks, panel solves, trailing tiles, ragged trtri levels) — exercised here although the product
-only sends NP <= 128 there.  What it replaces in the reference: GaussianProcessRegressor.fit at fixed theta and
+The debug build reads GPBO_FUSED_MAX_NP per call: 0 = the multi-launch path, 64 = the product's rule (above it the strip path of
+csrc/mid_fit.hip is faster: profiles/r05_small_fit_timing.json), 128 = one diagonal workgroup with its two 64-blocks, 512 = the fused
+kernel's general schedule (several diagonal blocks, panel solves, trailing tiles, ragged trtri levels) — exercised here although the
+product only sends NP <= 64 there.  What it replaces in the reference: GaussianProcessRegressor.fit at fixed theta and
 log_marginal_likelihood (sklearn _gpr.py:296-364, 575-652) at the sizes a maximize() loop lives at.
 """
-import contextlib
-import os
-
 import numpy as np
 import pytest
 
-from tests import helpers as H  # noqa: F401  (path set-up)
+from tests import helpers as H
 from oracle import gp_oracle as O
 
 pytestmark = pytest.mark.gpu
 
 
-@contextlib.contextmanager
 def fused_max_np(v):
-    old = os.environ.get("GPBO_FUSED_MAX_NP")
-    os.environ["GPBO_FUSED_MAX_NP"] = str(v)
-    try:
-        yield
-    finally:
-        if old is None:
-            os.environ.pop("GPBO_FUSED_MAX_NP", None)
-        else:
-            os.environ["GPBO_FUSED_MAX_NP"] = old
+    """The one-workgroup kernel up to NP = v, the multi-launch sequence above (the strip path of csrc/mid_fit.hip stays off: this
+    file compares against the launches the fused kernel replaces body for body)."""
+    return H.fit_paths(fused=v, mid=0)
 
 
 def problem(N, d, seed, per_dim=False):
@@ -53,7 +44,7 @@ def fit_state(eng, X, yn, kernel, ls, Xc, slot=0):
 CASES = [  # N, d, kernel, per-dimension length scales, fused limit
     (5, 2, O.RBF, False, 128), (25, 2, O.RBF, False, 128), (64, 8, O.MATERN25, True, 128), (65, 3, O.MATERN25, False, 128),
     (100, 17, O.RBF, True, 128), (128, 8, O.MATERN25, False, 128),
-    # the general schedule (not what the product dispatches: NP > 128 stays on the multi-launch path)
+    # the general schedule (not what the product dispatches)
     (129, 4, O.MATERN25, False, 512), (192, 8, O.RBF, True, 512), (256, 5, O.MATERN25, False, 512), (300, 8, O.MATERN25, True, 512),
     (448, 16, O.MATERN25, False, 512), (512, 8, O.MATERN25, False, 512),
 ]
@@ -144,8 +135,8 @@ def test_fused_overlapped_fits_append_and_not_pd(debug_engine):
 
 
 def test_product_library_uses_the_fused_kernel_and_agrees_with_the_debug_build(engine, debug_engine):
-    """The product has no switch: its NP <= 128 fits ARE the fused kernel.  Same bits as the debug build's multi-launch path."""
-    X, yn, ls, Xc = problem(77, 5, 11, True)
+    """The product has no switch: its NP <= 64 fits ARE the fused kernel.  Same bits as the debug build's multi-launch path."""
+    X, yn, ls, Xc = problem(57, 5, 11, True)
     with fused_max_np(0):
         ref = fit_state(debug_engine, X, yn, O.MATERN25, ls, Xc)
         ref_l = debug_engine.lml(X, yn, O.MATERN25, ls, 1e-6)
