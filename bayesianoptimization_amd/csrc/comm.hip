@@ -39,6 +39,7 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;      // optional: the failure path works without it, it only cannot unblock a peer
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;   // optional: only reported (gpbo_device_info)
 };
 
 static RcclApi g_rccl;
@@ -69,6 +70,7 @@ static int load_rccl(gpbo_ctx* ctx) {
   g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
   g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(h, "ncclCommAbort");
   g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+  g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommInitAll || !g_rccl.AllGather || !g_rccl.AllReduce ||
       !g_rccl.CommDestroy)
     GPBO_FAIL(ctx, GPBO_ERR_COMM, "librccl is missing a required symbol");
@@ -136,6 +138,16 @@ static void abort_comm(gpbo_ctx* ctx) {
   if (g_rccl.CommAbort) (void)g_rccl.CommAbort((ncclComm_t)c);
 }
 static void* comm_of(gpbo_ctx* ctx) { return __atomic_load_n(&ctx->comm, __ATOMIC_ACQUIRE); }
+
+// How many ranks RCCL itself says the context's communicator has (ncclCommCount): 0 = no communicator, -1 = not answered.
+// Reported by gpbo_device_info so that a multi-GPU bench line says what RCCL saw, not what the launcher asked for.
+int comm_nranks(gpbo_ctx* ctx) {
+  void* c = comm_of(ctx);
+  if (!c) return 0;
+  int n = -1;
+  if (!g_rccl.CommCount || g_rccl.CommCount((ncclComm_t)c, &n) != ncclSuccess) return -1;
+  return n;
+}
 
 // hipStreamSynchronize with a deadline; on expiry the communicator is aborted
 static int wait_collective(gpbo_ctx* ctx, const char* what) {

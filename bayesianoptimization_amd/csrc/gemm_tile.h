@@ -31,12 +31,14 @@ __device__ __forceinline__ int gemm_tile_barriers(const GemmArgs& g, const int b
   return nst > 0 ? 1 + nst : 0;
 }
 
-template <bool BT, bool AT>
+template <bool BT, bool AT, bool CT = false>
 // `tid` = the thread's index inside the 256 threads working on this tile (a 512-thread workgroup runs two tiles side by
 // side, each with its own LDS area and the same number of barriers); `write` false = go through the motions on a valid
 // tile but leave C alone (the partner half of such a workgroup when it has no tile of its own).
+// CT: the tile alpha * A B goes to the 64x64 row-major image `c_tile` (LDS of the caller: lml_kernels.hip consumes K^-1 tile
+// by tile without a round trip through memory) instead of C.
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn, int zl, int bz, double* lds, const int tid = threadIdx.x,
-                                               const bool write = true) {
+                                               const bool write = true, double* c_tile = nullptr) {
   if (g.lower_only && bn > bm) return;
   if (bn < g.skip00 && bm < g.skip00) return;      // the leading skip00 x skip00 tiles belong to other workgroups / launches
   // two LDS stages: the global loads of stage s+1 are issued before the MFMAs of stage s and parked in the other buffer
@@ -131,6 +133,15 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn
       if (st + j < nst) stage(st + j, ra[(j + 1) % GT_PF], rb[(j + 1) % GT_PF]);
   }
   if (!write) return;
+  if constexpr (CT) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c_tile[(wm + 16 * t + (lane >> 4) + 4 * r) * 64 + wn + 16 * u + (lane & 15)] = g.alpha * acc[t][u][r];
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll

@@ -277,12 +277,15 @@ int gpbo_device_info(gpbo_ctx* ctx, char* buf, int buflen) {
   if (!ctx || !buf || buflen < 64) return GPBO_ERR_INVALID;
   hipDeviceProp_t p;
   GPBO_HIP(ctx, hipGetDeviceProperties(&p, ctx->device));
+  char pci[32] = "?";
+  if (hipDeviceGetPCIBusId(pci, (int)sizeof(pci), ctx->device) != hipSuccess) { (void)hipGetLastError(); snprintf(pci, sizeof(pci), "?"); }
   snprintf(buf, buflen,
            "{\"name\": \"%s\", \"arch\": \"%s\", \"compute_units\": %d, \"clock_mhz\": %d, "
-           "\"memory_clock_mhz\": %d, \"hbm_gib\": %.1f, \"l2_mib\": %.1f, \"lds_per_block_kib\": %.0f}",
+           "\"memory_clock_mhz\": %d, \"hbm_gib\": %.1f, \"l2_mib\": %.1f, \"lds_per_block_kib\": %.0f, "
+           "\"device\": %d, \"pci_bus_id\": \"%s\", \"rank\": %d, \"world\": %d, \"rccl_nranks\": %d}",
            p.name, p.gcnArchName, p.multiProcessorCount, p.clockRate / 1000, p.memoryClockRate / 1000,
            (double)p.totalGlobalMem / (1024.0 * 1024.0 * 1024.0), (double)p.l2CacheSize / (1024.0 * 1024.0),
-           (double)p.sharedMemPerBlock / 1024.0);
+           (double)p.sharedMemPerBlock / 1024.0, ctx->device, pci, ctx->rank, ctx->world, comm_nranks(ctx));
   return GPBO_OK;
 }
 
@@ -664,16 +667,21 @@ static int lml_tail(gpbo_ctx* ctx, Model& m, int n_ls, int eval_gradient, double
   double* out_h = (double*)((char*)ctx->pinned + (ctx->lanes == 1 ? PIN_LML_OUT : PIN_LANE_OUT));
   double* out_d = (double*)pinned_dev(ctx, out_h);
   const int64_t pitch = (int64_t)(PIN_OUT_PITCH / sizeof(double));
-  if ((rc = launch_lml_terms(ctx, m, out_d, pitch))) return rc;
+  if (!eval_gradient && (rc = launch_lml_terms(ctx, m, out_d, pitch))) return rc;
   if (eval_gradient) {
-    // K^-1 = W^T W (lower tiles) into the K buffer, then the trace reduction; partials go to m.tmp
-    GemmArgs g{};
-    g.m = (int)m.NP; g.n = (int)m.NP; g.k = (int)m.NP; g.alpha = 1.0; g.beta = 0.0;
-    g.A = m.W; g.lda = m.NP; g.a_trans = 1;
-    g.B = m.W; g.ldb = m.NP;
-    g.C = m.K; g.ldc = m.NP; g.batch = 1; g.lower_only = 1; g.k_from_tile = 1;
-    if ((rc = launch_gemm(ctx, g))) return rc;
-    if ((rc = launch_lml_grad(ctx, m, n_ls, m.K, m.tmp, out_d + 2, pitch))) return rc;
+    if (m.NP <= mid_max_np()) {
+      // small problems: K^-1 tile by tile inside the gradient launch (kinv_grad_kernel), the two LML terms in its final launch
+      if ((rc = launch_lml_grad(ctx, m, n_ls, nullptr, m.tmp, out_d, pitch, true))) return rc;
+    } else {
+      // K^-1 = W^T W (lower tiles) into the K buffer, then the trace reduction; partials go to m.tmp
+      GemmArgs g{};
+      g.m = (int)m.NP; g.n = (int)m.NP; g.k = (int)m.NP; g.alpha = 1.0; g.beta = 0.0;
+      g.A = m.W; g.lda = m.NP; g.a_trans = 1;
+      g.B = m.W; g.ldb = m.NP;
+      g.C = m.K; g.ldc = m.NP; g.batch = 1; g.lower_only = 1; g.k_from_tile = 1;
+      if ((rc = launch_gemm(ctx, g))) return rc;
+      if ((rc = launch_lml_grad(ctx, m, n_ls, m.K, m.tmp, out_d, pitch, true))) return rc;     // ... and the two LML terms
+    }
   }
   ev_end(ctx, T_FIT);
   *out_host = out_h;

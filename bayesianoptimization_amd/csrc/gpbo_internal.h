@@ -168,11 +168,11 @@ namespace gpbo {
 
 constexpr size_t SMALL_PIN_IN = 128 * 1024, SMALL_PIN_OUT = 32 * 1024;   // bytes: candidates in; mu, sd out (each)
 constexpr size_t SMALL_PIN_BYTES = SMALL_PIN_IN + 2 * SMALL_PIN_OUT;
-constexpr unsigned ATTR_GEMM128 = 4u, ATTR_CHOL128 = 16u, ATTR_FUSED = 32u, ATTR_MID = 64u;
+constexpr unsigned ATTR_GEMM128 = 4u, ATTR_CHOL128 = 16u, ATTR_FUSED = 32u, ATTR_MID = 64u, ATTR_KINV_GRAD = 128u;
 // fused_small.hip: the whole fit / LML evaluation of a problem of NP <= fused_max_np() as one launch of one workgroup per model
 constexpr int FUSED_NP_DEFAULT = 64, FUSED_NP_CAP = 512;
 // mid_fit.hip: fused_max_np() < NP <= mid_max_np(): the strip algorithms, ~15 launches
-constexpr int MID_NP_DEFAULT = 512, MID_NP_CAP = 1024;
+constexpr int MID_NP_DEFAULT = 768, MID_NP_CAP = 1024;
 // pinned staging of a small host-side fit's X (N, d) | y (N), read by the first kernel directly (one window per PIN window)
 constexpr int STAGE_NP_CAP = MID_NP_CAP;
 static_assert(STAGE_NP_CAP >= FUSED_NP_CAP, "the staging window serves both small paths");
@@ -407,7 +407,10 @@ int launch_posterior_grad_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, d
 // lml_kernels.hip
 // (out / grad: lane l's words l * out_pitch doubles behind lane 0's — device memory or device-visible pinned host words)
 int launch_lml_terms(gpbo_ctx* ctx, Model& m, double* out2, int64_t out_pitch);
-int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, double* partial, double* grad, int64_t out_pitch);
+int launch_lml_grad(gpbo_ctx* ctx, Model& m, int n_ls, const double* Kinv, double* partial, double* out, int64_t out_pitch,
+                    bool with_terms);   // out[2..] = gradient; with_terms: out[0], out[1] too (launch_lml_terms' job, same arithmetic)
+// comm.hip: ncclCommCount of the context's communicator (0: none, -1: not answered)
+int comm_nranks(gpbo_ctx* ctx);
 // mt_jump.hip: states_dev[w] = block 1 + poly_idx[w] * stride_blocks of the MT19937 sequence whose block 0 is key_dev
 int mt_jump_states(gpbo_ctx* ctx, const unsigned* key_dev, int64_t stride_blocks, int max_k, const int* poly_idx_dev,
                    int n_states, unsigned* seq_dev, unsigned* states_dev, unsigned* windows_dev);

@@ -36,11 +36,12 @@ __device__ __forceinline__ void lml_terms_body(const double* y, const double* al
 }
 
 // Lower 64x64 tile (bi, bj <= bi) by a 256-thread group: sum over the tile of (alpha_i alpha_j - Kinv_ij) * dK_ij/dtheta_t.
-// `smem`: 2 * DP * 64 + 4 doubles; 1 + 2 * (n_ls == 1 ? 1 : n_ls) barriers.
-template <int KERNEL>
+// `smem`: 2 * DP * 64 + 4 doubles; 1 + 2 * (n_ls == 1 ? 1 : n_ls) barriers.  KT: the tile of K^-1 comes as the 64x64 row-major image
+// `ktile` (the fused K^-1 + gradient kernel keeps it in LDS) instead of from Kinv.
+template <int KERNEL, bool KT = false>
 __device__ __forceinline__ void lml_grad_tile_body(const double* Xs, const int DP, const int n_ls, const int64_t N, const int64_t NP,
                                                    const double* alpha, const double* Kinv, double* partial, const int bi, const int bj,
-                                                   double* smem, const int tid, const bool write) {
+                                                   double* smem, const int tid, const bool write, const double* ktile = nullptr) {
   double* XiT = smem;             // [DP][64]
   double* XjT = smem + DP * 64;   // [DP][64]
   double* sh = XjT + DP * 64;     // [4]
@@ -78,7 +79,9 @@ __device__ __forceinline__ void lml_grad_tile_body(const double* Xs, const int D
       double c = 0.0;
       if (i < N && j < N && i != j) {
         const double aj = alpha[j];
-        const double kin = Kinv[i * NP + j];
+        double kin;
+        if constexpr (KT) kin = ktile[(ty * 4 + a) * 64 + tx * 4 + b];
+        else kin = Kinv[i * NP + j];
         double g;
         if (KERNEL == GPBO_KERNEL_MATERN25) {
           const double tmp = sqrt(5.0 * d2[a][b]);

@@ -678,6 +678,17 @@ class GroupEngine(GpEngine):
                 self._orphans.append(borrowed)
             _lib.raise_for_status(self._lib, None, rc, info, group=self._g)
 
+    def per_device_info(self) -> list:
+        """`device_info()` of every device of the group: PCI bus id, rank / world and what RCCL says its communicator has
+        (ncclCommCount) — a multi-GPU bench line quotes these, not what the launcher asked for."""
+        out = []
+        for r in range(self.world_size):
+            buf = C.create_string_buffer(1024)
+            h = C.c_void_p(self._lib.gpbo_group_ctx(self._g, r))
+            self._check(self._lib.gpbo_device_info(h, buf, 1024))
+            out.append(json.loads(buf.value.decode()))
+        return out
+
     def per_device_timings(self) -> list:
         """`last_timings()` of every device of the group (HIP events on each device's own stream): a straggler shows here."""
         out = []

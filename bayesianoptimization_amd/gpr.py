@@ -364,8 +364,13 @@ class HipGPR(GaussianProcessRegressor):
         if not np.allclose(ls0, np.exp(starts[0]), rtol=1e-12, atol=0.0):
             raise RuntimeError("theta does not map to the length scale as expected")    # pragma: no cover
         uploaded = [False]
+        # how much work the search did (bench.py quotes the calls whose search ran >= 10 rounds separately)
+        self.theta_search_rounds_ = 0      # lockstep rounds = gpbo_lml_batch calls on the critical path
+        self.theta_search_evals_ = 0       # LML + gradient evaluations over all restarts
 
         def evaluate(thetas):
+            self.theta_search_rounds_ += 1
+            self.theta_search_evals_ += len(thetas)
             rows = np.empty((len(thetas), 1 + n_dims))
             scales = np.exp(np.asarray(thetas, dtype=np.float64))
             for lo in range(0, len(thetas), 8):
