@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
   int bm = (int)blockIdx.y, bn = (int)blockIdx.x;
   if (g.a_lower) bm = (int)(gridDim.y - 1 - blockIdx.y);
   if (g.b_lower) { bm = (int)blockIdx.x; bn = (int)blockIdx.y; }
+  if (g.tri_grid) lower_tile_of((int)blockIdx.x, bm, bn);      // live tiles only, rows from the top (W^T W: longest k first)
   __shared__ __attribute__((aligned(16))) double gt_lds[GT_LDS_DOUBLES];
   gemm_tile_body<BT, AT>(g, bm, bn, zl, bz, gt_lds);
 }
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   int bn = blockIdx.x, bm = blockIdx.y;                             // long k-ranges first (see gemm_f64_kernel)
   if (g.a_lower) bm = (int)(gridDim.y - 1 - blockIdx.y);
   if (g.b_lower) { bm = (int)blockIdx.x; bn = (int)blockIdx.y; }
+  if (g.tri_grid) lower_tile_of((int)blockIdx.x, bm, bn);          // live tiles only
   if (g.lower_only && bn > bm) return;
   const int zl = blockIdx.z / g.batch, bz = blockIdx.z - zl * g.batch;   // lane mode: z = lane * batch + b
   const int tid = threadIdx.x, lane = tid & 63;
@@ -295,6 +297,15 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
   // ... and W^T W (k_from_tile: the first tile's k-loop is the whole N) takes them while one 128x128 tile per slot would make that
   // tile the launch: N = 4096, 528 tiles: 1.04 ms, the longest tile alone 1.05 ms at a 512th of the chip's rate
   static const int tri64_limit = dbg_env("GPBO_TRI64_LIMIT") ? atoi(dbg_env("GPBO_TRI64_LIMIT")) : 600;
+  // Lower-only square products (W^T W, the SYRK-shaped trailing updates): a 1-D grid of the LIVE tiles in lower-triangle order
+  // instead of the square grid whose upper half exits at once.  The hardware deals workgroups to the 8 XCDs by id mod 8; in the
+  // square grid that is the column tile mod 8, and column c of a lower triangle has nt - c live tiles: XCD 0 carried 38 % more
+  // of W^T W's work at N = 4096 than XCD 7 (6672 against 4824 k-tiles; mean 5720) and the launch ended on it.  In lower-triangle
+  // order neighbouring ids are tiles of (almost) equal k-length — rows from the top = longest first for W^T W — so every XCD gets
+  // every eighth of them.  Same tiles, same arithmetic, same bits.  (GPBO_TRI_GRID=0: the square grid, debug build, A/B.)
+  const bool tri_grid = g.lower_only && g.m == g.n && !g.a_lower && !g.b_lower &&
+                        !(dbg_env("GPBO_TRI_GRID") && dbg_env("GPBO_TRI_GRID")[0] == '0');
+  g.tri_grid = tri_grid ? 1 : 0;
   const bool prefer64 = tri64 && triangular && (blocks128 < 512 || (g.k_from_tile && blocks128 < tri64_limit));
   if (gemm128_enabled() && !prefer64 && g.m >= 128 && g.n >= 128 && g.k >= 256 && blocks128 >= 192) {
     constexpr size_t lds = (size_t)4 * G2_TILE * sizeof(double);   // 65 536 B
@@ -309,6 +320,7 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
     }
     dim3 grid((unsigned)((g.n + 127) / 128), (unsigned)((g.m + 127) / 128), (unsigned)(g.batch * g.lanes));
     if (g.b_lower) std::swap(grid.x, grid.y);
+    if (tri_grid) { grid.x = grid.y * (grid.y + 1) / 2; grid.y = 1; }
     if (g.b_trans)
       gemm128_f64_kernel<true, false><<<grid, dim3(512), lds, ctx->stream>>>(g);
     else if (g.a_trans)
@@ -320,6 +332,7 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
   }
   dim3 grid((unsigned)(g.n / 64), (unsigned)(g.m / 64), (unsigned)(g.batch * g.lanes));
   if (g.b_lower) std::swap(grid.x, grid.y);
+  if (tri_grid) { grid.x = grid.y * (grid.y + 1) / 2; grid.y = 1; }
   if (g.b_trans)
     gemm_f64_kernel<true, false><<<grid, dim3(256), 0, ctx->stream>>>(g);
   else if (g.a_trans)

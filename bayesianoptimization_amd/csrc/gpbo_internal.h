@@ -341,6 +341,7 @@ struct GemmArgs {
   int b_lower;            // B is lower triangular (k == n, not transposed): k-loop starts at the column tile
   int a_trans;            // A given as (k,m) row-major (C = A^T B)
   int k_from_tile;        // k-loop starts at max(row tile, column tile): W^T W with W lower triangular
+  int tri_grid;           // set by launch_gemm: blockIdx.x = linear lower-triangle index of the output tile (lower_only products)
   int skip00;             // leave the leading skip00 x skip00 output tiles alone (64x64-tile kernel only): the diagonal-block
                           // workgroup of the same launch (or an earlier launch) owns them
 };

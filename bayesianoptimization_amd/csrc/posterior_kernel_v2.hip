@@ -62,12 +62,12 @@ constexpr int BUF_FLAGS = 0x00020000;   // gfx9 buffer descriptor word 3: raw bu
 // 268 MB round trip at N = 512, M = 65 536 and a second launch (C2: 0.09 + 0.29 ms).
 template <int DP, int KERNEL, int GEN, int BK = POST_BK, int WAVES = 8>
 __global__ __launch_bounds__(WAVES * 64, 4) void posterior_kernel_v2(PostArgs2 p) {
-  static_assert(BK == 16 || BK == 32, "stages of 16 or 32 train points");
-  static_assert(WAVES == 8 || (WAVES == 16 && GEN == 1 && BK == 32), "the 16-wave form is the fused kernel with 32-point stages");
+  static_assert(BK == 16 || BK == 32 || BK == 64, "stages of 16, 32 or 64 train points");
+  static_assert(WAVES == 8 || (WAVES == 16 && GEN == 1 && (BK == 32 || BK == 64)), "the 16-wave form is the fused kernel with 32- or 64-point stages");
   constexpr int NT = WAVES * 64;                   // threads
   constexpr int ROWS = WAVES * 32;                 // rows of W per workgroup (wave = two 16-row tiles)
   constexpr int E = BK / WAVES;                    // stage elements per thread (lane = candidate, wave = E train points)
-  static_assert(GEN == 2 || E == 2, "the in-kernel generation computes two train points per thread and stage");
+  static_assert(GEN == 2 || E == 2 || E == 4, "the in-kernel generation computes train points in pairs: one or two pairs per thread and stage");
   constexpr int KP = BK / 8;                       // k-pairs (8 columns of W) per stage
   extern __shared__ __attribute__((aligned(16))) double smem2[];
   double* Ks = smem2;                              // [2][BK][V2_STRIDE]
@@ -140,36 +140,39 @@ __global__ __launch_bounds__(WAVES * 64, 4) void posterior_kernel_v2(PostArgs2 p
         kv[e] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff8, (unsigned)e * row, 0));
       return;
     }
-    const double* xr = p.Xs + (int64_t)j0 * DP;  // wave-uniform -> scalar loads
-    double d2a = 0.0, d2b = 0.0;
-    if constexpr (DP <= 8) {
 #pragma unroll
-      for (int t = 0; t < DP; ++t) {
-        const double x = Xl[t * V2_CANDS + lane];
-        const double da = x - xr[t], db = x - xr[DP + t];
-        d2a = fma(da, da, d2a);
-        d2b = fma(db, db, d2b);
-      }
-    } else {
-#pragma unroll 1
-      for (int tb = 0; tb < DP; tb += 8) {
+    for (int e2 = 0; e2 < E; e2 += 2) {
+      const double* xr = p.Xs + (int64_t)(j0 + e2) * DP;  // wave-uniform -> scalar loads
+      double d2a = 0.0, d2b = 0.0;
+      if constexpr (DP <= 8) {
 #pragma unroll
-        for (int tt = 0; tt < 8; ++tt) {
-          const double x = Xl[(tb + tt) * V2_CANDS + lane];
-          const double da = x - xr[tb + tt], db = x - xr[DP + tb + tt];
+        for (int t = 0; t < DP; ++t) {
+          const double x = Xl[t * V2_CANDS + lane];
+          const double da = x - xr[t], db = x - xr[DP + t];
           d2a = fma(da, da, d2a);
           d2b = fma(db, db, d2b);
         }
+      } else {
+#pragma unroll 1
+        for (int tb = 0; tb < DP; tb += 8) {
+#pragma unroll
+          for (int tt = 0; tt < 8; ++tt) {
+            const double x = Xl[(tb + tt) * V2_CANDS + lane];
+            const double da = x - xr[tb + tt], db = x - xr[DP + tb + tt];
+            d2a = fma(da, da, d2a);
+            d2b = fma(db, db, d2b);
+          }
+        }
       }
+      kv[e2] = gpbo_kernel_value<KERNEL>(d2a);
+      // (16 waves = 128 VGPRs: with DP = 4 the two inlined evaluations, interleaved, spilled 15-29 registers; one after the other fits)
+      if constexpr (WAVES == 16 && (DP <= 4 || E > 2)) __builtin_amdgcn_sched_barrier(0);
+      kv[e2 + 1] = gpbo_kernel_value<KERNEL>(d2b);
+      if constexpr (WAVES == 16 && (DP <= 4 || E > 2)) __builtin_amdgcn_sched_barrier(0);
+      // mu_weight = 0 for the clamped (repeated) look-ahead of the last stage: it must not be counted twice
+      mu_acc = fma(kv[e2] * mu_weight, p.alpha[j0 + e2], mu_acc);
+      mu_acc = fma(kv[e2 + 1] * mu_weight, p.alpha[j0 + e2 + 1], mu_acc);
     }
-    kv[0] = gpbo_kernel_value<KERNEL>(d2a);
-    // (16 waves = 128 VGPRs: with DP = 4 the two inlined evaluations, interleaved, spilled 15-29 registers; one after the other fits)
-    if constexpr (WAVES == 16 && DP <= 4) __builtin_amdgcn_sched_barrier(0);
-    kv[1] = gpbo_kernel_value<KERNEL>(d2b);
-    if constexpr (WAVES == 16 && DP <= 4) __builtin_amdgcn_sched_barrier(0);
-    // mu_weight = 0 for the clamped (repeated) look-ahead of the last stage: it must not be counted twice
-    mu_acc = fma(kv[0] * mu_weight, p.alpha[j0], mu_acc);
-    mu_acc = fma(kv[1] * mu_weight, p.alpha[j0 + 1], mu_acc);
   };
   auto gen_store = [&](const double (&kv)[E], int buf) {
 #pragma unroll
@@ -447,6 +450,21 @@ static int launch_v2_k(gpbo_ctx* ctx, int DP, const PostArgs2& a, int64_t nblock
 // chunks the sum-of-squares partials are split into (what posterior_finalize_kernel sums over).
 template <int DP, int KERNEL>
 static int launch_v4_t(gpbo_ctx* ctx, const PostArgs2& a, int64_t nblocks) {
+#ifdef GPBO_DEBUG   // experiment (round 5): 64-point stages = half the workgroup barriers of the 1024-thread workgroup; GPBO_POST_V4_BK=64
+  if (dbg_env("GPBO_POST_V4_BK") && atoi(dbg_env("GPBO_POST_V4_BK")) == 64) {
+    const size_t lds64 = (size_t)(2 * 64 * V2_STRIDE + DP * V2_CANDS) * sizeof(double);
+    static bool attr[6] = {false, false, false, false, false, false};
+    const int ai = KERNEL * 3 + (DP <= 8 ? 0 : DP <= 16 ? 1 : 2);
+    if (!attr[ai]) {
+      GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(posterior_kernel_v2<DP, KERNEL, 1, 64, 16>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 64 * V2_STRIDE + 64 * V2_CANDS) * 8));
+      attr[ai] = true;
+    }
+    posterior_kernel_v2<DP, KERNEL, 1, 64, 16><<<dim3((unsigned)nblocks), dim3(1024), lds64, ctx->stream>>>(a);
+    GPBO_HIP(ctx, hipGetLastError());
+    return GPBO_OK;
+  }
+#endif
   const size_t lds = (size_t)(2 * 32 * V2_STRIDE + DP * V2_CANDS) * sizeof(double);
   posterior_kernel_v2<DP, KERNEL, 1, 32, 16><<<dim3((unsigned)nblocks), dim3(1024), lds, ctx->stream>>>(a);
   GPBO_HIP(ctx, hipGetLastError());
