@@ -858,6 +858,10 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
     static const bool la_lanes = dbg_env("GPBO_CHOL_LA_LANES") && dbg_env("GPBO_CHOL_LA_LANES")[0] == '1';
     ctx->no_lookahead = n_groups > 1 && !la_lanes;
     const bool fused = use_fused(m);     // one launch for the whole group: nothing to capture
+    // ... and the strip path's ~17 launches are enqueued faster than the device runs them: replaying them from a graph bought nothing
+    // at a fixed shape (six lanes at N = 512: 0.292 ms replayed, 0.283 launched) and cost a maximize() loop — whose N grows by one
+    // per step, a new shape every call — ~1 ms of capture + instantiation per suggest() (profiles/r05_maximize_loop.json)
+    const bool no_graph = fused || use_mid(m);
     auto enqueue = [&](double** oh, int** ih) {
       if (fused) return enqueue_fused(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, eval_gradient ? 2 : 1, n_ls, 0, ih, oh);
       int r = enqueue_factor(ctx, m, nullptr, nullptr, ctx->lml_X, ctx->lml_y, noise, ih, false);
@@ -871,13 +875,13 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
                       key.eval_gradient == eval_gradient && key.noise == noise && key.lanes == gl &&
                       key.X == ctx->lml_X && key.y == ctx->lml_y && key.K == gbase;
     bool launched = false;
-    if (same && key.exec && !fused) {
+    if (same && key.exec && !no_graph) {
       hipError_t e = hipGraphLaunch(key.exec, ctx->stream);
       if (e != hipSuccess) { restore(); GPBO_HIP(ctx, e); }
       launched = true;
     } else {
       if (key.exec) { (void)hipGraphExecDestroy(key.exec); key.exec = nullptr; }
-      if (same && graphs_allowed && !ctx->lml_graph_off && !fused) {
+      if (same && graphs_allowed && !ctx->lml_graph_off && !no_graph) {
         hipGraph_t graph = nullptr;
         double* oh = nullptr; int* ih = nullptr;
         hipError_t e;

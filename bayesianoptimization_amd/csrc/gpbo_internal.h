@@ -144,7 +144,8 @@ struct gpbo_ctx {
   // candidates and results cross PCIe through this pinned block instead of the caller's pageable arrays — the runtime
   // stages pageable copies through its own buffers and blocks on them, ~15-20 us per copy
   void* small_pinned = nullptr;          // SMALL_PIN_BYTES: [candidates in | mu out | sd out]
-  void* polish_pinned = nullptr;         // gpbo_polish_seeds: per model [mu | sd | dmu | dsd] of a round coming back
+  void* polish_pinned = nullptr;         // gpbo_polish_seeds: [the round's points | per model [dmu | dsd | mu | sd] coming back]
+  char* polish_pinned_dev = nullptr;     // ... as the device sees it: the round's kernels read / write it directly (no copy nodes)
   int64_t cap_polish_pinned = 0;
   hipEvent_t small_ev = nullptr;         // the last H2D out of small_pinned has completed
   bool small_ev_pending = false;
@@ -364,7 +365,9 @@ int launch_alpha_strip(gpbo_ctx* ctx, Model& m, int* info_out, int64_t info_pitc
 // posterior_kernel.hip
 int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std);
 int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std, double** dmu_dev, double** dsd_dev,
-                          double** packed_dev = nullptr);   // packed: [dmu | dsd | mu | sd] contiguous (mu / sd not in the model's buffers)
+                          double** packed_dev = nullptr,    // packed: [dmu | dsd | mu | sd] contiguous (mu / sd not in the model's buffers)
+                          const double* xc_in = nullptr,    // the points (M, d), device-visible, instead of the resident candidate set
+                          double* packed_out = nullptr);    // where the packed block goes (device-visible) instead of ctx->mu_part
 // posterior_kernel_v2.hip
 int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
 int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);

@@ -277,31 +277,38 @@ extern "C" int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, doubl
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
 
   const int n_models = 1 + n_constraints;
-  // pinned landing area: per model [dmu | dsd | mu | sd] of a round (pitch = the round's live runs), room for n_seeds points
+  // pinned block, device-visible: [the round's points (n_seeds, d)] then per model [dmu | dsd | mu | sd] of a round (pitch = the
+  // round's live runs).  The scaling kernel reads the points there and the last kernel of a model's evaluation writes its results
+  // there: a round is six launches and ONE stream synchronisation, no copy nodes (round 5; until then: H2D copy + event, D2H copy).
   const size_t per_model = (size_t)n_seeds * (2 + 2 * (size_t)d);
-  const size_t need = per_model * (size_t)n_models * sizeof(double);
+  const size_t pts = (size_t)n_seeds * (size_t)d;
+  const size_t need = (pts + per_model * (size_t)n_models) * sizeof(double);
   if ((int64_t)need > ctx->cap_polish_pinned) {
     if (ctx->polish_pinned) GPBO_HIP(ctx, hipHostFree(ctx->polish_pinned));
     ctx->polish_pinned = nullptr;
     ctx->cap_polish_pinned = 0;
     GPBO_HIP(ctx, hipHostMalloc(&ctx->polish_pinned, need, hipHostMallocDefault));
+    GPBO_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->polish_pinned_dev, ctx->polish_pinned, 0));
     ctx->cap_polish_pinned = (int64_t)need;
   }
-  double* land = (double*)ctx->polish_pinned;
+  double* pts_h = (double*)ctx->polish_pinned;
+  double* land = pts_h + pts;
+  const double* pts_d = (const double*)ctx->polish_pinned_dev;
+  double* land_d = (double*)ctx->polish_pinned_dev + pts;
+  const bool timing0 = ctx->no_timing;
 
   auto eval = [&](const double* batch, const int live, double* fv, double* gv) -> int {
     // ---- one batched evaluation: posterior + input gradient of every model at the live runs' trial points
-    int rc = gpbo_set_candidates(ctx, batch, live, d);
-    if (rc) return rc;
-    for (int j = 0; j < n_models; ++j) {
+    int rc = GPBO_OK;
+    memcpy(pts_h, batch, (size_t)live * d * sizeof(double));
+    ctx->no_timing = true;      // (no event records between the launches of a round)
+    for (int j = 0; j < n_models && rc == GPBO_OK; ++j) {
       Model& m = ctx->models[j];
-      double *dmu_dev = nullptr, *dsd_dev = nullptr, *packed = nullptr;
-      if ((rc = launch_posterior_grad(ctx, m, live, y_mean[j], y_std[j], &dmu_dev, &dsd_dev, &packed))) return rc;
-      // one copy per model and round: [dmu (live,d) | dsd (live,d) | mu (live) | sd (live)]; the scratch the kernels wrote
-      // to is shared by the models, so the copy of model j is enqueued before model j + 1's launches (same stream)
-      GPBO_HIP(ctx, hipMemcpyAsync(land + per_model * (size_t)j, packed, ((size_t)2 * live * d + 2 * (size_t)live) * sizeof(double),
-                                   hipMemcpyDeviceToHost, ctx->stream));
+      double *dmu_dev = nullptr, *dsd_dev = nullptr;
+      rc = launch_posterior_grad(ctx, m, live, y_mean[j], y_std[j], &dmu_dev, &dsd_dev, nullptr, pts_d, land_d + per_model * (size_t)j);
     }
+    ctx->no_timing = timing0;
+    if (rc) return rc;
     GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));
     // ---- f = -acq [* prod_j p_j] and its gradient (acquisition.py:198-217, 485, 660-661, 847-849; constraint.py:199-221)
     for (int t = 0; t < live; ++t) {

@@ -73,25 +73,29 @@ static int ensure_posterior_outputs(gpbo_ctx* ctx, Model& m, int64_t Mp) {
 
 // mu, sd and their gradients in the (raw) inputs for the M resident candidates (M <= 256): posterior_small.hip
 int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y_std, double** dmu_dev, double** dsd_dev,
-                          double** packed_dev) {
+                          double** packed_dev, const double* xc_in, double* packed_out) {
   const int64_t Mp = round_up(M, POST_CANDS);
   int rc;
   if ((rc = ensure(ctx, &ctx->Xcs, &ctx->cap_Xcs, Mp * m.DP))) return rc;
   if ((rc = ensure(ctx, &ctx->mu_part, &ctx->cap_mu_part, std::max<int64_t>((int64_t)2 * M * m.d + 2 * M, Mp)))) return rc;
   if ((rc = ensure_posterior_outputs(ctx, m, Mp))) return rc;
-  if ((rc = launch_prescale(ctx, ctx->Xc, M, m.d, m.DP, m.ls, ctx->Xcs, Mp))) return rc;
-  *dmu_dev = ctx->mu_part;
-  *dsd_dev = ctx->mu_part + M * m.d;
-  // packed_dev != NULL (gpbo_polish_seeds): mu and sd land right behind the gradients, [dmu | dsd | mu | sd], so that one
-  // copy brings a round's results back; the model's own mu / sd buffers are then NOT written
-  double* mu_out = packed_dev ? ctx->mu_part + 2 * M * m.d : m.mu;
-  double* sd_out = packed_dev ? mu_out + M : m.sd;
-  if (packed_dev) *packed_dev = ctx->mu_part;
+  // xc_in (gpbo_polish_seeds): the round's points in device-visible pinned host memory, read by the scaling kernel itself
+  if ((rc = launch_prescale(ctx, xc_in ? xc_in : ctx->Xc, M, m.d, m.DP, m.ls, ctx->Xcs, Mp))) return rc;
+  // packed (gpbo_polish_seeds): mu and sd land right behind the gradients, [dmu | dsd | mu | sd], so that one block brings a
+  // round's results back — in packed_out (device-visible pinned host memory, written by the last kernel itself) when given,
+  // else in ctx->mu_part for the caller to copy; the model's own mu / sd buffers are then NOT written
+  const bool packed = packed_dev || packed_out;
+  double* base = packed_out ? packed_out : ctx->mu_part;
+  *dmu_dev = base;
+  *dsd_dev = base + M * m.d;
+  double* mu_out = packed ? base + 2 * M * m.d : m.mu;
+  double* sd_out = packed ? mu_out + M : m.sd;
+  if (packed_dev) *packed_dev = base;
   ev_begin(ctx, T_POST_MAIN);
   rc = launch_posterior_grad_small(ctx, m, (int)M, y_mean, y_std, *dmu_dev, *dsd_dev, mu_out, sd_out);
   ev_end(ctx, T_POST_MAIN);
   if (rc) return rc;
-  m.M_post = packed_dev ? -1 : M;
+  m.M_post = packed ? -1 : M;
   return GPBO_OK;
 }
 

@@ -42,7 +42,8 @@ def black_box(x):
 
 def main():
     warnings.simplefilter("ignore")
-    eng = GpEngine(0)
+    eng = GpEngine(0, debug="--debug" in sys.argv)      # --debug: libgpbo_dbg.so (reads the A/B switches, e.g. GPBO_LML_GRAPH=0)
+    no_cpu = "--no-cpu" in sys.argv
     pb = {f"x{j}": (0.0, 1.0) for j in range(D)}
     sp = FloatSpace(pb)
     rng = np.random.RandomState(1)
@@ -62,7 +63,7 @@ def main():
         rows.append({"N": N, "ms": round(ms, 3), "theta_search_rounds": int(getattr(gp, "theta_search_rounds_", 0)),
                      "lml_evaluations": int(getattr(gp, "theta_search_evals_", 0)),
                      "length_scale": float(np.exp(gp.kernel_.theta[0]))})
-        if (N - N0) % CPU_EVERY == 0:
+        if (N - N0) % CPU_EVERY == 0 and not no_cpu:
             # the reference's own estimator on the host cores, same observations, same configuration, same acquisition class
             sk = GaussianProcessRegressor(kernel=Matern(nu=2.5), alpha=1e-6, normalize_y=True, n_restarts_optimizer=5,
                                           random_state=np.random.RandomState(1))
@@ -85,6 +86,10 @@ def main():
         return {"N": f"{lo}..{hi - 1}", "steps": int(m.sum()), "median_ms": float(np.median(ms[m])), "mean_ms": float(np.mean(ms[m])),
                 "max_ms": float(np.max(ms[m]))}
 
+    if no_cpu:
+        print(json.dumps({"device": {"steps": len(rows), "total_s": float(np.sum(ms) * 1e-3),
+                                     "bands": [band(16, 65), band(65, 129), band(129, 257), band(257, 385), band(385, 528)]}}, indent=1))
+        return
     cpu_at = {r["N"]: r["ms"] for r in cpu_rows}
     dev_at = {r["N"]: r["ms"] for r in rows}
     out = {
