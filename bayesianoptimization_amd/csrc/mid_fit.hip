@@ -138,17 +138,29 @@ struct WStripArgs {
   int pack;
 };
 
-// Workgroup (s, lane): strip s = columns 16 s ... 16 s + 15, inside 64-block c = s / 4.  256 threads = 4 waves; wave w owns the
-// 16-row tile w of every 64-row block.  Per block row r > c:
-//   T_r = sum_{t = c}^{r - 1} L_rt X_t      16 (r - c) v_mfma_f64_16x16x4_f64 per wave, two accumulators (even / odd k);
-//                                           A fragments straight from L (16 bytes per lane = two k-steps, requested one product
-//                                           ahead), B fragments = the strip's earlier blocks, LDS-resident as [ws_perm(k)][16]
-//   X_r = -D_r T_r                          the tiles of T exchanged through LDS, D_r lower triangular by 16-tiles
-// X_r goes to LDS (for the rows below) and to W.  LDS: (NP / 64 - c + 1) x 8 KiB.
-__global__ __launch_bounds__(256) void w_strip_kernel(WStripArgs a) {
+// Workgroup (s, lane): strip s = columns 16 s ... 16 s + 15, inside 64-block c = s / 4.  Row r = c + 1 ... nblk - 1 is a sequence of
+// r - c + 1 products of a 64x64 block with a 64x16 block: t = c ... r - 1 multiply L_rt (from L) with X_t, the last one (t = r)
+// multiplies D_r (from dinv, lower triangular by 16-tiles) with the row's sum T_r and gives X_r = -D_r T_r, which goes to LDS
+// (for the rows below) and to W.  LDS: (NP / 64 - c) x 8 KiB for the strip + 32 KiB of exchange.
+//
+// 1024 threads = 16 waves = FOUR per SIMD: wave w owns the 16-row tile ti = w & 3 of every block and the k-quarter kq = w >> 2
+// (k-steps h = 2 kq, 2 kq + 1) of every product — 4 v_mfma_f64_16x16x4_f64 per wave and product, two accumulators.  The first
+// version gave a product to four waves (one per SIMD, 16 MFMAs each) and ran at 140 cycles per MFMA: one wave cannot feed its
+// SIMD's fp64 matrix pipe (gpbo_mfma_f64_probe: 140 / 102 / 63 cycles per MFMA with 1 / 2 / 4 waves) — 47 us for the c = 0 strips
+// at NP = 512 against 15 us of pipe time.  The k-quarters of a row's sum meet in LDS (fixed order 0..3), so do those of D_r T_r.
+//
+// All operand addresses are known up front, and L has just been written by other compute units (its lines come from the memory
+// side, ~1.5-2 us): the A fragments run WS_AHEAD products ahead in a ring of register sets (static indices: the sequence is
+// walked in groups of WS_AHEAD + 1), across row ends and their LDS barriers.  Every request is the same two 16-byte loads
+// whatever it fetches (a request past the end repeats the last one) and sits in straight-line code: the compiler counts the loads
+// in flight exactly and waits for the oldest set only.
+constexpr int WS_THREADS = 1024;
+constexpr int WS_EXCH = 4 * 1024;       // doubles: [k-quarter][64 rows in image order][16]
+__global__ __launch_bounds__(WS_THREADS) void w_strip_kernel(WStripArgs a) {
   extern __shared__ __attribute__((aligned(16))) double ws_smem[];
   const int tid = (int)threadIdx.x, lane = tid & 63, lr = lane & 15, lk = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ti = w & 3, kq = w >> 2;
   const int s = (int)blockIdx.x, c = s >> 2, q = s & 3;
   const int64_t lo = (int64_t)blockIdx.y * a.lane_stride;
   const int64_t NP = a.NP;
@@ -156,71 +168,110 @@ __global__ __launch_bounds__(256) void w_strip_kernel(WStripArgs a) {
   const double* L = a.L + lo;
   const double* dinv = a.dinv + lo;
   double* W = a.W + lo;
-  double* XB = ws_smem;                         // [nblk - c][64][16]: the strip from block row c down, row-major
-  double* TB = ws_smem + (nblk - c) * 1024;     // [64][16]
+  double* XB = ws_smem;                         // [nblk - c][64][16]: the strip from block row c down, rows in image order (ws_perm)
+  double* EX = ws_smem + (nblk - c) * 1024;     // [4][64][16]: the k-quarters' partial sums of T_r, then of D_r T_r
   const int64_t col0 = 16 * (int64_t)s;
 
-  for (int idx = tid; idx < 64 * c * 16; idx += 256) W[(int64_t)(idx >> 4) * NP + col0 + (idx & 15)] = 0.0;   // above block row c
-  for (int idx = tid; idx < 1024; idx += 256) {                                                                // X_c = D_c[:, strip]
-    const int k = idx >> 4, n = idx & 15;
+  for (int idx = tid; idx < 64 * c * 16; idx += WS_THREADS) W[(int64_t)(idx >> 4) * NP + col0 + (idx & 15)] = 0.0;   // above block row c
+  {                                                                                                                  // X_c = D_c[:, strip]
+    const int k = tid >> 4, n = tid & 15;
     const double v = dinv[(int64_t)c * 4096 + k * 64 + 16 * q + n];
     XB[ws_perm(k) * 16 + n] = v;
     W[((int64_t)c * 64 + k) * NP + col0 + n] = v;
   }
   ws_barrier();
 
-  d2v an[8];           // A fragments of the next (r, t) product: L[64 r + 16 w + lr][64 t + 8 h + 2 lk + {0, 1}]
-  auto load_a = [&](const int r, const int t) {
-    const d2v* p = reinterpret_cast<const d2v*>(L + ((int64_t)64 * r + 16 * w + lr) * NP + 64 * t + 2 * lk);
-#pragma unroll
-    for (int h = 0; h < 8; ++h) an[h] = p[4 * h];
+  constexpr int WS_AHEAD = 3, WS_RING = WS_AHEAD + 1;
+  d2v abuf[WS_RING][2];    // the wave's A fragments of a product: block[16 ti + lr][8 h + 2 lk + {0, 1}], h = 2 kq, 2 kq + 1
+  // Both operand sources are read through buffer descriptors — a wave-uniform base in SGPRs, the lane's constant 32-bit offset, the
+  // walk over the blocks as the instruction's scalar offset — so a request is a few scalar instructions and two loads.  (With flat
+  // 64-bit per-lane addresses a product cost ~70 VALU and ~50 SALU instructions next to its 4 MFMAs: the loop was bound by its
+  // address arithmetic, 1.1 us per product whatever the look-ahead, the wave count or the state of the caches — rocprofv3:
+  // SQ_INSTS_VALU 491 k against SQ_INSTS_MFMA 26 k per launch at NP = 512.)
+  constexpr int WS_BUF_FLAGS = 0x00020000;       // gfx9 raw buffer descriptor word 3
+  const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(L), 0, 0x7fffffff, WS_BUF_FLAGS);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(dinv), 0, 0x7fffffff, WS_BUF_FLAGS);
+  const unsigned voff_l = (unsigned)(((16 * ti + lr) * (int)NP + 2 * lk + 16 * kq) * 8);
+  const unsigned voff_d = (unsigned)(((16 * ti + lr) * 64 + 2 * lk + 16 * kq) * 8);
+  int rq_r = c + 1, rq_t = c;                    // the next product to REQUEST
+  auto request = [&](d2v (&dst)[2]) {
+    const int rr = min(rq_r, nblk - 1), tt = (rq_r < nblk) ? rq_t : nblk - 1;
+    const bool is_d = tt == rr;
+    const unsigned soff = is_d ? (unsigned)rr * 4096u * 8u : ((unsigned)(64 * rr) * (unsigned)NP + 64u * (unsigned)tt) * 8u;
+    const unsigned voff = is_d ? voff_d : voff_l;
+    if (is_d) {
+      dst[0] = __builtin_bit_cast(d2v, __builtin_amdgcn_raw_buffer_load_b128(rs_d, voff, soff, 0));
+      dst[1] = __builtin_bit_cast(d2v, __builtin_amdgcn_raw_buffer_load_b128(rs_d, voff + 64u, soff, 0));
+    } else {
+      dst[0] = __builtin_bit_cast(d2v, __builtin_amdgcn_raw_buffer_load_b128(rs_l, voff, soff, 0));
+      dst[1] = __builtin_bit_cast(d2v, __builtin_amdgcn_raw_buffer_load_b128(rs_l, voff + 64u, soff, 0));
+    }
+    if (rq_r < nblk && ++rq_t > rq_r) { ++rq_r; rq_t = c; }
   };
-  if (c + 1 < nblk) load_a(c + 1, c);
-  for (int r = c + 1; r < nblk; ++r) {
-    double dd[4][4];   // D_r[16 w + lr][16 kt + 4 g + lk], kt <= w
-    {
-      const double* Dr = dinv + (int64_t)r * 4096 + (16 * w + lr) * 64 + lk;
 #pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
+  for (int j = 0; j < WS_AHEAD; ++j) request(abuf[j]);
+  int r = c + 1, t = c;                          // the product being multiplied
+  d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
+  const int boff = (16 * kq + lk) * 16 + lr;     // the wave's B fragment (h, e) of a [64][16] image: boff + (8 (h - 2 kq) + 4 e) * 16
+  while (r < nblk) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) dd[kt][g] = (kt <= w) ? Dr[16 * kt + 4 * g] : 0.0;
-    }
-    d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
-    for (int t = c; t < r; ++t) {
-      d2v ac[8];
+    for (int j = 0; j < WS_RING; ++j) {
+      request(abuf[(j + WS_AHEAD) % WS_RING]);      // unconditional (straight-line code: the loads in flight can be counted)
+      if (r < nblk) {
+        if (t < r) {       // T_r += L_rt X_t (this wave: its k-quarter)
+          const double* xb = XB + (t - c) * 1024 + boff;
+          const double b0 = xb[0], b1 = xb[4 * 16], b2 = xb[8 * 16], b3 = xb[12 * 16];
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[j][0].x, b0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[j][0].y, b1, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[j][1].x, b2, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[j][1].y, b3, acc1, 0, 0, 0);
+          ++t;
+        } else {           // X_r = -D_r T_r
+          {
+            const d4 part = acc0 + acc1;
 #pragma unroll
-      for (int h = 0; h < 8; ++h) ac[h] = an[h];
-      if (t + 1 < r) load_a(r, t + 1);
-      else if (r + 1 < nblk) load_a(r + 1, c);
-      const double* xb = XB + (t - c) * 1024 + lk * 16 + lr;
+            for (int rr = 0; rr < 4; ++rr) EX[kq * 1024 + ws_perm(16 * ti + lk + 4 * rr) * 16 + lr] = part[rr];
+          }
+          ws_barrier();
+          d4 p0 = d4{0.0, 0.0, 0.0, 0.0}, p1 = d4{0.0, 0.0, 0.0, 0.0};
+          if (kq <= ti) {  // (D_r is lower triangular by 16-tiles: k-quarter kq only reaches the row tiles ti >= kq)
+            double bt[4];
 #pragma unroll
-      for (int h = 0; h < 8; ++h) {
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[h].x, xb[(8 * h) * 16], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[h].y, xb[(8 * h + 4) * 16], acc1, 0, 0, 0);
-      }
-    }
-    const d4 T = acc0 + acc1;
+            for (int e = 0; e < 4; ++e) {
+              const double* ex = EX + boff + (4 * e) * 16;
+              bt[e] = ((ex[0] + ex[1024]) + ex[2048]) + ex[3072];       // T_r: the four k-quarters in order
+            }
+            p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[j][0].x, bt[0], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[j][0].y, bt[1], p1, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[j][1].x, bt[2], p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[j][1].y, bt[3], p1, 0, 0, 0);
+          }
+          ws_barrier();    // everybody has read the T partials: the exchange area takes the partial products now
+          if (kq <= ti) {
+            const d4 part = p0 + p1;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) TB[(16 * w + lk + 4 * rr) * 16 + lr] = T[rr];
-    ws_barrier();
-    d4 p0 = d4{0.0, 0.0, 0.0, 0.0}, p1 = d4{0.0, 0.0, 0.0, 0.0};
+            for (int rr = 0; rr < 4; ++rr) EX[kq * 1024 + (16 * ti + lk + 4 * rr) * 16 + lr] = part[rr];
+          }
+          ws_barrier();
+          if (kq == 0) {   // row tile ti: the k-quarters 0 .. ti in order, negated
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-      if (kt <= w) {
-#pragma unroll
-        for (int g = 0; g < 4; g += 2) {
-          p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(dd[kt][g], TB[(16 * kt + 4 * g + lk) * 16 + lr], p0, 0, 0, 0);
-          p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(dd[kt][g + 1], TB[(16 * kt + 4 * g + 4 + lk) * 16 + lr], p1, 0, 0, 0);
+            for (int rr = 0; rr < 4; ++rr) {
+              const int row = 16 * ti + lk + 4 * rr;
+              double v = EX[row * 16 + lr];
+              for (int qq = 1; qq <= ti; ++qq) v += EX[qq * 1024 + row * 16 + lr];
+              v = -v;
+              XB[(r - c) * 1024 + ws_perm(row) * 16 + lr] = v;
+              W[((int64_t)64 * r + row) * NP + col0 + lr] = v;
+            }
+          }
+          ws_barrier();    // X_r complete for everyone; the exchange area is free again
+          acc0 = d4{0.0, 0.0, 0.0, 0.0};
+          acc1 = d4{0.0, 0.0, 0.0, 0.0};
+          ++r;
+          t = c;
         }
       }
-    const d4 X = -(p0 + p1);
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int row = 16 * w + lk + 4 * rr;
-      XB[(r - c) * 1024 + ws_perm(row) * 16 + lr] = X[rr];
-      W[((int64_t)64 * r + row) * NP + col0 + lr] = X[rr];
     }
-    ws_barrier();      // X_r complete for everyone; TB free again
   }
 
   // the strip's contribution to t = W y: rows 64 c ... NP - 1, (row group, column) per thread, 16-lane shuffle tree
@@ -228,7 +279,7 @@ __global__ __launch_bounds__(256) void w_strip_kernel(WStripArgs a) {
   {
     const double yv = a.y[lo + col0 + (tid & 15)];
     double* part = a.partial + lo + (int64_t)s * NP + 64 * (int64_t)c;
-    for (int i0 = 0; i0 < nrows; i0 += 16) {
+    for (int i0 = 0; i0 < nrows; i0 += WS_THREADS / 16) {
       const int i = i0 + (tid >> 4);
       double v = XB[(i & ~63) * 16 + ws_perm(i & 63) * 16 + (tid & 15)] * yv;
       v += __shfl_xor(v, 8);
@@ -242,11 +293,11 @@ __global__ __launch_bounds__(256) void w_strip_kernel(WStripArgs a) {
   if (a.pack) {
     double* Wp = a.Wp + lo;
     const int64_t pairs = NP / 8;
-    for (int j = tid; j < (int)(NP * 16); j += 256) {
-      const int e = j & 1, ln = (j >> 1) & 63, t = (j >> 7) & 1, pp = (j >> 8) & 1;
+    for (int j = tid; j < (int)(NP * 16); j += WS_THREADS) {
+      const int e = j & 1, ln = (j >> 1) & 63, t2 = (j >> 7) & 1, pp = (j >> 8) & 1;
       const int64_t s32 = j >> 9;
       const int64_t p = 2 * (int64_t)s + pp;
-      const int64_t row = 32 * s32 + 16 * t + (ln & 15);
+      const int64_t row = 32 * s32 + 16 * t2 + (ln & 15);
       const int cn = 8 * pp + 4 * e + (ln >> 4);
       const int64_t colx = col0 + cn;
       double v = 0.0;
@@ -254,7 +305,7 @@ __global__ __launch_bounds__(256) void w_strip_kernel(WStripArgs a) {
         const int i = (int)(row - 64 * (int64_t)c);
         v = XB[(i & ~63) * 16 + ws_perm(i & 63) * 16 + cn];
       }
-      Wp[((s32 * pairs + p) * 2 + t) * 128 + ln * 2 + e] = v;
+      Wp[((s32 * pairs + p) * 2 + t2) * 128 + ln * 2 + e] = v;
     }
   }
 }
@@ -273,15 +324,29 @@ __global__ __launch_bounds__(256) void alpha_strip_kernel(const double* __restri
   const int64_t lo = (int64_t)blockIdx.y * lane_stride;
   W += lo; partial += lo;
   for (int64_t i = 64 * (int64_t)c + tid; i < NP; i += 256) {
-    const int ns = 4 * (int)(i >> 6) + 4;
+    const int ns = 4 * (int)(i >> 6) + 4;      // a multiple of 4: four loads in flight per step, added in ascending order
     double acc = 0.0;
-    for (int s2 = 0; s2 < ns; ++s2) acc += partial[(int64_t)s2 * NP + i];
+    for (int s2 = 0; s2 < ns; s2 += 4) {
+      const double p0 = partial[(int64_t)s2 * NP + i], p1 = partial[(int64_t)(s2 + 1) * NP + i];
+      const double p2 = partial[(int64_t)(s2 + 2) * NP + i], p3 = partial[(int64_t)(s2 + 3) * NP + i];
+      acc += p0; acc += p1; acc += p2; acc += p3;
+    }
     tv[i] = acc;
   }
   __syncthreads();
   const int n = tid & 15, g = tid >> 4;
   double acc = 0.0;
-  for (int64_t i = 64 * (int64_t)c + g; i < NP; i += 16) acc = fma(W[i * NP + 16 * (int64_t)s + n], tv[i], acc);
+  {
+    // rows in steps of 16 from block row c down: NP - 64 c is a multiple of 64, i.e. the trip count a multiple of 4
+    const double* wp = W + 16 * (int64_t)s + n;
+    for (int64_t i = 64 * (int64_t)c + g; i < NP; i += 64) {
+      const double w0 = wp[i * NP], w1 = wp[(i + 16) * NP], w2 = wp[(i + 32) * NP], w3 = wp[(i + 48) * NP];
+      acc = fma(w0, tv[i], acc);
+      acc = fma(w1, tv[i + 16], acc);
+      acc = fma(w2, tv[i + 32], acc);
+      acc = fma(w3, tv[i + 48], acc);
+    }
+  }
   red[g * 16 + n] = acc;
   __syncthreads();
   if (tid < 16) {
@@ -306,14 +371,15 @@ int mid_max_np() {
 int launch_w_strip(gpbo_ctx* ctx, Model& m, bool pack) {
   if (!(ctx->func_attrs & ATTR_MID)) {
     GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(w_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)((MID_NP_CAP / 64 + 1) * 1024 * sizeof(double))));
+                                      (int)((MID_NP_CAP / 64 * 1024 + WS_EXCH) * sizeof(double))));
     ctx->func_attrs |= ATTR_MID;
   }
   WStripArgs a{};
   a.L = m.L; a.dinv = m.dinv; a.y = m.yn; a.W = m.W; a.Wp = m.Wp; a.partial = m.tmp;
   a.N = m.N; a.NP = m.NP; a.lane_stride = ctx->lane_stride; a.pack = (pack && m.Wp) ? 1 : 0;
-  const size_t lds = (size_t)(m.NP / 64 + 1) * 1024 * sizeof(double);
-  w_strip_kernel<<<dim3((unsigned)(m.NP / 16), (unsigned)ctx->lanes), dim3(256), lds, ctx->stream>>>(a);
+
+  const size_t lds = (size_t)(m.NP / 64 * 1024 + WS_EXCH) * sizeof(double);
+  w_strip_kernel<<<dim3((unsigned)(m.NP / 16), (unsigned)ctx->lanes), dim3(WS_THREADS), lds, ctx->stream>>>(a);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
