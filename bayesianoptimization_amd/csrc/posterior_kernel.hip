@@ -12,7 +12,7 @@
 //   otherwise                    posterior_kernel_v2.hip  GEN = 2: k* slab generated once + MFMA GEMM ("v3")
 // The row-chunk partial sums every path writes are combined in a fixed order by posterior_finalize_kernel,
 // so results are run-to-run deterministic.  (The first version of the fused kernel — 128 candidates x 256
-// rows per workgroup, 2 waves/SIMD, 403 ms per C3 launch — is in the git history)
+// rows per workgroup, 2 waves/SIMD, 403 ms per C3 launch — is in the git history; docs/LAB_NOTEBOOK.md §4.1.)
 #include <algorithm>
 #include <cstdlib>
 

@@ -322,7 +322,7 @@ def measured_peak(eng, prec):
     """the spec peak AND the micro-benchmarked one.  ~0.2 s of device time: v_mfma_f64_16x16x4_f64 streams
     (gpbo_mfma_f64_probe, in-kernel s_memtime / s_memrealtime clocks) in the posterior GEMM's register pattern at 4 waves
     per SIMD and in the plain 8-accumulator pattern at 2 — `peak_measured` is the best of them, `sustained_mhz` the shader
-    clock under that load, `peak_at_sustained_clock` = 256 CUs x 4 SIMDs x 32 flop/clk x that clock (what the datasheet's
+    clock under that load, `peak_at_sustained_clock` = the device's CUs (256) x 4 SIMDs x 32 flop/clk x that clock (what the datasheet's
     78.6 TFLOP/s becomes at the clock this box holds; the fp32 matrix rate is twice that)."""
     probes = []
     for waves, mode in ((4, 2), (2, 0), (4, 0)):
@@ -331,10 +331,14 @@ def measured_peak(eng, prec):
                        "tflops_over_kernel_span": float(r["tflops"]), "shader_mhz": float(r["shader_mhz"]), "event_ms": float(r["ms"])})
     best = max(probes, key=lambda p: p["tflops_over_kernel_span"])
     scale = 2.0 if prec else 1.0
-    return {"peak_measured": best["tflops_over_kernel_span"] * scale, "sustained_mhz": best["shader_mhz"],
-            "peak_at_sustained_clock": 256 * 4 * 32 * best["shader_mhz"] * 1e6 / 1e12 * scale,
+    try:
+        cus = int(eng.device_info()["compute_units"])      # (hipDeviceProp.multiProcessorCount: 256 on an MI355X)
+    except Exception:  # noqa: BLE001
+        cus = 256
+    return {"peak_measured": best["tflops_over_kernel_span"] * scale, "sustained_mhz": best["shader_mhz"], "compute_units": cus,
+            "peak_at_sustained_clock": cus * 4 * 32 * best["shader_mhz"] * 1e6 / 1e12 * scale,
             "peak_measured_note": ("best of the v_mfma_f64_16x16x4_f64 micro-benchmarks below" + (" x 2 (fp32 matrix rate)" if prec else "")
-                                   + "; a register-constant MFMA stream is not a ceiling for a kernel (DESIGN.md §4.1 fact 3): "
+                                   + "; a register-constant MFMA stream is not a ceiling for a kernel (docs/LAB_NOTEBOOK.md §4.1 fact 3): "
                                      "frac_of_measured may exceed what frac_at_sustained_clock allows"),
             "mfma_probes": probes}
 

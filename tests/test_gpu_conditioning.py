@@ -2,7 +2,7 @@
 
 Every other parity test of the suite uses the max-norm `rel_err` (tests/conftest.py) on problems whose kernel matrix has a
 condition number <= 5e6.  The device does not do what the reference does: it forms W = L^-1 once per fit and multiplies
-(V = W K*^T, DESIGN.md), the reference back-substitutes per candidate (`solve_triangular`, sklearn _gpr.py:454-456, and
+(V = W K*^T, DESIGN.md §5.1), the reference back-substitutes per candidate (`solve_triangular`, sklearn _gpr.py:454-456, and
 `cho_solve` for alpha, :360-364).  The two agree to kappa(K) * eps, so this file runs them where kappa(K) = 1e8 .. 2e9 — the
 regime 2-D problems with a few hundred points, RBF kernels and `allow_duplicate_points=True`
 (/root/reference/bayes_opt/target_space.py:424-518) put real users in:

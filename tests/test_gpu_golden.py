@@ -88,7 +88,7 @@ def test_c5_shape_fp64_sample_matches_reference(engine):
 
 @pytest.mark.parametrize("name", ["T1", "T2"])
 def test_plateau_tie_order_against_reference(engine, name):
-    """Exact ties: T1 = POI underflowed to 0 for all 4096 candidates, T2 = EI underflowed to 0 for all but 9
+    """Exact ties (docs/LAB_NOTEBOOK.md §7, fidelity notes): T1 = POI underflowed to 0 for all 4096 candidates, T2 = EI underflowed to 0 for all but 9
     of 512.  `ys.argmin()` (acquisition.py:313) is the lowest index by NumPy's definition and must be reproduced; for
     `np.argsort(ys)[:k]` (acquisition.py:316) NumPy leaves the order of equal keys unspecified (the reference's own run
     returned 4088..4095, 4080.. on T1) and the device returns the documented one: ascending value, then ascending index,
