@@ -107,9 +107,25 @@ def cpu_baseline(w, X, y, c, Xc, y_max, gpu_ys, n_chunks=3):
             xs = Xc[ci * chunk:(ci + 1) * chunk]
             t0 = time.perf_counter()
             ys = acq(xs)
-            times.append(time.perf_counter() - t0)
+            dt = time.perf_counter() - t0
+            # a chunk that takes milliseconds (C1: 1024 candidates on 25 observations) is timed again until 0.2 s have gone by
+            # and quoted by its median: one 0.3 ms sample is noise, not a baseline (the first call also pays scikit-learn's
+            # lazily built predict state)
+            reps = [dt]
+            while sum(reps) < 0.2 and len(reps) < 200:
+                t0 = time.perf_counter()
+                acq(xs)
+                reps.append(time.perf_counter() - t0)
+            times.append(float(np.median(reps)))
             g = gpu_ys[ci * chunk:(ci + 1) * chunk]
             worst = max(worst, float(np.max(np.abs(g - ys)) / np.max(np.abs(ys))))
+    if fit_s < 0.05 and kind == "port":      # the same for a fit that takes milliseconds
+        fts = []
+        while sum(fts) < 0.2 and len(fts) < 50:
+            t0 = time.perf_counter()
+            GaussianProcessRegressor(kernel=mk(w.length_scale), alpha=w.noise, normalize_y=True, optimizer=None).fit(X, y)
+            fts.append(time.perf_counter() - t0)
+        fit_s = float(np.median(fts)) * (2 if w.constrained else 1)
     med = float(np.median(times))
     try:
         from threadpoolctl import threadpool_info
