@@ -685,6 +685,7 @@ def main():
     # what the hardware and RCCL say about this run (PCI bus ids, ncclCommCount), gathered before rank 0 prints: a first run on
     # more than one physical GPU judges itself from the line
     hw = {"rccl_nranks": None, "devices": None}
+    code, nr = -1.0, -1.0          # this rank's PCI (domain, bus) as one number, and what ncclCommCount says
     try:
         if mode == "group":
             infos = eng.per_device_info()
@@ -695,17 +696,23 @@ def main():
             info = eng.device_info()
             hw["devices"] = [info["pci_bus_id"]]
             hw["rccl_nranks"] = info["rccl_nranks"]
-            if mode == "ranks":
-                # every rank's PCI bus id as (domain:bus, rank) records over the same communicator
-                bus = info["pci_bus_id"].split(":")
-                code = float(int(bus[0], 16) * 256 + int(bus[1], 16)) if len(bus) >= 2 else -1.0
-                av, ai = eng.comm_allgather_best(np.array([code, float(info["rccl_nranks"])]), np.full(2, rank, dtype=np.int64))
-                av = np.asarray(av).reshape(world, 2)
-                hw["devices"] = [f"{int(v) // 256:04x}:{int(v) % 256:02x}" for v in av[:, 0]]
-                hw["rccl_nranks"] = [int(v) for v in av[:, 1]]
-                hw["distinct_physical_gpus"] = len(set(hw["devices"]))
+            bus = info["pci_bus_id"].split(":")
+            if len(bus) >= 2:
+                code = float(int(bus[0], 16) * 256 + int(bus[1], 16))
+            nr = float(info["rccl_nranks"])
     except Exception as e:  # noqa: BLE001
         hw["error"] = repr(e)
+    if mode == "ranks":
+        # every rank enters this exchange whatever happened above (a rank that skipped it would leave its peers waiting for the
+        # collective's deadline): (PCI domain:bus, ncclCommCount) of every rank as records over the same communicator
+        try:
+            av, _ = eng.comm_allgather_best(np.array([code, nr]), np.full(2, rank, dtype=np.int64))
+            av = np.asarray(av).reshape(world, 2)
+            hw["devices"] = [(f"{int(v) // 256:04x}:{int(v) % 256:02x}" if v >= 0 else "?") for v in av[:, 0]]
+            hw["rccl_nranks"] = [int(v) for v in av[:, 1]]
+            hw["distinct_physical_gpus"] = len(set(hw["devices"]))
+        except Exception as e:  # noqa: BLE001
+            hw["error"] = repr(e)
 
     if rank == 0:
         steps = args.steps
