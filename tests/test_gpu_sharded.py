@@ -269,6 +269,26 @@ def test_comm_acq_argbest_single_rank_is_acq_argbest(engine):
         engine.world_size, engine.rank = 1, 0
 
 
+def test_device_info_says_what_the_hardware_and_rccl_see():
+    """What `bench.py` prints as `config.devices` / `config.rccl_nranks` (round 5): the PCI bus id of the context's device and
+    ncclCommCount of its communicator — 0 before gpbo_comm_init, the world size RCCL itself reports after it; a device group
+    reports one entry per member (virtual ranks: the same bus id twice, which is how the line tells them from real devices)."""
+    import re
+
+    from bayesianoptimization_amd.engine import GpEngine
+
+    with GpEngine(0) as e:
+        info = e.device_info()
+        assert re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9]", info["pci_bus_id"]), info
+        assert info["rccl_nranks"] == 0 and info["world"] == 1 and info["rank"] == 0 and info["compute_units"] >= 1
+        e.comm_init(GpEngine.comm_unique_id(), 1, 0)
+        assert e.device_info()["rccl_nranks"] == 1
+    with GroupEngine([0, 0]) as grp:
+        infos = grp.per_device_info()
+        assert len(infos) == 2 and infos[0]["pci_bus_id"] == infos[1]["pci_bus_id"] == info["pci_bus_id"]
+        assert all(i["rccl_nranks"] == 0 for i in infos)      # virtual ranks merge on the host: no communicator to count
+
+
 def test_two_estimators_sharing_a_slot_do_not_read_each_others_factorisation(engine):
     """Two HipGPRs on slot 0 of one engine (two accelerated optimizers, or a clone): a read after the OTHER one refitted
     the slot must come from the reader's own model (the reference gives each estimator its own L_/alpha_)."""
