@@ -141,7 +141,7 @@ struct WStripArgs {
 // Workgroup (s, lane): strip s = columns 16 s ... 16 s + 15, inside 64-block c = s / 4.  Row r = c + 1 ... nblk - 1 is a sequence of
 // r - c + 1 products of a 64x64 block with a 64x16 block: t = c ... r - 1 multiply L_rt (from L) with X_t, the last one (t = r)
 // multiplies D_r (from dinv, lower triangular by 16-tiles) with the row's sum T_r and gives X_r = -D_r T_r, which goes to LDS
-// (for the rows below) and to W.  LDS: (NP / 64 - c) x 8 KiB for the strip + 32 KiB of exchange.
+// (for the rows below) and to W.  LDS: (NP / 64 - c) x 8 KiB for the strip + 2 x 32 KiB of exchange (one area beyond NP = 768).
 //
 // 1024 threads = 16 waves = FOUR per SIMD: wave w owns the 16-row tile ti = w & 3 of every block and the k-quarter kq = w >> 2
 // (k-steps h = 2 kq, 2 kq + 1) of every product — 4 v_mfma_f64_16x16x4_f64 per wave and product, two accumulators.  The first
@@ -169,7 +169,10 @@ __global__ __launch_bounds__(WS_THREADS) void w_strip_kernel(WStripArgs a) {
   const double* dinv = a.dinv + lo;
   double* W = a.W + lo;
   double* XB = ws_smem;                         // [nblk - c][64][16]: the strip from block row c down, rows in image order (ws_perm)
-  double* EX = ws_smem + (nblk - c) * 1024;     // [4][64][16]: the k-quarters' partial sums of T_r, then of D_r T_r
+  double* EX = ws_smem + (nblk - c) * 1024;     // [4][64][16]: the k-quarters' partial sums of T_r
+  // ... and of D_r T_r: an area of its own where the 160 KiB allow it (NP <= 768), else the same one behind one more barrier
+  const bool ex_alias = nblk > 12;
+  double* EX2 = ex_alias ? EX : EX + WS_EXCH;
   const int64_t col0 = 16 * (int64_t)s;
 
   for (int idx = tid; idx < 64 * c * 16; idx += WS_THREADS) W[(int64_t)(idx >> 4) * NP + col0 + (idx & 15)] = 0.0;   // above block row c
@@ -177,11 +180,10 @@ __global__ __launch_bounds__(WS_THREADS) void w_strip_kernel(WStripArgs a) {
     const int k = tid >> 4, n = tid & 15;
     const double v = dinv[(int64_t)c * 4096 + k * 64 + 16 * q + n];
     XB[ws_perm(k) * 16 + n] = v;
-    W[((int64_t)c * 64 + k) * NP + col0 + n] = v;
   }
   ws_barrier();
 
-  constexpr int WS_AHEAD = 3, WS_RING = WS_AHEAD + 1;
+  constexpr int WS_AHEAD = 3, WS_RING = WS_AHEAD + 1;     // (5: no faster — 43.8 vs 42.0 us at NP = 512; 7: spills)
   d2v abuf[WS_RING][2];    // the wave's A fragments of a product: block[16 ti + lr][8 h + 2 lk + {0, 1}], h = 2 kq, 2 kq + 1
   // Both operand sources are read through buffer descriptors — a wave-uniform base in SGPRs, the lane's constant 32-bit offset, the
   // walk over the blocks as the instruction's scalar offset — so a request is a few scalar instructions and two loads.  (With flat
@@ -213,12 +215,38 @@ __global__ __launch_bounds__(WS_THREADS) void w_strip_kernel(WStripArgs a) {
   int r = c + 1, t = c;                          // the product being multiplied
   d4 acc0 = d4{0.0, 0.0, 0.0, 0.0}, acc1 = d4{0.0, 0.0, 0.0, 0.0};
   const int boff = (16 * kq + lk) * 16 + lr;     // the wave's B fragment (h, e) of a [64][16] image: boff + (8 (h - 2 kq) + 4 e) * 16
+  // A row's end is a dependent chain — the k-quarters of T_r meet in LDS, D_r T_r, its k-quarters meet in LDS, X_r — that only the
+  // LAST product of the next row waits for (t = r needs X_r; t < r does not).  So the chain is spread over the next row's first
+  // steps instead of standing between the rows with the matrix pipe idle (round 5: 5 000 cycles per row end, 42 % of the loop; spread
+  // out: 47.3 -> 42.0 us per launch at NP = 512 — the chain itself, ~4.8 us per row, is what is left):
+  //   D step of row r:        T partials -> EX | barrier | D_r T_r by k-quarter -> EX2        (pend_sum: X_r still to be summed)
+  //   first product of r + 1: its MFMAs | barrier | waves kq = 0 sum the k-quarters -> X_r    (pend_x: X_r not yet visible to all)
+  //   last product of r + 1:  barrier | its MFMAs
+  // All flags are the same in every wave (they follow r and t), so every wave meets the same barriers in the same order.
+  bool pend_sum = false, pend_x = false;
+  int pend_row = 0;
+  auto sum_x = [&]() {     // waves kq = 0: row tile ti of X_{pend_row} = -(k-quarters 0 .. ti in order) -> the strip image
+    if (kq == 0) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int row = 16 * ti + lk + 4 * rr;
+        double v = EX2[row * 16 + lr];
+        for (int qq = 1; qq <= ti; ++qq) v += EX2[qq * 1024 + row * 16 + lr];
+        v = -v;
+        XB[(pend_row - c) * 1024 + ws_perm(row) * 16 + lr] = v;
+      }
+    }
+  };
   while (r < nblk) {
 #pragma unroll
     for (int j = 0; j < WS_RING; ++j) {
       request(abuf[(j + WS_AHEAD) % WS_RING]);      // unconditional (straight-line code: the loads in flight can be counted)
       if (r < nblk) {
         if (t < r) {       // T_r += L_rt X_t (this wave: its k-quarter)
+          if (pend_x && t == r - 1) {              // the one product that multiplies X_{r-1}
+            ws_barrier();
+            pend_x = false;
+          }
           const double* xb = XB + (t - c) * 1024 + boff;
           const double b0 = xb[0], b1 = xb[4 * 16], b2 = xb[8 * 16], b3 = xb[12 * 16];
           acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[j][0].x, b0, acc0, 0, 0, 0);
@@ -226,7 +254,13 @@ __global__ __launch_bounds__(WS_THREADS) void w_strip_kernel(WStripArgs a) {
           acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[j][1].x, b2, acc0, 0, 0, 0);
           acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[j][1].y, b3, acc1, 0, 0, 0);
           ++t;
-        } else {           // X_r = -D_r T_r
+          if (pend_sum) {                          // the previous row's partial products are all in EX2
+            ws_barrier();
+            pend_sum = false;
+            sum_x();
+            pend_x = true;
+          }
+        } else {           // X_r = -D_r T_r, first half
           {
             const d4 part = acc0 + acc1;
 #pragma unroll
@@ -246,25 +280,14 @@ __global__ __launch_bounds__(WS_THREADS) void w_strip_kernel(WStripArgs a) {
             p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[j][1].x, bt[2], p0, 0, 0, 0);
             p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[j][1].y, bt[3], p1, 0, 0, 0);
           }
-          ws_barrier();    // everybody has read the T partials: the exchange area takes the partial products now
+          if (ex_alias) ws_barrier();              // (one exchange area only: everybody has read the T partials first)
           if (kq <= ti) {
             const d4 part = p0 + p1;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) EX[kq * 1024 + (16 * ti + lk + 4 * rr) * 16 + lr] = part[rr];
+            for (int rr = 0; rr < 4; ++rr) EX2[kq * 1024 + (16 * ti + lk + 4 * rr) * 16 + lr] = part[rr];
           }
-          ws_barrier();
-          if (kq == 0) {   // row tile ti: the k-quarters 0 .. ti in order, negated
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              const int row = 16 * ti + lk + 4 * rr;
-              double v = EX[row * 16 + lr];
-              for (int qq = 1; qq <= ti; ++qq) v += EX[qq * 1024 + row * 16 + lr];
-              v = -v;
-              XB[(r - c) * 1024 + ws_perm(row) * 16 + lr] = v;
-              W[((int64_t)64 * r + row) * NP + col0 + lr] = v;
-            }
-          }
-          ws_barrier();    // X_r complete for everyone; the exchange area is free again
+          pend_sum = true;
+          pend_row = r;
           acc0 = d4{0.0, 0.0, 0.0, 0.0};
           acc1 = d4{0.0, 0.0, 0.0, 0.0};
           ++r;
@@ -273,7 +296,19 @@ __global__ __launch_bounds__(WS_THREADS) void w_strip_kernel(WStripArgs a) {
       }
     }
   }
+  if (pend_sum) {          // the last row
+    ws_barrier();
+    sum_x();
+  }
+  ws_barrier();            // the strip image is complete for everyone
 
+  // W from the strip image, in one pass at the end.  (No global store inside the product loop: the wave's memory counter is
+  // in-order, so a store issued between two operand requests makes the wait for the younger request a wait for the store's
+  // acknowledgement — ~2 us per row on the four summing waves, and everybody else meets them at the next barrier.)
+  for (int idx = tid; idx < (int)(NP - 64 * (int64_t)c) * 16; idx += WS_THREADS) {
+    const int i = idx >> 4, n = idx & 15;
+    W[((int64_t)64 * c + i) * NP + col0 + n] = XB[(i & ~63) * 16 + ws_perm(i & 63) * 16 + n];
+  }
   // the strip's contribution to t = W y: rows 64 c ... NP - 1, (row group, column) per thread, 16-lane shuffle tree
   const int nrows = (int)(NP - 64 * (int64_t)c);
   {
@@ -371,14 +406,14 @@ int mid_max_np() {
 int launch_w_strip(gpbo_ctx* ctx, Model& m, bool pack) {
   if (!(ctx->func_attrs & ATTR_MID)) {
     GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(w_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)((MID_NP_CAP / 64 * 1024 + WS_EXCH) * sizeof(double))));
+                                      (int)(160 * 1024)));
     ctx->func_attrs |= ATTR_MID;
   }
   WStripArgs a{};
   a.L = m.L; a.dinv = m.dinv; a.y = m.yn; a.W = m.W; a.Wp = m.Wp; a.partial = m.tmp;
   a.N = m.N; a.NP = m.NP; a.lane_stride = ctx->lane_stride; a.pack = (pack && m.Wp) ? 1 : 0;
 
-  const size_t lds = (size_t)(m.NP / 64 * 1024 + WS_EXCH) * sizeof(double);
+  const size_t lds = (size_t)(m.NP / 64 * 1024 + (m.NP / 64 > 12 ? 1 : 2) * WS_EXCH) * sizeof(double);
   w_strip_kernel<<<dim3((unsigned)(m.NP / 16), (unsigned)ctx->lanes), dim3(WS_THREADS), lds, ctx->stream>>>(a);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
