@@ -142,6 +142,48 @@ class FakeEngine:
         mu, sd, dmu, dsd = O.predict_grad(self.models[slot], np.asarray(Xc, dtype=np.float64))
         return y_std * mu + y_mean, sd * y_std, y_std * dmu, y_std * dsd
 
+    def polish_seeds(self, acq, param, y_max, lb, ub, y_means, y_stds, seeds, box, max_iter=0):
+        """The local-search stage as ONE engine call (GpEngine.polish_seeds / gpbo_polish_seeds), on the oracle: every seed's
+        L-BFGS-B run by SciPy over the oracle's -acquisition [x constraint probability] — analytic gradient (O.predict_grad + the
+        chain rule) without constraints, SciPy's finite differences with them.  Returns (x, f, status 0 | 2, rounds)."""
+        import copy
+
+        from scipy.optimize import minimize
+
+        self.calls.append(("polish_seeds", acq, len(seeds)))
+        gps = []
+        for j in range(len(y_means)):
+            g = copy.copy(self.models[j])
+            g.y_mean, g.y_std = float(y_means[j]), float(y_stds[j])
+            gps.append(g)
+        ym = 0.0 if y_max is None else float(y_max)
+        cons = (gps[1:], lb, ub) if len(gps) > 1 else None
+
+        def f_only(x):
+            return float(O.neg_acquisition(gps[0], x[None], acq, param, ym, cons)[0])
+
+        def f_grad(x):
+            mu, sd, dmu, dsd = (v[0] for v in O.predict_grad(gps[0], x[None]))
+            if acq == O.UCB:
+                a, ca, cs = mu + param * sd, 1.0, param
+            else:
+                aa = mu - ym - param
+                z = aa / sd
+                cdf, pdf = float(O.norm_cdf(z)), float(O.norm_pdf(z))
+                a, ca, cs = (aa * cdf + sd * pdf, cdf, pdf) if acq == O.EI else (cdf, pdf / sd, -pdf * z / sd)
+            return -a, -(ca * dmu + cs * dsd)
+
+        box = np.asarray(box, dtype=np.float64)
+        xs, fs, status = [], [], []
+        for s0 in np.asarray(seeds, dtype=np.float64):
+            res = minimize(f_grad, s0, jac=True, bounds=box, method="L-BFGS-B") if cons is None else \
+                minimize(f_only, s0, bounds=box, method="L-BFGS-B")
+            xs.append(res.x)
+            fs.append(float(np.squeeze(res.fun)))
+            status.append(0 if res.success else 2)
+        self._resident = False
+        return np.array(xs), np.array(fs), np.array(status, dtype=np.int32), 0
+
     def acq_argbest(self, acq, param, y_max=0.0, lb=None, ub=None, k_seeds=0, index_offset=0, return_values=False):
         self.calls.append(("acq_argbest", acq, k_seeds))
         mu, sd = self.post[0]

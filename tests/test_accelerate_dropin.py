@@ -449,3 +449,42 @@ def test_accelerate_with_an_unsupported_kernel_warns_once_and_keeps_the_optimize
         warnings.simplefilter("ignore")
         ref.maximize(init_points=2, n_iter=2)
     assert np.array_equal(mine.space.params, ref.space.params)
+
+
+def test_default_accelerate_path_reaches_the_references_acquisition_value():
+    """accelerate()'s DEFAULT configuration — theta search on the engine (`lml_on_device="auto"`) and the local searches as one
+    engine call (`local_search="auto"`, gpbo_polish_seeds) — is not bit for bit the reference: the same candidate
+    stage, the same seeds, another optimiser.  What must hold: after identical histories the point it suggests has an acquisition
+    value at least as good as the reference's own suggestion, up to the optimisers' tolerances (here: the oracle-backed engine
+    runs SciPy's L-BFGS-B with the analytic gradient where the reference differentiates numerically)."""
+    import_reference()
+    from bayes_opt import BayesianOptimization
+
+    from bayesianoptimization_amd import accelerate
+    from oracle import gp_oracle as O
+
+    ref = BayesianOptimization(f=black_box, pbounds=PB, random_state=5, verbose=0)
+    mine = BayesianOptimization(f=black_box, pbounds=PB, random_state=5, verbose=0)
+    eng = FakeEngine()
+    accelerate(mine, engine=eng)                       # every default
+    rng = np.random.RandomState(0)
+    for _ in range(12):                                # identical histories
+        p = {"x": float(rng.uniform(2, 4)), "y": float(rng.uniform(-3, 3))}
+        t = black_box(**p)
+        ref.register(params=p, target=t)
+        mine.register(params=p, target=t)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        x_ref = ref._space.params_to_array(ref.suggest())
+        x_mine = mine._space.params_to_array(mine.suggest())
+    assert any(c[0] == "polish_seeds" for c in eng.calls) and any(c[0] == "lml_batch" for c in eng.calls)    # the default path ran
+    # the acquisition both maximise, under the reference's own fitted GP (UCB, kappa = 2.576: bayes_opt's default)
+    gp = ref._gp
+    def ucb(x):
+        mu, sd = gp.predict(np.asarray(x, dtype=np.float64).reshape(1, -1), return_std=True)
+        return float(mu[0] + 2.576 * sd[0])
+    a_ref, a_mine = ucb(x_ref), ucb(x_mine)
+    scale = max(1.0, abs(a_ref))
+    assert a_mine >= a_ref - 1e-5 * scale, (a_mine, a_ref, x_mine, x_ref)
+    # ... and theta agrees to rounding (the engine's LML is the oracle's arithmetic, sklearn's up to the last bits)
+    assert np.allclose(mine._gp.kernel_.theta, ref._gp.kernel_.theta, rtol=1e-6, atol=1e-8)
