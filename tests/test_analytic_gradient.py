@@ -86,6 +86,7 @@ def test_suggest_with_analytic_gradient_is_at_least_as_good(policy, constrained)
     for analytic in (False, True):
         w, sp, gp, fn = _setup(constrained, policy)
         fn.analytic_gradient = analytic
+        fn.device_polish = False          # this test is about the Python driver over gpbo_predict_grad (the one-call stage has its own)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             x = fn.suggest(gp, sp, n_random=3000, n_smart=6, fit_gp=True, random_state=np.random.RandomState(11))
