@@ -1,4 +1,4 @@
-// The fit / log-marginal-likelihood evaluation of a MID-SIZE problem (fused_max_np() < NP <= mid_max_np(), i.e. 65 ... 512
+// The fit / log-marginal-likelihood evaluation of a MID-SIZE problem (fused_max_np() < NP <= mid_max_np(), i.e. 65 ... 768
 // observations in the product) in ~15 launches instead of ~45 (gfx950).
 //
 // What it replaces: GaussianProcessRegressor.fit at fixed theta and log_marginal_likelihood(theta, eval_gradient) for the sizes
@@ -394,7 +394,8 @@ __global__ __launch_bounds__(256) void alpha_strip_kernel(const double* __restri
 }
 
 // Largest padded size the strip path serves (fused_max_np() < NP <= mid_max_np()).  The strip's LDS image caps it at 1024; the
-// default is where it stops beating the recursive inverse's GEMMs (profiles/r05_mid_fit_timing.json).  (Debug build:
+// default (768) is where one lane stops beating the multi-launch path (profiles/r05_small_fit_timing.json: fit 0.31 vs 0.39 ms at
+// 768, 0.44 vs 0.49 at 1024 but a resident lane 0.52 vs 0.51 there).  (Debug build:
 // GPBO_MID_MAX_NP = 0 ... 1024 read per call, for the A/B tests and the crossover measurement.)
 int mid_max_np() {
   int v = MID_NP_DEFAULT;
