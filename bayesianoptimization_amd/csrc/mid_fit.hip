@@ -122,7 +122,7 @@ int launch_kmat_q(gpbo_ctx* ctx, Model& m, double noise, double* out) {
 }
 
 // ---- W = L^-1 by column strips -------------------------------------------------------------------------------------------------
-// LDS only between the four waves: the wait covers LDS traffic alone, so the global loads requested for the NEXT product stay in
+// LDS only between the waves: the wait covers LDS traffic alone, so the global loads requested for the NEXT product stay in
 // flight across the barrier (__syncthreads() would drain them: its workgroup-scope release waits for vmcnt too).
 __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -144,16 +144,21 @@ struct WStripArgs {
 // (for the rows below) and to W.  LDS: (NP / 64 - c) x 8 KiB for the strip + 2 x 32 KiB of exchange (one area beyond NP = 768).
 //
 // 1024 threads = 16 waves = FOUR per SIMD: wave w owns the 16-row tile ti = w & 3 of every block and the k-quarter kq = w >> 2
-// (k-steps h = 2 kq, 2 kq + 1) of every product — 4 v_mfma_f64_16x16x4_f64 per wave and product, two accumulators.  The first
-// version gave a product to four waves (one per SIMD, 16 MFMAs each) and ran at 140 cycles per MFMA: one wave cannot feed its
-// SIMD's fp64 matrix pipe (gpbo_mfma_f64_probe: 140 / 102 / 63 cycles per MFMA with 1 / 2 / 4 waves) — 47 us for the c = 0 strips
-// at NP = 512 against 15 us of pipe time.  The k-quarters of a row's sum meet in LDS (fixed order 0..3), so do those of D_r T_r.
+// (k-steps h = 2 kq, 2 kq + 1) of every product — 4 v_mfma_f64_16x16x4_f64 per wave and product, two accumulators (one wave per
+// SIMD cannot feed the fp64 matrix pipe: gpbo_mfma_f64_probe, 140 / 102 / 63 cycles per MFMA with 1 / 2 / 4 waves).  The
+// k-quarters of a row's sum meet in LDS (fixed order 0..3), so do those of D_r T_r.
 //
-// All operand addresses are known up front, and L has just been written by other compute units (its lines come from the memory
-// side, ~1.5-2 us): the A fragments run WS_AHEAD products ahead in a ring of register sets (static indices: the sequence is
-// walked in groups of WS_AHEAD + 1), across row ends and their LDS barriers.  Every request is the same two 16-byte loads
-// whatever it fetches (a request past the end repeats the last one) and sits in straight-line code: the compiler counts the loads
-// in flight exactly and waits for the oldest set only.
+// All operand addresses are known up front, and L has just been written by other compute units: the A fragments run WS_AHEAD
+// products ahead in a ring of register sets (static indices: the sequence is walked in groups of WS_AHEAD + 1), across row ends
+// and their LDS barriers.  Every request is the same two 16-byte loads whatever it fetches (a request past the end repeats the
+// last one) and sits in straight-line code: the compiler counts the loads in flight exactly and waits for the oldest set only
+// (loads issued under a branch make its waitcnt pass fall back to vmcnt(0)).
+//
+// What the kernel costs and why (NP = 512, the c = 0 strips: 35 products = 15 us of matrix-pipe time; measured 42 us, round 5): a
+// product step takes ~1 400 cycles (1 024 of pipe) and a row end ~5 500 cycles of five synchronisation points.  Measured on the way
+// and NOT the bound: operand latency (look-ahead 1 / 3 / 5, an up-front touch of everything the strip reads: same time), the wave
+// count by itself (4 waves with 16 MFMAs each: same time), the address arithmetic (flat 64-bit addresses: 491 k VALU instructions
+// against 26 k MFMAs per launch; buffer descriptors: a tenth of that, same time), stores inside the loop.  docs/LAB_NOTEBOOK.md §9.2.
 constexpr int WS_THREADS = 1024;
 constexpr int WS_EXCH = 4 * 1024;       // doubles: [k-quarter][64 rows in image order][16]
 __global__ __launch_bounds__(WS_THREADS) void w_strip_kernel(WStripArgs a) {
@@ -186,10 +191,8 @@ __global__ __launch_bounds__(WS_THREADS) void w_strip_kernel(WStripArgs a) {
   constexpr int WS_AHEAD = 3, WS_RING = WS_AHEAD + 1;     // (5: no faster — 43.8 vs 42.0 us at NP = 512; 7: spills)
   d2v abuf[WS_RING][2];    // the wave's A fragments of a product: block[16 ti + lr][8 h + 2 lk + {0, 1}], h = 2 kq, 2 kq + 1
   // Both operand sources are read through buffer descriptors — a wave-uniform base in SGPRs, the lane's constant 32-bit offset, the
-  // walk over the blocks as the instruction's scalar offset — so a request is a few scalar instructions and two loads.  (With flat
-  // 64-bit per-lane addresses a product cost ~70 VALU and ~50 SALU instructions next to its 4 MFMAs: the loop was bound by its
-  // address arithmetic, 1.1 us per product whatever the look-ahead, the wave count or the state of the caches — rocprofv3:
-  // SQ_INSTS_VALU 491 k against SQ_INSTS_MFMA 26 k per launch at NP = 512.)
+  // walk over the blocks as the instruction's scalar offset — so a request is a few scalar instructions and two loads (flat 64-bit
+  // per-lane addresses: ~70 VALU and ~50 SALU instructions per product next to its 4 MFMAs).
   constexpr int WS_BUF_FLAGS = 0x00020000;       // gfx9 raw buffer descriptor word 3
   const __amdgpu_buffer_rsrc_t rs_l = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(L), 0, 0x7fffffff, WS_BUF_FLAGS);
   const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(dinv), 0, 0x7fffffff, WS_BUF_FLAGS);
