@@ -131,6 +131,8 @@ DEBUG_SIGNATURES = {
                                         _c_double_p]),
     "gpbo_hybrid_probe": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _c_double_p]),
     "gpbo_debug_fail_next_acq": (C.c_int, [C.c_void_p]),
+    "gpbo_debug_polish_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, _c_double_p, C.c_int, C.c_int,
+                                         C.c_int, _c_double_p]),
 }
 
 _lib = None

@@ -34,6 +34,7 @@ SOURCES = {
     "posterior_kernel_v2.hip": [],
     "posterior_small.hip": [],
     "polish.hip": [],                          # gpbo_polish_seeds: the local-search stage as one C call (host optimiser, device evaluations)
+    "polish_fused.hip": [],                    # ... and as one launch for NP <= 768: one workgroup per local search, evaluations + optimiser inside
     "posterior_kernel_f32.hip": [],
     "posterior_cov.hip": [],
     "lml_kernels.hip": [],

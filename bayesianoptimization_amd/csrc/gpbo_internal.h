@@ -169,11 +169,13 @@ namespace gpbo {
 
 constexpr size_t SMALL_PIN_IN = 128 * 1024, SMALL_PIN_OUT = 32 * 1024;   // bytes: candidates in; mu, sd out (each)
 constexpr size_t SMALL_PIN_BYTES = SMALL_PIN_IN + 2 * SMALL_PIN_OUT;
-constexpr unsigned ATTR_GEMM128 = 4u, ATTR_CHOL128 = 16u, ATTR_FUSED = 32u, ATTR_MID = 64u, ATTR_KINV_GRAD = 128u;
+constexpr unsigned ATTR_GEMM128 = 4u, ATTR_CHOL128 = 16u, ATTR_FUSED = 32u, ATTR_MID = 64u, ATTR_KINV_GRAD = 128u, ATTR_POLISH_FUSED = 256u;
 // fused_small.hip: the whole fit / LML evaluation of a problem of NP <= fused_max_np() as one launch of one workgroup per model
 constexpr int FUSED_NP_DEFAULT = 64, FUSED_NP_CAP = 512;
 // mid_fit.hip: fused_max_np() < NP <= mid_max_np(): the strip algorithms, ~15 launches
 constexpr int MID_NP_DEFAULT = 768, MID_NP_CAP = 1024;
+// the local searches of gpbo_polish_seeds as one launch (polish_fused.hip): up to this padded size, one model
+constexpr int POLISH_FUSED_NP_DEFAULT = 256, POLISH_FUSED_NP_CAP = 768;
 // pinned staging of a small host-side fit's X (N, d) | y (N), read by the first kernel directly (one window per PIN window)
 constexpr int STAGE_NP_CAP = MID_NP_CAP;
 static_assert(STAGE_NP_CAP >= FUSED_NP_CAP, "the staging window serves both small paths");
@@ -406,6 +408,15 @@ int build_acq_args(gpbo_ctx* ctx, const char* who, int acq, double acq_param, do
 // posterior_small.hip
 int launch_posterior_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double y_std);
 int small_batch_limit(int64_t NP);   // largest M the GEMV path takes (posterior_small.hip)
+// polish_fused.hip: gpbo_polish_seeds' runs as one launch (one workgroup per run).  host_block / dev_block: the two addresses of one
+// device-visible pinned block of polish_fused_pinned_bytes(n_seeds, d); results land there (layout: polish_fused.hip).  eval_repeat = R > 0:
+// no search, R evaluations at every seed (the debug entry's timing and parity seam).
+int polish_fused_max_np();
+bool polish_fused_serves(const Model& m);
+size_t polish_fused_pinned_bytes(int n_seeds, int d);
+int launch_polish_fused(gpbo_ctx* ctx, Model& m, int acq, double acq_param, double y_max, double y_mean, double y_std, const double* seeds,
+                        int n_seeds, const double* box_lo, const double* box_hi, int max_iter, int eval_repeat, double* host_block,
+                        double* dev_block);
 int launch_posterior_grad_small(gpbo_ctx* ctx, Model& m, int M, double y_mean, double y_std, double* dmu_dev, double* dsd_dev,
                                 double* mu_out, double* sd_out);
 // lml_kernels.hip

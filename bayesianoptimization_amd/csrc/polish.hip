@@ -9,7 +9,12 @@
 // (launch_posterior_grad per model: mu, sd and their input gradients from one k*) and a few hundred
 // flops of optimiser arithmetic per seed on the host.
 //
-// The optimiser is a projected L-BFGS (two-loop recursion over the free variables, backtracking on the projected path
+// Round 5: for one model of NP <= 256 the whole stage is ONE LAUNCH instead (polish_fused.hip: a workgroup per run, evaluations and
+// optimiser inside it, the same bits as the rounds here for UCB): 20-37 us per evaluation against 41-51 us per round, and no
+// lockstep — a default suggest() spends 0.73 instead of 1.13 ms in its local searches at N <= 143.  The rounds below serve
+// everything else (larger models, constraint slots).
+//
+// The optimiser (polish_opt.h) is a projected L-BFGS (two-loop recursion over the free variables, backtracking on the projected path
 // with an Armijo test on the actual displacement), NOT a transcription of L-BFGS-B: no generalised Cauchy point, no
 // subspace minimisation.  It keeps L-BFGS-B's stopping rule as SciPy configures it for `minimize` (m = 10 corrections,
 // projected-gradient tolerance 1e-5, relative reduction 1e7 * eps, 20 line-search steps, 15000 iterations), and its
@@ -21,171 +26,14 @@
 #include <vector>
 
 #include "gpbo_internal.h"
+#include "polish_opt.h"
 
 namespace gpbo {
 
 namespace {
 
-constexpr int LBFGS_M = 10;
-constexpr double PGTOL = 1e-5;
-constexpr double FTOL = 1e7 * 2.220446049250313e-16;
-constexpr int MAXLS = 20;
-
 inline double norm_cdf(double z) { return 0.5 * std::erfc(-z * 0.70710678118654752440); }
 inline double norm_pdf(double z) { return std::exp(-0.5 * z * z) * 0.39894228040143267794; }
-
-struct Run {
-  int d = 0;
-  std::vector<double> x, g, xt, dir, S, Y;       // S, Y: LBFGS_M rows of d
-  double f = 0.0, alpha = 1.0;
-  int hist = 0, head = 0;       // pairs stored, next slot
-  int iter = 0, evals = 0, ls = 0;
-  int phase = 0;                // 0: first evaluation pending, 1: line search, 2: finished
-  int status = 2;               // 0: projected gradient, 1: relative reduction / no further progress, 2: iteration limit,
-                                // 3: line search exhausted (SciPy: ABNORMAL_TERMINATION_IN_LNSRCH, success = False)
-};
-
-// max_i |P(x - g)_i - x_i|
-double projected_gradient_norm(const Run& r, const double* lo, const double* hi) {
-  double m = 0.0;
-  for (int i = 0; i < r.d; ++i) {
-    const double t = std::min(std::max(r.x[i] - r.g[i], lo[i]), hi[i]) - r.x[i];
-    m = std::max(m, std::fabs(t));
-  }
-  return m;
-}
-
-// dir = -H g over the free variables (a variable sitting on a bound with the gradient pushing outwards stays there).
-// The correction pairs are restricted to the CURRENT free set before they are used (components of fixed variables are
-// dropped from s and y, a pair whose restricted curvature s.y is not positive is skipped): without that the pairs of
-// an earlier active set steer the step and the run needs 1.5-2x the iterations (measured against SciPy on C2 / C3).
-void new_direction(Run& r, const double* lo, const double* hi) {
-  const int d = r.d;
-  std::vector<char> freev((size_t)d);
-  for (int i = 0; i < d; ++i)
-    freev[i] = !((r.x[i] <= lo[i] && r.g[i] > 0.0) || (r.x[i] >= hi[i] && r.g[i] < 0.0));
-  std::vector<double> q((size_t)d);
-  for (int i = 0; i < d; ++i) q[i] = freev[i] ? r.g[i] : 0.0;
-  double a[LBFGS_M], rho[LBFGS_M];
-  int order[LBFGS_M], used = 0;        // newest first
-  double gamma = 1.0;
-  for (int t = 0; t < r.hist; ++t) {
-    const int k = (r.head - 1 - t + 2 * LBFGS_M) % LBFGS_M;
-    const double* s = &r.S[(size_t)k * d];
-    const double* y = &r.Y[(size_t)k * d];
-    double sy = 0.0, yy = 0.0;
-    for (int i = 0; i < d; ++i)
-      if (freev[i]) { sy += s[i] * y[i]; yy += y[i] * y[i]; }
-    if (!(sy > 2.2e-16 * yy) || !(yy > 0.0)) continue;
-    if (used == 0) gamma = sy / yy;
-    rho[used] = 1.0 / sy;
-    order[used++] = k;
-  }
-  for (int t = 0; t < used; ++t) {
-    const double* s = &r.S[(size_t)order[t] * d];
-    const double* y = &r.Y[(size_t)order[t] * d];
-    double sq = 0.0;
-    for (int i = 0; i < d; ++i) if (freev[i]) sq += s[i] * q[i];
-    a[t] = rho[t] * sq;
-    for (int i = 0; i < d; ++i) if (freev[i]) q[i] -= a[t] * y[i];
-  }
-  for (int i = 0; i < d; ++i) q[i] *= gamma;
-  for (int t = used - 1; t >= 0; --t) {
-    const double* s = &r.S[(size_t)order[t] * d];
-    const double* y = &r.Y[(size_t)order[t] * d];
-    double yq = 0.0;
-    for (int i = 0; i < d; ++i) if (freev[i]) yq += y[i] * q[i];
-    const double b = rho[t] * yq;
-    for (int i = 0; i < d; ++i) if (freev[i]) q[i] += (a[t] - b) * s[i];
-  }
-  double gd = 0.0, gn = 0.0;
-  for (int i = 0; i < d; ++i) {
-    r.dir[i] = freev[i] ? -q[i] : 0.0;
-    gd += r.dir[i] * r.g[i];
-    if (freev[i]) gn += r.g[i] * r.g[i];
-  }
-  if (!(gd < 0.0) || !std::isfinite(gd)) {     // not a descent direction: steepest descent over the free variables, history dropped
-    r.hist = 0;
-    used = 0;
-    for (int i = 0; i < d; ++i) r.dir[i] = freev[i] ? -r.g[i] : 0.0;
-  }
-  // L-BFGS-B takes a unit step except when it has no curvature information, where it starts from 1 / |d|
-  r.alpha = (used == 0) ? std::min(1.0, 1.0 / std::sqrt(std::max(gn, 1e-300))) : 1.0;
-  r.ls = 0;
-}
-
-void trial_point(Run& r, const double* lo, const double* hi) {
-  for (int i = 0; i < r.d; ++i) r.xt[i] = std::min(std::max(r.x[i] + r.alpha * r.dir[i], lo[i]), hi[i]);
-}
-
-// one answer (f_t, g_t at r.xt) of the objective; leaves the next request in r.xt unless the run has finished
-void advance(Run& r, double ft, const double* gt, const double* lo, const double* hi, int max_iter) {
-  const int d = r.d;
-  ++r.evals;
-  if (r.phase == 0) {
-    r.x = r.xt;
-    r.f = ft;
-    std::copy(gt, gt + d, r.g.begin());
-    if (!std::isfinite(ft)) { r.phase = 2; r.status = 2; return; }
-    if (projected_gradient_norm(r, lo, hi) <= PGTOL) { r.phase = 2; r.status = 0; return; }
-    new_direction(r, lo, hi);
-    trial_point(r, lo, hi);
-    r.phase = 1;
-    return;
-  }
-  double gs = 0.0, moved = 0.0;       // g . (x_t - x): the Armijo test on the displacement the projection left
-  for (int i = 0; i < d; ++i) {
-    const double s = r.xt[i] - r.x[i];
-    gs += r.g[i] * s;
-    moved = std::max(moved, std::fabs(s));
-  }
-  const bool ok = std::isfinite(ft) && ft <= r.f + 1e-4 * gs;
-  if (!ok) {
-    // no further progress along this path (x stays): the step no longer moves x, the line search is exhausted, or — after
-    // two shrinks — the values differ by less than the relative-reduction tolerance, i.e. the test is deciding on rounding
-    const bool flat = std::isfinite(ft) && r.ls >= 2 &&
-                      std::fabs(ft - r.f) <= FTOL * std::max(std::max(std::fabs(ft), std::fabs(r.f)), 1.0);
-    // (an exhausted line search is SciPy's "ABNORMAL" termination, success = False: the reference discards such a run,
-    //  acquisition.py:367 — its own status, so that the caller can do the same)
-    if (moved == 0.0 || flat) { r.phase = 2; r.status = 1; return; }
-    if (++r.ls >= MAXLS) { r.phase = 2; r.status = 3; return; }
-    // the minimiser of the parabola through f, its slope and f_t, kept inside [0.1, 0.5] of the step that failed
-    double shrink = 0.1;
-    if (std::isfinite(ft)) {
-      const double curv = ft - r.f - gs;
-      shrink = curv > 0.0 ? std::min(std::max(-gs / (2.0 * curv), 0.1), 0.5) : 0.5;
-    }
-    r.alpha *= shrink;
-    trial_point(r, lo, hi);
-    return;
-  }
-  // accepted
-  {
-    double* s = &r.S[(size_t)r.head * d];
-    double* y = &r.Y[(size_t)r.head * d];
-    double sy = 0.0, yy = 0.0;
-    for (int i = 0; i < d; ++i) {
-      s[i] = r.xt[i] - r.x[i];
-      y[i] = gt[i] - r.g[i];
-      sy += s[i] * y[i];
-      yy += y[i] * y[i];
-    }
-    if (sy > 2.2e-16 * yy && yy > 0.0) {          // L-BFGS-B's curvature test (repeated on the free set when the pair is used)
-      r.head = (r.head + 1) % LBFGS_M;
-      r.hist = std::min(r.hist + 1, LBFGS_M);
-    }
-  }
-  const double f_old = r.f;
-  r.x = r.xt;
-  r.f = ft;
-  std::copy(gt, gt + d, r.g.begin());
-  ++r.iter;
-  if (projected_gradient_norm(r, lo, hi) <= PGTOL) { r.phase = 2; r.status = 0; return; }
-  if ((f_old - ft) <= FTOL * std::max(std::max(std::fabs(f_old), std::fabs(ft)), 1.0)) { r.phase = 2; r.status = 1; return; }
-  if (r.iter >= max_iter) { r.phase = 2; r.status = 2; return; }
-  new_direction(r, lo, hi);
-  trial_point(r, lo, hi);
-}
 
 // All runs in lockstep: `eval(batch, live, f, g)` evaluates the objective and its gradient at the `live` trial points of the
 // round (rows of `batch`, d columns) in one go and returns a status code; the runs that are still alive get their answers
@@ -194,13 +42,13 @@ void advance(Run& r, double ft, const double* gt, const double* lo, const double
 template <class Eval>
 int lockstep_minimize(Eval&& eval, const double* seeds, int n_seeds, int d, const double* box_lo, const double* box_hi, int max_iter,
                       double* x_out, double* f_out, int* status_out, int* n_rounds_out, int* n_iter_out, int* n_eval_out) {
-  std::vector<Run> runs((size_t)n_seeds);
+  // (the optimiser itself: polish_opt.h — shared with the one-launch device path)
+  std::vector<PolishRun> runs((size_t)n_seeds);
+  std::vector<double> store((size_t)n_seeds * polish_run_doubles(d));
+  std::vector<int> istore((size_t)n_seeds * polish_run_ints(d));
   for (int s = 0; s < n_seeds; ++s) {
-    Run& r = runs[s];
-    r.d = d;
-    r.x.assign((size_t)d, 0.0); r.g.assign((size_t)d, 0.0); r.xt.assign((size_t)d, 0.0); r.dir.assign((size_t)d, 0.0);
-    r.S.assign((size_t)LBFGS_M * d, 0.0); r.Y.assign((size_t)LBFGS_M * d, 0.0);
-    for (int i = 0; i < d; ++i) r.xt[i] = std::min(std::max(seeds[(size_t)s * d + i], box_lo[i]), box_hi[i]);
+    polish_run_bind(runs[s], d, store.data() + (size_t)s * polish_run_doubles(d), istore.data() + (size_t)s * polish_run_ints(d));
+    polish_start(runs[s], seeds + (size_t)s * d, box_lo, box_hi);
   }
   std::vector<double> batch((size_t)n_seeds * d), fv((size_t)n_seeds), gv((size_t)n_seeds * d);
   std::vector<int> who((size_t)n_seeds);
@@ -209,7 +57,7 @@ int lockstep_minimize(Eval&& eval, const double* seeds, int n_seeds, int d, cons
     int live = 0;
     for (int s = 0; s < n_seeds; ++s)
       if (runs[s].phase != 2) {
-        std::copy(runs[s].xt.begin(), runs[s].xt.end(), batch.begin() + (size_t)live * d);
+        std::copy(runs[s].xt, runs[s].xt + d, batch.begin() + (size_t)live * d);
         who[live++] = s;
       }
     if (live == 0) break;
@@ -219,12 +67,12 @@ int lockstep_minimize(Eval&& eval, const double* seeds, int n_seeds, int d, cons
     for (int t = 0; t < live; ++t) {
       double* g = &gv[(size_t)t * d];
       for (int i = 0; i < d; ++i) if (!std::isfinite(g[i])) g[i] = 0.0;
-      advance(runs[who[t]], fv[t], g, box_lo, box_hi, max_iter);
+      polish_advance(runs[who[t]], fv[t], g, box_lo, box_hi, max_iter);
     }
     if (rounds > 4 * max_iter + 64) break;      // cannot happen (every run is bounded by max_iter * MAXLS); never spin
   }
   for (int s = 0; s < n_seeds; ++s) {
-    std::copy(runs[s].x.begin(), runs[s].x.end(), x_out + (size_t)s * d);
+    std::copy(runs[s].x, runs[s].x + d, x_out + (size_t)s * d);
     f_out[s] = runs[s].f;
     status_out[s] = runs[s].phase == 2 ? runs[s].status : 2;
     if (n_iter_out) n_iter_out[s] = runs[s].iter;
@@ -250,8 +98,39 @@ extern "C" int gpbo_debug_minimize_box(gpbo_fg_callback fg, void* user, const do
   for (int i = 0; i < d; ++i)
     if (!(box_lo[i] < box_hi[i])) return GPBO_ERR_INVALID;
   if (max_iter < 1) max_iter = 15000;
+  if (max_iter > 100000000) max_iter = 100000000;      // (4 * max_iter + 64 rounds is an int)
   return lockstep_minimize([&](const double* batch, int live, double* f, double* g) { return fg(batch, live, d, f, g, user); }, seeds,
                            n_seeds, d, box_lo, box_hi, max_iter, x_out, f_out, status_out, n_rounds_out, n_iter_out, n_eval_out);
+}
+#endif  // GPBO_DEBUG
+
+#ifdef GPBO_DEBUG
+// The one-launch path's objective at each of n points, evaluated `repeat` times in one launch (timing): out (n, 4 + 3 d) =
+// [f, mu, sd, 0 | g | dmu | dsd].
+extern "C" int gpbo_debug_polish_eval(gpbo_ctx* ctx, int acq, double acq_param, double y_max, double y_mean, double y_std,
+                                      const double* points, int n, int d, int repeat, double* out) {
+  if (!ctx || !points || !out || n < 1 || n > GPBO_MAX_SEEDS || repeat < 1) return GPBO_ERR_INVALID;
+  Model& m = ctx->models[0];
+  if (!m.fitted || m.d != d) GPBO_FAIL(ctx, GPBO_ERR_STATE, "debug_polish_eval: slot 0 is not fitted for this d");
+  if (!polish_fused_serves(m)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "debug_polish_eval: the model is outside the one-launch path's range");
+  GPBO_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t need = polish_fused_pinned_bytes(n, d);
+  if ((int64_t)need > ctx->cap_polish_pinned) {
+    if (ctx->polish_pinned) GPBO_HIP(ctx, hipHostFree(ctx->polish_pinned));
+    ctx->polish_pinned = nullptr;
+    ctx->cap_polish_pinned = 0;
+    GPBO_HIP(ctx, hipHostMalloc(&ctx->polish_pinned, need, hipHostMallocDefault));
+    GPBO_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->polish_pinned_dev, ctx->polish_pinned, 0));
+    ctx->cap_polish_pinned = (int64_t)need;
+  }
+  std::vector<double> lo((size_t)d, -1e300), hi((size_t)d, 1e300);
+  const int rc = launch_polish_fused(ctx, m, acq, acq_param, y_max, y_mean, y_std, points, n, lo.data(), hi.data(), 1, repeat,
+                                     (double*)ctx->polish_pinned, (double*)ctx->polish_pinned_dev);
+  if (rc) return rc;
+  const size_t S = (size_t)n;
+  const double* dbg = (const double*)ctx->polish_pinned + 2 * S * d + 2 * (size_t)d + S;
+  std::copy(dbg, dbg + S * (4 + 3 * (size_t)d), out);
+  return GPBO_OK;
 }
 #endif  // GPBO_DEBUG
 
@@ -267,6 +146,7 @@ extern "C" int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, doubl
   if (n_constraints < 0 || n_constraints >= GPBO_MAX_MODELS || (n_constraints > 0 && (!lb || !ub)))
     GPBO_FAIL(ctx, GPBO_ERR_INVALID, "polish_seeds: bad constraint arguments");
   if (max_iter < 1) max_iter = 15000;
+  if (max_iter > 100000000) max_iter = 100000000;      // (4 * max_iter + 64 rounds is an int)
   for (int j = 0; j <= n_constraints; ++j) {
     if (!ctx->models[j].fitted) GPBO_FAIL(ctx, GPBO_ERR_STATE, "polish_seeds: model slot has not been fitted");
     if (ctx->models[j].d != d) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "polish_seeds: d differs from the fitted model's");
@@ -282,7 +162,10 @@ extern "C" int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, doubl
   // there: a round is six launches and ONE stream synchronisation, no copy nodes (round 5; until then: H2D copy + event, D2H copy).
   const size_t per_model = (size_t)n_seeds * (2 + 2 * (size_t)d);
   const size_t pts = (size_t)n_seeds * (size_t)d;
-  const size_t need = (pts + per_model * (size_t)n_models) * sizeof(double);
+  // (NP <= polish_fused_max_np(), one model: the runs as ONE launch — polish_fused.hip; GPBO_POLISH_FUSED=0, debug build: never)
+  const char* pf_env = dbg_env("GPBO_POLISH_FUSED");
+  const bool fused = n_constraints == 0 && polish_fused_serves(ctx->models[0]) && !(pf_env && pf_env[0] == '0');
+  const size_t need = std::max((pts + per_model * (size_t)n_models) * sizeof(double), fused ? polish_fused_pinned_bytes(n_seeds, d) : (size_t)0);
   if ((int64_t)need > ctx->cap_polish_pinned) {
     if (ctx->polish_pinned) GPBO_HIP(ctx, hipHostFree(ctx->polish_pinned));
     ctx->polish_pinned = nullptr;
@@ -296,6 +179,27 @@ extern "C" int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, doubl
   const double* pts_d = (const double*)ctx->polish_pinned_dev;
   double* land_d = (double*)ctx->polish_pinned_dev + pts;
   const bool timing0 = ctx->no_timing;
+
+  if (fused) {
+    const int rc = launch_polish_fused(ctx, ctx->models[0], acq, acq_param, y_max, y_mean[0], y_std[0], seeds, n_seeds, box_lo, box_hi,
+                                       max_iter, 0, (double*)ctx->polish_pinned, (double*)ctx->polish_pinned_dev);
+    if (rc) return rc;
+    const size_t S = (size_t)n_seeds;
+    const double* xo = (const double*)ctx->polish_pinned + S * d + 2 * (size_t)d;
+    const double* fo = xo + S * d;
+    const int* io = (const int*)(fo + S + S * (4 + 3 * (size_t)d));
+    std::copy(xo, xo + S * d, x_out);
+    std::copy(fo, fo + S, f_out);
+    int rounds = 0;
+    for (int s = 0; s < n_seeds; ++s) {
+      status_out[s] = io[s];
+      if (n_iter_out) n_iter_out[s] = io[S + s];
+      if (n_eval_out) n_eval_out[s] = io[2 * S + s];
+      rounds = std::max(rounds, io[2 * S + s]);
+    }
+    if (n_rounds_out) *n_rounds_out = rounds;      // (what the lockstep path counts: batched evaluations = the longest run's)
+    return GPBO_OK;
+  }
 
   auto eval = [&](const double* batch, const int live, double* fv, double* gv) -> int {
     // ---- one batched evaluation: posterior + input gradient of every model at the live runs' trial points
@@ -317,18 +221,10 @@ extern "C" int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, doubl
       const double* dsd = o0 + (size_t)live * d + (size_t)t * d;
       const double mu = o0[2 * (size_t)live * d + t], sd = o0[2 * (size_t)live * d + live + t];
       double a, ca, cs;      // acq value; d acq = ca * dmu + cs * dsd
-      if (acq == GPBO_ACQ_UCB) {
-        a = mu + acq_param * sd; ca = 1.0; cs = acq_param;
-      } else {
-        const double aa = mu - y_max - acq_param;
-        const double z = aa / sd;
-        const double cdf = norm_cdf(z), pdf = norm_pdf(z);
-        if (acq == GPBO_ACQ_EI) { a = aa * cdf + sd * pdf; ca = cdf; cs = pdf; }
-        else { a = cdf; ca = pdf / sd; cs = -pdf * z / sd; }
-      }
+      polish_acq_coeffs(acq, acq_param, y_max, mu, sd, norm_cdf, norm_pdf, a, ca, cs);
       double f = -a;
       double* g = gv + (size_t)t * d;
-      for (int i = 0; i < d; ++i) g[i] = -(ca * dmu[i] + cs * dsd[i]);
+      for (int i = 0; i < d; ++i) g[i] = polish_acq_grad(ca, cs, dmu[i], dsd[i]);
       if (n_constraints > 0) {
         double p = 1.0;
         std::vector<double> pj((size_t)n_constraints), dp((size_t)n_constraints * d, 0.0);

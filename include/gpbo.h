@@ -235,6 +235,8 @@ int gpbo_predict_grad(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int 
  * from the posteriors of slots 0..n_constraints and their input gradients (as gpbo_predict_grad), and the optimiser
  * arithmetic (a projected L-BFGS with L-BFGS-B's stopping rule as SciPy configures it: 10 corrections, projected gradient
  * 1e-5, relative reduction 1e7 eps, 20 line-search steps, max_iter <= 0 -> 15000 iterations) runs on the host in between.
+ * One model of at most 256 (padded) observations: the runs are one launch, a workgroup each, evaluations and optimiser on the
+ * device — the same optimiser source, the same evaluation arithmetic, the same results (bit for bit for UCB).
  * Not the reference's iterates: parity is statistical (acquisition value at the returned point).
  * y_mean / y_std: (1 + n_constraints,) the targets' normalisation per slot; seeds (n_seeds,d), clipped into the box;
  * box_lo < box_hi (d,).  Outputs per seed: x_out (n_seeds,d) inside the box, f_out, status_out (0: projected gradient
@@ -359,7 +361,7 @@ int gpbo_hbm_copy_peak(gpbo_ctx* ctx, int64_t bytes, double* gbps);
 /* ==== DEBUG BUILD ONLY (-DGPBO_DEBUG: bayesianoptimization_amd/libgpbo_dbg.so) ==========================================
  * Self-test seams, single-kernel timers and micro-benchmarks the tests and scripts/ use.  The product library
  * (libgpbo.so) exports none of them, reads none of the A/B environment switches (GPBO_CHOL_*, GPBO_POST_*, GPBO_SMALL_MAX,
- * GPBO_SELECT_V2*, GPBO_MT_*, GPBO_F32_*, GPBO_GEMM128, GPBO_TRI64*, GPBO_LML_GRAPH) and contains no scratch-using kernel. */
+ * GPBO_SELECT_V2*, GPBO_MT_*, GPBO_F32_*, GPBO_GEMM128, GPBO_TRI64*, GPBO_LML_GRAPH, GPBO_POLISH_FUSED*) and contains no scratch-using kernel. */
 #ifdef GPBO_DEBUG
 /* The optimiser of gpbo_polish_seeds alone, over a host objective (self-test seam: no device, no context): `fg` is called
  * once per lockstep round with the trial points of the runs that are still alive — x (n_live,d) -> f (n_live), g (n_live,d) —
@@ -368,6 +370,12 @@ typedef int (*gpbo_fg_callback)(const double* x, int n_live, int d, double* f, d
 int gpbo_debug_minimize_box(gpbo_fg_callback fg, void* user, const double* seeds, int n_seeds, int d, const double* box_lo,
                             const double* box_hi, int max_iter, double* x_out, double* f_out, int* status_out, int* n_rounds_out,
                             int* n_iter_out, int* n_eval_out);
+
+/* The objective of gpbo_polish_seeds' one-launch path (polish_fused.hip; slot 0, no constraints) at each of n <= 64 points (n,d),
+ * evaluated `repeat` >= 1 times inside one launch (repeat > 1: for timing an evaluation): out (n, 4 + 3 d) = [f, mu, sd, 0 | df/dx (d) |
+ * dmu/dx (d) | dsd/dx (d)] — what gpbo_predict_grad's six kernels compute, from the one kernel (the tests require the same bits). */
+int gpbo_debug_polish_eval(gpbo_ctx* ctx, int acq, double acq_param, double y_max, double y_mean, double y_std, const double* points,
+                           int n, int d, int repeat, double* out);
 
 /* Multi-GPU failure path, self-test seam (no device needed): a group of workers without contexts, and a job in which
  * rank `fail_rank` returns `fail_code` and rank `hang_rank` sleeps `hang_ms` (either may be -1). */

@@ -17,6 +17,8 @@ MAP = {
     "theta_search_timing.json": "r05_theta_search_timing.json",
     "small_fit_timing.json": "r05_small_fit_timing.json", "maximize_loop.json": "r05_maximize_loop.json",
     "tri_grid_ab.json": "r05_tri_grid_ab.json", "r04_chol_chain.json": "r05_chol_chain.json",
+    "polish_fused_ab.json": "r05_polish_fused_ab.json", "suggest_host_profile.txt": "r05_suggest_host_profile.txt",
+    "polish_sweep.json": "r05_polish_sweep.json",
     "pytest.log": "r05_pytest_gpu.log", "smoke.log": "r05_smoke.log",
 }
 for src, dst in MAP.items():

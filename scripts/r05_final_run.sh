@@ -2,8 +2,8 @@
 # Round 5, end-of-round measurement run (on the GPU box through gpurun): the whole -m gpu suite, smoke(), the rocprofv3 passes of the
 # bench command for C3 and C2 (their summaries are put under profiles/ ON THE BOX first, so that the bench line quotes PMC numbers of
 # the very library it runs), the default bench line, the 2-virtual-rank group line, a kernel trace of the C2 step, the SQ passes over
-# the C2 posterior kernel, the theta-search timing, the small-fit timing of the three fit paths, the maximize() loop and the
-# live-tile-grid A/B.  Everything lands in gpurun_out/r05f/ (scripts/r05_collect_final.py copies it to profiles/).
+# the C2 posterior kernel, the theta-search timing, the small-fit timing of the three fit paths, the maximize() loop, the
+# live-tile-grid A/B, the one-launch / lockstep local-search A/B and the host profile of a default suggest().  Everything lands in gpurun_out/r05f/ (scripts/r05_collect_final.py copies it to profiles/).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 F=gpurun_out/r05f; rm -rf $F; mkdir -p $F
@@ -41,6 +41,9 @@ timeout 300 python scripts/r05_small_fit_timing.py > $F/small_fit_timing.json 2>
 timeout 400 python scripts/r05_maximize_loop.py > $F/maximize_loop.json 2> $F/maximize_loop.err; tail -2 $F/maximize_loop.err
 timeout 300 python scripts/r05_tri_grid_ab.py > $F/tri_grid_ab.json 2> $F/tri_grid_ab.err; tail -2 $F/tri_grid_ab.err
 timeout 100 python scripts/r04_chol_chain.py 128 512 2048 4096 > $F/chol_chain.log 2>&1; cp gpurun_out/r04_chol_chain.json $F/ 2>/dev/null
+timeout 200 python scripts/r05_polish_fused_ab.py > $F/polish_fused_ab.json 2> $F/polish_fused_ab.err; tail -1 $F/polish_fused_ab.err | cut -c1-200
+timeout 200 python scripts/r05_suggest_host_profile.py > $F/suggest_host_profile.txt 2>&1; head -2 $F/suggest_host_profile.txt
+cp gpurun_out/r04_polish_sweep.json $F/polish_sweep.json 2>/dev/null
 find $F gpurun_out/r05_pmc_C2_posterior -name '*.db' -delete
 ls $F
 echo done
