@@ -46,6 +46,9 @@ def advance_mt19937(random_state, n_words: int, lib=None):
     random_state.set_state((name, key_out, (n_words - avail - 1) % 624 + 1, has_gauss, cached))
 
 
+_INT_ARRAYS: dict = {}      # ctypes array types by length (creating one costs ~2 us per call)
+
+
 class GpEngine:
     """One engine context = one GPU, one HIP stream, 8 model slots (0 = target GP, 1.. = constraint GPs) and one resident
     candidate matrix.  Calls are synchronous from the host's point of view unless noted (`posterior(fetch=False)` only
@@ -208,19 +211,31 @@ class GpEngine:
         """[(lml, grad)] for every row of `length_scales` (n_theta x n_ls), evaluated side by side on the device
         (gpbo_lml_batch); each entry is bitwise what `lml()` returns for that row.  Model slots are not touched.
         reuse_inputs=True: (X, y_norm) are the arrays of the previous call and are not uploaded again."""
+        vals, grads = self.lml_batch_arrays(X, y_norm, kernel, length_scales, noise, eval_gradient, reuse_inputs)
+        return [(float(vals[i]), grads[i].copy()) for i in range(vals.shape[0])]
+
+    def lml_batch_arrays(self, X, y_norm, kernel: int, length_scales, noise: float, eval_gradient=True, reuse_inputs=False):
+        """`lml_batch` as two arrays — values (n_theta,) and gradients (n_theta, n_ls): what a theta-search round needs, without
+        the per-lane tuples (a round is ~50-100 us of device time at small N: every microsecond of Python around it shows)."""
         self._settle()
-        X = np.ascontiguousarray(X, dtype=np.float64)
-        y_norm = np.ascontiguousarray(y_norm, dtype=np.float64).ravel()
         ls = np.ascontiguousarray(np.atleast_2d(np.asarray(length_scales, dtype=np.float64)))
         n, n_ls = ls.shape
         vals = np.zeros(n)
         grads = np.zeros((n, n_ls))
-        infos = (C.c_int * n)()
-        rc = self._lib.gpbo_lml_batch(self._h, n, None if reuse_inputs else dptr(X), None if reuse_inputs else dptr(y_norm),
-                                      X.shape[0], X.shape[1], int(kernel), dptr(ls),
-                                      n_ls, float(noise), int(bool(eval_gradient)), dptr(vals), dptr(grads), infos)
-        self._check(rc)
-        return [(float(vals[i]), grads[i].copy()) for i in range(n)]
+        infos = _INT_ARRAYS.get(n)
+        if infos is None:
+            infos = _INT_ARRAYS[n] = C.c_int * n
+        if reuse_inputs:
+            xp = yp = None
+        else:
+            X = np.ascontiguousarray(X, dtype=np.float64)
+            y_norm = np.ascontiguousarray(y_norm, dtype=np.float64).ravel()
+            xp, yp = dptr(X), dptr(y_norm)
+        rc = self._lib.gpbo_lml_batch(self._h, n, xp, yp, X.shape[0], X.shape[1], int(kernel), dptr(ls), n_ls, float(noise),
+                                      int(bool(eval_gradient)), dptr(vals), dptr(grads), infos())
+        if rc:
+            self._check(rc)
+        return vals, grads
 
     def _touch(self, slot: int) -> int:
         """Every call that rewrites a slot's factorisation bumps its serial; an estimator compares the serial it got

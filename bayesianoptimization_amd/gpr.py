@@ -80,6 +80,36 @@ def describe_kernel(kernel):
     return kind, np.atleast_1d(np.asarray(k.length_scale, dtype=np.float64))
 
 
+def _bare_length_scale_kernel(kernel) -> bool:
+    """True for a bare Matern / RBF (or a wrap_kernel subclass of one) whose length scale is free: its theta IS log(length_scale)
+    and its bounds ARE log(length_scale_bounds) (kernels.py: Hyperparameter("length_scale", "numeric", bounds, n_elements)), so the
+    fit can read and write them as attributes instead of through Kernel.theta / .bounds / .n_dims — each of which walks
+    dir(kernel) and inspect.signature (~0.05 ms a time, eight times per fit: a fifth of a small-N suggest's host time)."""
+    cls = type(kernel)
+    ok = _BARE_CLASSES.get(cls)
+    if ok is None:      # once per class (wrap_kernel makes one class per optimizer): length_scale is its ONLY hyper-parameter
+        ok = _BARE_CLASSES[cls] = issubclass(cls, RBF) and [a for a in dir(cls) if a.startswith("hyperparameter_")] == ["hyperparameter_length_scale"]
+    return ok and not isinstance(kernel.length_scale_bounds, str)
+
+
+_BARE_CLASSES: dict = {}
+
+
+def _length_scale_theta(kernel):
+    """(theta, bounds) of such a kernel, as Kernel.theta / Kernel.bounds return them (kernels.py:285-343)."""
+    ls = np.atleast_1d(np.asarray(kernel.length_scale, dtype=np.float64))
+    b = np.atleast_2d(np.asarray(kernel.length_scale_bounds, dtype=np.float64))
+    if ls.shape[0] > 1 and b.shape[0] == 1:
+        b = np.repeat(b, ls.shape[0], 0)
+    return np.log(ls), np.log(b)
+
+
+def _set_length_scale_theta(kernel, theta):
+    """Kernel.theta = theta for such a kernel (kernels.py:309-334: a scalar for one element, an array for several)."""
+    theta = np.asarray(theta, dtype=np.float64)
+    kernel.length_scale = np.exp(theta) if np.iterable(kernel.length_scale) and len(kernel.length_scale) > 1 else np.exp(theta[0])
+
+
 class HipGPR(GaussianProcessRegressor):
     """GaussianProcessRegressor whose fixed-theta fit and posterior run on the MI355X engine."""
 
@@ -190,6 +220,8 @@ class HipGPR(GaussianProcessRegressor):
             _, ls = describe_kernel(kernel)
         except NotImplementedError:
             return False
+        if _bare_length_scale_kernel(kernel):
+            return True
         free = [h for h in kernel.hyperparameters if not h.fixed]
         return len(free) == 1 and free[0].name.endswith("length_scale") and kernel.n_dims == ls.shape[0]
 
@@ -306,7 +338,9 @@ class HipGPR(GaussianProcessRegressor):
         self.__dict__.pop("_alpha_cache", None)
 
         self._in_fit = True
-        if self.optimizer is not None and self.kernel_.n_dims > 0:  # _gpr.py:296-338 (L-BFGS-B on the host;
+        bare = _bare_length_scale_kernel(self.kernel_)
+        theta0, bounds = _length_scale_theta(self.kernel_) if bare else (None, None)
+        if self.optimizer is not None and (theta0.shape[0] if bare else self.kernel_.n_dims) > 0:  # _gpr.py:296-338 (L-BFGS-B on the host;
             # each objective evaluation runs on the device when _device_lml_ok)
             def obj_func(theta, eval_gradient=True):
                 if eval_gradient:
@@ -316,8 +350,9 @@ class HipGPR(GaussianProcessRegressor):
 
             # sklearn draws each restart's start right before running it (_gpr.py:325-334); the runs never touch the
             # RandomState, so drawing all starts first consumes the stream identically
-            bounds = self.kernel_.bounds
-            starts = [self.kernel_.theta]
+            if not bare:
+                theta0, bounds = self.kernel_.theta, self.kernel_.bounds
+            starts = [theta0]
             if self.n_restarts_optimizer > 0:
                 if not np.isfinite(bounds).all():
                     raise ValueError("Multiple optimizer restarts (n_restarts_optimizer>0) requires that all bounds are finite.")
@@ -330,8 +365,15 @@ class HipGPR(GaussianProcessRegressor):
             else:
                 optima = [self._constrained_optimization(obj_func, start, bounds) for start in starts]
             lml_values = list(map(itemgetter(1), optima))
-            self.kernel_.theta = optima[np.argmin(lml_values)][0]
-            self.kernel_._check_bounds_params()
+            theta_opt = optima[np.argmin(lml_values)][0]
+            if bare:
+                _set_length_scale_theta(self.kernel_, theta_opt)
+                # (_check_bounds_params warns for the entries np.isclose finds on a bound: ask it only when there is one)
+                if np.isclose(bounds, np.atleast_2d(theta_opt).T).any():
+                    self.kernel_._check_bounds_params()
+            else:
+                self.kernel_.theta = theta_opt
+                self.kernel_._check_bounds_params()
             self.log_marginal_likelihood_value_ = -np.min(lml_values)
         else:
             self.__dict__.pop("log_marginal_likelihood_value_", None)   # evaluated lazily (property below): _gpr.py:339-342
@@ -361,12 +403,14 @@ class HipGPR(GaussianProcessRegressor):
         # kernels.py:Hyperparameter/theta); checked once here — starts[0] IS kernel_.theta — instead of cloning the kernel
         # for every evaluation (a clone costs ~0.1 ms of sklearn's get_params / signature machinery)
         kind, ls0 = describe_kernel(self.kernel_)
-        if not np.allclose(ls0, np.exp(starts[0]), rtol=1e-12, atol=0.0):
+        if not np.all(np.abs(ls0 - np.exp(starts[0])) <= 1e-12 * np.abs(np.exp(starts[0]))):
             raise RuntimeError("theta does not map to the length scale as expected")    # pragma: no cover
         uploaded = [False]
         # how much work the search did (bench.py quotes the calls whose search ran >= 10 rounds separately)
         self.theta_search_rounds_ = 0      # lockstep rounds = gpbo_lml_batch calls on the critical path
         self.theta_search_evals_ = 0       # LML + gradient evaluations over all restarts
+
+        batch_arrays = getattr(eng, "lml_batch_arrays", None)      # (GpEngine; engines without it: the list form)
 
         def evaluate(thetas):
             self.theta_search_rounds_ += 1
@@ -374,11 +418,16 @@ class HipGPR(GaussianProcessRegressor):
             rows = np.empty((len(thetas), 1 + n_dims))
             scales = np.exp(np.asarray(thetas, dtype=np.float64))
             for lo in range(0, len(thetas), 8):
-                part = eng.lml_batch(X, y, kind, scales[lo:lo + 8], noise, eval_gradient=True, reuse_inputs=uploaded[0])
+                if batch_arrays is not None:
+                    vals, grads = batch_arrays(X, y, kind, scales[lo:lo + 8], noise, True, uploaded[0])
+                    rows[lo:lo + len(vals), 0] = vals
+                    rows[lo:lo + len(vals), 1:] = grads
+                else:
+                    part = eng.lml_batch(X, y, kind, scales[lo:lo + 8], noise, eval_gradient=True, reuse_inputs=uploaded[0])
+                    for j, (val, grad) in enumerate(part):
+                        rows[lo + j, 0] = val
+                        rows[lo + j, 1:] = grad
                 uploaded[0] = True
-                for j, (val, grad) in enumerate(part):
-                    rows[lo + j, 0] = val
-                    rows[lo + j, 1:] = grad
             return rows
 
         from . import lbfgsb_lockstep

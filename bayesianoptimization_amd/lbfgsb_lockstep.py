@@ -228,15 +228,18 @@ def _drive(evaluate, evals_per_request, starts, box, maxcor, ftol, gtol, maxfun,
     def step(run):
         """Advance one run to its next f/g request at a NEW point (returns True) or to its end (False)."""
         while True:
-            run.g = run.g.astype(np.float64)
+            if run.g.dtype != np.float64:       # (_minimize_lbfgsb: g = g.astype(np.float64) — only the initial int32 zeros need it)
+                run.g = run.g.astype(np.float64)
             setulb(maxcor, run.x, low_bnd, upper_bnd, nbd, run.f, run.g, factr, gtol, run.wa, run.iwa, run.task,
                    run.lsave, run.isave, run.dsave, maxls, run.ln_task)
-            if run.task[0] == _TASK_FG:
-                if run.x_seen is not None and np.array_equal(run.x, run.x_seen):
-                    run.f, run.g = run.f_seen, run.g_seen      # ScalarFunction answers a repeated x from its cache
+            task = int(run.task[0])
+            if task == _TASK_FG:
+                # ScalarFunction answers a repeated x from its cache (np.array_equal: elementwise ==, so a NaN never matches)
+                if run.x_seen is not None and bool((run.x == run.x_seen).all()):
+                    run.f, run.g = run.f_seen, run.g_seen
                     continue
                 return True
-            if run.task[0] == _TASK_NEW_X:
+            if task == _TASK_NEW_X:
                 run.nit += 1
                 if run.nit >= maxiter:
                     run.task[0], run.task[1] = _TASK_STOP, 504

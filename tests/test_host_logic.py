@@ -424,3 +424,62 @@ def test_blas_single_thread_is_reentrant_and_thread_safe():
     for t in ts:
         t.join(20)
     assert blas_threads() == before and D._BLAS_USERS == 0
+
+
+def test_bare_length_scale_kernels_are_read_and_written_as_sklearn_does():
+    """HipGPR.fit reads theta / bounds of a bare Matern / RBF from its attributes and writes the optimum back the same way
+    (gpr._length_scale_theta / _set_length_scale_theta) instead of through Kernel.theta / .bounds — which walk dir() and
+    inspect.signature on every access.  Same arrays, same attribute types as sklearn's own accessors (kernels.py:285-343)."""
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Hyperparameter, Matern
+
+    from bayesianoptimization_amd import gpr as G
+
+    class Wrapped(Matern):          # what bayes_opt.parameter.wrap_kernel makes: a dynamic subclass, same hyper-parameters
+        pass
+
+    class Extra(RBF):               # a subclass with a second hyper-parameter is NOT bare
+        @property
+        def hyperparameter_other(self):
+            return Hyperparameter("other", "numeric", (1e-2, 1e2))
+
+    for k in (Matern(nu=2.5), RBF(0.7), Matern(length_scale=[0.5, 2.0, 1.0], nu=2.5), RBF(length_scale=[0.3, 0.4], length_scale_bounds=(1e-3, 1e2)),
+              Matern(length_scale=[1.5], nu=2.5), Wrapped(length_scale=0.2, nu=2.5),
+              RBF(length_scale=[0.3, 0.4], length_scale_bounds=[(1e-3, 1e2), (1e-1, 1e1)])):
+        assert G._bare_length_scale_kernel(k)
+        theta, bounds = G._length_scale_theta(k)
+        assert np.array_equal(theta, k.theta) and np.array_equal(bounds, k.bounds)
+        new = theta + np.linspace(0.1, 0.3, theta.shape[0])
+        ref = k.clone_with_theta(new)
+        G._set_length_scale_theta(k, new)
+        assert type(k.length_scale) is type(ref.length_scale) and np.array_equal(k.length_scale, ref.length_scale)
+        assert np.array_equal(k.theta, ref.theta)
+    for k in (RBF(1.0, length_scale_bounds="fixed"), ConstantKernel(1.0, "fixed") * RBF(1.0), Extra(1.0)):
+        assert not G._bare_length_scale_kernel(k)
+
+
+def test_an_optimum_on_a_bound_still_warns_as_sklearn_does():
+    import warnings
+
+    from sklearn.exceptions import ConvergenceWarning
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF
+
+    import helpers as H
+    from bayesianoptimization_amd.gpr import HipGPR
+
+    rng = np.random.RandomState(0)
+    X = rng.uniform(size=(40, 1))
+    y = np.sin(25 * X[:, 0]) + 0.05 * rng.standard_normal(40)      # wiggly: the search runs into the lower bound 0.9
+    eng = H.FakeEngine()
+    gp = HipGPR(kernel=RBF(1.0, length_scale_bounds=(0.9, 1.1)), alpha=1e-6, normalize_y=True, n_restarts_optimizer=2,
+                random_state=np.random.RandomState(1), engine=eng)
+    sk = GaussianProcessRegressor(kernel=RBF(1.0, length_scale_bounds=(0.9, 1.1)), alpha=1e-6, normalize_y=True, n_restarts_optimizer=2,
+                                  random_state=np.random.RandomState(1))
+    msgs = []
+    for est in (gp, sk):
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            est.fit(X, y)
+        msgs.append(sorted(str(x.message) for x in w if issubclass(x.category, ConvergenceWarning) and "close to the specified" in str(x.message)))
+    assert msgs[0] == msgs[1] and len(msgs[1]) >= 1
+    assert gp.kernel_.length_scale == pytest.approx(sk.kernel_.length_scale, rel=1e-6)
