@@ -12,10 +12,11 @@
 //   optimiser   = the arithmetic of polish_opt.h (the host's source) laid over wave 0: lane i owns variable i, every sum over the
 //                 variables is taken in the host's order (a chain of v_readlane + add), contraction off as on the host.
 // The runs are independent (no lockstep); the result of a run is the host path's bit for bit for UCB and to the rounding of
-// erfc / exp for EI / POI (std:: on the host, the device library here).  alpha, the length scales and (when they fit) the
-// training points are staged in LDS once; W is read twice per evaluation from L2 by ONE compute unit (N^2 / 2 * 8 B per pass), which
-// is why the path stops at NP = polish_fused_max_np(): from N ~ 300 on, one CU's load rate makes an evaluation slower than
-// the six launches that spread W over the chip (profiles/r05_polish_fused_ab.json).  One model (no constraint slots).
+// erfc / exp for EI / POI (std:: on the host, the device library here).  alpha, the length scales, the training points (when
+// they fit) and, for NP <= 128, W itself (packed lower triangle) are staged in LDS once; above that W is read twice per evaluation
+// from L2 by ONE compute unit (N^2 / 2 * 8 B per pass), which is why the path stops at NP = polish_fused_max_np(): from N ~ 300 on,
+// one CU's load rate makes an evaluation slower than the six launches that spread W over the chip
+// (profiles/r05_polish_fused_ab.json).  One model (no constraint slots).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -59,12 +60,21 @@ __host__ __device__ inline int pf_shared_region(int NP) { return PF_SPLITS * NP 
 __host__ __device__ inline int pf_lds_base(int NP, int d, int DP) {
   return PF_FIXED + 5 * NP + pf_shared_region(NP) + PF_KSL * 2 * DP + 2 * LBFGS_M * d;
 }
-// (staged only where the whole image still fits the 160 KiB: at NP > 512 the row splits take the room)
+constexpr int PF_LDS_CAP = 160 * 128 - 8;      // doubles in 160 KiB, less the flag words
+// W = L^-1 as a packed lower triangle in LDS for NP <= 128 (66 KB at 128): the two passes of an evaluation then cost LDS latency
+// instead of two dependent trips to L2 (~5 us of a 22-26 us evaluation)
+__host__ __device__ inline int pf_w_stage(int NP, int d, int DP) {
+  const int want = NP * (NP + 1) / 2;
+  return (NP <= 128 && pf_lds_base(NP, d, DP) + want <= PF_LDS_CAP) ? want : 0;
+}
+// (the training points: staged only where the whole image still fits — at NP > 512 the row splits take the room)
 __host__ __device__ inline int pf_xs_stage(int NP, int d, int DP) {
   const int want = NP * (DP + 1);
-  return (want <= PF_XS_STAGE && pf_lds_base(NP, d, DP) + want <= 160 * 128 - 8) ? want : 0;
+  return (want <= PF_XS_STAGE && pf_lds_base(NP, d, DP) + pf_w_stage(NP, d, DP) + want <= PF_LDS_CAP) ? want : 0;
 }
-__host__ __device__ inline int pf_lds_doubles(int NP, int d, int DP) { return pf_lds_base(NP, d, DP) + pf_xs_stage(NP, d, DP); }
+__host__ __device__ inline int pf_lds_doubles(int NP, int d, int DP) {
+  return pf_lds_base(NP, d, DP) + pf_w_stage(NP, d, DP) + pf_xs_stage(NP, d, DP);
+}
 __host__ __device__ inline int pf_lds_ints(int) { return 4; }
 
 // ---- the optimiser over wave 0 -----------------------------------------------------------------------------------------
@@ -232,9 +242,15 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
   double* gpart = partial + pf_shared_region(NP);   // [PF_KSL][2][DP]
   double* Sh = gpart + PF_KSL * 2 * DP;              // [LBFGS_M][d] correction pairs
   double* Yh = Sh + LBFGS_M * d;
-  double* Xl = Yh + LBFGS_M * d;                     // [NP][DP + 1] training points (when staged)
+  double* Wl = Yh + LBFGS_M * d;                     // W, packed lower triangle by rows (when staged)
+  const int w_staged = pf_w_stage(NP, d, DP);
+  double* Xl = Wl + w_staged;                        // [NP][DP + 1] training points (when staged)
   const int xs_staged = pf_xs_stage(NP, d, DP);
   int* flag = (int*)(Xl + xs_staged);
+  // W[i][k]: the LDS triangle (an explicit zero above the diagonal, as the matrix in memory has) or the matrix in memory — the
+  // two W phases are instantiated once for each, so that neither carries the other's address space in its load loops
+  auto w_lds = [&](int i, int k) -> double { return (k <= i) ? Wl[i * (i + 1) / 2 + k] : 0.0; };
+  auto w_mem = [&](int i, int k) -> double { return W[(int64_t)i * NP + k]; };
   // the training points: LDS rows of DP + 1 (conflict-free for the row walk of P1 and the dimension walk of P5), else global rows
   const double* __restrict__ Xs = xs_staged ? Xl : a.Xs;
   const int xld = xs_staged ? DP + 1 : DP;
@@ -246,6 +262,9 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
       const int k = e / DP, t = e - k * DP;
       Xl[k * (DP + 1) + t] = a.Xs[e];
     }
+  if (w_staged)
+    for (int i = wave; i < NP; i += PF_THREADS / 64)
+      for (int k = lane; k <= i; k += 64) Wl[i * (i + 1) / 2 + k] = W[(int64_t)i * NP + k];
   WaveRun run{};
   if (wave == 0) {
     const bool mine = lane < d;
@@ -256,6 +275,8 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
     run.f = 0.0; run.alpha = 1.0;
     run.hist = 0; run.head = 0; run.iter = 0; run.evals = 0; run.ls = 0; run.phase = 0; run.status = 2;
     if (mine) xt_s[lane] = run.xt;
+    // the trial point over the length scales (prescale_elem), zero padded: written here and after every step of the optimiser
+    if (lane < DP) xs[lane] = mine ? run.xt / a.ls[lane] : 0.0;
     if (lane == 0) flag[0] = 0;
   }
   __syncthreads();
@@ -266,9 +287,6 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
   const int round_cap = 4 * a.max_iter + 64;
 
   for (int round = 0;; ++round) {
-    // ---- P0: the trial point over the length scales (prescale_elem)
-    if (tid < DP) xs[tid] = (tid < d) ? xt_s[tid] / ls_s[tid] : 0.0;
-    __syncthreads();
     // ---- P1: k* and the gradient factor f (kstar_grad_small_kernel)
     for (int k = tid; k < NP; k += PF_THREADS) {
       const double* xr = Xs + (int64_t)k * xld;
@@ -292,7 +310,7 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
     // ---- P2: v = W k* (gemv_small_v_kernel<8, 2>: rows in pairs, lane = k mod 64, ascending k, xor tree).  Four pairs and two
     // k-steps per turn: 16 loads in flight per lane.  Loads past a pair's last k (or past the last pair) are clamped into the
     // matrix and not accumulated.
-    {
+    auto phase_v = [&](auto w_at) {
       const int npairs = NP >> 1;
       for (int p0 = wave * 4; p0 < npairs; p0 += (PF_THREADS / 64) * 4) {
         double acc[4][2];
@@ -314,8 +332,8 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int i0 = 2 * min(p0 + q, npairs - 1);
-              w[q][0][e] = W[(int64_t)i0 * NP + kc];
-              w[q][1][e] = W[(int64_t)(i0 + 1) * NP + kc];
+              w[q][0][e] = w_at(i0, kc);
+              w[q][1][e] = w_at(i0 + 1, kc);
             }
           }
 #pragma unroll
@@ -338,10 +356,12 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
             if (lane == 0 && p0 + q < npairs) vv[i] = (i < N) ? v : 0.0;
           }
       }
-    }
+    };
+    if (w_staged) phase_v(w_lds); else phase_v(w_mem);
     __syncthreads();
     // ---- P3: the row splits of u = W^T v (gemvt_small_kernel<4>: per 64-column block the rows below it in PF_SPLITS chunks, four
     // row lanes i = r0 + ig (mod 4) each summed by itself and added in order)
+    auto phase_u = [&](auto w_at) {
     for (int it = tid; it < PF_SPLITS * NP; it += PF_THREADS) {
       const int sp = it / NP, j = it - sp * NP;
       const int j0 = j & ~63;
@@ -353,7 +373,7 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const int iq = min(ib + q, NP - 1);
-          w[q] = W[(int64_t)iq * NP + j];
+          w[q] = w_at(iq, j);
           vi[q] = vv[iq];
         }
 #pragma unroll
@@ -370,6 +390,8 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
       sum += a3;
       partial[sp * NP + j] = sum;
     }
+    };
+    if (w_staged) phase_u(w_lds); else phase_u(w_mem);
     __syncthreads();
     // ---- P4: u_k = the splits in order (grad_small_kernel's inner sum)
     for (int k = tid; k < NP; k += PF_THREADS) {
@@ -461,6 +483,7 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
       } else {
         pf_advance(run, -av, g, d, lane, Sh, Yh, a.max_iter);
         if (lane < d) xt_s[lane] = run.xt;
+        if (lane < DP) xs[lane] = (lane < d) ? run.xt / ls_s[lane] : 0.0;       // (P1 and P5 of this round are behind the barrier above)
         if (lane == 0) flag[0] = (run.phase == 2 || round + 1 > round_cap) ? 1 : 0;      // (the cap cannot bind: a run is bounded by max_iter * MAXLS)
       }
     }

@@ -65,7 +65,7 @@ def _polish_eval(eng, acq, param, y_max, ym, ys, pts, repeat=1):
             "dsd": out[:, 4 + 2 * d:4 + 3 * d]}
 
 
-SHAPES = [(25, 2), (64, 4), (65, 3), (100, 5), (130, 8), (200, 2), (250, 32), (256, 64), (300, 6), (448, 16), (512, 8), (640, 12), (700, 32), (768, 3)]
+SHAPES = [(25, 2), (64, 4), (65, 3), (100, 5), (120, 40), (128, 16), (130, 8), (200, 2), (250, 32), (256, 64), (300, 6), (448, 16), (512, 8), (640, 12), (700, 32), (768, 3)]
 
 
 @pytest.fixture
@@ -145,7 +145,7 @@ def _both(eng, switch, acq, param, y_max, ym, ys, seeds, box, max_iter=0):
 
 
 @pytest.mark.parametrize("kernel", [O.MATERN25, O.RBF])
-@pytest.mark.parametrize("N,d", [(25, 2), (64, 4), (100, 5), (200, 2), (300, 6), (512, 8), (700, 16), (768, 3)])
+@pytest.mark.parametrize("N,d", [(25, 2), (64, 4), (100, 5), (128, 12), (200, 2), (300, 6), (512, 8), (700, 16), (768, 3)])
 def test_a_whole_ucb_search_is_bitwise_the_lockstep_path(debug_engine, lockstep_only, any_size, kernel, N, d):
     eng = debug_engine
     X, y, ls = _problem(N, d, 100 + N, kernel)
