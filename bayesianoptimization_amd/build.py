@@ -61,6 +61,35 @@ def _hipcc() -> str:
     return exe
 
 
+def _code_only(src: str) -> str:
+    """C / C++ source without its comments, trailing blanks and empty lines (string and character literals are left alone).
+    The fingerprint below is taken over THIS: it names the code a library was built from, so that a measurement stamped with it
+    (profiles/*pmc*.json) stays attached to that code when only its commentary is edited."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if c in "\"'":                                   # a literal: copy it whole (escapes included)
+            j = i + 1
+            while j < n and src[j] != c:
+                j += 2 if src[j] == "\\" else 1
+            out.append(src[i:j + 1])
+            i = j + 1
+        elif c == "/" and i + 1 < n and src[i + 1] == "/":     # to the end of the line (a backslash-newline continues it)
+            j = i
+            while j < n and src[j] != "\n":
+                j += 2 if (src[j] == "\\" and j + 1 < n) else 1
+            i = j
+        elif c == "/" and i + 1 < n and src[i + 1] == "*":
+            j = src.find("*/", i + 2)
+            out.append(" ")
+            i = n if j < 0 else j + 2
+        else:
+            out.append(c)
+            i += 1
+    lines = [ln.rstrip() for ln in "".join(out).split("\n")]
+    return "\n".join(ln for ln in lines if ln)
+
+
 def _fingerprint() -> str:
     h = hashlib.sha256()
     names = sorted(os.listdir(CSRC)) + ["../../include/gpbo.h"]
@@ -68,7 +97,7 @@ def _fingerprint() -> str:
         p = os.path.normpath(os.path.join(CSRC, n))
         if os.path.isfile(p):
             h.update(n.encode())
-            h.update(open(p, "rb").read())
+            h.update(_code_only(open(p, "r", encoding="utf-8").read()).encode())
     h.update(repr(sorted(SOURCES.items())).encode())
     h.update(repr(sorted(DEBUG_ONLY_SOURCES.items())).encode())
     # flags without the absolute include paths: the same sources must give the same fingerprint wherever the tree lies

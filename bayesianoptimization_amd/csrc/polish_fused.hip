@@ -61,8 +61,9 @@ __host__ __device__ inline int pf_lds_base(int NP, int d, int DP) {
   return PF_FIXED + 5 * NP + pf_shared_region(NP) + PF_KSL * 2 * DP + 2 * LBFGS_M * d;
 }
 constexpr int PF_LDS_CAP = 160 * 128 - 8;      // doubles in 160 KiB, less the flag words
-// W = L^-1 as a packed lower triangle in LDS for NP <= 128 (66 KB at 128): the two passes of an evaluation then cost LDS latency
-// instead of two dependent trips to L2 (~5 us of a 22-26 us evaluation)
+// W = L^-1 as a packed lower triangle in LDS for NP <= 128 (66 KB at 128): the two passes of an evaluation read LDS instead of L2.
+// Measured: no faster (bare evaluation 13.4 / 13.5 / 19.0 us at N = 32 / 64 / 128 against 14.0 / 14.1 / 19.2 from L2) — an
+// evaluation waits on its nine barriers and the LDS round trips between them, not on W (docs/LAB_NOTEBOOK.md §9.9).  Kept: same bits.
 __host__ __device__ inline int pf_w_stage(int NP, int d, int DP) {
   const int want = NP * (NP + 1) / 2;
   return (NP <= 128 && pf_lds_base(NP, d, DP) + want <= PF_LDS_CAP) ? want : 0;

@@ -173,3 +173,24 @@ def test_rendezvous_files_are_never_written_through_a_symlink_and_the_key_is_per
     assert ticks.isdigit() and ticks in os.path.basename(rendezvous._path())
     monkeypatch.setenv("MASTER_PORT", "29511")
     assert f"29511_{os.getppid()}_{ticks}_" in os.path.basename(rendezvous._path())
+
+
+def test_the_build_fingerprint_names_the_code_not_its_comments(tmp_path, monkeypatch):
+    """profiles/*pmc*.json are stamped with build._fingerprint(): it must move with every code change and with nothing else."""
+    from bayesianoptimization_amd import build
+
+    src = 'int a = 1; // one\n/* two\n lines */ const char* s = "// kept /* kept */"; char q = \'"\';\n\n#define M(x) \\\n  x // three\n'
+    code = build._code_only(src)
+    assert code == 'int a = 1;\n  const char* s = "// kept /* kept */"; char q = \'"\';\n#define M(x) \\\n  x'
+    assert build._code_only(src.replace("// one", "// another comment").replace("two", "2")) == code
+    assert build._code_only(src.replace("a = 1", "a = 2")) != code
+    assert build._code_only(src.replace("// kept", "// Kept")) != code           # inside a string literal: code
+    csrc = tmp_path / "csrc"
+    csrc.mkdir()
+    (csrc / "k.hip").write_text("__global__ void k() {}  // v1\n")
+    monkeypatch.setattr(build, "CSRC", str(csrc))
+    a = build._fingerprint()
+    (csrc / "k.hip").write_text("// a new header comment\n__global__ void k() {}\n")
+    assert build._fingerprint() == a
+    (csrc / "k.hip").write_text("__global__ void k() { __syncthreads(); }\n")
+    assert build._fingerprint() != a
