@@ -42,7 +42,7 @@ inline double norm_pdf(double z) { return std::exp(-0.5 * z * z) * 0.39894228040
 template <class Eval>
 int lockstep_minimize(Eval&& eval, const double* seeds, int n_seeds, int d, const double* box_lo, const double* box_hi, int max_iter,
                       double* x_out, double* f_out, int* status_out, int* n_rounds_out, int* n_iter_out, int* n_eval_out) {
-  // (the optimiser itself: polish_opt.h — shared with the one-launch device path)
+  // (the optimiser itself: polish_opt.h; the one-launch device path restates it lane-parallel and is held to its bits)
   std::vector<PolishRun> runs((size_t)n_seeds);
   std::vector<double> store((size_t)n_seeds * polish_run_doubles(d));
   std::vector<int> istore((size_t)n_seeds * polish_run_ints(d));

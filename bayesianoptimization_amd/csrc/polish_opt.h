@@ -1,5 +1,9 @@
-// The optimiser of gpbo_polish_seeds — ONE source for the host (polish.hip: the runs advance in lockstep, a batched device
-// evaluation per round) and for the device (polish_fused.hip: one workgroup per run, evaluations and optimiser in one launch).
+// The optimiser of gpbo_polish_seeds: the host's walk of it (polish.hip: the runs advance in lockstep, a batched device
+// evaluation per round) and everything the device's walk shares with it — constants, min / max, the acquisition's value and
+// gradient coefficients.  polish_fused.hip (one workgroup per run, evaluations and optimiser in one launch) restates the same
+// arithmetic with lane i of a wave owning variable i (pf_new_direction / pf_advance there follow polish_new_direction /
+// polish_advance here statement by statement, every sum in the same order); tests/test_gpu_polish_fused.py holds the two to the
+// same bits: end point, value, status, iteration and evaluation counts of whole searches.
 //
 // A projected L-BFGS (two-loop recursion over the free variables, backtracking on the projected path with an Armijo test on
 // the actual displacement), NOT a transcription of L-BFGS-B: no generalised Cauchy point, no subspace minimisation.  It keeps
@@ -8,10 +12,10 @@
 // replaces: the optimiser inside AcquisitionFunction._smart_minimize (bayes_opt/acquisition.py:364-374,
 // scipy.optimize.minimize(method="L-BFGS-B")); parity is statistical.
 //
-// Every function is plain sequential arithmetic on arrays the caller owns (the host: one std::vector per run; the device:
-// the workgroup's LDS, walked by one thread), in one fixed order and with floating-point contraction OFF, so that both sides
-// produce the same iterates from the same function values (x86-64 has no fused multiply-add in its baseline: the host never
-// contracts; the device would).
+// Every function is plain sequential arithmetic on arrays the caller owns, in one fixed order and with floating-point
+// contraction OFF, so that both sides produce the same iterates from the same function values (x86-64 has no fused multiply-add
+// in its baseline: the host never contracts; the device would).  (A first device version ran these very functions on one thread
+// over LDS: correct, and 27 us per evaluation of pure LDS latency — docs/LAB_NOTEBOOK.md §9.7.)
 #pragma once
 #include <cstddef>
 

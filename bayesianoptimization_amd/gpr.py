@@ -25,6 +25,7 @@ implementation of the device path: a supported model never leaves the GPU, and f
 from __future__ import annotations
 
 import warnings
+import weakref
 from operator import itemgetter
 
 import numpy as np
@@ -92,7 +93,7 @@ def _bare_length_scale_kernel(kernel) -> bool:
     return ok and not isinstance(kernel.length_scale_bounds, str)
 
 
-_BARE_CLASSES: dict = {}
+_BARE_CLASSES = weakref.WeakKeyDictionary()      # (wrap_kernel's dynamic classes die with their optimizer)
 
 
 def _length_scale_theta(kernel):

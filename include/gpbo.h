@@ -236,7 +236,7 @@ int gpbo_predict_grad(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int 
  * arithmetic (a projected L-BFGS with L-BFGS-B's stopping rule as SciPy configures it: 10 corrections, projected gradient
  * 1e-5, relative reduction 1e7 eps, 20 line-search steps, max_iter <= 0 -> 15000 iterations) runs on the host in between.
  * One model of at most 256 (padded) observations: the runs are one launch, a workgroup each, evaluations and optimiser on the
- * device — the same optimiser source, the same evaluation arithmetic, the same results (bit for bit for UCB).
+ * device — the same optimiser arithmetic, the same evaluation arithmetic, the same results (bit for bit for UCB).
  * Not the reference's iterates: parity is statistical (acquisition value at the returned point).
  * y_mean / y_std: (1 + n_constraints,) the targets' normalisation per slot; seeds (n_seeds,d), clipped into the box;
  * box_lo < box_hi (d,).  Outputs per seed: x_out (n_seeds,d) inside the box, f_out, status_out (0: projected gradient

@@ -2,8 +2,9 @@
 evaluations and the optimiser inside it) against the lockstep path it replaces for NP <= 256 (csrc/polish.hip: six launches and a
 stream synchronisation per round, the optimiser on the host).
 
-What it replaces: AcquisitionFunction._smart_minimize (bayes_opt/acquisition.py:322-420).  Both paths run ONE optimiser source
-(csrc/polish_opt.h) over the same evaluation arithmetic, so the bar here is tighter than the stage's statistical parity with SciPy
+What it replaces: AcquisitionFunction._smart_minimize (bayes_opt/acquisition.py:322-420).  Both paths run ONE optimiser arithmetic
+(csrc/polish_opt.h on the host; restated with a lane per variable in csrc/polish_fused.hip) over the same evaluation arithmetic, so the
+bar here is tighter than the stage's statistical parity with SciPy
 (tests/test_gpu_polish.py, which the product engine now also runs through this kernel for its N <= 256 problems):
   * one evaluation — f, mu, sd and the three gradients — is bitwise what gpbo_predict_grad's kernels return;
   * a whole UCB search — end point, value, status, iterations, evaluations — is bitwise the lockstep path's;
