@@ -448,6 +448,7 @@ static int prepare_model(gpbo_ctx* ctx, Model& m, const char* who, bool have_inp
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
 
   m.fitted = false;
+  m.wp_packed = false;     // (set by the small fit paths at enqueue time; a failure before finish_enqueue must not leave it behind)
   m.M_post = -1;
   const int64_t NP = round_up(N, NB);
   const int DP = pad_dim(d);
@@ -611,6 +612,7 @@ int gpbo_fit_append(gpbo_ctx* ctx, int slot, const double* x_new, int64_t n_new,
   if (n_total > (1 << 16)) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gpbo_fit_append: N out of range [1, 65536]");
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
   m.fitted = false;
+  m.wp_packed = false;
   m.M_post = -1;
   const int64_t N0 = m.N;
   const int64_t NP_new = round_up(n_total, NB);

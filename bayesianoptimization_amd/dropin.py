@@ -11,7 +11,10 @@ from __future__ import annotations
 
 import warnings
 
+import numpy as np
+
 from . import fused_acquisition as A
+from ._lib import MAX_DIM
 from .gpr import HipGPR, describe_kernel, shared_engine
 
 
@@ -63,8 +66,73 @@ def _convert_acquisition(fn):
     return new
 
 
+#: observation counts of the warm-up problems: one per dispatch band of a small-N suggest() — the one-workgroup fit and the one-launch
+#: local searches (NP = 64), the strip path with one-launch local searches (NP = 128, 256), the strip path with lockstep rounds
+#: (NP = 320), and the first size of the next padding step
+WARM_SIZES = (12, 70, 200, 270, 330)
+
+
+def warm_up(engine, bounds, acquisition=None, kernel=None, n_restarts_optimizer: int = 5, n_constraints: int = 0,
+            n_random: int = 10_000, lml_on_device="auto", sizes=WARM_SIZES) -> float:
+    """Pay the first-use costs of a small-N suggest() now instead of inside the user's maximize() loop: every code object is
+    loaded, every buffer family allocated for this dimension, every dispatch band's launch sequence (and its captured graph)
+    run once.  Five synthetic default-configuration suggest() calls (theta search with restarts, candidates on the device,
+    posterior, acquisition, local searches) over a stand-in space with the optimizer's bounds; own RandomStates — the
+    optimizer's stream is not touched — and the engine's slots are left unfitted-by-anyone (the next real fit rewrites them).
+    Returns the seconds it took.  What it replaces: nothing in the reference — `bayes_opt` has no device to warm; without it
+    profiles/r05_maximize_loop.json shows 32 / 79 / 46 ms steps at N = 16 / 28 / 272 against 2-6 ms medians."""
+    import copy
+    import time
+
+    from sklearn.base import clone
+    from sklearn.gaussian_process.kernels import Matern
+
+    from .float_space import FloatSpace
+
+    t0 = time.perf_counter()
+    bounds = np.asarray(bounds, dtype=np.float64).reshape(-1, 2)
+    d = bounds.shape[0]
+    if d < 1 or d > MAX_DIM:
+        return 0.0
+    span = np.where(bounds[:, 1] > bounds[:, 0], bounds[:, 1] - bounds[:, 0], 1.0)
+    rng = np.random.RandomState(20240601)
+    fn0 = acquisition if isinstance(acquisition, A.AcquisitionFunction) else A.UpperConfidenceBound(kappa=2.576)
+    if kernel is None:
+        kernel = Matern(nu=2.5)
+    try:
+        describe_kernel(kernel)
+    except NotImplementedError:
+        return 0.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for N in sizes:
+            U = rng.uniform(size=(N, d))
+            X = bounds[:, 0] + U * span
+            y = np.exp(-((U - 0.4) ** 2).sum(1)) + 0.05 * rng.standard_normal(N)
+            cm = None
+            if n_constraints:
+                from .constraint_model import HipConstraintModel
+
+                cm = HipConstraintModel(None, np.full(n_constraints, -np.inf), np.full(n_constraints, 0.5), engine=engine,
+                                        random_state=np.random.RandomState(3))
+                for m in cm._model:
+                    m.lml_on_device = lml_on_device
+            sp = FloatSpace({f"w{j}": (bounds[j, 0], bounds[j, 0] + span[j]) for j in range(d)}, constraint=cm)
+            cv = None if cm is None else np.cos(2.0 * U.sum(1))[:, None].repeat(n_constraints, 1).squeeze()
+            sp.register_bulk(X, y, cv)
+            gp = HipGPR(kernel=clone(kernel), alpha=1e-6, normalize_y=True, n_restarts_optimizer=n_restarts_optimizer,
+                        random_state=np.random.RandomState(1), engine=engine)
+            gp.lml_on_device = lml_on_device
+            fn = copy.deepcopy(fn0)
+            try:
+                fn.suggest(gp, sp, n_random=n_random, n_smart=10, fit_gp=True, random_state=np.random.RandomState(2))
+            except Exception:      # a policy that cannot run on synthetic data (EI without y_max, ...) warms what it reached
+                pass
+    return time.perf_counter() - t0
+
+
 def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=None, precision: str = "f64",
-               devices=None, local_search: str = "auto", lml_on_device="auto"):
+               devices=None, local_search: str = "auto", lml_on_device="auto", warm: bool = True):
     """Swap the GP(s) and the acquisition function of `optimizer` in place; returns `optimizer`.
 
     `devices=[0, 1, ...]`: shard the random stage of every suggest() over these GPUs from this ONE process (GroupEngine:
@@ -89,6 +157,9 @@ def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=N
     transform) and stock UCB / EI / POI policies; mixed spaces and custom policies keep the reference-shaped stage.
     "device" asks for the same explicitly; "reference" keeps SciPy's L-BFGS-B over finite differences, iterate for iterate
     the reference's local searches (bayes_opt/acquisition.py:364-374).
+    `warm` (default True): run `warm_up` once per engine and dimension — five synthetic suggest() calls (~0.3 s) that load the
+    code objects, allocate and launch every small-N path, so that no suggest() of the user's loop carries a first-use spike.
+    The optimizer's RandomState is not touched.
     """
     if local_search not in ("auto", "reference", "device"):
         raise ValueError("local_search must be 'auto', 'reference' or 'device'")
@@ -97,6 +168,15 @@ def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=N
     space = optimizer._space
     transform = None if _identity_transform(space) else space.kernel_transform
     noted = _note_unsupported(optimizer._gp.kernel, "the target GP")
+    width = int(getattr(space, "bounds", np.zeros((0, 2))).shape[0])      # columns in kernel space (categoricals are one-hot there)
+    too_wide = None
+    if width > MAX_DIM:
+        too_wide = f"HIP path supports up to {MAX_DIM} dimensions in kernel space, this space has {width}"
+        if not noted:
+            warnings.warn(f"accelerate(): the space is {width} columns in kernel space (parameter.py:434-449: a categorical is "
+                          f"one-hot), the HIP engine takes {MAX_DIM}; the models keep running scikit-learn's "
+                          "GaussianProcessRegressor on the host (the reference's path)", UserWarning, stacklevel=2)
+        noted = noted or too_wide
     optimizer._gp = HipGPR.from_sklearn(optimizer._gp, transform=transform, engine=engine, slot=0, precision=precision)
     optimizer._gp.lml_on_device = lml_on_device
     if noted:
@@ -106,7 +186,7 @@ def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=N
         if len(constraint._model) > 7:
             raise NotImplementedError("at most 7 constraint GPs fit the engine's model slots")
         for j, m in enumerate(constraint._model):
-            noted = _note_unsupported(m.kernel, f"constraint GP {j}")
+            noted = _note_unsupported(m.kernel, f"constraint GP {j}") or too_wide
             constraint._model[j] = HipGPR.from_sklearn(m, transform=transform, engine=engine, slot=j + 1, precision=precision)
             constraint._model[j].lml_on_device = lml_on_device
             if noted:
@@ -119,4 +199,15 @@ def accelerate(optimizer, device: int = 0, n_random: int | None = None, engine=N
         for f in [fn, getattr(fn, "base_acquisition", None), *getattr(fn, "base_acquisitions", [])]:
             if isinstance(f, A.AcquisitionFunction):
                 f.device_polish = (local_search == "device")
+    from .engine import GpEngine
+
+    if warm and isinstance(engine, GpEngine) and transform is None and not too_wide and not engine.__dict__.get("_warmed", {}).get(width):
+        # (a real engine only: test doubles have nothing to warm; mixed spaces run their local searches on the host and warm
+        # as they go; once per engine and dimension)
+        fn = optimizer._acquisition_function
+        warm_up(engine, space.bounds, acquisition=fn if isinstance(fn, A.AcquisitionFunction) else None,
+                kernel=optimizer._gp.kernel, n_restarts_optimizer=int(optimizer._gp.n_restarts_optimizer or 0),
+                n_constraints=0 if constraint is None else len(constraint._model),
+                n_random=int(getattr(fn, "default_n_random", 10_000)), lml_on_device=lml_on_device)
+        engine.__dict__.setdefault("_warmed", {})[width] = True
     return optimizer

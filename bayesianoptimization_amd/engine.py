@@ -773,11 +773,11 @@ class GroupEngine(GpEngine):
         self._gcheck(rc, info.value, borrowed=(x_new, y_norm, info))
         return self._touch(slot)
 
-    def lml_batch(self, X, y_norm, kernel: int, length_scales, noise: float, eval_gradient=True, reuse_inputs=False):
+    def lml_batch_arrays(self, X, y_norm, kernel: int, length_scales, noise: float, eval_gradient=True, reuse_inputs=False):
         """The lanes of one lockstep round of the theta search spread over the group's devices (gpbo_group_lml_batch: lane
         i on device i mod G; inputs made resident on every device by the first call of a search).  Same return value as
-        GpEngine.lml_batch, every entry bitwise what `lml()` returns on one device; `last_lane_devices` says where each
-        lane ran."""
+        GpEngine.lml_batch_arrays, every lane bitwise what `lml()` returns on one device; `last_lane_devices` says where
+        each lane ran.  (`lml_batch`, inherited, is built on this: both forms of a round go through the group.)"""
         X = np.ascontiguousarray(X, dtype=np.float64)
         y_norm = np.ascontiguousarray(y_norm, dtype=np.float64).ravel()
         ls = np.ascontiguousarray(np.atleast_2d(np.asarray(length_scales, dtype=np.float64)))
@@ -791,7 +791,7 @@ class GroupEngine(GpEngine):
                                             int(bool(eval_gradient)), dptr(vals), dptr(grads), infos, where)
         self._gcheck(rc, borrowed=(X, y_norm, ls, vals, grads, infos, where))
         self.last_lane_devices = list(where)
-        return [(float(vals[i]), grads[i].copy()) for i in range(n)]
+        return vals, grads
 
     # -- sharded candidates ----------------------------------------------------------------------
     def set_candidates(self, Xc):

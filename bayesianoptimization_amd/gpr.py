@@ -35,6 +35,7 @@ from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern, Produc
 from sklearn.utils import check_random_state
 from sklearn.utils.validation import validate_data
 
+from ._lib import MAX_DIM
 from .engine import MATERN25, GpEngine
 from .engine import RBF as K_RBF
 
@@ -145,7 +146,7 @@ class HipGPR(GaussianProcessRegressor):
     #: True after a fit that the device path does not cover: every numeric method is then the base class's
     _host_mode = False
 
-    def _unsupported_reason(self, kernel, y=None):
+    def _unsupported_reason(self, kernel, y=None, X=None):
         """Why this configuration is outside the device path (None when it is inside)."""
         try:
             describe_kernel(kernel)
@@ -155,7 +156,25 @@ class HipGPR(GaussianProcessRegressor):
             return "HIP path supports a scalar alpha only"
         if y is not None and np.ndim(y) == 2 and np.shape(y)[1] != 1:
             return "HIP path supports a single target"
+        if X is not None:
+            # the width the device sees is the TRANSFORMED one: a CategoricalParameter is one-hot in kernel space
+            # (bayes_opt/parameter.py:434-449 through target_space.py:340-347), so a few wide categoricals pass GPBO_MAX_DIM
+            # where the parameter count does not
+            width = self._device_width(X)
+            if width is not None and width > MAX_DIM:
+                return f"HIP path supports up to {MAX_DIM} dimensions in kernel space, this space has {width}"
         return None
+
+    def _device_width(self, X):
+        """Number of columns `gpbo_fit` would receive for X (None when X is not a non-empty 2-D array: sklearn's validation
+        will say so)."""
+        try:
+            X = np.asarray(X, dtype=np.float64)
+            if X.ndim != 2 or X.shape[0] == 0:
+                return None
+            return int(self._tx(X[:1]).shape[1]) if self.transform is not None else int(X.shape[1])
+        except (TypeError, ValueError):
+            return None
 
     def _warn_host(self, reason, stacklevel=3):
         if self.__dict__.get("_host_warned") != reason:
@@ -177,11 +196,16 @@ class HipGPR(GaussianProcessRegressor):
     def _fit_on_host(self, X, y, reason):
         """scikit-learn's own fit for a model the device path does not cover (one warning per estimator and reason)."""
         self._warn_host(reason, stacklevel=4)
-        self._host_mode = True
+        # The device state goes first (a host model must never read an engine slot through the lazy L_ / alpha_), the flag last:
+        # if the base fit raises (NaN input, a kernel matrix that is not positive definite) the estimator is left UNFITTED —
+        # no X_train_ of an earlier device fit next to `_host_mode` — and not as a host model without its attributes.
         self._held = None
-        for k in ("_kind", "_ls", "_L_cache", "_alpha_cache", "log_marginal_likelihood_value_", "_lml_lazy"):
+        for k in ("_kind", "_ls", "_L_cache", "_alpha_cache", "log_marginal_likelihood_value_", "_lml_lazy", "X_train_", "y_train_"):
             self.__dict__.pop(k, None)
-        return GaussianProcessRegressor.fit(self, X, y)
+        self._host_mode = False
+        out = GaussianProcessRegressor.fit(self, X, y)
+        self._host_mode = True
+        return out
 
     # -- plumbing ------------------------------------------------------------------------------
     def _engine(self) -> GpEngine:
@@ -310,7 +334,7 @@ class HipGPR(GaussianProcessRegressor):
             self.kernel_ = ConstantKernel(1.0, constant_value_bounds="fixed") * RBF(1.0, length_scale_bounds="fixed")
         else:
             self.kernel_ = clone(self.kernel)
-        reason = self._unsupported_reason(self.kernel_, y)
+        reason = self._unsupported_reason(self.kernel_, y, X)
         if reason is not None:       # before any work, and before the RandomState is touched: the base class does all of it
             return self._fit_on_host(X, y, reason)
         self._host_mode = False

@@ -304,6 +304,119 @@ def suggest_latency(w, X, y, eng, M, reps=3):
     return res
 
 
+def suggest_fixed_total(w, X, eng, M_total, n_gpus, mode):
+    """The strong-scaling half of BASELINE.json's metric ("ms/suggest at N=4096 d=16, 1/2/4/8 GPUs"): THE SAME suggest() — the job's
+    candidates fixed at M_total (2^20 for C3 / C4) however many GPUs share them — where `suggest_ms` above grows the job with the
+    GPUs (n_random = M x n_gpus).  Two calls through the seams (FloatSpace + HipGPR + fused acquisition, as accelerate(optimizer,
+    devices=[...]) installs them): fixed theta with n_smart = 0, and the reference's default call (theta search with 5 restarts in
+    the fit + 10 local searches) on the smooth target, whose every restart seed ends at an interior optimum.  What does not shard
+    is quoted by name: `theta_search_ms` (the fit incl. its search: replicated, or its lanes spread over the group),
+    `posterior_ms_max_device` (the slowest device's posterior pass of the last call: the part that shrinks with 1/G) and
+    `serial_fraction` = 1 - posterior_ms_max_device / default_call_ms.  Reference: bayes_opt/bayesian_optimization.py:323-333."""
+    import warnings
+
+    from sklearn.gaussian_process.kernels import Matern, RBF
+
+    from bayesianoptimization_amd import fused_acquisition as A
+    from bayesianoptimization_amd.float_space import FloatSpace
+    from bayesianoptimization_amd.gpr import HipGPR
+
+    def post_max():
+        try:
+            if mode == "group":
+                return float(max(t["posterior_main"] for t in eng.per_device_timings()))
+            return float(eng.last_timings()["posterior_main"])
+        except Exception:  # noqa: BLE001
+            return None
+
+    fn = {W.UCB: lambda: A.UpperConfidenceBound(kappa=w.acq_param), W.EI: lambda: A.ExpectedImprovement(xi=w.acq_param),
+          W.POI: lambda: A.ProbabilityOfImprovement(xi=w.acq_param)}[w.acq]()
+    rng2 = np.random.RandomState(0)
+    y2 = np.exp(-((X - 0.5) ** 2).sum(1)) + 0.01 * rng2.standard_normal(len(X))
+    sp = FloatSpace(w.pbounds())
+    sp.register_bulk(X, y2)
+    kern = Matern(nu=2.5, length_scale=w.length_scale) if w.kernel == W.MATERN25 else RBF(length_scale=w.length_scale)
+    out = {"n_random_total": int(M_total), "n_gpus": int(n_gpus), "scaling": "strong",
+           "target": "smooth: exp(-sum((x - 0.5)^2)) + 0.01 * RandomState(0).standard_normal(N) on the workload's X"}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        gp = HipGPR(kernel=kern, alpha=w.noise, normalize_y=True, optimizer=None, engine=eng, incremental=False)
+        fn.device_polish = False
+        ts = []
+        for rep in range(4):
+            t0 = time.perf_counter()
+            fn.suggest(gp, sp, n_random=M_total, n_smart=0, fit_gp=True, random_state=np.random.RandomState(7 + rep))
+            ts.append((time.perf_counter() - t0) * 1e3)
+        out["fixed_theta_n_smart_0_ms"] = float(np.median(ts[1:]))
+        out["fixed_theta_posterior_ms_max_device"] = post_max()
+        gp_t = HipGPR(kernel=Matern(nu=2.5), alpha=1e-6, normalize_y=True, n_restarts_optimizer=5,
+                      random_state=np.random.RandomState(1), engine=eng, incremental=False)
+        fit0, fits = gp_t.fit, []
+
+        def timed_fit(X_, y_):
+            t0 = time.perf_counter()
+            r = fit0(X_, y_)
+            fits.append(((time.perf_counter() - t0) * 1e3, int(getattr(gp_t, "theta_search_rounds_", 0))))
+            return r
+
+        gp_t.fit = timed_fit
+        fn.device_polish = "auto"
+        ts = []
+        for r, seed in enumerate((100, 100, 101, 102)):
+            gp_t.random_state = np.random.RandomState(seed)
+            t0 = time.perf_counter()
+            fn.suggest(gp_t, sp, n_random=M_total, n_smart=10, fit_gp=True, random_state=np.random.RandomState(7 + r))
+            ts.append((time.perf_counter() - t0) * 1e3)
+        fn.device_polish = False
+    out["default_call_ms"] = float(np.median(ts[1:]))
+    out["theta_search_ms"] = float(np.median([f[0] for f in fits[1:]]))
+    out["theta_search_rounds"] = [f[1] for f in fits[1:]]
+    out["posterior_ms_max_device"] = post_max()
+    if out["posterior_ms_max_device"]:
+        out["serial_fraction"] = 1.0 - out["posterior_ms_max_device"] / out["default_call_ms"]
+    if getattr(eng, "last_lane_devices", None) is not None:
+        out["theta_search_lane_devices_last_round"] = list(eng.last_lane_devices)
+    return out
+
+
+def summary_of(out):
+    """<= 1.5 KB digest, printed as the LAST key of the line: the driver's record keeps the headline keys and a tail of the
+    line, and the per-seed tables of suggest_ms are long — the small configs' numbers used to fall off the front."""
+    def r(v, n=4):
+        return None if v is None else (round(float(v), n) if isinstance(v, (int, float)) else v)
+
+    sm = {}
+    for key, c_ in (out.get("configs") or {}).items():
+        if "error" in c_:
+            sm[key] = {"error": c_["error"][:60]}
+            continue
+        par = c_.get("parity") or {}
+        sm[key] = {"ms": r(c_.get("ms_per_step")), "fit_ms": r(c_.get("fit_ms")), "frac": r(c_["roofline"]["frac"]),
+                   "frac_step": r(c_["roofline"]["frac_of_whole_step"]),
+                   "argmin_ok": par.get("argmin_equals_reference"), "top10_ok": par.get("top10_equals_reference")}
+        sg = c_.get("suggest_ms") or {}
+        if sg and "error" not in sg:
+            sm[key]["suggest"] = {"n_smart_0": r(sg.get("n_smart_0"), 3), "default_interior": r(sg.get("default_call_interior"), 3),
+                                  "default_smooth": r((sg.get("smooth_target") or {}).get("default_call"), 3)}
+    sg = out.get("suggest_ms") or {}
+    head = {"ms": r(out.get("ms_per_step")), "frac": r(out["roofline"]["frac"]), "fit_ms": r(out["roofline_fit"].get("fit_ms_per_gp")),
+            "chol_ms": r(out["roofline_fit"].get("chol_ms")),
+            "argmin_ok": (out.get("parity") or {}).get("argmin_equals_reference"),
+            "top10_ok": (out.get("parity") or {}).get("top10_equals_reference")}
+    if sg and "error" not in sg:
+        head["suggest"] = {"n_smart_0": r(sg.get("n_smart_0"), 3), "default_interior": r(sg.get("default_call_interior"), 3),
+                           "default_interior_minus_n_smart_0": r(sg.get("default_call_interior_minus_n_smart_0"), 3),
+                           "default_smooth": r((sg.get("smooth_target") or {}).get("default_call"), 3)}
+    ft = out.get("suggest_ms_fixed_total") or {}
+    if ft and "error" not in ft:
+        head["fixed_total"] = {k_: r(ft.get(k_), 3) for k_ in ("fixed_theta_n_smart_0_ms", "default_call_ms", "theta_search_ms",
+                                                              "posterior_ms_max_device", "serial_fraction")}
+    sm[out["config"]["workload"].split(":")[0]] = head
+    sm["n_gpus"] = out.get("n_gpus")
+    sm["cpu"] = r((out.get("cpu_baseline") or {}).get("value"), 1)
+    return sm
+
+
 def reference_golden(name, n_shards, M_shard):
     """The reference's answer for the job this run evaluates, from the committed goldens (tests/golden/, generated by
     oracle/gen_golden*.py driving bayes_opt itself): C3 -> C3.npz; C4/C5 at n_shards GPUs -> shards 0..n-1 merged as the
@@ -456,7 +569,13 @@ def run_extra_config(eng, name, steps=5, warmup=2, cpu_chunks=0):
     fit_ms = float(np.median(per_fit)) * steps
     fl = flops_per_candidate(w.N, w.d, n_gp) * M
     peak = FP32_MFMA_PEAK_TFLOPS if prec else FP64_MFMA_PEAK_TFLOPS
-    out = {"workload": f"{w.name}{' shard 0 of 8' if w.name in SHARDED else ''}: d={w.d} N={w.N} {W.ACQ_NAMES[w.acq]} M={M}, {n_gp} GP(s)",
+    theta_note = ""
+    if name == "C2":
+        theta_note = (f", FIXED length_scale={w.length_scale} (SURVEY.md §8(d) asks for the sklearn-fitted value at N <= 512: on this "
+                      "generator sklearn's own search ends at the lower bound 1e-5, K = I — workloads.py; fitted theta: golden F1)")
+    elif w.length_scale is not None:
+        theta_note = f", fixed length_scale={w.length_scale}"
+    out = {"workload": f"{w.name}{' shard 0 of 8' if w.name in SHARDED else ''}: d={w.d} N={w.N} {W.ACQ_NAMES[w.acq]} M={M}, {n_gp} GP(s){theta_note}",
            "dtype": "f32" if prec else "f64", "steps": steps, "ms_per_step": ms, "ms_per_step_is": "median of the steps, each clocked by itself",
            "ms_per_step_mean": float(np.mean(per_step)), "ms_per_step_max": float(np.max(per_step)),
            "value": M / (ms * 1e-3), "unit": "candidates/s",
@@ -609,6 +728,10 @@ def main():
     if args.suggest_only:
         res = suggest_latency(w, X, y, eng, M * n_gpus)
         res["engine"] = (f"GroupEngine over {n_gpus} device(s) ({collective})" if mode == "group" else "GpEngine") + f", n_random = {M * n_gpus}"
+        try:
+            res["fixed_total"] = suggest_fixed_total(w, X, eng, M, n_gpus, mode)
+        except Exception as e:  # noqa: BLE001
+            res["fixed_total"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
         eng.close()
         return
@@ -840,6 +963,18 @@ def main():
             # GroupEngine), so rank 0 measures it in a child process that owns all N devices while the other ranks idle at
             # the closing barrier; a child that fails or exceeds its deadline costs only this key
             out["suggest_ms"] = suggest_in_child(n_gpus, w.name)
+        if mode in ("single", "group") and not w.constrained and not args.no_suggest:
+            # ... and the same suggest() with the job's candidates FIXED at the config's own M (2^20), however many GPUs share it
+            try:
+                out["suggest_ms_fixed_total"] = suggest_fixed_total(w, X, eng, M, n_gpus, mode)
+            except Exception as e:  # noqa: BLE001
+                out["suggest_ms_fixed_total"] = {"error": repr(e)}
+        elif mode == "ranks" and isinstance(out.get("suggest_ms"), dict) and "fixed_total" in out["suggest_ms"]:
+            out["suggest_ms_fixed_total"] = out["suggest_ms"].pop("fixed_total")
+        try:
+            out["summary"] = summary_of(out)       # LAST key: survives a record that keeps only the line's tail
+        except Exception as e:  # noqa: BLE001
+            out["summary"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if mode == "ranks":
         # the other ranks sleep on the HOST while rank 0 measures ms/suggest in its child process (their GPUs stay idle for

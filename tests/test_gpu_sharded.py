@@ -14,7 +14,7 @@ import pytest
 
 from bayesianoptimization_amd import workloads as W
 from bayesianoptimization_amd.distributed import merge_best
-from bayesianoptimization_amd.engine import F32, F64, GroupEngine
+from bayesianoptimization_amd.engine import F32, F64, GpEngine, GroupEngine
 from conftest import GOLDEN_DIR, rel_err
 from oracle import gp_oracle as O
 
@@ -409,8 +409,13 @@ def test_theta_search_lanes_spread_over_the_group_are_bitwise_the_single_device_
                         engine=eng, lml_on_device=True).fit(X, y)
             return gp.kernel_.theta.copy(), gp.log_marginal_likelihood_value_, rs.uniform()
 
+        grp.last_lane_devices = None
         a, b = fit(engine), fit(grp)
         assert np.array_equal(a[0], b[0]) and a[1] == b[1] and a[2] == b[2]
+        # the search inside HipGPR.fit goes through the group's lanes (lml_batch_arrays is the group's override, not GpEngine's
+        # single-device call on the borrowed rank-0 context): the last round left its lane -> device map behind
+        assert GroupEngine.lml_batch_arrays is not GpEngine.lml_batch_arrays
+        assert grp.last_lane_devices is not None and len(grp.last_lane_devices) >= 1
 
 
 def test_one_process_per_gpu_ranks_draw_their_rows_of_the_one_reference_stream(engine):
