@@ -18,6 +18,7 @@
 #include <cstdlib>
 
 #include "chol_bodies.h"
+#include "fit_bodies.h"
 
 namespace gpbo {
 
@@ -26,7 +27,7 @@ namespace gpbo {
 // brought up to date).
 // (waves_per_eu(2, 2): the launch's dynamic LDS gives every workgroup a CU to itself, so 256 VGPRs are there for the taking — 156 used)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void chol128_step_kernel(double* L, int64_t ld, int kb, int nblk, double* dinv, int* info,
-                                                            GemmArgs g, int tiles_n, int tiles, int64_t lane_stride, long long* stamps) {
+                                                            GemmArgs g, int tiles_n, int tiles, int live, int64_t lane_stride, long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) double c128_smem[];
   const int zl = (int)blockIdx.y;
   if (blockIdx.x == 0) {
@@ -36,8 +37,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   const int half = (int)(threadIdx.x >> 8);
   const int t = 2 * ((int)blockIdx.x - 1) + half;
-  int bm = t / tiles_n, bn = t - bm * tiles_n;
-  const bool mine = t < tiles && !(g.lower_only && bn > bm) && !(bn < g.skip00 && bm < g.skip00);
+  int bm, bn;
+  bool mine;
+  if (live) {
+    // LIVE tiles only (round 6), in the order [lower triangle of the leading tiles_n x tiles_n tiles, by rows | the full rows below it],
+    // the leading skip00 (skip00 + 1) / 2 of which belong to chol128_diag_update_kernel.  The square grid's dead upper tiles were
+    // not free: a dead tile goes through the loads and barriers of a live one beside its partner half, so a one-panel factorisation
+    // (NP <= 2048) ran twice the workgroups it needed — 392 for 203 live pairs at the second step of N = 2048: two rounds over the
+    // chip's 256 CUs (the launch's dynamic LDS admits one workgroup per CU), 39 us against the diagonal workgroup's 23.
+    const int tt = t + g.skip00 * (g.skip00 + 1) / 2;
+    const int tri = tiles_n * (tiles_n + 1) / 2;
+    if (tt < tri) lower_tile_of(tt, bm, bn);
+    else { bm = tiles_n + (tt - tri) / tiles_n; bn = (tt - tri) - (bm - tiles_n) * tiles_n; }
+    mine = t < tiles;
+  } else {
+    bm = t / tiles_n; bn = t - bm * tiles_n;
+    mine = t < tiles && !(g.lower_only && bn > bm) && !(bn < g.skip00 && bm < g.skip00);
+  }
   if (!mine) { bm = g.m / 64 - 1; bn = 0; }   // a tile that exists (the last row tile): loads only, same barrier count
   GemmArgs h = g;
   h.lower_only = 0; h.skip00 = 0;            // decided above
@@ -66,16 +82,20 @@ static int launch_step(gpbo_ctx* ctx, Model& m, int kb, int nblk, const GemmArgs
     ctx->func_attrs |= ATTR_CHOL128;
   }
   GemmArgs g{};
-  int tiles = 0, tiles_n = 1;
+  int tiles = 0, tiles_n = 1, live = 0;
   if (upd) {
     g = *upd;
     g.lanes = ctx->lanes; g.lane_stride = ctx->lane_stride; g.batch = 1;
     tiles_n = g.n / 64;
-    tiles = (g.m / 64) * tiles_n;
-    if (g.m / 64 <= g.skip00 && tiles_n <= g.skip00) tiles = 0;   // nothing but the block the diagonal workgroup owns
+    const int tiles_m = g.m / 64;
+    const char* sq = dbg_env("GPBO_CHOL_SQUARE_TILES");     // debug A/B: 1 = the square enumeration of rounds 3-5
+    live = g.lower_only && tiles_m >= tiles_n && !(sq && sq[0] == '1');
+    // live tiles: the lower triangle of the leading tiles_n rows + the full rows below, less the leading skip00-block's
+    tiles = live ? tiles_n * (tiles_n + 1) / 2 + (tiles_m - tiles_n) * tiles_n - g.skip00 * (g.skip00 + 1) / 2 : tiles_m * tiles_n;
+    if (tiles_m <= g.skip00 && tiles_n <= g.skip00) tiles = 0;   // nothing but the block the diagonal workgroup owns
   }
   chol128_step_kernel<<<dim3((unsigned)(1 + (tiles + 1) / 2), (unsigned)ctx->lanes), dim3(512), C128_LDS_BYTES, ctx->stream>>>(
-      m.L, m.NP, kb, nblk, m.dinv, ctx->info_dev, g, tiles_n, tiles, ctx->lane_stride, stamps);
+      m.L, m.NP, kb, nblk, m.dinv, ctx->info_dev, g, tiles_n, tiles, live, ctx->lane_stride, stamps);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }
@@ -177,6 +197,10 @@ int launch_cholesky128(gpbo_ctx* ctx, Model& m, int outer, long long* stamps) {
       t.k = (oe - ob) * NB; t.alpha = -1.0; t.beta = 1.0;
       t.lda = m.NP; t.ldb = m.NP; t.b_trans = 1; t.ldc = m.NP;
       t.batch = 1; t.lower_only = 1;
+      // one decision for the whole update, whichever way it is launched below (whole, or the next panel's columns + the rest): the
+      // sixteen-wave tile kernel sums k in another order, and L must not depend on the look-ahead
+      t.m = rem2; t.n = rem2;
+      t.fat = gemm_fat_rule(t) ? 1 : -1;
       const int nw = rem2 < outer ? rem2 : outer;       // the next panel's columns
       if (!la || rem2 <= nw) {
         if (la && pidx > 0) GPBO_HIP(ctx, hipStreamWaitEvent(ctx->stream, la->ev[2 * (pidx - 1) + 1], 0));

@@ -79,18 +79,74 @@ int launch_kmat(gpbo_ctx* ctx, Model& m, double noise, double* out) {
 // ------------------------------------------------------------------------------------------------
 // (The 64-column Cholesky steps of rounds 1-2 — potrf_diag_kernel / chol_step_kernel — lived here; the factorisation is
 // chol_kernels.hip's 128-column schedule since round 3 and the old kernels were retired in round 4.)
-template <bool BT, bool AT>
-__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
-  const int zl = blockIdx.z / g.batch, bz = blockIdx.z - zl * g.batch;   // lane mode: z = lane * batch + b
-  // Longest k-ranges first (workgroups are handed out in block-id order, x fastest).  A lower triangular: row tile bm
-  // multiplies bm + 1 k-tiles -> rows from the bottom up.  B lower triangular: column tile bn starts at k-tile bn -> the
-  // grid is transposed (x = row tile), so all tiles of column 0 go first, then column 1, ...
-  int bm = (int)blockIdx.y, bn = (int)blockIdx.x;
+// Output tile of a workgroup of the 64x64-tile kernels.  Longest k-ranges first (workgroups are handed out in block-id order, x
+// fastest).  A lower triangular: row tile bm multiplies bm + 1 k-tiles -> rows from the bottom up.  B lower triangular: column
+// tile bn starts at k-tile bn -> the grid is transposed (x = row tile), so all tiles of column 0 go first, then column 1, ...
+__device__ __forceinline__ void gemm64_tile_of_block(const GemmArgs& g, int& bm, int& bn) {
+  bm = (int)blockIdx.y; bn = (int)blockIdx.x;
   if (g.a_lower) bm = (int)(gridDim.y - 1 - blockIdx.y);
   if (g.b_lower) { bm = (int)blockIdx.x; bn = (int)blockIdx.y; }
   if (g.tri_grid) lower_tile_of((int)blockIdx.x, bm, bn);      // live tiles only, rows from the top (W^T W: longest k first)
+}
+
+template <bool BT, bool AT>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmArgs g) {
+  const int zl = blockIdx.z / g.batch, bz = blockIdx.z - zl * g.batch;   // lane mode: z = lane * batch + b
+  int bm, bn;
+  gemm64_tile_of_block(g, bm, bn);
   __shared__ __attribute__((aligned(16))) double gt_lds[GT_LDS_DOUBLES];
   gemm_tile_body<BT, AT>(g, bm, bn, zl, bz, gt_lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same 64x64 tile by SIXTEEN waves (round 6): four 256-thread groups of one 1024-thread workgroup each run the tile body
+// over a QUARTER of the tile's k-range, park their partial tiles in LDS (each in its own staging area, free by then) and all
+// 1024 threads add them in a fixed order — ((q0 + q1) + (q2 + q3)), then alpha, beta as the one-group kernel applies them — and
+// store the tile in 32-byte row pieces.  Deterministic; NOT the bits of the one-group kernel (another summation order over k),
+// so launch_gemm's rule for it depends on the product's own shape only (never on lanes): a lane of gpbo_lml_batch stays bitwise
+// gpbo_lml, and no product of a fit with NP <= 2048 is deep enough to take it (the three fit paths keep their bits).
+// Why.  fp64 MFMAs reach their 64-cycle cadence only with four waves on a SIMD (posterior_kernel_v2.hip: 1 wave 140 cycles per
+// instruction, 2 waves 102, 4 waves 63), and a 64x64 tile is ONE wave per SIMD: a tile with the full k-range of a triangular
+// product at N = 4096 (k = 2048: 128 stages x 16 MFMAs) needs >= 119 us even with a CU to itself — more than the whole product
+// needs at the matrix peak (109 us) — and was the launch (175 us measured; profiles/r06_before_lml_4096_timeline.txt).  The levels
+// of W = L^-1 and the rank-1024 trailing updates of the Cholesky have 128 ... 1024 such tiles: too few for four one-group
+// workgroups per CU to fill every SIMD, too uneven for 128x128 tiles.  With sixteen waves per tile a CU works on one tile at
+// the pipe's full rate, the longest tile takes a quarter of the stages per wave, and the tiles are still dealt longest first.
+constexpr size_t FAT_LDS_BYTES = (size_t)4 * GT_LDS_DOUBLES * sizeof(double);   // 139 264 B: one workgroup per CU
+template <bool BT, bool AT>
+__global__ __launch_bounds__(1024) void gemm_fat_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) double fat_lds[];
+  const int zl = blockIdx.z / g.batch, bz = blockIdx.z - zl * g.batch;
+  int bm, bn;
+  gemm64_tile_of_block(g, bm, bn);
+  if (g.lower_only && bn > bm) return;
+  if (bn < g.skip00 && bm < g.skip00) return;
+  int kbeg, kend;
+  gemm_tile_krange(g, bm, bn, kbeg, kend);
+  const int q = max(kend - kbeg, 0) / 4;              // a multiple of 16 (launch_gemm: k and the triangular cuts are multiples of 64)
+  const int grp = (int)(threadIdx.x >> 8);
+  double* part = fat_lds + grp * GT_LDS_DOUBLES;       // staging buffers of the group's k-loop, then its 64x64 partial tile
+  GemmArgs h = g;
+  h.alpha = 1.0;
+  gemm_tile_body_k<BT, AT, true>(h, bm, bn, zl, bz, part, (int)(threadIdx.x & 255), true, part, kbeg + grp * q, kbeg + (grp + 1) * q);
+  __syncthreads();
+  const int row = (int)(threadIdx.x >> 4), c4 = (int)(threadIdx.x & 15) * 4;
+  const d4 p0 = *reinterpret_cast<const d4*>(fat_lds + row * 64 + c4);
+  const d4 p1 = *reinterpret_cast<const d4*>(fat_lds + GT_LDS_DOUBLES + row * 64 + c4);
+  const d4 p2 = *reinterpret_cast<const d4*>(fat_lds + 2 * GT_LDS_DOUBLES + row * 64 + c4);
+  const d4 p3 = *reinterpret_cast<const d4*>(fat_lds + 3 * GT_LDS_DOUBLES + row * 64 + c4);
+  const d4 sum = (p0 + p1) + (p2 + p3);
+  double* C = g.C + (int64_t)zl * g.lane_stride + (int64_t)bz * g.strideC;
+  d4* cp = reinterpret_cast<d4*>(C + ((int64_t)bm * 64 + row) * g.ldc + (int64_t)bn * 64 + c4);
+  d4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = g.alpha * sum[e];
+  if (g.beta != 0.0) {
+    const d4 c0 = *cp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] += g.beta * c0[e];
+  }
+  *cp = v;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -274,6 +330,25 @@ static bool gemm128_enabled() {
   return on;
 }
 
+// Sixteen waves per 64x64 tile (gemm_fat_kernel) where one wave per SIMD and tile is what holds a product back: products over a
+// TRIANGULAR operand (every tile another k-length, the longest tile is the launch) with at most ~2 tiles per CU, and any deep
+// product with less than one tile per CU.  Measured at N = 4096 (profiles/r06_gemm_fat_ab.json, r06 timelines): the 2048-level of
+// W = L^-1 (2 x 256 tiles, k <= 1024) 82.8 -> 54.9 us per launch, the last trailing update (136 tiles, k = 1024) 55 -> 44; NOT the
+// 4096-level (1024 tiles: 175 us either way — the tile body's own ~0.77 of the matrix pipe and the operand traffic of a 64x64
+// tile, 8 flop per byte, bound it) and not the rank-1024 updates with 400-650 uniform tiles (130 -> 140: four one-group workgroups
+// per CU already put four waves on every SIMD there).  The rule reads the product's OWN shape, never g.lanes: a lane of
+// gpbo_lml_batch stays bitwise gpbo_lml.  Debug build: GPBO_GEMM_FAT=0 off; GPBO_GEMM_FAT_LIMIT / _SMALL / _MINK the thresholds.
+bool gemm_fat_rule(const GemmArgs& g) {
+  const char* fe = dbg_env("GPBO_GEMM_FAT");
+  if (fe && fe[0] == '0') return false;
+  const int limit = dbg_env("GPBO_GEMM_FAT_LIMIT") ? atoi(dbg_env("GPBO_GEMM_FAT_LIMIT")) : 600;
+  const int small = dbg_env("GPBO_GEMM_FAT_SMALL") ? atoi(dbg_env("GPBO_GEMM_FAT_SMALL")) : 200;
+  const int mink = dbg_env("GPBO_GEMM_FAT_MINK") ? atoi(dbg_env("GPBO_GEMM_FAT_MINK")) : 512;
+  if (g.k % 64 || g.k < mink || g.k_from_tile || (g.ldc % 4)) return false;
+  const int64_t tiles64 = (int64_t)(g.m / 64) * (g.n / 64) * g.batch / (g.lower_only ? 2 : 1);
+  return ((g.a_lower || g.b_lower) && tiles64 <= limit) || tiles64 <= small;
+}
+
 int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
   if (g_in.m <= 0 || g_in.n <= 0 || g_in.batch <= 0) return GPBO_OK;
   GemmArgs g = g_in;
@@ -306,6 +381,30 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
   const bool tri_grid = g.lower_only && g.m == g.n && !g.a_lower && !g.b_lower &&
                         !(dbg_env("GPBO_TRI_GRID") && dbg_env("GPBO_TRI_GRID")[0] == '0');
   g.tri_grid = tri_grid ? 1 : 0;
+  {
+    if (g.fat > 0 || (g.fat == 0 && gemm_fat_rule(g))) {
+      if (!(ctx->func_attrs & ATTR_GEMM_FAT)) {
+        GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fat_kernel<true, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)FAT_LDS_BYTES));
+        GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fat_kernel<false, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)FAT_LDS_BYTES));
+        GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fat_kernel<false, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)FAT_LDS_BYTES));
+        ctx->func_attrs |= ATTR_GEMM_FAT;
+      }
+      dim3 grid((unsigned)(g.n / 64), (unsigned)(g.m / 64), (unsigned)(g.batch * g.lanes));
+      if (g.b_lower) std::swap(grid.x, grid.y);
+      if (tri_grid) { grid.x = grid.y * (grid.y + 1) / 2; grid.y = 1; }
+      if (g.b_trans)
+        gemm_fat_kernel<true, false><<<grid, dim3(1024), FAT_LDS_BYTES, ctx->stream>>>(g);
+      else if (g.a_trans)
+        gemm_fat_kernel<false, true><<<grid, dim3(1024), FAT_LDS_BYTES, ctx->stream>>>(g);
+      else
+        gemm_fat_kernel<false, false><<<grid, dim3(1024), FAT_LDS_BYTES, ctx->stream>>>(g);
+      GPBO_HIP(ctx, hipGetLastError());
+      return GPBO_OK;
+    }
+  }
   const bool prefer64 = tri64 && triangular && (blocks128 < 512 || (g.k_from_tile && blocks128 < tri64_limit));
   if (gemm128_enabled() && !prefer64 && g.m >= 128 && g.n >= 128 && g.k >= 256 && blocks128 >= 192) {
     constexpr size_t lds = (size_t)4 * G2_TILE * sizeof(double);   // 65 536 B

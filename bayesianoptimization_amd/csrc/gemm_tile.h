@@ -31,16 +31,38 @@ __device__ __forceinline__ int gemm_tile_barriers(const GemmArgs& g, const int b
   return nst > 0 ? 1 + nst : 0;
 }
 
+// k-range [kbeg, kend) of output tile (bm, bn): what the operands' triangular shapes leave of [0, k)
+__device__ __forceinline__ void gemm_tile_krange(const GemmArgs& g, const int bm, const int bn, int& kbeg, int& kend) {
+  kbeg = 0; kend = g.k;
+  if (g.a_lower) kend = min(kend, (bm + 1) * 64);
+  if (g.b_lower) kbeg = bn * 64;
+  if (g.k_from_tile) kbeg = max(bm, bn) * 64;   // both operands vanish above their diagonal tiles
+}
+
 template <bool BT, bool AT, bool CT = false>
 // `tid` = the thread's index inside the 256 threads working on this tile (a 512-thread workgroup runs two tiles side by
 // side, each with its own LDS area and the same number of barriers); `write` false = go through the motions on a valid
 // tile but leave C alone (the partner half of such a workgroup when it has no tile of its own).
 // CT: the tile alpha * A B goes to the 64x64 row-major image `c_tile` (LDS of the caller: lml_kernels.hip consumes K^-1 tile
 // by tile without a round trip through memory) instead of C.
+// gemm_tile_body_k: the same over an explicit k-range [kbeg, kend) (a multiple of 16 long) — a k-slice of the tile
+// (gemm_fat_kernel: four 256-thread groups of one workgroup each take a quarter of the tile's k-range).
+__device__ __forceinline__ void gemm_tile_body_k(const GemmArgs& g, int bm, int bn, int zl, int bz, double* lds, const int tid,
+                                                 const bool write, double* c_tile, const int kbeg, const int kend);
+
+template <bool BT, bool AT, bool CT = false>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn, int zl, int bz, double* lds, const int tid = threadIdx.x,
                                                const bool write = true, double* c_tile = nullptr) {
   if (g.lower_only && bn > bm) return;
   if (bn < g.skip00 && bm < g.skip00) return;      // the leading skip00 x skip00 tiles belong to other workgroups / launches
+  int kbeg, kend;
+  gemm_tile_krange(g, bm, bn, kbeg, kend);
+  gemm_tile_body_k<BT, AT, CT>(g, bm, bn, zl, bz, lds, tid, write, c_tile, kbeg, kend);
+}
+
+template <bool BT, bool AT, bool CT>
+__device__ __forceinline__ void gemm_tile_body_k(const GemmArgs& g, int bm, int bn, int zl, int bz, double* lds, const int tid,
+                                                 const bool write, double* c_tile, const int kbeg, const int kend) {
   // two LDS stages: the global loads of stage s+1 are issued before the MFMAs of stage s and parked in the other buffer
   // afterwards — one barrier per 16-deep stage (round 1: one buffer, two barriers, loads exposed in front of every stage)
   typedef double (*stage_t)[16][68];
@@ -51,10 +73,6 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& g, int bm, int bn
   const double* A = g.A + lo + (int64_t)bz * g.strideA + (AT ? (int64_t)bm * 64 : (int64_t)bm * 64 * g.lda);
   const double* B = g.B + lo + (int64_t)bz * g.strideB + (BT ? (int64_t)bn * 64 * g.ldb : (int64_t)bn * 64);
   double* C = g.C + lo + (int64_t)bz * g.strideC;
-  int kbeg = 0, kend = g.k;
-  if (g.a_lower) kend = min(kend, (bm + 1) * 64);
-  if (g.b_lower) kbeg = bn * 64;
-  if (g.k_from_tile) kbeg = max(bm, bn) * 64;   // both operands vanish above their diagonal tiles
   const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
   d4 acc[2][2];
 #pragma unroll

@@ -169,7 +169,7 @@ namespace gpbo {
 
 constexpr size_t SMALL_PIN_IN = 128 * 1024, SMALL_PIN_OUT = 32 * 1024;   // bytes: candidates in; mu, sd out (each)
 constexpr size_t SMALL_PIN_BYTES = SMALL_PIN_IN + 2 * SMALL_PIN_OUT;
-constexpr unsigned ATTR_GEMM128 = 4u, ATTR_CHOL128 = 16u, ATTR_FUSED = 32u, ATTR_MID = 64u, ATTR_KINV_GRAD = 128u, ATTR_POLISH_FUSED = 256u;
+constexpr unsigned ATTR_GEMM128 = 4u, ATTR_CHOL128 = 16u, ATTR_FUSED = 32u, ATTR_MID = 64u, ATTR_KINV_GRAD = 128u, ATTR_POLISH_FUSED = 256u, ATTR_GEMM_FAT = 512u;
 // fused_small.hip: the whole fit / LML evaluation of a problem of NP <= fused_max_np() as one launch of one workgroup per model
 constexpr int FUSED_NP_DEFAULT = 64, FUSED_NP_CAP = 512;
 // mid_fit.hip: fused_max_np() < NP <= mid_max_np(): the strip algorithms, ~15 launches
@@ -347,8 +347,13 @@ struct GemmArgs {
   int tri_grid;           // set by launch_gemm: blockIdx.x = linear lower-triangle index of the output tile (lower_only products)
   int skip00;             // leave the leading skip00 x skip00 output tiles alone (64x64-tile kernel only): the diagonal-block
                           // workgroup of the same launch (or an earlier launch) owns them
+  int fat;                // 0: launch_gemm decides from this product's shape whether the sixteen-wave tile kernel takes it (another
+                          // summation order over k, i.e. other bits); +1 / -1: the caller has decided — a product that one code path
+                          // launches whole and another in pieces (the Cholesky's trailing updates) must come out the same either way
 };
 int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g);
+// launch_gemm's own rule for g.fat == 0 (exposed for callers that split a product)
+bool gemm_fat_rule(const GemmArgs& g);
 // chol_kernels.hip: blocked Cholesky of m.L in place + inverted 64x64 diagonal blocks (128-column steps, `outer`-column panels);
 // stamps (device, >= 8 words, may be null): in-kernel clocks of the first diagonal workgroup
 int launch_cholesky128(gpbo_ctx* ctx, Model& m, int outer, long long* stamps);
