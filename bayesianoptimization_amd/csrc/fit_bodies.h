@@ -90,12 +90,17 @@ __device__ __forceinline__ void lower_tile_of(const int b, int& bi, int& bj) {
   bj = b - bi * (bi + 1) / 2;
 }
 
-// W := blockdiag(dinv) (W has been zero-filled): diagonal block kb by a 256-thread group
-__device__ __forceinline__ void fill_w_diag_body(const double* dinv, double* W, const int64_t NP, const int kb, const int tid) {
+// W := blockdiag(dinv): diagonal block kb by a 256-thread group.  `zero_right`: W has NOT been zero-filled (an LML evaluation,
+// trtri in gpbo_api.hip) — the 64x64 tile right of an even diagonal block is cleared here, so that a reader that cuts its k-range
+// at 128-row granularity (gemm128_f64_kernel over a triangular operand) still finds zeros above the diagonal of its 128-blocks.
+__device__ __forceinline__ void fill_w_diag_body(const double* dinv, double* W, const int64_t NP, const int kb, const int tid,
+                                                 const bool zero_right = false) {
   const double* D = dinv + (int64_t)kb * 4096;
+  const bool right = zero_right && !(kb & 1) && ((int64_t)kb + 2) * 64 <= NP;
   for (int e = tid; e < 4096; e += 256) {
     int r = e >> 6, c = e & 63;
     W[((int64_t)kb * 64 + r) * NP + (int64_t)kb * 64 + c] = D[e];
+    if (right) W[((int64_t)kb * 64 + r) * NP + (int64_t)(kb + 1) * 64 + c] = 0.0;
   }
 }
 

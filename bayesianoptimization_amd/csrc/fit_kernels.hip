@@ -443,21 +443,28 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// W := blockdiag(dinv) (W has been zero-filled).
+// W := blockdiag(dinv), behind a zero fill of the whole square when `zero_fill` (see trtri, gpbo_api.hip).
 __global__ __launch_bounds__(256) void fill_w_diag_kernel(const double* __restrict__ dinv,
-                                                          double* __restrict__ W, int64_t NP, int64_t lane_stride) {
+                                                          double* __restrict__ W, int64_t NP, int64_t lane_stride, int zero_right) {
   fill_w_diag_body(dinv + (int64_t)blockIdx.y * lane_stride, W + (int64_t)blockIdx.y * lane_stride, NP, (int)blockIdx.x,
-                   (int)threadIdx.x);
+                   (int)threadIdx.x, zero_right != 0);
 }
 
-int launch_fill_w_diag(gpbo_ctx* ctx, Model& m) {
-  if (ctx->lanes == 1)
-    GPBO_HIP(ctx, hipMemsetAsync(m.W, 0, (size_t)m.NP * m.NP * sizeof(double), ctx->stream));
-  else
-    GPBO_HIP(ctx, hipMemset2DAsync(m.W, (size_t)ctx->lane_stride * sizeof(double), 0, (size_t)m.NP * m.NP * sizeof(double),
-                                   (size_t)ctx->lanes, ctx->stream));
+int launch_fill_w_diag(gpbo_ctx* ctx, Model& m, bool zero_fill) {
+  if (!zero_fill && dbg_env("GPBO_POISON_W")) {
+    // debug build (tests/test_gpu_parity.py): what an LML evaluation must not read is made of NaNs instead of being left as it was
+    for (int l = 0; l < ctx->lanes; ++l)
+      GPBO_HIP(ctx, hipMemsetAsync(m.W + (int64_t)l * ctx->lane_stride, 0xFF, (size_t)m.NP * m.NP * sizeof(double), ctx->stream));
+  }
+  if (zero_fill) {
+    if (ctx->lanes == 1)
+      GPBO_HIP(ctx, hipMemsetAsync(m.W, 0, (size_t)m.NP * m.NP * sizeof(double), ctx->stream));
+    else
+      GPBO_HIP(ctx, hipMemset2DAsync(m.W, (size_t)ctx->lane_stride * sizeof(double), 0, (size_t)m.NP * m.NP * sizeof(double),
+                                     (size_t)ctx->lanes, ctx->stream));
+  }
   fill_w_diag_kernel<<<dim3((unsigned)(m.NP / 64), (unsigned)ctx->lanes), dim3(256), 0, ctx->stream>>>(m.dinv, m.W, m.NP,
-                                                                                                      ctx->lane_stride);
+                                                                                                      ctx->lane_stride, zero_fill ? 0 : 1);
   GPBO_HIP(ctx, hipGetLastError());
   return GPBO_OK;
 }

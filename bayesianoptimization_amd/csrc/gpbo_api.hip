@@ -95,9 +95,12 @@ static int cholesky(gpbo_ctx* ctx, Model& m) { return launch_cholesky128(ctx, m,
 
 // W = L^-1 by recursive doubling from the inverted 64x64 diagonal blocks:
 //   [[A,0],[C,B]]^-1 = [[A^-1,0],[-B^-1 C A^-1, B^-1]]  — two batched GEMMs per level.
-static int trtri(gpbo_ctx* ctx, Model& m) {
+// `zero_above`: W's strict upper block triangle is zero-filled first (a fit: the posterior pack and gpbo_get_Linv read W as a
+// square).  An LML evaluation reads W by tiles at and below the diagonal only — these products, t = W y, alpha = W^T t, W^T W with
+// its k-loop cut at the tiles' diagonal — and skips the 8 NP^2-byte fill (18 us + a 6 us gap at N = 4096).
+static int trtri(gpbo_ctx* ctx, Model& m, bool zero_above = true) {
   int rc;
-  if ((rc = launch_fill_w_diag(ctx, m))) return rc;
+  if ((rc = launch_fill_w_diag(ctx, m, zero_above))) return rc;
   const int64_t NP = m.NP;
   for (int64_t b = NB; b < NP; b *= 2) {
     const int64_t full = NP / (2 * b);               // pairs with a full-size second block
@@ -421,7 +424,7 @@ static int factor_resident(gpbo_ctx* ctx, Model& m, double noise, int** info_hos
   GPBO_HIP(ctx, lane_d2h(ctx, info_h, PIN_INFO_PITCH, ctx->info_dev, sizeof(int)));
   // W and alpha are issued before the info check resolves (harmless on failure)
   ev_begin(ctx, T_TRTRI);
-  if ((rc = trtri(ctx, m))) return rc;
+  if ((rc = trtri(ctx, m, pack))) return rc;      // (pack == false: an LML evaluation)
   ev_end(ctx, T_TRTRI);
   if ((rc = launch_trmv(ctx, m))) return rc;
   *info_host = info_h;

@@ -326,7 +326,7 @@ int64_t kstar_slab_budget_bytes(gpbo_ctx* ctx, int64_t want_bytes_if_unlimited);
 int launch_prescale(gpbo_ctx* ctx, const double* X, int64_t n, int d, int DP, const double* ls,
                     double* out, int64_t n_pad);
 int launch_kmat(gpbo_ctx* ctx, Model& m, double noise, double* out);   // out: m.K, or m.L (factorised in place)
-int launch_fill_w_diag(gpbo_ctx* ctx, Model& m);
+int launch_fill_w_diag(gpbo_ctx* ctx, Model& m, bool zero_fill = true);
 int launch_trmv(gpbo_ctx* ctx, Model& m);
 int launch_append_row(gpbo_ctx* ctx, Model& m, int64_t j);   // row j (== current m.N) from the prescaled m.Xs[j]
 int launch_pack_w(gpbo_ctx* ctx, Model& m);

@@ -741,3 +741,28 @@ def test_overlapped_fits_are_bitwise_the_sequential_fits(engine):
     assert lib.gpbo_fit(engine._h, 0, _lib.dptr(Xc_), _lib.dptr(yn), N, d, O.MATERN25, _lib.dptr(ls), 1, 1e-6, 0, C.byref(info)) == _lib.ERR_STATE
     assert lib.gpbo_fit_wait(engine._h, 0, C.byref(info)) == _lib.GPBO_OK and info.value == 0
     assert np.array_equal(engine.get_L(N, 0), ref[0][0])
+
+
+@pytest.mark.parametrize("N,d", [(700, 6), (1500, 8), (4096, 16), (8192, 16)])
+def test_lml_evaluations_do_not_read_above_the_diagonal_of_W(debug_engine, N, d):
+    """Round 6: an LML evaluation no longer zero-fills W before W = L^-1 is built (8 N^2 bytes: 18 us of a 2.85 ms evaluation at
+    N = 4096) — every reader of the evaluation cuts its k-range at the operand's diagonal tile, and the one tile a 128-row
+    granularity can reach (right of an even diagonal block) is cleared with the diagonal blocks.  Here the rest of W is filled
+    with NaNs first (libgpbo_dbg.so, GPBO_POISON_W): value and gradient, single and in lanes, stay bitwise what they are without."""
+    import os
+
+    X, y = _data(N, d, seed=5)
+    yn, _, _ = O.normalize_targets(y)
+    scales = np.array([[0.8], [1.3], [2.0]])
+    want1 = debug_engine.lml(X, yn, O.MATERN25, 1.3, 1e-6)
+    want = debug_engine.lml_batch(X, yn, O.MATERN25, scales, 1e-6)
+    os.environ["GPBO_POISON_W"] = "1"           # (the second call of a shape is the one that captures the lanes' graph: poison included)
+    try:
+        got1 = debug_engine.lml(X, yn, O.MATERN25, 1.3, 1e-6)
+        got = debug_engine.lml_batch(X, yn, O.MATERN25, scales, 1e-6)
+    finally:
+        os.environ.pop("GPBO_POISON_W")
+    assert np.isfinite(got1[0]) and got1[0] == want1[0] and np.array_equal(got1[1], want1[1])
+    for (v, g), (v0, g0) in zip(got, want):
+        assert v == v0 and np.array_equal(g, g0)
+    assert want[1][0] == want1[0]
