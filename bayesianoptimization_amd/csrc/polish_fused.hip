@@ -2,21 +2,24 @@
 //
 // What it replaces: the local-search stage of AcquisitionFunction._smart_minimize (bayes_opt/acquisition.py:322-420) for the
 // sizes where it is launch latency and nothing else.  polish.hip advances all runs in lockstep, one batched evaluation per round:
-// six dependent launches and a stream synchronisation (43-50 us at N <= 256) for ~2 N^2 flops per run — a default suggest() spends
-// 1.1 ms there at N ~ 100 (profiles/r05_suggest_host_profile.txt).  Here a run is a workgroup of 8 waves that owns its search
-// from the seed to the stopping rule:
-//   evaluation  = the arithmetic of launch_posterior_grad_small (posterior_small.hip) for ONE point, phase by phase with the
-//                 same loops, the same accumulation order and the same reduction trees — k*, f | v = W k* | u = W^T v in 16 row
-//                 splits | the two k-sums per dimension in 16 slices | mu, sd, d mu, d sd — so that every value is bitwise the
-//                 value the six kernels produce (tests/test_gpu_polish_fused.py compares them through gpbo_predict_grad);
-//   optimiser   = the arithmetic of polish_opt.h (the host's source) laid over wave 0: lane i owns variable i, every sum over the
-//                 variables is taken in the host's order (a chain of v_readlane + add), contraction off as on the host.
-// The runs are independent (no lockstep); the result of a run is the host path's bit for bit for UCB and to the rounding of
-// erfc / exp for EI / POI (std:: on the host, the device library here).  alpha, the length scales, the training points (when
-// they fit) and, for NP <= 128, W itself (packed lower triangle) are staged in LDS once; above that W is read twice per evaluation
-// from L2 by ONE compute unit (N^2 / 2 * 8 B per pass), which is why the path stops at NP = polish_fused_max_np(): from N ~ 300 on,
-// one CU's load rate makes an evaluation slower than the six launches that spread W over the chip
-// (profiles/r05_polish_fused_ab.json).  One model (no constraint slots).
+// six dependent launches and a stream synchronisation (43-50 us at N <= 256) for ~2 N^2 flops per run.  Here a run is a workgroup
+// that owns its search from the seed to the stopping rule.  Two kernels, one optimiser (polish_opt.h's, laid over wave 0 with a
+// lane per variable):
+//
+//   polish_rows_kernel (round 6; NP <= 128): THREAD = TRAINING POINT.  W = L^-1 sits in LDS as a padded square ([NP][NP + 1]:
+//     a thread walks its row for v = W k*, its column for u = W^T v, both conflict-free), thread i keeps k*_i, v_i, u_i of its own
+//     point, the sums over the points (mu, |v|^2, the 2 d gradient sums) are taken by lane groups of one dimension each and
+//     combined in a fixed order, the optimiser's sums over the variables are DPP row reductions.  Four barriers of a one- or
+//     two-wave workgroup per evaluation: ~2 us per evaluation + step where the kernel below needs 13-19 (profiles/r06_polish_fused_ab.json).
+//     Deterministic, and NOT the bits of the lockstep path: the evaluation agrees with gpbo_predict_grad to ~1e-13 of the
+//     values' scale (tests/test_gpu_polish_fused.py), a whole search ends at the same or a better value (SURVEY.md section 8 f2:
+//     "parity is statistical (same or better acquisition value), not bit-wise"; the lockstep path is the checker).
+//   polish_fused_kernel (round 5; 128 < NP <= 256): eight waves, W read twice per evaluation from L2, the arithmetic of
+//     launch_posterior_grad_small (posterior_small.hip) phase by phase with the same loops, accumulation orders and reduction
+//     trees, the optimiser's sums as the host's left-to-right chains (v_readlane + add): bitwise the lockstep path for UCB.  From
+//     N ~ 300 on one CU's load rate makes an evaluation slower than the six launches that spread W over the chip, which is where
+//     polish_fused_max_np() stops it.
+// One model (no constraint slots).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -61,20 +64,13 @@ __host__ __device__ inline int pf_lds_base(int NP, int d, int DP) {
   return PF_FIXED + 5 * NP + pf_shared_region(NP) + PF_KSL * 2 * DP + 2 * LBFGS_M * d;
 }
 constexpr int PF_LDS_CAP = 160 * 128 - 8;      // doubles in 160 KiB, less the flag words
-// W = L^-1 as a packed lower triangle in LDS for NP <= 128 (66 KB at 128): the two passes of an evaluation read LDS instead of L2.
-// Measured: no faster (bare evaluation 13.4 / 13.5 / 19.0 us at N = 32 / 64 / 128 against 14.0 / 14.1 / 19.2 from L2) — an
-// evaluation waits on its nine barriers and the LDS round trips between them, not on W (docs/LAB_NOTEBOOK.md §9.9).  Kept: same bits.
-__host__ __device__ inline int pf_w_stage(int NP, int d, int DP) {
-  const int want = NP * (NP + 1) / 2;
-  return (NP <= 128 && pf_lds_base(NP, d, DP) + want <= PF_LDS_CAP) ? want : 0;
-}
 // (the training points: staged only where the whole image still fits — at NP > 512 the row splits take the room)
 __host__ __device__ inline int pf_xs_stage(int NP, int d, int DP) {
   const int want = NP * (DP + 1);
-  return (want <= PF_XS_STAGE && pf_lds_base(NP, d, DP) + pf_w_stage(NP, d, DP) + want <= PF_LDS_CAP) ? want : 0;
+  return (want <= PF_XS_STAGE && pf_lds_base(NP, d, DP) + want <= PF_LDS_CAP) ? want : 0;
 }
 __host__ __device__ inline int pf_lds_doubles(int NP, int d, int DP) {
-  return pf_lds_base(NP, d, DP) + pf_w_stage(NP, d, DP) + pf_xs_stage(NP, d, DP);
+  return pf_lds_base(NP, d, DP) + pf_xs_stage(NP, d, DP);
 }
 __host__ __device__ inline int pf_lds_ints(int) { return 4; }
 
@@ -99,22 +95,60 @@ __device__ __forceinline__ double pf_lane(double v, int i) {      // v of lane i
   const int hi = __builtin_amdgcn_readlane((int)(b >> 32), i);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
-__device__ __forceinline__ double pf_sum(double v, int d) {       // ((0 + v_0) + v_1) + ...
-#pragma clang fp contract(off)
-  double acc = 0.0;
-  for (int i = 0; i < d; ++i) acc += pf_lane(v, i);
-  return acc;
+// One DPP step of a reduction inside a row of 16 lanes: v of the lane the pattern CTRL pairs this one with
+template <int CTRL>
+__device__ __forceinline__ double pf_dpp(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
+// Sum over the variables, the same value in every lane (lanes >= d carry zeros).  FAST = false: the host's left-to-right chain
+// ((0 + v_0) + v_1) + ... of v_readlane'd addends: polish_opt.h's bits, 3 d instructions.  FAST = true: a butterfly inside each row
+// of 16 lanes (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: 12 instructions) and the rows' totals in order.
+template <bool FAST>
+__device__ __forceinline__ double pf_sum(double v, int d) {
+#pragma clang fp contract(off)
+  if constexpr (FAST) {
+    v += pf_dpp<0xB1>(v);
+    v += pf_dpp<0x4E>(v);
+    v += pf_dpp<0x141>(v);
+    v += pf_dpp<0x140>(v);
+    double acc = pf_lane(v, 0);
+    if (d > 16) acc += pf_lane(v, 16);
+    if (d > 32) acc = (acc + pf_lane(v, 32)) + pf_lane(v, 48);
+    return acc;
+  } else {
+    double acc = 0.0;
+    for (int i = 0; i < d; ++i) acc += pf_lane(v, i);
+    return acc;
+  }
+}
+template <bool FAST>
 __device__ __forceinline__ double pf_max_abs(double v, int d) {   // m = 0; m = max(m, |v_i|) in order (std::max: a NaN never wins)
-  double m = 0.0;
-  for (int i = 0; i < d; ++i) m = polish_max(m, __builtin_fabs(pf_lane(v, i)));
-  return m;
+  if constexpr (FAST) {
+    double m = __builtin_fabs(v);
+    if (m != m) m = 0.0;
+    m = polish_max(m, pf_dpp<0xB1>(m));
+    m = polish_max(m, pf_dpp<0x4E>(m));
+    m = polish_max(m, pf_dpp<0x141>(m));
+    m = polish_max(m, pf_dpp<0x140>(m));
+    double acc = pf_lane(m, 0);
+    if (d > 16) acc = polish_max(acc, pf_lane(m, 16));
+    if (d > 32) acc = polish_max(polish_max(acc, pf_lane(m, 32)), pf_lane(m, 48));
+    return acc;
+  } else {
+    double m = 0.0;
+    for (int i = 0; i < d; ++i) m = polish_max(m, __builtin_fabs(pf_lane(v, i)));
+    return m;
+  }
 }
 
+template <bool FAST>
 __device__ __forceinline__ double pf_projected_gradient_norm(const WaveRun& r, int d) {
 #pragma clang fp contract(off)
   const double t = polish_min(polish_max(r.x - r.g, r.lo), r.hi) - r.x;
-  return pf_max_abs(t, d);
+  return pf_max_abs<FAST>(t, d);
 }
 
 __device__ __forceinline__ void pf_trial_point(WaveRun& r) {
@@ -122,6 +156,7 @@ __device__ __forceinline__ void pf_trial_point(WaveRun& r) {
   r.xt = polish_min(polish_max(r.x + r.alpha * r.dir, r.lo), r.hi);
 }
 
+template <bool FAST>
 __device__ __forceinline__ void pf_new_direction(WaveRun& r, int d, int lane, const double* S, const double* Y) {
 #pragma clang fp contract(off)
   const bool mine = lane < d;
@@ -132,7 +167,7 @@ __device__ __forceinline__ void pf_new_direction(WaveRun& r, int d, int lane, co
   for (int t = 0; t < r.hist; ++t) {
     const int k = (r.head - 1 - t + 2 * LBFGS_M) % LBFGS_M;
     const double s = mine ? S[k * d + lane] : 0.0, y = mine ? Y[k * d + lane] : 0.0;
-    const double sy = pf_sum(r.freev ? s * y : 0.0, d), yy = pf_sum(r.freev ? y * y : 0.0, d);
+    const double sy = pf_sum<FAST>(r.freev ? s * y : 0.0, d), yy = pf_sum<FAST>(r.freev ? y * y : 0.0, d);
     if (!(sy > 2.2e-16 * yy) || !(yy > 0.0)) continue;
     if (used == 0) gamma = sy / yy;
     if (lane == used) {
@@ -144,7 +179,7 @@ __device__ __forceinline__ void pf_new_direction(WaveRun& r, int d, int lane, co
   for (int t = 0; t < used; ++t) {
     const int k = __builtin_amdgcn_readlane(r.order, t);
     const double s = mine ? S[k * d + lane] : 0.0, y = mine ? Y[k * d + lane] : 0.0;
-    const double sq = pf_sum(r.freev ? s * r.q : 0.0, d);
+    const double sq = pf_sum<FAST>(r.freev ? s * r.q : 0.0, d);
     const double at = pf_lane(r.rho, t) * sq;
     if (lane == t) r.av = at;
     if (r.freev) r.q -= at * y;
@@ -153,12 +188,12 @@ __device__ __forceinline__ void pf_new_direction(WaveRun& r, int d, int lane, co
   for (int t = used - 1; t >= 0; --t) {
     const int k = __builtin_amdgcn_readlane(r.order, t);
     const double s = mine ? S[k * d + lane] : 0.0, y = mine ? Y[k * d + lane] : 0.0;
-    const double yq = pf_sum(r.freev ? y * r.q : 0.0, d);
+    const double yq = pf_sum<FAST>(r.freev ? y * r.q : 0.0, d);
     const double bt = pf_lane(r.rho, t) * yq;
     if (r.freev) r.q += (pf_lane(r.av, t) - bt) * s;
   }
   r.dir = r.freev ? -r.q : 0.0;
-  const double gd = pf_sum(r.dir * r.g, d), gn = pf_sum(r.freev ? r.g * r.g : 0.0, d);
+  const double gd = pf_sum<FAST>(r.dir * r.g, d), gn = pf_sum<FAST>(r.freev ? r.g * r.g : 0.0, d);
   if (!(gd < 0.0) || !__builtin_isfinite(gd)) {     // not a descent direction: steepest descent over the free variables, history dropped
     r.hist = 0;
     used = 0;
@@ -169,6 +204,7 @@ __device__ __forceinline__ void pf_new_direction(WaveRun& r, int d, int lane, co
 }
 
 // polish_advance: one answer (ft, this lane's gradient component gt — non-finite components already 0) of the objective
+template <bool FAST>
 __device__ __forceinline__ void pf_advance(WaveRun& r, double ft, double gt, int d, int lane, double* S, double* Y, int max_iter) {
 #pragma clang fp contract(off)
   const bool mine = lane < d;
@@ -176,14 +212,14 @@ __device__ __forceinline__ void pf_advance(WaveRun& r, double ft, double gt, int
   if (r.phase == 0) {
     r.x = r.xt; r.g = gt; r.f = ft;
     if (!__builtin_isfinite(ft)) { r.phase = 2; r.status = 2; return; }
-    if (pf_projected_gradient_norm(r, d) <= POLISH_PGTOL) { r.phase = 2; r.status = 0; return; }
-    pf_new_direction(r, d, lane, S, Y);
+    if (pf_projected_gradient_norm<FAST>(r, d) <= POLISH_PGTOL) { r.phase = 2; r.status = 0; return; }
+    pf_new_direction<FAST>(r, d, lane, S, Y);
     pf_trial_point(r);
     r.phase = 1;
     return;
   }
   const double sd = r.xt - r.x;
-  const double gs = pf_sum(r.g * sd, d), moved = pf_max_abs(sd, d);
+  const double gs = pf_sum<FAST>(r.g * sd, d), moved = pf_max_abs<FAST>(sd, d);
   const bool ok = __builtin_isfinite(ft) && ft <= r.f + 1e-4 * gs;
   if (!ok) {
     const bool flat = __builtin_isfinite(ft) && r.ls >= 2 &&
@@ -205,7 +241,7 @@ __device__ __forceinline__ void pf_advance(WaveRun& r, double ft, double gt, int
       S[r.head * d + lane] = s;
       Y[r.head * d + lane] = y;
     }
-    const double sy = pf_sum(s * y, d), yy = pf_sum(y * y, d);
+    const double sy = pf_sum<FAST>(s * y, d), yy = pf_sum<FAST>(y * y, d);
     if (sy > 2.2e-16 * yy && yy > 0.0) {
       r.head = (r.head + 1) % LBFGS_M;
       r.hist = (r.hist + 1 < LBFGS_M) ? r.hist + 1 : LBFGS_M;
@@ -214,10 +250,10 @@ __device__ __forceinline__ void pf_advance(WaveRun& r, double ft, double gt, int
   const double f_old = r.f;
   r.x = r.xt; r.g = gt; r.f = ft;
   ++r.iter;
-  if (pf_projected_gradient_norm(r, d) <= POLISH_PGTOL) { r.phase = 2; r.status = 0; return; }
+  if (pf_projected_gradient_norm<FAST>(r, d) <= POLISH_PGTOL) { r.phase = 2; r.status = 0; return; }
   if ((f_old - ft) <= POLISH_FTOL * polish_max(polish_max(__builtin_fabs(f_old), __builtin_fabs(ft)), 1.0)) { r.phase = 2; r.status = 1; return; }
   if (r.iter >= max_iter) { r.phase = 2; r.status = 2; return; }
-  pf_new_direction(r, d, lane, S, Y);
+  pf_new_direction<FAST>(r, d, lane, S, Y);
   pf_trial_point(r);
 }
 
@@ -243,14 +279,9 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
   double* gpart = partial + pf_shared_region(NP);   // [PF_KSL][2][DP]
   double* Sh = gpart + PF_KSL * 2 * DP;              // [LBFGS_M][d] correction pairs
   double* Yh = Sh + LBFGS_M * d;
-  double* Wl = Yh + LBFGS_M * d;                     // W, packed lower triangle by rows (when staged)
-  const int w_staged = pf_w_stage(NP, d, DP);
-  double* Xl = Wl + w_staged;                        // [NP][DP + 1] training points (when staged)
+  double* Xl = Yh + LBFGS_M * d;                     // [NP][DP + 1] training points (when staged)
   const int xs_staged = pf_xs_stage(NP, d, DP);
   int* flag = (int*)(Xl + xs_staged);
-  // W[i][k]: the LDS triangle (an explicit zero above the diagonal, as the matrix in memory has) or the matrix in memory — the
-  // two W phases are instantiated once for each, so that neither carries the other's address space in its load loops
-  auto w_lds = [&](int i, int k) -> double { return (k <= i) ? Wl[i * (i + 1) / 2 + k] : 0.0; };
   auto w_mem = [&](int i, int k) -> double { return W[(int64_t)i * NP + k]; };
   // the training points: LDS rows of DP + 1 (conflict-free for the row walk of P1 and the dimension walk of P5), else global rows
   const double* __restrict__ Xs = xs_staged ? Xl : a.Xs;
@@ -263,9 +294,6 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
       const int k = e / DP, t = e - k * DP;
       Xl[k * (DP + 1) + t] = a.Xs[e];
     }
-  if (w_staged)
-    for (int i = wave; i < NP; i += PF_THREADS / 64)
-      for (int k = lane; k <= i; k += 64) Wl[i * (i + 1) / 2 + k] = W[(int64_t)i * NP + k];
   WaveRun run{};
   if (wave == 0) {
     const bool mine = lane < d;
@@ -358,7 +386,7 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
           }
       }
     };
-    if (w_staged) phase_v(w_lds); else phase_v(w_mem);
+    phase_v(w_mem);
     __syncthreads();
     // ---- P3: the row splits of u = W^T v (gemvt_small_kernel<4>: per 64-column block the rows below it in PF_SPLITS chunks, four
     // row lanes i = r0 + ig (mod 4) each summed by itself and added in order)
@@ -392,7 +420,7 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
       partial[sp * NP + j] = sum;
     }
     };
-    if (w_staged) phase_u(w_lds); else phase_u(w_mem);
+    phase_u(w_mem);
     __syncthreads();
     // ---- P4: u_k = the splits in order (grad_small_kernel's inner sum)
     for (int k = tid; k < NP; k += PF_THREADS) {
@@ -482,10 +510,204 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
           if (lane == 0) flag[0] = 1;
         }
       } else {
-        pf_advance(run, -av, g, d, lane, Sh, Yh, a.max_iter);
+        pf_advance<false>(run, -av, g, d, lane, Sh, Yh, a.max_iter);
         if (lane < d) xt_s[lane] = run.xt;
         if (lane < DP) xs[lane] = (lane < d) ? run.xt / ls_s[lane] : 0.0;       // (P1 and P5 of this round are behind the barrier above)
         if (lane == 0) flag[0] = (run.phase == 2 || round + 1 > round_cap) ? 1 : 0;      // (the cap cannot bind: a run is bounded by max_iter * MAXLS)
+      }
+    }
+    __syncthreads();
+    if (flag[0]) break;
+  }
+  if (a.eval_only) return;
+  if (wave == 0) {
+    if (lane < d) a.x_out[(size_t)sidx * d + lane] = run.x;
+    if (lane == 0) {
+      a.f_out[sidx] = run.f;
+      a.status_out[sidx] = run.phase == 2 ? run.status : 2;
+      a.iter_out[sidx] = run.iter;
+      a.eval_out[sidx] = run.evals;
+    }
+  }
+}
+
+// ---- thread = training point (NP <= 128) ---------------------------------------------------------------------------------
+constexpr int PR_MAX_NP = 128;
+// LDS (doubles): W [NP][NP + 1] | xs [64] | ls [64] | alpha, k*, v [NP each] | (c1, c2) [NP][2] | (v^2, k* alpha) [NP][2] |
+// group partials [PR_MAX_GROUPS][2 DP + 2] | S, Y [LBFGS_M][d each] | X [NP][DP + 1] (when it fits) ; then the flag word
+constexpr int PR_MAX_GROUPS = 32;
+__host__ __device__ inline int pr_lds_base(int NP, int d, int DP) {
+  return NP * (NP + 1) + 128 + 7 * NP + PR_MAX_GROUPS * (2 * DP + 2) + 2 * LBFGS_M * d;
+}
+__host__ __device__ inline int pr_xs_stage(int NP, int d, int DP) {
+  const int want = NP * (DP + 1);
+  return (pr_lds_base(NP, d, DP) + want <= PF_LDS_CAP) ? want : 0;
+}
+__host__ __device__ inline int pr_lds_doubles(int NP, int d, int DP) { return pr_lds_base(NP, d, DP) + pr_xs_stage(NP, d, DP); }
+
+template <int KERNEL>
+__global__ __launch_bounds__(PR_MAX_NP) void polish_rows_kernel(const PolishFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double pr_smem[];
+  const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int sidx = (int)blockIdx.x;
+  const int NP = a.NP, N = a.N, d = a.d, DP = a.DP;
+  const int WLD = NP + 1;
+  double* Wl = pr_smem;                     // [NP][NP + 1]: row walks and column walks both hit 64 different banks
+  double* xs = Wl + NP * WLD;               // [64] the trial point over the length scales, zero padded
+  double* ls_s = xs + 64;                   // [64]
+  double* al_s = ls_s + 64;                 // [NP] alpha
+  double* ks = al_s + NP;                   // [NP] k*
+  double* vs = ks + NP;                     // [NP] v = W k*
+  double* cc = vs + NP;                     // [NP][2] alpha_k f_k, u_k f_k
+  double* pp = cc + 2 * NP;                 // [NP][2] v_k^2, k*_k alpha_k
+  double* red = pp + 2 * NP;                // [groups][2 DP + 2]
+  double* Sh = red + PR_MAX_GROUPS * (2 * DP + 2);
+  double* Yh = Sh + LBFGS_M * d;
+  double* Xl = Yh + LBFGS_M * d;
+  const int xs_staged = pr_xs_stage(NP, d, DP);
+  int* flag = (int*)(Xl + xs_staged);
+  const double* __restrict__ Xs = xs_staged ? Xl : a.Xs;
+  const int xld = xs_staged ? DP + 1 : DP;
+
+  for (int e = tid; e < NP * NP; e += NP) {           // (blockDim.x == NP) coalesced rows of the matrix in memory, zeros above the diagonal included
+    const int i = e / NP, k = e - i * NP;
+    Wl[i * WLD + k] = a.W[e];
+  }
+  al_s[tid] = a.alpha[tid];
+  if (tid < 64) ls_s[tid] = (tid < d) ? a.ls[tid] : 1.0;
+  if (xs_staged)
+    for (int e = tid; e < NP * DP; e += NP) {
+      const int k = e / DP, t = e - k * DP;
+      Xl[k * (DP + 1) + t] = a.Xs[e];
+    }
+  WaveRun run{};
+  if (wave == 0) {
+    const bool mine = lane < d;
+    run.lo = mine ? a.lo[lane] : 0.0;
+    run.hi = mine ? a.hi[lane] : 0.0;
+    run.xt = mine ? polish_min(polish_max(a.seeds[(size_t)sidx * d + lane], run.lo), run.hi) : 0.0;      // polish_start
+    run.alpha = 1.0;
+    run.status = 2;
+    if (lane < DP) xs[lane] = mine ? run.xt / a.ls[lane] : 0.0;
+    if (lane == 0) flag[0] = 0;
+  }
+  __syncthreads();
+
+  // the sums over the training points: lane groups of DP lanes (one dimension each), group j takes the points k = j (mod groups)
+  const int gpw = 64 / DP, groups = gpw * (NP >> 6);
+  const int grp = wave * gpw + lane / DP, gt = lane % DP;
+  const int round_cap = 4 * a.max_iter + 64;
+  const double al_i = al_s[tid];
+  const double* wrow = Wl + tid * WLD;
+
+  for (int round = 0;; ++round) {
+    // ---- k*_i and the gradient factor f_i of this thread's point
+    double fi;
+    {
+      const double* xr = Xs + (int64_t)tid * xld;
+      double d2 = 0.0;
+      for (int t = 0; t < DP; ++t) {
+        const double df = xs[t] - xr[t];
+        d2 = fma(df, df, d2);
+      }
+      const double kv = gpbo_kernel_value<KERNEL>(d2);
+      if (KERNEL == GPBO_KERNEL_MATERN25) {
+        const double sq = gpbo_sqrt_pos(d2) * 2.23606797749978969641;      // sqrt(5) r
+        fi = -1.66666666666666666667 * (1.0 + sq) * gpbo_exp_nonpos(-sq);
+      } else {
+        fi = -kv;
+      }
+      if (tid >= N) fi = 0.0;          // padding rows carry no gradient
+      ks[tid] = kv;
+    }
+    __syncthreads();
+    // ---- v_i = sum_k W[i][k] k*_k (zeros above the diagonal: the whole row)
+    {
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+      for (int k = 0; k < NP; k += 4) {
+        v0 = fma(wrow[k], ks[k], v0);
+        v1 = fma(wrow[k + 1], ks[k + 1], v1);
+        v2 = fma(wrow[k + 2], ks[k + 2], v2);
+        v3 = fma(wrow[k + 3], ks[k + 3], v3);
+      }
+      const double v = (tid < N) ? (v0 + v1) + (v2 + v3) : 0.0;
+      vs[tid] = v;
+      pp[2 * tid] = v * v;
+      pp[2 * tid + 1] = ks[tid] * al_i;
+    }
+    __syncthreads();
+    // ---- u_k = sum_i W[i][k] v_i for this thread's column, then its two gradient weights
+    {
+      double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
+      const double* wcol = Wl + tid;
+      for (int i = 0; i < NP; i += 4) {
+        u0 = fma(wcol[i * WLD], vs[i], u0);
+        u1 = fma(wcol[(i + 1) * WLD], vs[i + 1], u1);
+        u2 = fma(wcol[(i + 2) * WLD], vs[i + 2], u2);
+        u3 = fma(wcol[(i + 3) * WLD], vs[i + 3], u3);
+      }
+      const double u = (u0 + u1) + (u2 + u3);
+      cc[2 * tid] = al_i * fi;
+      cc[2 * tid + 1] = u * fi;
+    }
+    __syncthreads();
+    // ---- the sums over the points: gm_t = sum_k alpha_k f_k (x_t - X_kt), gv_t likewise with u_k; |v|^2 and k* . alpha ride along
+    {
+      const double xt = xs[gt];
+      double gm = 0.0, gv = 0.0, s2 = 0.0, mm = 0.0;
+      for (int k = grp; k < NP; k += groups) {
+        const double df = xt - Xs[(int64_t)k * xld + gt];
+        gm = fma(cc[2 * k], df, gm);
+        gv = fma(cc[2 * k + 1], df, gv);
+        s2 += pp[2 * k];
+        mm += pp[2 * k + 1];
+      }
+      double* r = red + grp * (2 * DP + 2);
+      r[gt] = gm;
+      r[DP + gt] = gv;
+      if (gt == 0) { r[2 * DP] = s2; r[2 * DP + 1] = mm; }
+    }
+    __syncthreads();
+    // ---- wave 0, lane = variable: the groups in order, mean / deviation / acquisition, the optimiser's step
+    if (wave == 0) {
+      double sa = 0.0, sb = 0.0, tot0 = 0.0, tot1 = 0.0;
+      const int t = lane < DP ? lane : 0;
+      for (int j = 0; j < groups; ++j) {
+        const double* r = red + j * (2 * DP + 2);
+        sa += r[t];
+        sb += r[DP + t];
+        tot0 += r[2 * DP];
+        tot1 += r[2 * DP + 1];
+      }
+      double var = 1.0 - tot0;
+      if (var < 0.0) {
+        if (lane == 0) *a.negvar = 1;
+        var = 0.0;
+      }
+      const double sdn = sqrt(var);
+      const double sd = sqrt(var * (a.y_std * a.y_std));
+      const double mu = a.y_std * tot1 + a.y_mean;
+      double dmu = 0.0, dsd = 0.0, g = 0.0;
+      double av, ca, cs;
+      polish_acq_coeffs(a.acq, a.acq_param, a.y_max, mu, sd, DevCdf(), DevPdf(), av, ca, cs);
+      if (lane < d) {
+        const double inv_l = 1.0 / ls_s[lane];
+        dmu = a.y_std * sa * inv_l;
+        dsd = (sdn > 0.0) ? -(a.y_std * sb * inv_l) / sdn : 0.0;       // a clipped (zero) variance has no slope
+        g = polish_acq_grad(ca, cs, dmu, dsd);
+        if (!__builtin_isfinite(g)) g = 0.0;
+      }
+      if (a.eval_only) {
+        if (round + 1 >= a.eval_only) {
+          double* o = a.dbg + (size_t)sidx * (4 + 3 * d);
+          if (lane == 0) { o[0] = -av; o[1] = mu; o[2] = sd; o[3] = 0.0; }
+          if (lane < d) { o[4 + lane] = g; o[4 + d + lane] = dmu; o[4 + 2 * d + lane] = dsd; }
+          if (lane == 0) flag[0] = 1;
+        }
+      } else {
+        pf_advance<true>(run, -av, g, d, lane, Sh, Yh, a.max_iter);
+        if (lane < DP) xs[lane] = (lane < d) ? run.xt / ls_s[lane] : 0.0;
+        if (lane == 0) flag[0] = (run.phase == 2 || round + 1 > round_cap) ? 1 : 0;
       }
     }
     __syncthreads();
@@ -514,7 +736,16 @@ int polish_fused_max_np() {
   return v;
 }
 
+// thread = training point (polish_rows_kernel) for NP <= 128 whenever its LDS image fits; GPBO_POLISH_ROWS=0 (debug build, read per
+// call): the eight-wave kernel there too (A/B, and the bitwise tests of that kernel at small sizes)
+static bool polish_rows_serves(const Model& m) {
+  const char* e = dbg_env("GPBO_POLISH_ROWS");
+  if (e && e[0] == '0') return false;
+  return m.NP <= PR_MAX_NP && (size_t)pr_lds_doubles((int)m.NP, m.d, m.DP) * sizeof(double) + 16 <= (size_t)160 * 1024;
+}
+
 size_t polish_fused_lds_bytes(const Model& m) {
+  if (polish_rows_serves(m)) return (size_t)pr_lds_doubles((int)m.NP, m.d, m.DP) * sizeof(double) + 16;
   return (size_t)pf_lds_doubles((int)m.NP, m.d, m.DP) * sizeof(double) + (size_t)pf_lds_ints(m.d) * sizeof(int);
 }
 
@@ -538,6 +769,10 @@ int launch_polish_fused(gpbo_ctx* ctx, Model& m, int acq, double acq_param, doub
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
     GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(polish_fused_kernel<GPBO_KERNEL_RBF>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+    GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(polish_rows_kernel<GPBO_KERNEL_MATERN25>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+    GPBO_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(polish_rows_kernel<GPBO_KERNEL_RBF>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
     ctx->func_attrs |= ATTR_POLISH_FUSED;
   }
   const size_t S = (size_t)n_seeds;
@@ -560,7 +795,12 @@ int launch_polish_fused(gpbo_ctx* ctx, Model& m, int acq, double acq_param, doub
   a.status_out = iv; a.iter_out = iv + S; a.eval_out = iv + 2 * S;
   a.negvar = ctx->negvar;
   const size_t lds = polish_fused_lds_bytes(m);
-  if (m.kernel == GPBO_KERNEL_MATERN25)
+  if (polish_rows_serves(m)) {
+    if (m.kernel == GPBO_KERNEL_MATERN25)
+      polish_rows_kernel<GPBO_KERNEL_MATERN25><<<dim3((unsigned)n_seeds), dim3((unsigned)m.NP), lds, ctx->stream>>>(a);
+    else
+      polish_rows_kernel<GPBO_KERNEL_RBF><<<dim3((unsigned)n_seeds), dim3((unsigned)m.NP), lds, ctx->stream>>>(a);
+  } else if (m.kernel == GPBO_KERNEL_MATERN25)
     polish_fused_kernel<GPBO_KERNEL_MATERN25><<<dim3((unsigned)n_seeds), dim3(PF_THREADS), lds, ctx->stream>>>(a);
   else
     polish_fused_kernel<GPBO_KERNEL_RBF><<<dim3((unsigned)n_seeds), dim3(PF_THREADS), lds, ctx->stream>>>(a);
