@@ -95,60 +95,22 @@ __device__ __forceinline__ double pf_lane(double v, int i) {      // v of lane i
   const int hi = __builtin_amdgcn_readlane((int)(b >> 32), i);
   return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
 }
-// One DPP step of a reduction inside a row of 16 lanes: v of the lane the pattern CTRL pairs this one with
-template <int CTRL>
-__device__ __forceinline__ double pf_dpp(double v) {
-  const long long b = __builtin_bit_cast(long long, v);
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
-  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
-}
-// Sum over the variables, the same value in every lane (lanes >= d carry zeros).  FAST = false: the host's left-to-right chain
-// ((0 + v_0) + v_1) + ... of v_readlane'd addends: polish_opt.h's bits, 3 d instructions.  FAST = true: a butterfly inside each row
-// of 16 lanes (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: 12 instructions) and the rows' totals in order.
-template <bool FAST>
-__device__ __forceinline__ double pf_sum(double v, int d) {
+__device__ __forceinline__ double pf_sum(double v, int d) {       // ((0 + v_0) + v_1) + ...
 #pragma clang fp contract(off)
-  if constexpr (FAST) {
-    v += pf_dpp<0xB1>(v);
-    v += pf_dpp<0x4E>(v);
-    v += pf_dpp<0x141>(v);
-    v += pf_dpp<0x140>(v);
-    double acc = pf_lane(v, 0);
-    if (d > 16) acc += pf_lane(v, 16);
-    if (d > 32) acc = (acc + pf_lane(v, 32)) + pf_lane(v, 48);
-    return acc;
-  } else {
-    double acc = 0.0;
-    for (int i = 0; i < d; ++i) acc += pf_lane(v, i);
-    return acc;
-  }
+  double acc = 0.0;
+  for (int i = 0; i < d; ++i) acc += pf_lane(v, i);
+  return acc;
 }
-template <bool FAST>
 __device__ __forceinline__ double pf_max_abs(double v, int d) {   // m = 0; m = max(m, |v_i|) in order (std::max: a NaN never wins)
-  if constexpr (FAST) {
-    double m = __builtin_fabs(v);
-    if (m != m) m = 0.0;
-    m = polish_max(m, pf_dpp<0xB1>(m));
-    m = polish_max(m, pf_dpp<0x4E>(m));
-    m = polish_max(m, pf_dpp<0x141>(m));
-    m = polish_max(m, pf_dpp<0x140>(m));
-    double acc = pf_lane(m, 0);
-    if (d > 16) acc = polish_max(acc, pf_lane(m, 16));
-    if (d > 32) acc = polish_max(polish_max(acc, pf_lane(m, 32)), pf_lane(m, 48));
-    return acc;
-  } else {
-    double m = 0.0;
-    for (int i = 0; i < d; ++i) m = polish_max(m, __builtin_fabs(pf_lane(v, i)));
-    return m;
-  }
+  double m = 0.0;
+  for (int i = 0; i < d; ++i) m = polish_max(m, __builtin_fabs(pf_lane(v, i)));
+  return m;
 }
 
-template <bool FAST>
 __device__ __forceinline__ double pf_projected_gradient_norm(const WaveRun& r, int d) {
 #pragma clang fp contract(off)
   const double t = polish_min(polish_max(r.x - r.g, r.lo), r.hi) - r.x;
-  return pf_max_abs<FAST>(t, d);
+  return pf_max_abs(t, d);
 }
 
 __device__ __forceinline__ void pf_trial_point(WaveRun& r) {
@@ -156,7 +118,6 @@ __device__ __forceinline__ void pf_trial_point(WaveRun& r) {
   r.xt = polish_min(polish_max(r.x + r.alpha * r.dir, r.lo), r.hi);
 }
 
-template <bool FAST>
 __device__ __forceinline__ void pf_new_direction(WaveRun& r, int d, int lane, const double* S, const double* Y) {
 #pragma clang fp contract(off)
   const bool mine = lane < d;
@@ -167,7 +128,7 @@ __device__ __forceinline__ void pf_new_direction(WaveRun& r, int d, int lane, co
   for (int t = 0; t < r.hist; ++t) {
     const int k = (r.head - 1 - t + 2 * LBFGS_M) % LBFGS_M;
     const double s = mine ? S[k * d + lane] : 0.0, y = mine ? Y[k * d + lane] : 0.0;
-    const double sy = pf_sum<FAST>(r.freev ? s * y : 0.0, d), yy = pf_sum<FAST>(r.freev ? y * y : 0.0, d);
+    const double sy = pf_sum(r.freev ? s * y : 0.0, d), yy = pf_sum(r.freev ? y * y : 0.0, d);
     if (!(sy > 2.2e-16 * yy) || !(yy > 0.0)) continue;
     if (used == 0) gamma = sy / yy;
     if (lane == used) {
@@ -179,7 +140,7 @@ __device__ __forceinline__ void pf_new_direction(WaveRun& r, int d, int lane, co
   for (int t = 0; t < used; ++t) {
     const int k = __builtin_amdgcn_readlane(r.order, t);
     const double s = mine ? S[k * d + lane] : 0.0, y = mine ? Y[k * d + lane] : 0.0;
-    const double sq = pf_sum<FAST>(r.freev ? s * r.q : 0.0, d);
+    const double sq = pf_sum(r.freev ? s * r.q : 0.0, d);
     const double at = pf_lane(r.rho, t) * sq;
     if (lane == t) r.av = at;
     if (r.freev) r.q -= at * y;
@@ -188,12 +149,12 @@ __device__ __forceinline__ void pf_new_direction(WaveRun& r, int d, int lane, co
   for (int t = used - 1; t >= 0; --t) {
     const int k = __builtin_amdgcn_readlane(r.order, t);
     const double s = mine ? S[k * d + lane] : 0.0, y = mine ? Y[k * d + lane] : 0.0;
-    const double yq = pf_sum<FAST>(r.freev ? y * r.q : 0.0, d);
+    const double yq = pf_sum(r.freev ? y * r.q : 0.0, d);
     const double bt = pf_lane(r.rho, t) * yq;
     if (r.freev) r.q += (pf_lane(r.av, t) - bt) * s;
   }
   r.dir = r.freev ? -r.q : 0.0;
-  const double gd = pf_sum<FAST>(r.dir * r.g, d), gn = pf_sum<FAST>(r.freev ? r.g * r.g : 0.0, d);
+  const double gd = pf_sum(r.dir * r.g, d), gn = pf_sum(r.freev ? r.g * r.g : 0.0, d);
   if (!(gd < 0.0) || !__builtin_isfinite(gd)) {     // not a descent direction: steepest descent over the free variables, history dropped
     r.hist = 0;
     used = 0;
@@ -204,7 +165,6 @@ __device__ __forceinline__ void pf_new_direction(WaveRun& r, int d, int lane, co
 }
 
 // polish_advance: one answer (ft, this lane's gradient component gt — non-finite components already 0) of the objective
-template <bool FAST>
 __device__ __forceinline__ void pf_advance(WaveRun& r, double ft, double gt, int d, int lane, double* S, double* Y, int max_iter) {
 #pragma clang fp contract(off)
   const bool mine = lane < d;
@@ -212,14 +172,14 @@ __device__ __forceinline__ void pf_advance(WaveRun& r, double ft, double gt, int
   if (r.phase == 0) {
     r.x = r.xt; r.g = gt; r.f = ft;
     if (!__builtin_isfinite(ft)) { r.phase = 2; r.status = 2; return; }
-    if (pf_projected_gradient_norm<FAST>(r, d) <= POLISH_PGTOL) { r.phase = 2; r.status = 0; return; }
-    pf_new_direction<FAST>(r, d, lane, S, Y);
+    if (pf_projected_gradient_norm(r, d) <= POLISH_PGTOL) { r.phase = 2; r.status = 0; return; }
+    pf_new_direction(r, d, lane, S, Y);
     pf_trial_point(r);
     r.phase = 1;
     return;
   }
   const double sd = r.xt - r.x;
-  const double gs = pf_sum<FAST>(r.g * sd, d), moved = pf_max_abs<FAST>(sd, d);
+  const double gs = pf_sum(r.g * sd, d), moved = pf_max_abs(sd, d);
   const bool ok = __builtin_isfinite(ft) && ft <= r.f + 1e-4 * gs;
   if (!ok) {
     const bool flat = __builtin_isfinite(ft) && r.ls >= 2 &&
@@ -241,7 +201,7 @@ __device__ __forceinline__ void pf_advance(WaveRun& r, double ft, double gt, int
       S[r.head * d + lane] = s;
       Y[r.head * d + lane] = y;
     }
-    const double sy = pf_sum<FAST>(s * y, d), yy = pf_sum<FAST>(y * y, d);
+    const double sy = pf_sum(s * y, d), yy = pf_sum(y * y, d);
     if (sy > 2.2e-16 * yy && yy > 0.0) {
       r.head = (r.head + 1) % LBFGS_M;
       r.hist = (r.hist + 1 < LBFGS_M) ? r.hist + 1 : LBFGS_M;
@@ -250,10 +210,10 @@ __device__ __forceinline__ void pf_advance(WaveRun& r, double ft, double gt, int
   const double f_old = r.f;
   r.x = r.xt; r.g = gt; r.f = ft;
   ++r.iter;
-  if (pf_projected_gradient_norm<FAST>(r, d) <= POLISH_PGTOL) { r.phase = 2; r.status = 0; return; }
+  if (pf_projected_gradient_norm(r, d) <= POLISH_PGTOL) { r.phase = 2; r.status = 0; return; }
   if ((f_old - ft) <= POLISH_FTOL * polish_max(polish_max(__builtin_fabs(f_old), __builtin_fabs(ft)), 1.0)) { r.phase = 2; r.status = 1; return; }
   if (r.iter >= max_iter) { r.phase = 2; r.status = 2; return; }
-  pf_new_direction<FAST>(r, d, lane, S, Y);
+  pf_new_direction(r, d, lane, S, Y);
   pf_trial_point(r);
 }
 
@@ -510,7 +470,7 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
           if (lane == 0) flag[0] = 1;
         }
       } else {
-        pf_advance<false>(run, -av, g, d, lane, Sh, Yh, a.max_iter);
+        pf_advance(run, -av, g, d, lane, Sh, Yh, a.max_iter);
         if (lane < d) xt_s[lane] = run.xt;
         if (lane < DP) xs[lane] = (lane < d) ? run.xt / ls_s[lane] : 0.0;       // (P1 and P5 of this round are behind the barrier above)
         if (lane == 0) flag[0] = (run.phase == 2 || round + 1 > round_cap) ? 1 : 0;      // (the cap cannot bind: a run is bounded by max_iter * MAXLS)
@@ -531,13 +491,176 @@ __global__ __launch_bounds__(PF_THREADS) void polish_fused_kernel(const PolishFu
   }
 }
 
+// ---- the optimiser of polish_rows_kernel: the same steps (polish_opt.h), other arithmetic and a SMALL body -------------------
+// Lane i owns variable i on wave 0, as above.  What differs: (a) a sum over the variables is a DPP butterfly inside the rows of 16
+// lanes + the rows' totals (the chain above: 3 d instructions); (b) s.y and y.y of a correction pair are kept from the step that
+// stored it — the recursion recomputes them only while some variable sits on a bound (the sums then run over the free variables);
+// (c) the CODE is kept short: the two loops of the recursion are ONE rolled loop with one reduction in its body, the new direction
+// is formed at one place.  (c) is what the time hangs on: with every loop unrolled and the routines inlined at each call site the
+// kernel was 65 KB of instructions, more than the instruction cache two CUs share — in-kernel clocks: 8-9 000 cycles per step AND
+// the evaluation beside it 14 000 instead of the 8 200 it takes alone (profiles/r06_polish_fused_ab.json, notes).
+template <int CTRL>
+__device__ __forceinline__ double pr_dpp(double v) {      // v of the lane the DPP pattern CTRL pairs this one with (inside a row of 16)
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: after the four steps every lane holds its row's total
+__device__ __forceinline__ double pr_sum(double v, int d) {      // lanes >= d carry zeros
+#pragma clang fp contract(off)
+  v += pr_dpp<0xB1>(v);
+  v += pr_dpp<0x4E>(v);
+  v += pr_dpp<0x141>(v);
+  v += pr_dpp<0x140>(v);
+  double acc = pf_lane(v, 0);
+  if (d > 16) acc += pf_lane(v, 16);
+  if (d > 32) acc = (acc + pf_lane(v, 32)) + pf_lane(v, 48);
+  return acc;
+}
+__device__ __forceinline__ double pr_max_abs(double v, int d) {  // max |v_i|, a NaN never wins (polish_opt.h)
+  double m = __builtin_fabs(v);
+  if (m != m) m = 0.0;
+  m = polish_max(m, pr_dpp<0xB1>(m));
+  m = polish_max(m, pr_dpp<0x4E>(m));
+  m = polish_max(m, pr_dpp<0x141>(m));
+  m = polish_max(m, pr_dpp<0x140>(m));
+  double acc = pf_lane(m, 0);
+  if (d > 16) acc = polish_max(acc, pf_lane(m, 16));
+  if (d > 32) acc = polish_max(polish_max(acc, pf_lane(m, 32)), pf_lane(m, 48));
+  return acc;
+}
+
+struct RowsRun {
+  double x, g, xt, dir, lo, hi;        // this lane's variable
+  bool freev;
+  double f, alpha;
+  int hist, head, iter, evals, ls, phase, status;
+};
+// LDS of the optimiser (doubles): S, Y [LBFGS_M][d] (lane i reads and writes column i) | s.y, y.y over ALL variables, rho, a
+// [LBFGS_M each] (written and read by every lane alike: program order within the one wave)
+__host__ __device__ inline int pr_opt_doubles(int d) { return 2 * LBFGS_M * d + 4 * LBFGS_M; }
+
+// one answer (ft, this lane's gradient component gt — non-finite components already 0) of the objective: polish_advance
+__device__ __forceinline__ void pr_advance(RowsRun& r, double ft, double gt, int d, int lane, double* opt, int max_iter) {
+#pragma clang fp contract(off)
+  double* S = opt;
+  double* Y = S + LBFGS_M * d;
+  double* SY = Y + LBFGS_M * d;
+  double* YY = SY + LBFGS_M;
+  double* RHO = YY + LBFGS_M;
+  double* AV = RHO + LBFGS_M;
+  const bool mine = lane < d;
+  ++r.evals;
+  bool fresh = false;      // a new direction is due
+  if (r.phase == 0) {
+    r.x = r.xt; r.g = gt; r.f = ft;
+    if (!__builtin_isfinite(ft)) { r.phase = 2; r.status = 2; return; }
+    r.phase = 1;
+    fresh = true;
+  } else {
+    const double sd = r.xt - r.x;
+    const double gs = pr_sum(r.g * sd, d), moved = pr_max_abs(sd, d);
+    const bool ok = __builtin_isfinite(ft) && ft <= r.f + 1e-4 * gs;
+    if (!ok) {
+      const bool flat = __builtin_isfinite(ft) && r.ls >= 2 &&
+                        __builtin_fabs(ft - r.f) <= POLISH_FTOL * polish_max(polish_max(__builtin_fabs(ft), __builtin_fabs(r.f)), 1.0);
+      if (moved == 0.0 || flat) { r.phase = 2; r.status = 1; return; }
+      if (++r.ls >= POLISH_MAXLS) { r.phase = 2; r.status = 3; return; }
+      double shrink = 0.1;
+      if (__builtin_isfinite(ft)) {
+        const double curv = ft - r.f - gs;
+        shrink = curv > 0.0 ? polish_min(polish_max(-gs / (2.0 * curv), 0.1), 0.5) : 0.5;
+      }
+      r.alpha *= shrink;
+    } else {
+      // accepted: the pair (s, y) joins the ring when it is usable
+      const double s = sd, y = gt - r.g;
+      const double sy = pr_sum(s * y, d), yy = pr_sum(y * y, d);
+      if (sy > 2.2e-16 * yy && yy > 0.0) {
+        if (mine) {
+          S[r.head * d + lane] = s;
+          Y[r.head * d + lane] = y;
+        }
+        SY[r.head] = sy;
+        YY[r.head] = yy;
+        r.head = (r.head + 1) % LBFGS_M;
+        r.hist = (r.hist + 1 < LBFGS_M) ? r.hist + 1 : LBFGS_M;
+      }
+      const double f_old = r.f;
+      r.x = r.xt; r.g = gt; r.f = ft;
+      ++r.iter;
+      if ((f_old - ft) <= POLISH_FTOL * polish_max(polish_max(__builtin_fabs(f_old), __builtin_fabs(ft)), 1.0)) {
+        // (the projected-gradient test comes first in polish_advance: status 0 wins where both hold)
+        r.phase = 2;
+        r.status = (pr_max_abs(polish_min(polish_max(r.x - r.g, r.lo), r.hi) - r.x, d) <= POLISH_PGTOL) ? 0 : 1;
+        return;
+      }
+      fresh = true;
+    }
+  }
+  if (fresh) {
+    if (pr_max_abs(polish_min(polish_max(r.x - r.g, r.lo), r.hi) - r.x, d) <= POLISH_PGTOL) { r.phase = 2; r.status = 0; return; }
+    if (r.iter >= max_iter && r.iter > 0) { r.phase = 2; r.status = 2; return; }
+    // ---- the new direction: two-loop recursion over the free variables (polish_new_direction)
+    r.freev = mine && !((r.x <= r.lo && r.g > 0.0) || (r.x >= r.hi && r.g < 0.0));
+    const bool allfree = __ballot(r.freev) == __ballot(mine);
+    int usable = 0, used = 0;          // bit t: the t-th newest pair takes part
+    double gamma = 1.0;
+    for (int t = 0; t < r.hist; ++t) {
+      const int k = (r.head - 1 - t + 2 * LBFGS_M) % LBFGS_M;
+      double sy = SY[k], yy = YY[k];
+      if (!allfree) {
+        const double s = mine ? S[k * d + lane] : 0.0, y = mine ? Y[k * d + lane] : 0.0;
+        sy = pr_sum(r.freev ? s * y : 0.0, d);
+        yy = pr_sum(r.freev ? y * y : 0.0, d);
+      }
+      if ((sy > 2.2e-16 * yy) && (yy > 0.0)) {
+        usable |= 1 << t;
+        RHO[k] = 1.0 / sy;
+        if (used == 0) gamma = sy / yy;
+        ++used;
+      }
+    }
+    double q = r.freev ? r.g : 0.0;
+    // j < hist: the t = j-th newest pair, q -= a_t y_t; then q *= gamma; j >= hist: back from the oldest, q += (a_t - b_t) s_t
+    for (int j = 0; j < 2 * r.hist; ++j) {
+      const bool first = j < r.hist;
+      const int t = first ? j : 2 * r.hist - 1 - j;
+      if (j == r.hist) q *= gamma;
+      if (!((usable >> t) & 1)) continue;
+      const int k = (r.head - 1 - t + 2 * LBFGS_M) % LBFGS_M;
+      const double s = mine ? S[k * d + lane] : 0.0, y = mine ? Y[k * d + lane] : 0.0;
+      const double dot = pr_sum(r.freev ? (first ? s : y) * q : 0.0, d);
+      const double c = RHO[k] * dot;
+      if (first) {
+        AV[k] = c;
+        if (r.freev) q -= c * y;
+      } else {
+        if (r.freev) q += (AV[k] - c) * s;
+      }
+    }
+    if (r.hist == 0) q *= gamma;
+    r.dir = r.freev ? -q : 0.0;
+    const double gd = pr_sum(r.dir * r.g, d), gn = pr_sum(r.freev ? r.g * r.g : 0.0, d);
+    if (!(gd < 0.0) || !__builtin_isfinite(gd)) {     // not a descent direction: steepest descent over the free variables, history dropped
+      r.hist = 0;
+      used = 0;
+      r.dir = r.freev ? -r.g : 0.0;
+    }
+    r.alpha = (used == 0) ? polish_min(1.0, 1.0 / __builtin_sqrt(polish_max(gn, 1e-300))) : 1.0;
+    r.ls = 0;
+  }
+  r.xt = polish_min(polish_max(r.x + r.alpha * r.dir, r.lo), r.hi);      // the trial point (polish_trial_point)
+}
+
 // ---- thread = training point (NP <= 128) ---------------------------------------------------------------------------------
 constexpr int PR_MAX_NP = 128;
 // LDS (doubles): W [NP][NP + 1] | xs [64] | ls [64] | alpha, k*, v [NP each] | (c1, c2) [NP][2] | (v^2, k* alpha) [NP][2] |
-// group partials [PR_MAX_GROUPS][2 DP + 2] | S, Y [LBFGS_M][d each] | X [NP][DP + 1] (when it fits) ; then the flag word
+// group partials [PR_MAX_GROUPS][2 DP + 2] | the optimiser's block (pr_opt_doubles) | X [NP][DP + 1] (when it fits) ; then the flag word
 constexpr int PR_MAX_GROUPS = 32;
 __host__ __device__ inline int pr_lds_base(int NP, int d, int DP) {
-  return NP * (NP + 1) + 128 + 7 * NP + PR_MAX_GROUPS * (2 * DP + 2) + 2 * LBFGS_M * d;
+  return NP * (NP + 1) + 128 + 7 * NP + PR_MAX_GROUPS * (2 * DP + 2) + pr_opt_doubles(d);
 }
 __host__ __device__ inline int pr_xs_stage(int NP, int d, int DP) {
   const int want = NP * (DP + 1);
@@ -561,9 +684,8 @@ __global__ __launch_bounds__(PR_MAX_NP) void polish_rows_kernel(const PolishFuse
   double* cc = vs + NP;                     // [NP][2] alpha_k f_k, u_k f_k
   double* pp = cc + 2 * NP;                 // [NP][2] v_k^2, k*_k alpha_k
   double* red = pp + 2 * NP;                // [groups][2 DP + 2]
-  double* Sh = red + PR_MAX_GROUPS * (2 * DP + 2);
-  double* Yh = Sh + LBFGS_M * d;
-  double* Xl = Yh + LBFGS_M * d;
+  double* opt = red + PR_MAX_GROUPS * (2 * DP + 2);
+  double* Xl = opt + pr_opt_doubles(d);
   const int xs_staged = pr_xs_stage(NP, d, DP);
   int* flag = (int*)(Xl + xs_staged);
   const double* __restrict__ Xs = xs_staged ? Xl : a.Xs;
@@ -580,7 +702,7 @@ __global__ __launch_bounds__(PR_MAX_NP) void polish_rows_kernel(const PolishFuse
       const int k = e / DP, t = e - k * DP;
       Xl[k * (DP + 1) + t] = a.Xs[e];
     }
-  WaveRun run{};
+  RowsRun run{};
   if (wave == 0) {
     const bool mine = lane < d;
     run.lo = mine ? a.lo[lane] : 0.0;
@@ -705,7 +827,7 @@ __global__ __launch_bounds__(PR_MAX_NP) void polish_rows_kernel(const PolishFuse
           if (lane == 0) flag[0] = 1;
         }
       } else {
-        pf_advance<true>(run, -av, g, d, lane, Sh, Yh, a.max_iter);
+        pr_advance(run, -av, g, d, lane, opt, a.max_iter);
         if (lane < DP) xs[lane] = (lane < d) ? run.xt / ls_s[lane] : 0.0;
         if (lane == 0) flag[0] = (run.phase == 2 || round + 1 > round_cap) ? 1 : 0;
       }
