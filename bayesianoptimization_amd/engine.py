@@ -237,6 +237,35 @@ class GpEngine:
             self._check(rc)
         return vals, grads
 
+    def lml_search_rounds(self, X, y_norm, kernel: int, n_ls: int, noise: float):
+        """`round(scales (n <= 8, n_ls)) -> (values (n,), gradients (n, n_ls))` for the rounds of ONE theta search: the inputs are
+        uploaded by the first round and stay resident (gpbo_lml_batch with X = y = NULL afterwards), and everything a round needs
+        around the library call — the length-scale block, the result arrays, their ctypes pointers — is made once here instead of
+        per round (a round at N <= 64 is a 41 us kernel: the ~10 us of argument handling around it showed).  The arrays returned are
+        the frame's own: valid until the next round."""
+        self._settle()
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        y_norm = np.ascontiguousarray(y_norm, dtype=np.float64).ravel()
+        N, d = int(X.shape[0]), int(X.shape[1])
+        ls = np.ones((8, n_ls))
+        vals = np.zeros(8)
+        grads = np.zeros((8, n_ls))
+        infos = (C.c_int * 8)()
+        p_ls, p_vals, p_grads = dptr(ls), dptr(vals), dptr(grads)
+        xp, yp = [dptr(X)], [dptr(y_norm)]
+        call, h, kind, nz, ck = self._lib.gpbo_lml_batch, self._h, int(kernel), float(noise), self._check
+
+        def one_round(scales):
+            n = scales.shape[0]
+            ls[:n] = scales
+            rc = call(h, n, xp[0], yp[0], N, d, kind, p_ls, n_ls, nz, 1, p_vals, p_grads, infos)
+            xp[0] = yp[0] = None              # (X, y_norm stay referenced by this closure for the search's lifetime)
+            if rc:
+                ck(rc)
+            return vals[:n], grads[:n]
+
+        return one_round
+
     def _touch(self, slot: int) -> int:
         """Every call that rewrites a slot's factorisation bumps its serial; an estimator compares the serial it got
         from its last fit with `fit_serial(slot)` to know whether the slot still holds ITS model."""

@@ -436,6 +436,8 @@ class HipGPR(GaussianProcessRegressor):
         self.theta_search_evals_ = 0       # LML + gradient evaluations over all restarts
 
         batch_arrays = getattr(eng, "lml_batch_arrays", None)      # (GpEngine; engines without it: the list form)
+        # a single device (not a group, whose lanes go to other devices through lml_batch_arrays): one call frame for the whole search
+        frame = eng.lml_search_rounds(X, y, kind, n_dims, noise) if type(eng).__name__ == "GpEngine" else None
 
         def evaluate(thetas):
             self.theta_search_rounds_ += 1
@@ -443,7 +445,11 @@ class HipGPR(GaussianProcessRegressor):
             rows = np.empty((len(thetas), 1 + n_dims))
             scales = np.exp(np.asarray(thetas, dtype=np.float64))
             for lo in range(0, len(thetas), 8):
-                if batch_arrays is not None:
+                if frame is not None:
+                    vals, grads = frame(scales[lo:lo + 8])
+                    rows[lo:lo + len(vals), 0] = vals
+                    rows[lo:lo + len(vals), 1:] = grads
+                elif batch_arrays is not None:
                     vals, grads = batch_arrays(X, y, kind, scales[lo:lo + 8], noise, True, uploaded[0])
                     rows[lo:lo + len(vals), 0] = vals
                     rows[lo:lo + len(vals), 1:] = grads

@@ -46,6 +46,7 @@ def black_box(x):
 
 def main():
     warnings.simplefilter("ignore")
+    seed = int(sys.argv[sys.argv.index("--seed") + 1]) if "--seed" in sys.argv else 1      # (1: the run profiles/ quotes)
     eng = GpEngine(0, debug="--debug" in sys.argv)      # --debug: libgpbo_dbg.so (reads the A/B switches, e.g. GPBO_LML_GRAPH=0)
     no_cpu = "--no-cpu" in sys.argv
     warm_s = None
@@ -54,13 +55,13 @@ def main():
         warm_s = warm_up(eng, np.array([[0.0, 1.0]] * D))
     pb = {f"x{j}": (0.0, 1.0) for j in range(D)}
     sp = FloatSpace(pb)
-    rng = np.random.RandomState(1)
+    rng = np.random.RandomState(seed)
     X0 = rng.uniform(size=(N0, D))
     sp.register_bulk(X0, np.array([black_box(x) for x in X0]))
     gp = HipGPR(kernel=Matern(nu=2.5), alpha=1e-6, normalize_y=True, n_restarts_optimizer=5,
-                random_state=np.random.RandomState(1), engine=eng)
+                random_state=np.random.RandomState(seed), engine=eng)
     fn = A.UpperConfidenceBound(kappa=2.576)                       # the reference's default acquisition
-    rs = np.random.RandomState(7)
+    rs = np.random.RandomState(6 + seed)
     rows, cpu_rows = [], []
     t_all = time.perf_counter()
     while len(sp) < N1:

@@ -58,7 +58,7 @@ def loop(n0, n1, profile):
 
 def main():
     warnings.simplefilter("ignore")
-    n0, n1 = 16, 144
+    n0, n1 = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (16, 144)
     ms, rounds = loop(n0, n1, None)
     print(f"unprofiled: {len(ms)} suggest() calls, N = {n0 + 1} ... {n1 - 1}: median {np.median(ms):.3f} ms, mean {np.mean(ms):.3f} ms, "
           f"theta-search rounds median {np.median(rounds):.0f}, ms per round (median of ratios) {np.median(ms / np.maximum(rounds, 1)):.4f}")
