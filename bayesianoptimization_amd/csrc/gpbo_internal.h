@@ -169,7 +169,7 @@ namespace gpbo {
 
 constexpr size_t SMALL_PIN_IN = 128 * 1024, SMALL_PIN_OUT = 32 * 1024;   // bytes: candidates in; mu, sd out (each)
 constexpr size_t SMALL_PIN_BYTES = SMALL_PIN_IN + 2 * SMALL_PIN_OUT;
-constexpr unsigned ATTR_GEMM128 = 4u, ATTR_CHOL128 = 16u, ATTR_FUSED = 32u, ATTR_MID = 64u, ATTR_KINV_GRAD = 128u, ATTR_POLISH_FUSED = 256u, ATTR_GEMM_FAT = 512u;
+constexpr unsigned ATTR_GEMM128 = 4u, ATTR_CHOL128 = 16u, ATTR_FUSED = 32u, ATTR_MID = 64u, ATTR_KINV_GRAD = 128u, ATTR_POLISH_FUSED = 256u, ATTR_GEMM_FAT = 512u, ATTR_CHOL_FUSED = 1024u;
 // fused_small.hip: the whole fit / LML evaluation of a problem of NP <= fused_max_np() as one launch of one workgroup per model
 constexpr int FUSED_NP_DEFAULT = 64, FUSED_NP_CAP = 512;
 // mid_fit.hip: fused_max_np() < NP <= mid_max_np(): the strip algorithms, ~15 launches

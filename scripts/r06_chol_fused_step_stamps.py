@@ -1,0 +1,36 @@
+"""In-kernel clocks of the one-launch step's first step (GPBO_CHOL_FUSED_STEP=1, libgpbo_dbg.so): when the diagonal workgroup
+published, when the first panel group saw it, when that group had stored and published, when the first next-diagonal tile saw the
+panel and when it had stored — microseconds since the diagonal workgroup started, on the 100 MHz wall clock all CUs share.
+
+    python scripts/r06_chol_fused_step_stamps.py >> profiles/r06_chol_fused_step_ab.json (merged by hand)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
+from oracle import gp_oracle as O  # noqa: E402
+
+eng = GpEngine(0, debug=True)
+out = {}
+for N in (1024, 4096):
+    rng = np.random.RandomState(N)
+    X = rng.uniform(size=(N, 16))
+    K = O.kernel_matrix(1, X, None, np.array([0.9]))
+    K[np.diag_indices_from(K)] += 1e-6
+    for setting in ("0", "1"):
+        os.environ["GPBO_CHOL_FUSED_STEP"] = setting
+        L, dinv, st, ms, info = eng.debug_cholesky(K, variant=3, iters=10)
+        st = np.asarray(st, dtype=np.int64)
+        rel = None
+        if setting == "1":      # 100 MHz wall clock (10 ns ticks), the same on every CU
+            rel = {k: round(float(st[i] - st[13]) * 0.01, 2) for k, i in (("diag_body_end", 14), ("diag_published", 8), ("panel_group0_saw_flag", 9),
+                                                                         ("panel_group0_stored_and_published", 10), ("next_diag_tile0_saw_panel", 11),
+                                                                         ("next_diag_tile0_stored", 12))}
+        out[f"N{N}_fused{setting}"] = {"cholesky_ms": round(ms, 4), "info": int(info), "diag_body_cycles": int(st[6] - st[0]),
+                                       "first_step_us_since_the_diagonal_workgroup_started": rel}
+os.environ.pop("GPBO_CHOL_FUSED_STEP", None)
+print(json.dumps(out, indent=1))
