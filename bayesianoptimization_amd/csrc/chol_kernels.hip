@@ -115,7 +115,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int bid = (int)blockIdx.x, tid = (int)threadIdx.x;
   if (bid == 0) {
     // (stamps 8 .. 13: the first step's hand-off times on the 100 MHz wall clock every CU shares — s_memtime counters differ between CUs)
-    if (stamps && tid == 0) stamps[13] = wall_clock64();
     diag128_body(Lz, ld, kb, nblk, dz, iz, c128_smem, stamps, tid);
     __syncthreads();
     if (tid == 0) {
@@ -162,6 +161,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (stamps && tid == 0 && grp == 0) stamps[9] = wall_clock64();
     chol128_panel_body(Lz, ld, kb, dz, grp, c128_smem + half * C128_PANEL_LDS_DOUBLES, t256);
     __syncthreads();
+    if (stamps && tid == 0 && grp == 0) stamps[13] = wall_clock64();
     if (t256 == 0 && grp < nt_next) cf_publish(flags + 1);
     if (stamps && tid == 0 && grp == 0) stamps[10] = wall_clock64();
     return;

@@ -27,10 +27,10 @@ for N in (1024, 4096):
         st = np.asarray(st, dtype=np.int64)
         rel = None
         if setting == "1":      # 100 MHz wall clock (10 ns ticks), the same on every CU
-            rel = {k: round(float(st[i] - st[13]) * 0.01, 2) for k, i in (("diag_body_end", 14), ("diag_published", 8), ("panel_group0_saw_flag", 9),
-                                                                         ("panel_group0_stored_and_published", 10), ("next_diag_tile0_saw_panel", 11),
+            rel = {k: round(float(st[i] - st[14]) * 0.01, 2) for k, i in (("diag_body_end", 14), ("diag_published", 8), ("panel_group0_saw_flag", 9),
+                                                                         ("panel_group0_body_done", 13), ("panel_group0_stored_and_published", 10), ("next_diag_tile0_saw_panel", 11),
                                                                          ("next_diag_tile0_stored", 12))}
         out[f"N{N}_fused{setting}"] = {"cholesky_ms": round(ms, 4), "info": int(info), "diag_body_cycles": int(st[6] - st[0]),
-                                       "first_step_us_since_the_diagonal_workgroup_started": rel}
+                                       "first_step_us_after_the_diagonal_body_ended": rel}
 os.environ.pop("GPBO_CHOL_FUSED_STEP", None)
 print(json.dumps(out, indent=1))
