@@ -52,9 +52,8 @@ struct AcqDev {
   const double* sd[GPBO_MAX_MODELS];
 };
 
-__global__ __launch_bounds__(256) void acq_kernel(AcqDev a, int64_t M, double* __restrict__ ys) {
-  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (m >= M) return;
+// -1 * base_acq(mean, std) [* p_constraints] of candidate m (acquisition.py:198-217), from the models' resident mu / sd
+__device__ __forceinline__ double acq_value(const AcqDev& a, const int64_t m) {
   const double mean = a.mu[0][m], sd = a.sd[0][m];
   double base;
   if (a.acq == GPBO_ACQ_UCB) {
@@ -77,7 +76,13 @@ __global__ __launch_bounds__(256) void acq_kernel(AcqDev a, int64_t M, double* _
     }
     v = v * p;
   }
-  ys[m] = v;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void acq_kernel(AcqDev a, int64_t M, double* __restrict__ ys) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  ys[m] = acq_value(a, m);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -304,20 +309,32 @@ __device__ void sel2_emit(int n_listed, int k, const double* __restrict__ ys, Ke
   }
 }
 
-__global__ __launch_bounds__(SEL_BLOCK) void select_block_topk_v2_kernel(const double* __restrict__ ys, int64_t M, int k, int cap,
+// ITEMS values per thread: 16 for the big batches (a chip's worth of workgroups at M = 2^20), 4 up to M = 2^18, where 16 left the
+// block stage to 16 workgroups at BASELINE config 2 (M = 65 536: 24.6 us; round 6).  ACQ: the values are not read but MADE here —
+// acq_value over the resident mu / sd, written to ys on the way (the separate acq_kernel launch and its pass over ys go away).
+// A grid of ONE workgroup (M <= 256 ITEMS: BASELINE config 1) is its own merge: the picks and the state go straight to `picks` / `st`.
+template <int ITEMS, bool ACQ>
+__global__ __launch_bounds__(SEL_BLOCK) void select_block_topk_v2_kernel(double* __restrict__ ys, int64_t M, int k, int cap,
                                                                          Key* __restrict__ partial,
-                                                                         int64_t* __restrict__ nan_partial) {
+                                                                         int64_t* __restrict__ nan_partial, AcqDev acq, SelState* st,
+                                                                         Key* __restrict__ picks) {
   __shared__ Sel2Shared sh;
   __shared__ Key shk[SEL_BLOCK / 64];
   __shared__ int64_t shn[SEL_BLOCK / 64];
-  const int64_t base = (int64_t)blockIdx.x * (SEL_BLOCK * SEL_ITEMS) + threadIdx.x;
-  double v[SEL_ITEMS];
+  const int64_t base = (int64_t)blockIdx.x * (SEL_BLOCK * ITEMS) + threadIdx.x;
+  const bool single = gridDim.x == 1;
+  double v[ITEMS];
   int64_t fn = INT64_MAX;
   IKey mine = ikey_sentinel();
 #pragma unroll
-  for (int it = 0; it < SEL_ITEMS; ++it) {
+  for (int it = 0; it < ITEMS; ++it) {
     const int64_t m = base + (int64_t)it * SEL_BLOCK;
-    v[it] = (m < M) ? ys[m] : 0.0;
+    if (ACQ) {
+      v[it] = (m < M) ? acq_value(acq, m) : 0.0;
+      if (m < M) ys[m] = v[it];
+    } else {
+      v[it] = (m < M) ? ys[m] : 0.0;
+    }
     if (m < M) {
       if (v[it] != v[it] && m < fn) fn = m;
       IKey c;
@@ -328,16 +345,16 @@ __global__ __launch_bounds__(SEL_BLOCK) void select_block_topk_v2_kernel(const d
   }
   const IKey tau = sel2_threshold(mine, k, sh);
 #pragma unroll
-  for (int it = 0; it < SEL_ITEMS; ++it) {
+  for (int it = 0; it < ITEMS; ++it) {
     const int64_t m = base + (int64_t)it * SEL_BLOCK;
     IKey c;
     c.kv = order_bits(v[it]);
     c.i = (m < M) ? m : INT64_MAX;
     sel2_list(c, tau, cap, sh);
   }
-  __syncthreads();
+  __syncthreads();      // (ACQ: this workgroup's stores to ys are also behind it — sel2_emit reads the listed values back)
   const int n_listed = sh.count;
-  Key* out = partial + (int64_t)blockIdx.x * k;
+  Key* out = single ? picks : partial + (int64_t)blockIdx.x * k;
   if (n_listed <= cap) {
     sel2_emit(n_listed, k, ys, out, sh);
   } else {
@@ -349,7 +366,7 @@ __global__ __launch_bounds__(SEL_BLOCK) void select_block_topk_v2_kernel(const d
       best.v = std::numeric_limits<double>::quiet_NaN();
       best.i = INT64_MAX;
 #pragma unroll
-      for (int it = 0; it < SEL_ITEMS; ++it) {
+      for (int it = 0; it < ITEMS; ++it) {
         Key c;
         c.v = v[it];
         c.i = base + (int64_t)it * SEL_BLOCK;
@@ -370,7 +387,13 @@ __global__ __launch_bounds__(SEL_BLOCK) void select_block_topk_v2_kernel(const d
   if (threadIdx.x == 0) {
     int64_t f = shn[0];
     for (int w = 1; w < SEL_BLOCK / 64; ++w) f = shn[w] < f ? shn[w] : f;
-    nan_partial[blockIdx.x] = f;
+    if (single) {      // (the __syncthreads above also orders this workgroup's picks[] stores before the read below)
+      st->first_nan = f;
+      __threadfence();
+      st->prev = picks[k - 1];
+    } else {
+      nan_partial[blockIdx.x] = f;
+    }
   }
 }
 
@@ -438,9 +461,12 @@ static bool select_v2_enabled() {
 }
 
 // the two selection launches over ctx->ys[0..M): SelState and picks[npass] at the head of ctx->red
-static int enqueue_select(gpbo_ctx* ctx, int64_t M, int npass, bool v2, SelState** st_out, Key** picks_out) {
+// `acq` (v2 only): the values are made by the block stage itself from the models' mu / sd (and stored to ctx->ys)
+static int enqueue_select(gpbo_ctx* ctx, int64_t M, int npass, bool v2, SelState** st_out, Key** picks_out, const AcqDev* acq = nullptr) {
   int rc;
-  const int nblocks = (int)((M + SEL_BLOCK * SEL_ITEMS - 1) / (SEL_BLOCK * SEL_ITEMS));
+  const char* ie = dbg_env("GPBO_SELECT_ITEMS");      // debug build: 16 = rounds 2-5 (A/B)
+  const int items = v2 ? ((ie && atoi(ie) == 16) ? 16 : (M <= ((int64_t)1 << 18) ? 4 : 16)) : SEL_ITEMS;
+  const int nblocks = (int)((M + SEL_BLOCK * items - 1) / (SEL_BLOCK * items));
   // scratch layout: SelState | picks[npass] | partial[nblocks][npass] | nan_partial[nblocks]
   const int64_t bytes = sizeof(SelState) + sizeof(Key) * (npass + (int64_t)nblocks * npass) + sizeof(int64_t) * nblocks + 64;
   {
@@ -457,8 +483,14 @@ static int enqueue_select(gpbo_ctx* ctx, int64_t M, int npass, bool v2, SelState
   int64_t* nan_partial = (int64_t*)(partial + (int64_t)nblocks * npass);
   if (v2) {
     const int cap = select_v2_cap();
-    select_block_topk_v2_kernel<<<dim3((unsigned)nblocks), dim3(SEL_BLOCK), 0, ctx->stream>>>(ctx->ys, M, npass, cap, partial, nan_partial);
-    select_merge_topk_v2_kernel<<<dim3(1), dim3(SEL_BLOCK), 0, ctx->stream>>>(ctx->ys, partial, nan_partial, nblocks, npass, cap, st, picks);
+    const AcqDev none{};
+    const dim3 grid((unsigned)nblocks), block(SEL_BLOCK);
+    if (items == 4 && acq) select_block_topk_v2_kernel<4, true><<<grid, block, 0, ctx->stream>>>(ctx->ys, M, npass, cap, partial, nan_partial, *acq, st, picks);
+    else if (items == 4) select_block_topk_v2_kernel<4, false><<<grid, block, 0, ctx->stream>>>(ctx->ys, M, npass, cap, partial, nan_partial, none, st, picks);
+    else if (acq) select_block_topk_v2_kernel<16, true><<<grid, block, 0, ctx->stream>>>(ctx->ys, M, npass, cap, partial, nan_partial, *acq, st, picks);
+    else select_block_topk_v2_kernel<16, false><<<grid, block, 0, ctx->stream>>>(ctx->ys, M, npass, cap, partial, nan_partial, none, st, picks);
+    if (nblocks > 1)
+      select_merge_topk_v2_kernel<<<dim3(1), dim3(SEL_BLOCK), 0, ctx->stream>>>(ctx->ys, partial, nan_partial, nblocks, npass, cap, st, picks);
   } else {
     select_block_topk_kernel<<<dim3((unsigned)nblocks), dim3(SEL_BLOCK), 0, ctx->stream>>>(ctx->ys, M, npass, partial, nan_partial);
     select_merge_topk_kernel<<<dim3(1), dim3(SEL_BLOCK), 0, ctx->stream>>>(partial, nan_partial, nblocks, npass, st, picks);
@@ -477,10 +509,15 @@ static int enqueue_acq_select(gpbo_ctx* ctx, const AcqArgs& a, int64_t M, int k_
   AcqDev d;
   d.acq = a.acq; d.param = a.param; d.y_max = a.y_max; d.n_constraints = a.n_constraints;
   for (int j = 0; j < GPBO_MAX_MODELS; ++j) { d.lb[j] = a.lb[j]; d.ub[j] = a.ub[j]; d.mu[j] = a.mu[j]; d.sd[j] = a.sd[j]; }
-  acq_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream>>>(d, M, ctx->ys);
-  GPBO_HIP(ctx, hipGetLastError());
   // one or two picks: the passes are the shorter chain (k = 1: 11 us against 16, profiles/r03_select_probe.json)
-  if ((rc = enqueue_select(ctx, M, npass, select_v2_enabled() && npass >= 3, st_out, picks_out))) return rc;
+  const bool v2 = select_v2_enabled() && npass >= 3;
+  const char* fe = dbg_env("GPBO_SELECT_FUSED_ACQ");      // debug build: 0 = the separate acq_kernel launch of rounds 1-5 (A/B)
+  const bool fused_acq = v2 && !(fe && fe[0] == '0');
+  if (!fused_acq) {
+    acq_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream>>>(d, M, ctx->ys);
+    GPBO_HIP(ctx, hipGetLastError());
+  }
+  if ((rc = enqueue_select(ctx, M, npass, v2, st_out, picks_out, fused_acq ? &d : nullptr))) return rc;
   *npass_out = npass;
   return GPBO_OK;
 }
