@@ -29,17 +29,17 @@ ARCH = "gfx950"
 SOURCES = {
     "gpbo_api.hip": [],
     "fit_kernels.hip": [],
-    "chol_kernels.hip": os.environ.get("GPBO_CHOL_EXTRA_FLAGS", "").split(),   # probe builds (scripts/r03_*): -D switches
+    "chol_kernels.hip": os.environ.get("GPBO_CHOL_EXTRA_FLAGS", "").split(),   # probe builds (scripts/archive/r03_*): -D switches
     "posterior_kernel.hip": [],
     "posterior_kernel_v2.hip": [],
     "posterior_small.hip": [],
     "polish.hip": [],                          # gpbo_polish_seeds: the local-search stage as one C call (host optimiser, device evaluations)
-    "polish_fused.hip": [],                    # ... and as one launch for NP <= 768: one workgroup per local search, evaluations + optimiser inside
+    "polish_fused.hip": [],                    # ... and as one launch for NP <= 256: one workgroup per local search (NP <= 128: thread = training point), evaluations + optimiser inside
     "posterior_kernel_f32.hip": [],
     "posterior_cov.hip": [],
     "lml_kernels.hip": [],
     "fused_small.hip": [],                     # fit / LML evaluation of a small problem (NP <= 64) as ONE launch of ONE workgroup
-    "mid_fit.hip": [],                         # 64 < NP <= 512: inputs, quarter-tile K, W = L^-1 by column strips, alpha (~15 launches per fit)
+    "mid_fit.hip": [],                         # 64 < NP <= 768: inputs, quarter-tile K, W = L^-1 by column strips, alpha (~15 launches per fit)
     "acq_kernels.hip": ["-ffp-contract=off"],  # elementwise formulas follow NumPy op by op
     "candidates.hip": [],
     "mt19937.hip": ["-ffp-contract=off"],      # lo + (hi - lo) * u as NumPy computes it
@@ -68,7 +68,17 @@ def _code_only(src: str) -> str:
     out, i, n = [], 0, len(src)
     while i < n:
         c = src[i]
-        if c in "\"'":                                   # a literal: copy it whole (escapes included)
+        if c == "'" and i > 0 and (src[i - 1].isalnum() or src[i - 1] == "_") and i + 1 < n and src[i + 1].isalnum():
+            out.append(c)                                 # a C++14 digit separator (1'000), not the start of a character literal
+            i += 1
+        elif c == '"' and i > 0 and src[i - 1] == "R":    # a raw string literal R"delim( ... )delim": copied whole, nothing inside is a comment
+            k = src.find("(", i)
+            delim = src[i + 1:k] if k >= 0 else ""
+            end = src.find(")" + delim + '"', k) if k >= 0 else -1
+            j = n if end < 0 else end + len(delim) + 2
+            out.append(src[i:j])
+            i = j
+        elif c in "\"'":                                 # a literal: copy it whole (escapes included)
             j = i + 1
             while j < n and src[j] != c:
                 j += 2 if src[j] == "\\" else 1

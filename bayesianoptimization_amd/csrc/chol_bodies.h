@@ -48,7 +48,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // C0 + c (the rows of the wave's diagonal 8x8 block sit in lanes 0..7): v_readlane_b32 into FIXED scalar registers,
 // consumed by the v_fma_f64 directly.  Written out because the compiler's version of the same thing hoists every
 // v_readlane of a column to the front, runs out of SGPRs (the GEMM half of the step kernel keeps ~60 live) and spills
-// them with v_writelane_b32 at 28 cycles apiece (scripts/r03_col_stamps.py: 2/3 of a column's time), and because a
+// them with v_writelane_b32 at 28 cycles apiece (scripts/archive/r03_col_stamps.py: 2/3 of a column's time), and because a
 // v_readlane whose lane number comes from an SGPR instead of an inline constant is no faster.  The readlane -> fma
 // distance satisfies the 2 wait states a VALU-written SGPR needs before a VALU reads it.
 #define GPBO_RL(S, C) "v_readlane_b32 s" #S ", %[lo], %[" #C "]\n\tv_readlane_b32 s" GPBO_RL_NEXT_##S ", %[hi], %[" #C "]\n\t"
@@ -135,7 +135,7 @@ __device__ __forceinline__ void bcast_fma_from(double* a, double* a2, const doub
   }
 }
 
-// What one step costs (scripts/r03_latency_probe.py, one wave on its SIMD): every plain VALU instruction — v_fma_f64
+// What one step costs (scripts/archive/r03_latency_probe.py, one wave on its SIMD): every plain VALU instruction — v_fma_f64
 // dependent or not, v_readlane_b32, v_mov — occupies the wave for 4 cycles, v_rsq_f64 16, a v_writelane_b32 (what an
 // SGPR spill turns into) 28, a ds_write2_b64 ~18; an LDS write -> read round trip is ~90 cycles and a broadcast
 // ds_read_b128 holds the LDS pipeline ~8 cycles.  The chain of one column (2 v_readlane of the pivot, v_rsq_f64, two
@@ -172,7 +172,7 @@ __device__ __forceinline__ void factor_block8(double (&a)[8], double (&a2)[8], d
     // k + 1).  LDS time is what the waves compete for — a waiting wave that keeps re-reading slows the chain wave's
     // stores — so a waiting wave reads ONE word, the marker, and sleeps until the owner's s_wakeup (sent behind every
     // second column) or the sleep's own end; the data is read once, after the marker.
-    // Measured and dropped (scripts/r03_col_stamps.py, 64 columns + riding rows = 19 000 cycles with this loop): the next
+    // Measured and dropped (scripts/archive/r03_col_stamps.py, 64 columns + riding rows = 19 000 cycles with this loop): the next
     // turn's reads issued before this turn's arithmetic (two register sets) 22 500; one column per turn 22 000; the
     // multipliers by v_readlane from the rows just read (a third of the LDS traffic, twice the VALU work) 22 800 — every
     // variant that makes the waiting waves faster makes the owner slower, through LDS time or through the SIMD the

@@ -227,7 +227,7 @@ static int lookahead_min_np() {
     const char* e = dbg_env("GPBO_CHOL_LA");
     if (e && e[0] == '0') return 1 << 30;
     const char* f = dbg_env("GPBO_CHOL_LA_MIN_NP");
-    return f ? atoi(f) : 4096;     // measured (scripts/r03_la_probe.py): 2048 0.709 -> 0.721 ms, 4096 1.82 -> 1.75, 8192 6.42 -> 6.17
+    return f ? atoi(f) : 4096;     // measured (scripts/archive/r03_la_probe.py): 2048 0.709 -> 0.721 ms, 4096 1.82 -> 1.75, 8192 6.42 -> 6.17
   }();
   return v;
 }

@@ -50,7 +50,7 @@ int launch_prescale(gpbo_ctx* ctx, const double* X, int64_t n, int d, int DP, co
 // measured) — at d = 32 the arithmetic alone caps the store rate at 2.9 TB/s = 0.46 of a copy's 6.29.  Round 3 measured a
 // row-walking variant (lane = column with its point in registers, the row's coordinates as SGPR operands through
 // s_load_dwordx16, one full 512-byte row segment per store, no LDS): the same bits, 44 / 158 us — no faster, 2x slower
-// at N <= 1024 (each row is a fresh scalar-cache miss) — and dropped it (scripts/r03_kmat_probe.py, profiles/r03_kmat_probe.json).
+// at N <= 1024 (each row is a fresh scalar-cache miss) — and dropped it (scripts/archive/r03_kmat_probe.py, profiles/r03_kmat_probe.json).
 template <int KERNEL>
 __global__ __launch_bounds__(256) void kmat_kernel(const double* __restrict__ Xs, int DP, int64_t N,
                                                    int64_t NP, double noise, double* __restrict__ K,
@@ -358,7 +358,7 @@ int launch_gemm(gpbo_ctx* ctx, const GemmArgs& g_in) {
   if (g.a_trans && g.b_trans) GPBO_FAIL(ctx, GPBO_ERR_INVALID, "gemm: a_trans with b_trans is not instantiated");
   // big products -> the 128x128 double-buffered kernel; panels and small blocks -> the 64x64 kernel
   // (a triangular k-range must start/stop on a 128 boundary there, which the callers' block sizes guarantee from 128 on)
-  // Measured (scripts/r02_fit_probe.py, MI355X): 4096^3 60 vs 50 TFLOP/s, rank-512 SYRK at 3584 / 7680 rows 44 / 47 vs 38 / 41 —
+  // Measured (scripts/archive/r02_fit_probe.py, MI355X): 4096^3 60 vs 50 TFLOP/s, rank-512 SYRK at 3584 / 7680 rows 44 / 47 vs 38 / 41 —
   // but the 64x64 kernel wins where there are too few 128-blocks to fill 256 CUs (1024^3: 15 vs 28) and on rank-64 panel
   // updates (8 vs 15), so: deep k and at least ~a chip's worth of 128x128 blocks.
   const int64_t blocks128 = (int64_t)((g.m + 127) / 128) * ((g.n + 127) / 128) * g.batch * g.lanes / (g.lower_only ? 2 : 1);

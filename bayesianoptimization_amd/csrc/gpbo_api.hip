@@ -17,7 +17,7 @@ static std::shared_mutex g_capture_mu;
 #ifndef GPBO_CAPTURE_MODE
 #define GPBO_CAPTURE_MODE hipStreamCaptureModeThreadLocal
 #endif
-#ifdef GPBO_CAPTURE_NOLOCK           // experiment builds (scripts/r04_capture_stress.sh)
+#ifdef GPBO_CAPTURE_NOLOCK           // experiment builds (scripts/archive/r04_capture_stress.sh)
 #define CAPTURE_LOCK
 #else
 #define CAPTURE_LOCK std::unique_lock<std::shared_mutex> capture_lock(g_capture_mu)
@@ -80,7 +80,7 @@ static int alloc_model(gpbo_ctx* ctx, Model& m, int64_t NP, int DP) {
 // matrix is read and written N / outer times instead of N / 128 times.  (Round 2's 64-column schedules — potrf_diag_kernel /
 // chol_step_kernel — were retired in round 4.)
 static int chol_outer_width(int64_t NP) {
-  // Outer panel width by size (scripts/r03_chol_probe.py, round-3 schedule): up to NP = 2048 one panel — the rank-128
+  // Outer panel width by size (scripts/archive/r03_chol_probe.py, round-3 schedule): up to NP = 2048 one panel — the rank-128
   // updates of the steps reach the whole trailing matrix, whose traffic is still small, and no latency-bound
   // rank-`outer` GEMM stands between the steps (NP = 1024: 0.312 -> 0.283 ms, 2048: 0.683 -> 0.618); 1024 up to NP = 4096
   // (1.70 -> 1.66-1.68); 512 beyond (8192: 6.0 against 6.36 with 1024), where the trailing matrix no longer fits the
@@ -753,7 +753,7 @@ int lml_upload_inputs(gpbo_ctx* ctx, const double* X, const double* y_norm, int6
 #endif
   if ((rc = ensure(ctx, &ctx->lml_X, &ctx->cap_lml_X, N * d))) return rc;
   if ((rc = ensure(ctx, &ctx->lml_y, &ctx->cap_lml_y, N))) return rc;
-#ifdef GPBO_LML_SYNC_UPLOAD          // experiment builds (scripts/r04_capture_stress.sh): the legacy-stream copies of rounds 2-3
+#ifdef GPBO_LML_SYNC_UPLOAD          // experiment builds (scripts/archive/r04_capture_stress.sh): the legacy-stream copies of rounds 2-3
   GPBO_HIP(ctx, hipMemcpy(ctx->lml_X, X, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice));
   GPBO_HIP(ctx, hipMemcpy(ctx->lml_y, y_norm, (size_t)N * sizeof(double), hipMemcpyHostToDevice));
 #else

@@ -19,7 +19,7 @@
 // subspace minimisation.  It keeps L-BFGS-B's stopping rule as SciPy configures it for `minimize` (m = 10 corrections,
 // projected-gradient tolerance 1e-5, relative reduction 1e7 * eps, 20 line-search steps, 15000 iterations), and its
 // iterates are always inside the box.  Parity is statistical: the acquisition value at the returned
-// point is compared with the reference's (tests/test_gpu_seams.py, scripts/r03_polish_modes.py), not the path.
+// point is compared with the reference's (tests/test_gpu_seams.py, scripts/archive/r03_polish_modes.py), not the path.
 #include <algorithm>
 #include <cmath>
 #include <limits>

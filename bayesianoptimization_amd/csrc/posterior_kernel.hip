@@ -127,7 +127,7 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
   // beside them, and the slab GEMM's loop carries no other VALU work (posterior_kernel_v2.hip).  For 384 <= NP <= 512 and a
   // batch that fills the chip, v4 (round 4): ONE 16-wave workgroup covers all rows, so k* is generated once and never
   // crosses HBM (the slab route: a 268 MB round trip and a second launch at C2).  Measured at M = 65 536 (scripts/
-  // r04_post_small_np_ab.py, profiles/r04_post_small_np_ab.json; round 2: scripts/r02_small_n_posterior_ab.py):
+  // r04_post_small_np_ab.py, profiles/r04_post_small_np_ab.json; round 2: scripts/archive/r02_small_n_posterior_ab.py):
   //   NP = 512, d = 8 : v2 0.406  v3 0.374  v4 0.352 ms (0.58 / 0.62 / 0.66 of the fp64 matrix peak)      -> v4
   //   NP = 448, d = 8 : v2 0.357  v3 0.332  v4 0.327                                                      -> v4
   //   NP = 1024, d = 16: v2 1.48   v3 1.19   v4 1.31 (two 512-row chunks: k* generated 1.5 times)          -> v3

@@ -127,7 +127,7 @@ class HipGPR(GaussianProcessRegressor):
         self.slot = slot
         # theta search: evaluate log_marginal_likelihood(theta, eval_gradient=True) on the GPU (True), with sklearn's host
         # code (False), or "auto" = on the GPU whenever the kernel is one the device evaluates.  Until round 4 "auto" meant
-        # N >= 512, a threshold no measurement backed; scripts/r04_lml_crossover.py (profiles/r04_lml_crossover.json, MI355X
+        # N >= 512, a threshold no measurement backed; scripts/archive/r04_lml_crossover.py (profiles/r04_lml_crossover.json, MI355X
         # + 256 host threads) finds no crossover to speak of: one value + gradient on the device costs 0.13 ms at N = 16 ..
         # 64 (host: 0.10 / 0.13 / 0.19 ms), 0.16 vs 0.44 at N = 128, 0.35 vs 10 at N = 512, and the whole default fit (5
         # restarts, lockstep lanes) is faster on the device at EVERY size: 1.0 vs 2.0 ms at N = 16, 3.2 vs 96 at N = 128,

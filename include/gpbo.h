@@ -241,8 +241,12 @@ int gpbo_predict_grad(gpbo_ctx* ctx, int slot, const double* Xc, int64_t M, int 
  * y_mean / y_std: (1 + n_constraints,) the targets' normalisation per slot; seeds (n_seeds,d), clipped into the box;
  * box_lo < box_hi (d,).  Outputs per seed: x_out (n_seeds,d) inside the box, f_out, status_out (0: projected gradient
  * below tolerance, 1: relative reduction below tolerance / no further progress, 2: iteration limit or a non-finite start —
- * SciPy's success = False), n_rounds_out (optional) = batched evaluations issued; n_iter_out / n_eval_out (optional, per seed) =
- * accepted steps / objective evaluations, SciPy's nit / nfev.  Like gpbo_predict, the call uses the context's candidate
+ * SciPy's success = False), n_rounds_out (optional) = batched evaluations issued by the lockstep path, or — one model of
+ * NP <= 256, where the whole stage is ONE launch (a workgroup per run) — the longest run's evaluation count; n_iter_out /
+ * n_eval_out (optional, per seed) = accepted steps / objective evaluations, SciPy's nit / nfev.  The one-launch form returns when
+ * its longest run has stopped: the calling thread and the context's stream are held for that long (a run is bounded by
+ * 4 * max_iter + 64 evaluations of 4-40 us each; with the default max_iter = 15 000 a pathological run is ~1 s) — callers that
+ * need a tighter bound pass a smaller max_iter (status 2 marks the runs it cut).  Like gpbo_predict, the call uses the context's candidate
  * buffer for its trial points: the resident candidate set is gone afterwards (fetch x_min / the seeds with
  * gpbo_get_candidate_rows first, as the reference reads x_tries before it starts its local searches, acquisition.py:313-317). */
 int gpbo_polish_seeds(gpbo_ctx* ctx, int acq, double acq_param, double y_max, int n_constraints, const double* lb,

@@ -40,7 +40,7 @@ timeout 200 python scripts/theta_search_timing.py > $F/theta_search_timing.log 2
 timeout 300 python scripts/r05_small_fit_timing.py > $F/small_fit_timing.json 2> $F/small_fit_timing.err
 timeout 400 python scripts/r05_maximize_loop.py > $F/maximize_loop.json 2> $F/maximize_loop.err; tail -2 $F/maximize_loop.err
 timeout 300 python scripts/r05_tri_grid_ab.py > $F/tri_grid_ab.json 2> $F/tri_grid_ab.err; tail -2 $F/tri_grid_ab.err
-timeout 100 python scripts/r04_chol_chain.py 128 512 2048 4096 > $F/chol_chain.log 2>&1; cp gpurun_out/r04_chol_chain.json $F/ 2>/dev/null
+timeout 100 python scripts/archive/r04_chol_chain.py 128 512 2048 4096 > $F/chol_chain.log 2>&1; cp gpurun_out/r04_chol_chain.json $F/ 2>/dev/null
 timeout 200 python scripts/r05_polish_fused_ab.py > $F/polish_fused_ab.json 2> $F/polish_fused_ab.err; tail -1 $F/polish_fused_ab.err | cut -c1-200
 timeout 200 python scripts/r05_suggest_host_profile.py > $F/suggest_host_profile.txt 2>&1; head -2 $F/suggest_host_profile.txt
 cp gpurun_out/r04_polish_sweep.json $F/polish_sweep.json 2>/dev/null

@@ -185,6 +185,13 @@ def test_the_build_fingerprint_names_the_code_not_its_comments(tmp_path, monkeyp
     assert build._code_only(src.replace("// one", "// another comment").replace("two", "2")) == code
     assert build._code_only(src.replace("a = 1", "a = 2")) != code
     assert build._code_only(src.replace("// kept", "// Kept")) != code           # inside a string literal: code
+    # digit separators, raw strings and character literals are code too: nothing behind them is swallowed
+    tricky = 'int n = 1\'000\'000; // sep\nconst char* r = R"x(// not a comment */ ")x"; /* gone */ char q = \'"\'; int z = 2; // tail\n'
+    got = build._code_only(tricky)
+    assert "1'000'000;" in got and "sep" not in got and "gone" not in got and "tail" not in got
+    assert 'R"x(// not a comment */ ")x";' in got and "char q = '\"';" in got and "int z = 2;" in got
+    assert build._code_only(tricky.replace("// sep", "// another")) == got
+    assert build._code_only(tricky.replace("int z = 2", "int z = 3")) != got
     csrc = tmp_path / "csrc"
     csrc.mkdir()
     (csrc / "k.hip").write_text("__global__ void k() {}  // v1\n")

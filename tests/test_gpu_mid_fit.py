@@ -1,4 +1,4 @@
-"""The strip path of mid-size fits / LML evaluations (csrc/mid_fit.hip: 128 < NP <= 512 in the product, up to 1024 by switch)
+"""The strip path of mid-size fits / LML evaluations (csrc/mid_fit.hip: 64 < NP <= 768 in the product, up to 1024 by switch)
 against the multi-launch sequence it replaces and against the oracle.
 
 What must be BITWISE the multi-launch path: K (kmat_q_kernel is kmat_kernel's arithmetic element for element) and L with its pivot

@@ -452,7 +452,7 @@ def test_graph_capture_on_one_rank_while_the_others_upload(engine):
     hipGraph the second time a shape comes by, and a synchronous legacy-stream hipMemcpy on ANOTHER thread (a neighbour rank still
     uploading the theta-search inputs) invalidated that capture — 34 of 200 iterations with the round-3 upload.  Now the upload
     runs on the context's own stream and captures are taken under a process-wide lock; this is the sharp loop of
-    scripts/r04_capture_stress.py, shortened: switch the kernel (cached graphs no longer fit), evaluate directly, evaluate again
+    scripts/archive/r04_capture_stress.py, shortened: switch the kernel (cached graphs no longer fit), evaluate directly, evaluate again
     WITH the inputs handed over (upload + capture on three threads at once), replay — every lane bitwise the first answer."""
     rng = np.random.RandomState(5)
     X = rng.uniform(size=(2100, 16))
