@@ -452,6 +452,7 @@ static int prepare_model(gpbo_ctx* ctx, Model& m, const char* who, bool have_inp
 
   m.fitted = false;
   m.wp_packed = false;     // (set by the small fit paths at enqueue time; a failure before finish_enqueue must not leave it behind)
+  m.wt_valid = false;      // (K no longer holds the transpose of this slot's W)
   m.M_post = -1;
   const int64_t NP = round_up(N, NB);
   const int DP = pad_dim(d);
@@ -616,6 +617,7 @@ int gpbo_fit_append(gpbo_ctx* ctx, int slot, const double* x_new, int64_t n_new,
   GPBO_HIP(ctx, hipSetDevice(ctx->device));
   m.fitted = false;
   m.wp_packed = false;
+  m.wt_valid = false;
   m.M_post = -1;
   const int64_t N0 = m.N;
   const int64_t NP_new = round_up(n_total, NB);
@@ -973,6 +975,7 @@ int gpbo_get_K(gpbo_ctx* ctx, int slot, double* out) {
   // the fit assembles K directly into the buffer it factorises; the parity accessor re-assembles it from the
   // device-resident scaled inputs (same kernel, same bits)
   Model& m = ctx->models[slot];
+  m.wt_valid = false;
   if ((rc = use_mid(m) ? launch_kmat_q(ctx, m, m.noise, m.K) : launch_kmat(ctx, m, m.noise, m.K))) return rc;   // the fit's own kernel
   return copy_square(ctx, m, m.K, out, 0);
 }
@@ -1157,6 +1160,7 @@ int gpbo_debug_cholesky(gpbo_ctx* ctx, const double* A, int64_t n, int variant, 
   if (hipMalloc((void**)&stamps_dev, 16 * sizeof(long long)) != hipSuccess) return done(GPBO_ERR_HIP);
   (void)hipMemset(stamps_dev, 0, 16 * sizeof(long long));
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  m.wt_valid = false;
   if (hipMemcpy(m.K, A, sq, hipMemcpyHostToDevice) != hipSuccess) return done(GPBO_ERR_HIP);
   double best = 1e30;
   for (int it = 0; it < iters && !rc; ++it) {

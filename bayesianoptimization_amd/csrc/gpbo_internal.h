@@ -26,6 +26,7 @@ enum TimingSlot {
 struct Model {
   bool fitted = false;
   bool wp_packed = false;  // the fused small-problem fit has already written Wp (finish_enqueue skips pack_w_kernel)
+  bool wt_valid = false;   // K holds W^T for the slot's current fit (polish_fused.hip: the row walk of the local searches with W in memory)
   int64_t N = 0, NP = 0;   // observations, padded to a multiple of NB
   int d = 0, DP = 0;       // input dimension, padded to {4,8,16,32,64}
   int kernel = 0;
@@ -175,7 +176,7 @@ constexpr int FUSED_NP_DEFAULT = 64, FUSED_NP_CAP = 512;
 // mid_fit.hip: fused_max_np() < NP <= mid_max_np(): the strip algorithms, ~15 launches
 constexpr int MID_NP_DEFAULT = 768, MID_NP_CAP = 1024;
 // the local searches of gpbo_polish_seeds as one launch (polish_fused.hip): up to this padded size, one model
-constexpr int POLISH_FUSED_NP_DEFAULT = 256, POLISH_FUSED_NP_CAP = 768;
+constexpr int POLISH_FUSED_NP_DEFAULT = 384;
 // pinned staging of a small host-side fit's X (N, d) | y (N), read by the first kernel directly (one window per PIN window)
 constexpr int STAGE_NP_CAP = MID_NP_CAP;
 static_assert(STAGE_NP_CAP >= FUSED_NP_CAP, "the staging window serves both small paths");

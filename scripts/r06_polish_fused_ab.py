@@ -1,6 +1,6 @@
-"""gpbo_polish_seeds: the runs as ONE launch (csrc/polish_fused.hip) against the lockstep rounds (csrc/polish.hip), same seeds, on
-libgpbo_dbg.so — round 6: three arms, lockstep | the eight-wave kernel (round 5; GPBO_POLISH_ROWS=0) | thread = training point
-(polish_rows_kernel, NP <= 128; above it the one launch IS the eight-wave kernel).
+"""gpbo_polish_seeds: the runs as ONE launch (csrc/polish_fused.hip: polish_rows_kernel, thread = training point; W in LDS up to
+NP = 128, streamed from memory above) against the lockstep rounds (csrc/polish.hip), same seeds, on libgpbo_dbg.so.  (The
+eight-wave kernel of round 5 was measured beside both until it was removed: profiles/r06_polish_fused_ab_three_arms.json.)
 
     python scripts/r06_polish_fused_ab.py > profiles/r06_polish_fused_ab.json
 
@@ -38,11 +38,11 @@ def eval_us(eng, acq, param, y_max, ym, ys, pts, repeat=200):
 
 
 def main():
-    os.environ["GPBO_POLISH_FUSED_MAX_NP"] = "768"      # (the product's limit is 256: this table is where that number comes from)
+    os.environ["GPBO_POLISH_FUSED_MAX_NP"] = "512"      # (the product's limit is 384: this table is where that number comes from)
     eng = GpEngine(0, debug=True)
     rows = []
     for d in (4, 8):
-        for N in (17, 32, 64, 100, 128, 143, 256, 384):
+        for N in (17, 32, 64, 100, 128, 143, 256, 384, 512):
             rng = np.random.RandomState(N + d)
             X = rng.uniform(size=(N, d))
             y = np.exp(-np.sum((X - 0.5) ** 2, axis=1)) + 0.01 * rng.standard_normal(N)
@@ -58,12 +58,11 @@ def main():
                 best = eng.acq_argbest(acq, param, y_max, None, None, k_seeds=10)
                 seeds = np.ascontiguousarray(cand[np.asarray(best[2], dtype=np.int64)])
                 out = {}
-                for name, env, renv in (("lockstep", "0", None), ("eight_waves", None, "0"), ("one_launch", None, None)):
-                    for k_, v_ in (("GPBO_POLISH_FUSED", env), ("GPBO_POLISH_ROWS", renv)):
-                        if v_ is None:
-                            os.environ.pop(k_, None)
-                        else:
-                            os.environ[k_] = v_
+                for name, env in (("lockstep", "0"), ("one_launch", None)):
+                    if env is None:
+                        os.environ.pop("GPBO_POLISH_FUSED", None)
+                    else:
+                        os.environ["GPBO_POLISH_FUSED"] = env
                     ts = []
                     for it in range(18):
                         t0 = time.perf_counter()
@@ -74,12 +73,9 @@ def main():
                 os.environ.pop("GPBO_POLISH_FUSED", None)
                 a, b = out["lockstep"]["res"], out["one_launch"]["res"]
                 same = bool(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]))
-                os.environ["GPBO_POLISH_ROWS"] = "0"
-                ev8 = eval_us(eng, acq, param, y_max, ym, ys, seeds)
-                os.environ.pop("GPBO_POLISH_ROWS", None)
-                ev = eval_us(eng, acq, param, y_max, ym, ys, seeds) if N <= 768 else None
-                rows.append({"N": N, "d": d, "acq": "ucb" if acq == UCB else "ei", "one_launch_us_per_bare_evaluation": None if ev is None else round(ev, 2), "eight_waves_us_per_bare_evaluation": round(ev8, 2),
-                             "lockstep_ms": round(out["lockstep"]["ms"], 4), "eight_waves_ms": round(out["eight_waves"]["ms"], 4),
+                ev = eval_us(eng, acq, param, y_max, ym, ys, seeds) if N <= 512 else None
+                rows.append({"N": N, "d": d, "acq": "ucb" if acq == UCB else "ei", "one_launch_us_per_bare_evaluation": None if ev is None else round(ev, 2),
+                             "lockstep_ms": round(out["lockstep"]["ms"], 4),
                              "one_launch_evals_mean": out["one_launch"]["evals_mean"],
                              "one_launch_ms": round(out["one_launch"]["ms"], 4), "rounds": out["lockstep"]["rounds"],
                              "one_launch_longest_run_evals": out["one_launch"]["rounds"], "evals_mean": out["lockstep"]["evals_mean"],
@@ -87,7 +83,7 @@ def main():
                              "us_per_round_lockstep": round(1e3 * out["lockstep"]["ms"] / max(out["lockstep"]["rounds"], 1), 2),
                              "us_per_eval_one_launch": round(1e3 * out["one_launch"]["ms"] / max(out["one_launch"]["rounds"], 1), 2)})
                 print(rows[-1], file=sys.stderr, flush=True)
-    print(json.dumps({"what": __doc__.strip().split("\n")[0], "note": "one_launch = what the product runs: polish_rows_kernel for NP <= 128, the eight-wave kernel above",
+    print(json.dumps({"what": __doc__.strip().split("\n")[0], "note": "the product takes the one launch up to NP = 384 (N = 512: a 48-evaluation EI run loses to the lockstep rounds)",
                       "rows": rows}, indent=1))
 
 
