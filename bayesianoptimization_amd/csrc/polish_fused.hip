@@ -234,17 +234,17 @@ __global__ __launch_bounds__(256) void transpose_w_kernel(const double* __restri
 
 // ---- thread = training point (NP <= 512) ---------------------------------------------------------------------------------
 #ifndef GPBO_PR_INFLIGHT
-#define GPBO_PR_INFLIGHT 32
+#define GPBO_PR_INFLIGHT 16
 #endif
-constexpr int PR_INFLIGHT = GPBO_PR_INFLIGHT;      // loads in flight per lane in the walks over W in memory (64 must be a multiple)
+constexpr int PR_INFLIGHT = GPBO_PR_INFLIGHT;      // 16-byte loads in flight per lane in the walks over W in memory (128 is a multiple)
 constexpr int PR_LDS_NP = 128;       // W fits the LDS up to here (a padded square: 132 KB at 128)
 constexpr int PR_MAX_NP = 512;       // ... and is streamed from memory above (W for the column walk, its transpose for the row walk): 8 waves,
                                      // 256 VGPRs each (12 waves for NP = 768 would spill the optimiser's registers to scratch)
-// LDS (doubles): [W [NP][NP + 1]] | xs [64] | ls [64] | alpha, k*, v [NP each] | (c1, c2) [NP][2] | (v^2, k* alpha) [NP][2] |
+// LDS (doubles): [W [NP][NP + 1]] | xs [64] | ls [64] | alpha, k*, v [NP each] | (c1, c2) [NP][2] | (v^2, k* alpha) [NP][2] | u [NP] |
 // group partials [groups][2 DP + 2] | the optimiser's block (pr_opt_doubles) | X [NP][DP + 1] (when it fits) ; then the flag word
 __host__ __device__ inline int pr_groups(int NP, int DP) { return (64 / DP) * (NP >> 6); }
 __host__ __device__ inline int pr_lds_base(int NP, int d, int DP, bool wlds) {
-  return (wlds ? NP * (NP + 1) : 0) + 128 + 7 * NP + pr_groups(NP, DP) * (2 * DP + 2) + pr_opt_doubles(d);
+  return (wlds ? NP * (NP + 1) : 0) + 128 + 8 * NP + pr_groups(NP, DP) * (2 * DP + 2) + pr_opt_doubles(d);
 }
 __host__ __device__ inline int pr_xs_stage(int NP, int d, int DP, bool wlds) {
   const int want = NP * (DP + 1);
@@ -254,10 +254,9 @@ __host__ __device__ inline int pr_lds_doubles(int NP, int d, int DP, bool wlds) 
   return pr_lds_base(NP, d, DP, wlds) + pr_xs_stage(NP, d, DP, wlds);
 }
 
-// WLDS = false (round 6, 128 < NP <= 512): W stays in memory.  Thread i still owns row i of v = W k* and column i of u = W^T v, and
-// both walks are COALESCED: the row walk reads the transposed copy (Wt[k][i], lanes = consecutive i), the column walk reads W itself
-// (W[i'][k], lanes = consecutive k); wave w walks the 64 (w + 1) columns / the NP - 64 w rows its triangle part has (zeros beyond are
-// never loaded), PR_INFLIGHT loads in flight per lane.  A CU pulls NP^2 / 2 * 8 B per walk at ~64 B per clock: 0.4 us at NP = 256, 1.7 us
+// WLDS = false (round 6, 128 < NP <= 512): W stays in memory and both walks are COALESCED: the row walk reads the transposed copy
+// (Wt[k][i], lanes = consecutive i), the column walk reads W itself (W[i'][k], lanes = consecutive k), two rows (columns) per thread
+// with 16-byte loads, PR_INFLIGHT of them in flight per lane.  A CU pulls NP^2 / 2 * 8 B per walk at ~64 B per clock: 0.4 us at NP = 256, 1.7 us
 // at 512 — against two passes of the eight-wave kernel at 25 GB/s per CU and against the 41-75 us of a six-launch lockstep round.
 template <int KERNEL, bool WLDS>
 __global__ __launch_bounds__(WLDS ? PR_LDS_NP : PR_MAX_NP) void polish_rows_kernel(const PolishFusedArgs a) {
@@ -274,7 +273,8 @@ __global__ __launch_bounds__(WLDS ? PR_LDS_NP : PR_MAX_NP) void polish_rows_kern
   double* vs = ks + NP;                     // [NP] v = W k*
   double* cc = vs + NP;                     // [NP][2] alpha_k f_k, u_k f_k
   double* pp = cc + 2 * NP;                 // [NP][2] v_k^2, k*_k alpha_k
-  double* red = pp + 2 * NP;                // [groups][2 DP + 2]
+  double* us = pp + 2 * NP;                 // [NP] u = W^T v (W in memory: the pair threads hand their columns' sums over)
+  double* red = us + NP;                    // [groups][2 DP + 2]
   double* opt = red + pr_groups(NP, DP) * (2 * DP + 2);
   double* Xl = opt + pr_opt_doubles(d);
   const int xs_staged = pr_xs_stage(NP, d, DP, WLDS);
@@ -335,67 +335,80 @@ __global__ __launch_bounds__(WLDS ? PR_LDS_NP : PR_MAX_NP) void polish_rows_kern
       ks[tid] = kv;
     }
     __syncthreads();
-    // ---- v_i = sum_k W[i][k] k*_k (zeros above the diagonal: the whole row)
-    {
+    // ---- v = W k* and u = W^T v, then every point's two gradient weights and its terms of |v|^2 and k* . alpha
+    if (WLDS) {
+      // thread i: row i of W for v_i (zeros above the diagonal: the whole row), column i for u_i
       double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-      if (WLDS) {
-        for (int k = 0; k < NP; k += 4) {
-          v0 = fma(wrow[k], ks[k], v0);
-          v1 = fma(wrow[k + 1], ks[k + 1], v1);
-          v2 = fma(wrow[k + 2], ks[k + 2], v2);
-          v3 = fma(wrow[k + 3], ks[k + 3], v3);
-        }
-      } else {
-        const double* __restrict__ wt = a.Wt + tid;          // Wt[k][i] = W[i][k]: zero for k > i, i.e. beyond this wave's 64 (w + 1) columns
-        const int kend = 64 * (wave + 1);
-        for (int k = 0; k < kend; k += PR_INFLIGHT) {
-          double w[PR_INFLIGHT];
-#pragma unroll
-          for (int e = 0; e < PR_INFLIGHT; ++e) w[e] = wt[(int64_t)(k + e) * NP];
-#pragma unroll
-          for (int e = 0; e < PR_INFLIGHT; e += 4) {
-            v0 = fma(w[e], ks[k + e], v0);
-            v1 = fma(w[e + 1], ks[k + e + 1], v1);
-            v2 = fma(w[e + 2], ks[k + e + 2], v2);
-            v3 = fma(w[e + 3], ks[k + e + 3], v3);
-          }
-        }
+      for (int k = 0; k < NP; k += 4) {
+        v0 = fma(wrow[k], ks[k], v0);
+        v1 = fma(wrow[k + 1], ks[k + 1], v1);
+        v2 = fma(wrow[k + 2], ks[k + 2], v2);
+        v3 = fma(wrow[k + 3], ks[k + 3], v3);
       }
       const double v = (tid < N) ? (v0 + v1) + (v2 + v3) : 0.0;
       vs[tid] = v;
       pp[2 * tid] = v * v;
       pp[2 * tid + 1] = ks[tid] * al_i;
-    }
-    __syncthreads();
-    // ---- u_k = sum_i W[i][k] v_i for this thread's column, then its two gradient weights
-    {
+      __syncthreads();
       double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
-      if (WLDS) {
-        const double* wcol = Wl + tid;
-        for (int i = 0; i < NP; i += 4) {
-          u0 = fma(wcol[i * WLD], vs[i], u0);
-          u1 = fma(wcol[(i + 1) * WLD], vs[i + 1], u1);
-          u2 = fma(wcol[(i + 2) * WLD], vs[i + 2], u2);
-          u3 = fma(wcol[(i + 3) * WLD], vs[i + 3], u3);
-        }
-      } else {
-        const double* __restrict__ wc = a.W + tid;           // W[i][k]: zero for i < k, i.e. above this wave's first row 64 w
-        for (int i = 64 * wave; i < NP; i += PR_INFLIGHT) {
-          double w[PR_INFLIGHT];
+      const double* wcol = Wl + tid;
+      for (int i = 0; i < NP; i += 4) {
+        u0 = fma(wcol[i * WLD], vs[i], u0);
+        u1 = fma(wcol[(i + 1) * WLD], vs[i + 1], u1);
+        u2 = fma(wcol[(i + 2) * WLD], vs[i + 2], u2);
+        u3 = fma(wcol[(i + 3) * WLD], vs[i + 3], u3);
+      }
+      cc[2 * tid] = al_i * fi;
+      cc[2 * tid + 1] = ((u0 + u1) + (u2 + u3)) * fi;
+    } else {
+      // W in memory: the first NP / 2 threads walk TWO rows (columns) each with 16-byte loads — a wave instruction is 1 KB of one row
+      // of Wt (of W) — wave w the rows 128 w .. 128 w + 127, whose columns end at 128 (w + 1) (the columns 128 w .., whose rows
+      // start at 128 w): the zeros of the triangle are never loaded.  The sums come back through LDS to the points' own threads.
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      const int ld2 = NP / 2;
+      if (tid < ld2) {
+        const d2* __restrict__ wt = reinterpret_cast<const d2*>(a.Wt) + tid;      // Wt[k][2 tid .. 2 tid + 1] = W[2 tid ..][k]
+        const int kend = min(NP, 128 * (wave + 1));
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+        for (int k = 0; k < kend; k += PR_INFLIGHT) {
+          d2 w[PR_INFLIGHT];
 #pragma unroll
-          for (int e = 0; e < PR_INFLIGHT; ++e) w[e] = wc[(int64_t)(i + e) * NP];
+          for (int e = 0; e < PR_INFLIGHT; ++e) w[e] = wt[(int64_t)(k + e) * ld2];
 #pragma unroll
-          for (int e = 0; e < PR_INFLIGHT; e += 4) {
-            u0 = fma(w[e], vs[i + e], u0);
-            u1 = fma(w[e + 1], vs[i + e + 1], u1);
-            u2 = fma(w[e + 2], vs[i + e + 2], u2);
-            u3 = fma(w[e + 3], vs[i + e + 3], u3);
+          for (int e = 0; e < PR_INFLIGHT; e += 2) {
+            a0 = fma(w[e].x, ks[k + e], a0);
+            b0 = fma(w[e].y, ks[k + e], b0);
+            a1 = fma(w[e + 1].x, ks[k + e + 1], a1);
+            b1 = fma(w[e + 1].y, ks[k + e + 1], b1);
           }
         }
+        vs[2 * tid] = (2 * tid < N) ? a0 + a1 : 0.0;
+        vs[2 * tid + 1] = (2 * tid + 1 < N) ? b0 + b1 : 0.0;
       }
-      const double u = (u0 + u1) + (u2 + u3);
+      __syncthreads();
+      pp[2 * tid] = vs[tid] * vs[tid];
+      pp[2 * tid + 1] = ks[tid] * al_i;
+      if (tid < ld2) {
+        const d2* __restrict__ wc = reinterpret_cast<const d2*>(a.W) + tid;       // W[i][2 tid .. 2 tid + 1]
+        double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+        for (int i = 128 * wave; i < NP; i += PR_INFLIGHT) {
+          d2 w[PR_INFLIGHT];
+#pragma unroll
+          for (int e = 0; e < PR_INFLIGHT; ++e) w[e] = wc[(int64_t)(i + e) * ld2];
+#pragma unroll
+          for (int e = 0; e < PR_INFLIGHT; e += 2) {
+            a0 = fma(w[e].x, vs[i + e], a0);
+            b0 = fma(w[e].y, vs[i + e], b0);
+            a1 = fma(w[e + 1].x, vs[i + e + 1], a1);
+            b1 = fma(w[e + 1].y, vs[i + e + 1], b1);
+          }
+        }
+        us[2 * tid] = a0 + a1;
+        us[2 * tid + 1] = b0 + b1;
+      }
+      __syncthreads();
       cc[2 * tid] = al_i * fi;
-      cc[2 * tid + 1] = u * fi;
+      cc[2 * tid + 1] = us[tid] * fi;
     }
     __syncthreads();
     // ---- the sums over the points: gm_t = sum_k alpha_k f_k (x_t - X_kt), gv_t likewise with u_k; |v|^2 and k* . alpha ride along
