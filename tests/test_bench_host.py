@@ -201,3 +201,41 @@ def test_the_build_fingerprint_names_the_code_not_its_comments(tmp_path, monkeyp
     assert build._fingerprint() == a
     (csrc / "k.hip").write_text("__global__ void k() { __syncthreads(); }\n")
     assert build._fingerprint() != a
+
+
+def test_the_summary_is_the_last_key_material_and_stays_small():
+    """Round 6: the driver's record keeps the headline keys and a TAIL of the line, so the small configs' numbers ride in a digest
+    printed as the last key (bench.summary_of).  From a real line of the GPU box (profiles/r06_bench_default_C3_with_configs.json
+    when it exists, else a synthetic one of the same shape): every config's ms / fit / frac / parity, the suggest() latencies of C2
+    and C3, the strong-scaling block — in at most 1.5 KB."""
+    b = _bench()
+    p = os.path.join(ROOT, "profiles", "r06_bench_default_C3_with_configs.json")
+    line = None
+    if os.path.exists(p):
+        rows = [ln for ln in open(p).read().splitlines() if ln.startswith("{")]
+        line = json.loads(rows[-1]) if rows else None
+    if line is None:
+        cfg = {"ms_per_step": 0.641, "fit_ms": 0.1895, "roofline": {"frac": 0.6623, "frac_of_whole_step": 0.3649},
+               "parity": {"argmin_equals_reference": True, "top10_equals_reference": True},
+               "suggest_ms": {"n_smart_0": 1.18, "default_call_interior": 6.77, "smooth_target": {"default_call": 4.7}}}
+        line = {"ms_per_step": 255.1, "n_gpus": 1, "roofline": {"frac": 0.899}, "roofline_fit": {"fit_ms_per_gp": 2.32, "chol_ms": 1.55},
+                "parity": {"argmin_equals_reference": True, "top10_equals_reference": True}, "config": {"workload": "C3: d=16 ..."},
+                "configs": {"C1": dict(cfg, suggest_ms=None), "C2": cfg, "C4_s0": dict(cfg, suggest_ms=None), "C5_f32_s0": {"error": "x" * 200}},
+                "suggest_ms": {"n_smart_0": 257.7, "default_call_interior": 313.0, "default_call_interior_minus_n_smart_0": 55.3,
+                               "smooth_target": {"default_call": 339.2}},
+                "suggest_ms_fixed_total": {"fixed_theta_n_smart_0_ms": 257.1, "default_call_ms": 338.4, "theta_search_ms": 81.5,
+                                           "posterior_ms_max_device": 255.5, "serial_fraction": 0.245},
+                "cpu_baseline": {"value": 13317.7}}
+    sm = b.summary_of(line)
+    assert len(json.dumps(sm)) <= 1536
+    head = sm[line["config"]["workload"].split(":")[0]]
+    assert head["ms"] == round(line["ms_per_step"], 4) and head["frac"] == round(line["roofline"]["frac"], 4)
+    assert set(head["fixed_total"]) == {"fixed_theta_n_smart_0_ms", "default_call_ms", "theta_search_ms", "posterior_ms_max_device", "serial_fraction"}
+    assert head["suggest"]["default_interior_minus_n_smart_0"] is not None
+    for key in ("C1", "C2", "C4_s0"):
+        assert {"ms", "fit_ms", "frac", "frac_step", "argmin_ok", "top10_ok"} <= set(sm[key])
+    assert "suggest" in sm["C2"] and sm["n_gpus"] == line["n_gpus"]
+    # the line itself ends with it
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index('out["summary"] = summary_of(out)') < src.index("print(json.dumps(out), flush=True)")
+    assert src.count('out["') and src[src.index('out["summary"] = summary_of(out)'):src.index("print(json.dumps(out), flush=True)")].count('out["') <= 2
