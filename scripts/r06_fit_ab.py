@@ -16,9 +16,18 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bayesianoptimization_amd.engine import GpEngine  # noqa: E402
-from oracle import gp_oracle as O  # noqa: E402  (the checker: K for the Cholesky-alone entry, and the LAPACK factor beside it)
 
 MATERN25 = 1
+
+
+def matern25_K(X, ls, noise):
+    """A positive definite test matrix for the Cholesky-alone entry: Matern-2.5 over X / ls + noise I (kernels.py:1711-1738)."""
+    Z = X / ls
+    d2 = np.maximum((Z * Z).sum(1)[:, None] + (Z * Z).sum(1)[None, :] - 2.0 * Z @ Z.T, 0.0)
+    r = np.sqrt(5.0 * d2)
+    K = (1.0 + r + r * r / 3.0) * np.exp(-r)
+    K[np.diag_indices_from(K)] = 1.0 + noise
+    return K
 
 
 def data(N, d=16):
@@ -51,8 +60,7 @@ def main():
         for N in sizes:
             X, yn = data(N)
             if N <= 4096:
-                K = O.kernel_matrix(MATERN25, X, None, np.array([0.9]))
-                K[np.diag_indices_from(K)] += 1e-6
+                K = matern25_K(X, 0.9, 1e-6)
                 L, dinv, stamps, ms, info = eng.debug_cholesky(K, variant=3, iters=10)
                 vals[(setting, N, "L")] = L
                 r[f"cholesky_N{N}_ms"] = round(ms, 4)
