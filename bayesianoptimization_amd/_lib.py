@@ -73,6 +73,7 @@ SIGNATURES = {
                                    _c_double_p, C.c_int, C.c_int64, _c_int64_p, _c_double_p, _c_int64_p,
                                    _c_double_p, _c_double_p]),
     "gpbo_last_timings": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
+    "gpbo_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "gpbo_comm_unique_id": (C.c_int, [C.c_char_p]),
     "gpbo_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "gpbo_comm_allgather_best": (C.c_int, [C.c_void_p, _c_double_p, _c_int64_p, C.c_int, _c_double_p,

@@ -18,6 +18,20 @@ __device__ __forceinline__ void prescale_elem(const double* X, const int64_t n, 
   out[idx] = v;
 }
 
+// mu = y_std * (k* . alpha) + y_mean ; sd = sqrt(max(1 - |W k*|^2, 0) * y_std^2) for one candidate (sklearn _gpr.py:444-447, 474-494):
+// posterior_finalize_kernel's element, also the epilogue of a fused posterior launch that owns all rows of its candidates.
+__device__ __forceinline__ void posterior_finalize_elem(const double ss, const double mun, const double y_mean, const double y_std,
+                                                        double* mu, double* sd, int* negvar) {
+  double var = 1.0 - ss;
+  if (var < 0.0) {                   // _gpr.py:479-485 (NaN stays NaN, as in numpy); the host warns as sklearn does
+    *negvar = 1;
+    var = 0.0;
+  }
+  var = var * (y_std * y_std);
+  *sd = sqrt(var);
+  *mu = y_std * mun + y_mean;
+}
+
 // Kernel value from a squared scaled distance: ONE arithmetic for both sides of the GP (gpbo_kernel_value in
 // gpbo_internal.h: v_rsq-seeded sqrt, K^2 * (1/3)) — the fit-side K and the posterior-side k* agree bit for bit
 // for equal distances, and both stay within ~1 ulp of sklearn's expression (kernels.py:1722-1724, 1559-1560).

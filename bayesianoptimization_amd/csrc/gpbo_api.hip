@@ -1125,6 +1125,14 @@ int gpbo_acq_argbest(gpbo_ctx* ctx, int acq, double acq_param, double y_max, int
   return GPBO_OK;
 }
 
+int gpbo_set_timing(gpbo_ctx* ctx, int on) {
+  if (!ctx) return GPBO_ERR_INVALID;
+  ctx->timing_off = !on;
+  if (!on)
+    for (int i = 0; i < T_COUNT; ++i) ctx->ev[i].used = false;     // gpbo_last_timings answers -1 from here on
+  return GPBO_OK;
+}
+
 int gpbo_last_timings(gpbo_ctx* ctx, float* ms, int n) {
   if (!ctx || !ms) return GPBO_ERR_INVALID;
   GPBO_HIP(ctx, hipStreamSynchronize(ctx->stream));

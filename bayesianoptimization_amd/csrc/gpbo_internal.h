@@ -87,6 +87,7 @@ struct gpbo_ctx {
   // gpbo_lml_batch: its stream (lml_stream[0]); the lanes' buffers live in lml_slab
   hipStream_t lml_stream[GPBO_LML_BATCH_MAX] = {};
   bool no_timing = false;   // batch lanes do not touch the timing events
+  bool timing_off = false;  // gpbo_set_timing(ctx, 0): no event records at all (a record is a marker packet on the stream)
   bool no_lookahead = false;   // several lane streams in flight: the Cholesky look-ahead would only add streams to a full chip
   // gpbo_fit_begin / gpbo_fit_wait: a slot's fit enqueued on the slot's own stream, its staging words in pinned window
   // 1 + slot (the windows gpbo_lml_batch uses for its groups — it waits for pending fits first), its pivot word in info_slots
@@ -377,9 +378,22 @@ int launch_posterior_grad(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, dou
                           const double* xc_in = nullptr,    // the points (M, d), device-visible, instead of the resident candidate set
                           double* packed_out = nullptr);    // where the packed block goes (device-visible) instead of ctx->mu_part
 // posterior_kernel_v2.hip
-int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
+// Both ends of a posterior pass inside the fused kernel's launch (round 6), when ONE workgroup owns every row of its candidates
+// (one row chunk): the candidate tile is scaled on its way into LDS (prescale_elem's division: no prescale launch, no scaled
+// image in memory) and the epilogue writes mu and sd itself (posterior_finalize_elem: no partials, no finalize launch).
+struct PostEnds {
+  const double* Xc;     // raw candidates [M][d]
+  const double* ls;     // length scales [d]
+  int d;
+  int64_t M;
+  double y_mean, y_std;
+  double* mu;
+  double* sd;
+  int* negvar;
+};
+int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, const PostEnds* ends = nullptr);
 int launch_posterior_v3(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks);
-int launch_posterior_v4(gpbo_ctx* ctx, Model& m, int64_t Mp, int* part_chunks);   // fused, 512-row chunks (NP <= 1024)
+int launch_posterior_v4(gpbo_ctx* ctx, Model& m, int64_t Mp, int* part_chunks, const PostEnds* ends = nullptr);   // fused, 512-row chunks (NP <= 1024)
 int launch_kstar_slab(gpbo_ctx* ctx, Model& m, double* Kst, int64_t ldk, int64_t Mp, int64_t m0, int nchunks);
 // posterior_cov.hip
 int launch_posterior_cov(gpbo_ctx* ctx, Model& m, int64_t M, double y_std, double** cov_dev, int64_t* ld_cov);
@@ -446,14 +460,14 @@ int run_latency_probe(gpbo_ctx* ctx, long long* out_host, int n);
 #endif
 
 inline void ev_begin(gpbo_ctx* ctx, int slot) {
-  if (ctx->no_timing) return;
+  if (ctx->no_timing || ctx->timing_off) return;
   EventPair& e = ctx->ev[slot];
   if (!e.a) { (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b); }
   (void)hipEventRecord(e.a, ctx->stream);
   e.used = false;
 }
 inline void ev_end(gpbo_ctx* ctx, int slot) {
-  if (ctx->no_timing) return;
+  if (ctx->no_timing || ctx->timing_off) return;
   EventPair& e = ctx->ev[slot];
   (void)hipEventRecord(e.b, ctx->stream);
   e.used = true;

@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "gpbo_internal.h"
+#include "fit_bodies.h"
 
 namespace gpbo {
 
@@ -33,16 +34,9 @@ __global__ __launch_bounds__(256) void posterior_finalize_kernel(const double* _
   if (m >= M) return;
   double ss = 0.0;
   for (int r = 0; r < nchunks; ++r) ss += part[(int64_t)r * Mp + m];
-  double var = 1.0 - ss;
-  if (var < 0.0) {                   // _gpr.py:479-485 (NaN stays NaN, as in numpy); the host warns as sklearn does
-    *negvar = 1;
-    var = 0.0;
-  }
-  var = var * (y_std * y_std);
-  sd[m] = sqrt(var);
   double mun = 0.0;
   for (int q = 0; q < n_mu; ++q) mun += mu_part[(int64_t)q * Mp + m];
-  mu[m] = y_std * mun + y_mean;
+  posterior_finalize_elem(ss, mun, y_mean, y_std, mu + m, sd + m, negvar);
 }
 
 int64_t kstar_slab_budget_bytes(gpbo_ctx* ctx, int64_t want_bytes_if_unlimited) {
@@ -107,11 +101,22 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
   if ((rc = ensure(ctx, &ctx->part, &ctx->cap_part, (int64_t)nchunks * Mp))) return rc;
   if ((rc = ensure(ctx, &ctx->mu_part, &ctx->cap_mu_part, (int64_t)nchunks * Mp))) return rc;
   if ((rc = ensure_posterior_outputs(ctx, m, Mp))) return rc;
-  if ((rc = launch_prescale(ctx, ctx->Xc, M, m.d, m.DP, m.ls, ctx->Xcs, Mp))) return rc;
+  // v2 = fused generation (one kernel, 256-row chunks); v3 = k* slab + GEMM; v4 = fused generation with 512-row chunks (the
+  // long comment below).  Decided first: a fused kernel whose workgroups hold ALL rows of their candidates (one row chunk) takes the
+  // raw candidates in and writes mu / sd itself (round 6: three launches -> one; GPBO_POST_FUSE_ENDS=0, debug build: the three).
+  const char* kv = dbg_env("GPBO_POST_KERNEL");
+  const bool use_f32 = (m.precision == GPBO_F32);   // fp32 slab + f32 MFMA GEMM (posterior_kernel_f32.hip)
+  int path = (nchunks <= 1 || (nchunks == 2 && Mp < 8192)) ? 2 : ((m.NP >= 384 && m.NP <= 512 && Mp >= 16384) ? 4 : 3);
+  if (kv && (kv[0] == '2' || kv[0] == '3' || (kv[0] == '4' && m.NP <= 1024))) path = kv[0] - '0';
+  const bool use_v2 = path == 2, use_v4 = path == 4;
+  const char* sm = dbg_env("GPBO_POST_SMALL");
+  const bool small = M <= small_batch_limit(m.NP) && !(sm && sm[0] == '0');
+  const char* fe = dbg_env("GPBO_POST_FUSE_ENDS");
+  const bool fuse_ends = !small && !use_f32 && !(fe && fe[0] == '0') && ((use_v2 && nchunks == 1) || (use_v4 && m.NP <= 512));
+  if (!fuse_ends && (rc = launch_prescale(ctx, ctx->Xc, M, m.d, m.DP, m.ls, ctx->Xcs, Mp))) return rc;
   {
     // latency path: a handful of candidates (HipGPR.predict from the host optimiser) -> batched GEMV
-    const char* sm = dbg_env("GPBO_POST_SMALL");
-    if (M <= small_batch_limit(m.NP) && !(sm && sm[0] == '0')) {
+    if (small) {
       ev_begin(ctx, T_POST_MAIN);
       rc = launch_posterior_small(ctx, m, (int)M, y_mean, y_std);
       ev_end(ctx, T_POST_MAIN);
@@ -122,8 +127,7 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
       return GPBO_OK;
     }
   }
-  // v2 = fused generation (one kernel, 256-row chunks); v3 = k* slab + GEMM; v4 = fused generation with 512-row chunks.
-  // v3 as soon as k* would be generated more than once: the fp64 VALU work of the generation runs instead of MFMAs, not
+  // The path rule (decided at the top).  v3 as soon as k* would be generated more than once: the fp64 VALU work of the generation runs instead of MFMAs, not
   // beside them, and the slab GEMM's loop carries no other VALU work (posterior_kernel_v2.hip).  For 384 <= NP <= 512 and a
   // batch that fills the chip, v4 (round 4): ONE 16-wave workgroup covers all rows, so k* is generated once and never
   // crosses HBM (the slab route: a 268 MB round trip and a second launch at C2).  Measured at M = 65 536 (scripts/
@@ -138,23 +142,20 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
   // (0.25 ms) + one generation of k* on the same datapath (~0.09 ms); one 1024-thread workgroup per CU also means every
   // s_barrier stalls the whole CU (the 16-wave slab kernel measured 3 % slower at C3 for the same reason).
   // GPBO_POST_KERNEL=2|3|4 forces a path (debug build: A/B runs; 4 only up to NP = 1024).
-  const char* kv = dbg_env("GPBO_POST_KERNEL");
-  const bool use_f32 = (m.precision == GPBO_F32);   // fp32 slab + f32 MFMA GEMM (posterior_kernel_f32.hip)
-  int path = (nchunks <= 1 || (nchunks == 2 && Mp < 8192)) ? 2 : ((m.NP >= 384 && m.NP <= 512 && Mp >= 16384) ? 4 : 3);
-  if (kv && (kv[0] == '2' || kv[0] == '3' || (kv[0] == '4' && m.NP <= 1024))) path = kv[0] - '0';
-  const bool use_v2 = path == 2, use_v4 = path == 4;
   const int n_mu = (use_f32 || path == 3) ? nchunks : 1;
+  PostEnds ends{ctx->Xc, m.ls, m.d, M, y_mean, y_std, m.mu, m.sd, ctx->negvar};
   ev_begin(ctx, T_POST_MAIN);
   int part_chunks = nchunks;   // row chunks the sum-of-squares partials are split into (fp32 path, v4: 512-row chunks)
   if (use_f32) rc = launch_posterior_f32(ctx, m, Mp, nchunks, &part_chunks);
-  else if (use_v2) rc = launch_posterior_v2(ctx, m, Mp, nchunks);
-  else if (use_v4) rc = launch_posterior_v4(ctx, m, Mp, &part_chunks);
+  else if (use_v2) rc = launch_posterior_v2(ctx, m, Mp, nchunks, fuse_ends ? &ends : nullptr);
+  else if (use_v4) rc = launch_posterior_v4(ctx, m, Mp, &part_chunks, fuse_ends ? &ends : nullptr);
   else rc = launch_posterior_v3(ctx, m, Mp, nchunks);
   ev_end(ctx, T_POST_MAIN);
   if (rc) return rc;
   ev_begin(ctx, T_POST_FINAL);
-  posterior_finalize_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream>>>(
-      ctx->part, ctx->mu_part, part_chunks, n_mu, Mp, M, y_mean, y_std, m.mu, m.sd, ctx->negvar);
+  if (!fuse_ends)
+    posterior_finalize_kernel<<<dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream>>>(
+        ctx->part, ctx->mu_part, part_chunks, n_mu, Mp, M, y_mean, y_std, m.mu, m.sd, ctx->negvar);
   ev_end(ctx, T_POST_FINAL);
   GPBO_HIP(ctx, hipGetLastError());
   m.M_post = M;

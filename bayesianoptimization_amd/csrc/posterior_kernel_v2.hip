@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "gpbo_internal.h"
+#include "fit_bodies.h"
 
 namespace gpbo {
 
@@ -45,6 +46,8 @@ struct PostArgs2 {
   const double* Kst;   // GEN == 2: materialised k* slab [NP][ldk], candidate-contiguous
   int64_t ldk;
   int64_t m0;          // first candidate of the slab (outputs are indexed m0 + local)
+  int fuse_ends = 0;   // GEN == 1, one row chunk: raw candidates in, mu / sd out (PostEnds, gpbo_internal.h)
+  PostEnds ends = {};
 };
 
 constexpr int BUF_FLAGS = 0x00020000;   // gfx9 buffer descriptor word 3: raw buffer, 32-bit data format
@@ -90,10 +93,21 @@ __global__ __launch_bounds__(WAVES * 64, 4) void posterior_kernel_v2(PostArgs2 p
 
   // candidate tile -> LDS (thread t loads candidate t>>3, dims (t&7)*DP/8 ...)
   if constexpr (GEN != 2) {
-    const double* src = p.Xcs + (int64_t)ct * V2_CANDS * DP;
-    for (int e = tid; e < V2_CANDS * DP; e += NT) {
-      const int cnd = e / DP, t = e - cnd * DP;
-      Xl[t * V2_CANDS + cnd] = src[e];
+    if (p.fuse_ends) {
+      // the raw tile, scaled on the way in: prescale_elem's element (row < M and t < d: X / length_scale, else 0), into LDS instead of memory
+      for (int e = tid; e < V2_CANDS * DP; e += NT) {
+        const int cnd = e / DP, t = e - cnd * DP;
+        const int64_t row = (int64_t)ct * V2_CANDS + cnd;
+        double v = 0.0;
+        if (row < p.ends.M && t < p.ends.d) v = p.ends.Xc[row * p.ends.d + t] / p.ends.ls[t];
+        Xl[t * V2_CANDS + cnd] = v;
+      }
+    } else {
+      const double* src = p.Xcs + (int64_t)ct * V2_CANDS * DP;
+      for (int e = tid; e < V2_CANDS * DP; e += NT) {
+        const int cnd = e / DP, t = e - cnd * DP;
+        Xl[t * V2_CANDS + cnd] = src[e];
+      }
     }
   }
 
@@ -280,6 +294,16 @@ __global__ __launch_bounds__(WAVES * 64, 4) void posterior_kernel_v2(PostArgs2 p
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) v += red[w * V2_CANDS + tid];
     const int64_t m = p.m0 + (int64_t)ct * V2_CANDS + tid;
+    if (GEN != 2 && p.fuse_ends) {
+      // this workgroup holds every row of its candidates: mu and sd from here (what posterior_finalize_kernel makes of ONE partial
+      // each: 0.0 + v and 0.0 + u are v and u)
+      double u = 0.0;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) u += mured[w * V2_CANDS + tid];
+      if (m < p.ends.M)
+        posterior_finalize_elem(0.0 + v, 0.0 + u, p.ends.y_mean, p.ends.y_std, p.ends.mu + m, p.ends.sd + m, p.ends.negvar);
+      return;
+    }
     p.part[(int64_t)r * p.Mp + m] = v;
     if (GEN != 2 && last) {
       double u = 0.0;
@@ -481,9 +505,11 @@ static int launch_v4_k(gpbo_ctx* ctx, int DP, const PostArgs2& a, int64_t nblock
   }
   GPBO_FAIL(ctx, GPBO_ERR_UNSUPPORTED, "posterior: unsupported padded dimension");
 }
-int launch_posterior_v4(gpbo_ctx* ctx, Model& m, int64_t Mp, int* part_chunks) {
+int launch_posterior_v4(gpbo_ctx* ctx, Model& m, int64_t Mp, int* part_chunks, const PostEnds* ends) {
   const int nch = (int)((m.NP + 511) / 512);
+  if (ends && nch != 1) GPBO_FAIL(ctx, GPBO_ERR_STATE, "posterior: fused ends need one row chunk");
   PostArgs2 a;
+  if (ends) { a.fuse_ends = 1; a.ends = *ends; }
   a.Wp = m.Wp; a.Xs = m.Xs; a.alpha = m.alpha; a.Xcs = ctx->Xcs; a.part = ctx->part;
   a.mu_part = ctx->mu_part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nch;
   a.n_ctiles = (int)(Mp / V2_CANDS);
@@ -496,8 +522,10 @@ int launch_posterior_v4(gpbo_ctx* ctx, Model& m, int64_t Mp, int* part_chunks) {
 }
 
 // Mp must be a multiple of 128 (the v1 tile) — also a multiple of 64.
-int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks) {
+int launch_posterior_v2(gpbo_ctx* ctx, Model& m, int64_t Mp, int nchunks, const PostEnds* ends) {
+  if (ends && nchunks != 1) GPBO_FAIL(ctx, GPBO_ERR_STATE, "posterior: fused ends need one row chunk");
   PostArgs2 a;
+  if (ends) { a.fuse_ends = 1; a.ends = *ends; }
   a.Wp = m.Wp; a.Xs = m.Xs; a.alpha = m.alpha; a.Xcs = ctx->Xcs; a.part = ctx->part;
   a.mu_part = ctx->mu_part; a.NP = (int)m.NP; a.Mp = Mp; a.nchunks = nchunks;
   a.n_ctiles = (int)(Mp / V2_CANDS);

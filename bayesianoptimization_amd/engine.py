@@ -71,6 +71,7 @@ class GpEngine:
         self._serial: dict[int, int] = {}    # slot -> number of times its factorisation was rewritten
         self._overlap_depth = 0              # > 0 inside overlapped_fits()
         self._pending_fits: set[int] = set()  # slots with a gpbo_fit_begin not yet waited for
+        self.timing = True                   # the calls record their HIP event pairs (set_timing)
 
     # -- lifecycle ---------------------------------------------------------------------------
     def __deepcopy__(self, memo):
@@ -543,6 +544,12 @@ class GpEngine:
         self._need_debug("gpbo_debug_fail_next_acq")
         self._check(self._lib.gpbo_debug_fail_next_acq(self._h))
 
+    def set_timing(self, on: bool):
+        """gpbo_set_timing: whether the calls record their HIP event pairs (what `last_timings()` reads; a new engine does).
+        A record is a marker packet on the stream: a 0.1 ms step notices its eight."""
+        self._check(self._lib.gpbo_set_timing(self._h, 1 if on else 0))
+        self.timing = bool(on)
+
     def last_timings(self) -> dict:
         ms = (C.c_float * 8)()
         self._check(self._lib.gpbo_last_timings(self._h, ms, 8))
@@ -703,6 +710,7 @@ class GroupEngine(GpEngine):
         self._serial = {}
         self._overlap_depth = 0     # group fits are synchronous on every device: overlapped_fits() is a plain block
         self._pending_fits = set()  # (never filled: the inherited accessors only look at it)
+        self.timing = True
         self._resident = False      # the group's candidate shards are in place (a small predict on device 0 clobbers them)
         self.collective = self._lib.gpbo_group_collective(g).decode()
         self._orphans = []          # arrays of failed calls (see _gcheck)
@@ -732,6 +740,12 @@ class GroupEngine(GpEngine):
             self._check(self._lib.gpbo_device_info(h, buf, 1024))
             out.append(json.loads(buf.value.decode()))
         return out
+
+    def set_timing(self, on: bool):
+        for r in range(self.world_size):
+            h = C.c_void_p(self._lib.gpbo_group_ctx(self._g, r))
+            self._check(self._lib.gpbo_set_timing(h, 1 if on else 0))
+        self.timing = bool(on)
 
     def per_device_timings(self) -> list:
         """`last_timings()` of every device of the group (HIP events on each device's own stream): a straggler shows here."""

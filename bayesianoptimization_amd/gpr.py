@@ -45,14 +45,18 @@ LML_DEVICE_MIN_N = 1      # lml_on_device="auto": device from this many observat
 
 def shared_engine(device=0) -> GpEngine:
     """One context per device — or one device group per tuple of devices — per process (created on first use; raises
-    without a GPU).  `device`: an int, or a sequence of ints for a single-process multi-GPU group (GroupEngine)."""
+    without a GPU).  `device`: an int, or a sequence of ints for a single-process multi-GPU group (GroupEngine).
+    The seams never read `last_timings()`, so this engine does not record HIP event pairs (`set_timing(False)`: a step of
+    BASELINE config 1 is 91 instead of 119 us without its eight marker packets); `set_timing(True)` brings them back."""
     key = int(device) if np.isscalar(device) else tuple(int(x) for x in device)
     if key not in _shared_engines:
         if isinstance(key, tuple):
             from .engine import GroupEngine
-            _shared_engines[key] = GroupEngine(key)
+            eng = GroupEngine(key)
         else:
-            _shared_engines[key] = GpEngine(key)
+            eng = GpEngine(key)
+        eng.set_timing(False)
+        _shared_engines[key] = eng
     return _shared_engines[key]
 
 

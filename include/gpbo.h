@@ -274,6 +274,11 @@ int gpbo_acq_argbest(gpbo_ctx* ctx, int acq, double acq_param, double y_max, int
 /* Milliseconds spent in the last call's kernels: [0] fit total, [1] posterior main kernel,
  * [2] posterior finalize, [3] acquisition + arg-best, [4] kmat assembly, [5] cholesky, [6] trtri. */
 int gpbo_last_timings(gpbo_ctx* ctx, float* ms, int n);
+/* on = 0: the calls stop recording their event pairs (gpbo_last_timings then answers -1 everywhere); on = 1 (the state of a
+ * new context): they record them.  A record is a marker packet on the stream — a step of BASELINE config 1 (0.12 ms: fit + posterior +
+ * acquisition + arg-best) carries eight of them — so callers that never read the timings (accelerate(), bayes_opt's loop) switch
+ * them off.  No result depends on it. */
+int gpbo_set_timing(gpbo_ctx* ctx, int on);
 
 /* ---- multi-GPU (RCCL over xGMI) --------------------------------------------------------- */
 /* The candidate rows are independent (sklearn _gpr.py:443-494 is row-wise; bayes_opt/acquisition.py:312-317 needs only

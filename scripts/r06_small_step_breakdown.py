@@ -1,7 +1,8 @@
 """Where one bench step of the two small configs goes (C1: N = 25, M = 1024; C2: N = 512, M = 65 536): wall time of each of the
 three engine calls of a step (fit at fixed theta | posterior | acquisition + arg-best), each ended by its own stream
 synchronisation, beside the whole step clocked as bench.py clocks it (one synchronisation, inside the arg-best read-back), the
-device's own event times, and a cProfile of 2000 steps by own time.
+device's own event times, and a cProfile of 2000 steps by own time — once with the calls recording their HIP event pairs (a new
+engine's state) and once without (gpbo_set_timing(ctx, 0): what accelerate() sets).
 
     python scripts/r06_small_step_breakdown.py > profiles/r06_small_step_breakdown.txt
 """
@@ -96,8 +97,11 @@ def one(eng, name, n):
 
 def main():
     eng = GpEngine(0)
-    one(eng, "C1", 400)
-    one(eng, "C2", 200)
+    for timing in (True, False):
+        eng.set_timing(timing)
+        print(f"######## event pairs recorded: {timing} (gpbo_set_timing)")
+        one(eng, "C1", 400)
+        one(eng, "C2", 200)
 
 
 if __name__ == "__main__":

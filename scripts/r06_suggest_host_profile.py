@@ -32,6 +32,8 @@ def black_box(x):
 
 def loop(n0, n1, profile):
     eng = GpEngine(0)
+    if os.environ.get("GPBO_SCRIPT_TIMING") == "0":
+        eng.set_timing(False)
     sp = FloatSpace({f"x{j}": (0.0, 1.0) for j in range(D)})
     rng = np.random.RandomState(1)
     X0 = rng.uniform(size=(n0, D))

@@ -279,6 +279,36 @@ def test_bitwise_determinism(engine):
         assert o[4:] == outs[0][4:]
 
 
+def test_event_records_can_be_switched_off_and_change_no_result(engine):
+    """gpbo_set_timing(ctx, 0): the calls stop recording their HIP event pairs (marker packets on the stream: 28 us of a
+    119 us step of BASELINE config 1), gpbo_last_timings answers -1, every result keeps its bits; 1 brings the timings back."""
+    w = W.P1
+    oc = oracle_case(w, 0.4)
+    yn, ym, ys_ = O.normalize_targets(oc["y"])
+
+    def run():
+        engine.fit(oc["X"], yn, w.kernel, 0.4, w.noise)
+        engine.set_candidates(oc["Xc"])
+        mu, sd = engine.posterior(0, ym, ys_)
+        bi, bv, si, sv, ys = engine.acq_argbest(O.EI, 0.01, oc["y_max"], k_seeds=10, return_values=True)
+        return mu, sd, ys, bi, tuple(si)
+
+    on = run()
+    t_on = engine.last_timings()
+    assert t_on["fit"] > 0 and t_on["posterior_main"] > 0 and t_on["acq_argbest"] > 0
+    try:
+        engine.set_timing(False)
+        assert not engine.timing
+        off = run()
+        assert all(v == -1.0 for v in engine.last_timings().values())
+    finally:
+        engine.set_timing(True)
+    assert all(np.array_equal(a, b) for a, b in zip(on[:3], off[:3])) and on[3:] == off[3:]
+    again = run()
+    assert engine.last_timings()["posterior_main"] > 0
+    assert all(np.array_equal(a, b) for a, b in zip(on[:3], again[:3]))
+
+
 def test_virtual_rank_sharding_equals_single_pass(engine):
     """SURVEY.md §8e 'testing without 8 GPUs': G virtual ranks on one device + host merge == one pass."""
     from bayesianoptimization_amd.distributed import merge_best, shard_range
@@ -407,6 +437,41 @@ def test_small_batch_path_equals_oracle_and_big_kernel(debug_engine, M, N, d, ke
     # kappa(K)*eps noise as the comparison with LAPACK (RBF, N=70, d=2: kappa ~ 4e7, |alpha| ~ 1e5)
     assert np.max(np.abs(mu - mu_b)) <= tol * np.max(np.abs(mu_o))
     assert np.max(np.abs(sd - sd_b)) <= tol * max(np.max(np.abs(sd_o)), 1e-3)
+
+
+@pytest.mark.parametrize("M", [9, 1000, 1024, 20001])
+@pytest.mark.parametrize("N,d,kernel,ls", [(25, 2, O.MATERN25, 2.2), (64, 3, O.RBF, 0.3), (200, 6, O.MATERN25, 0.8), (256, 17, O.MATERN25, 1.1),
+                                              (400, 5, O.RBF, 0.4), (512, 8, O.MATERN25, [0.6 + 0.1 * t for t in range(8)])])
+def test_posterior_with_both_ends_in_the_launch_is_bitwise_the_three_launches(debug_engine, N, d, kernel, ls, M):
+    """Round 6: when one workgroup of the fused posterior kernel holds every row of its candidates (NP <= 256 on the 8-wave kernel,
+    384 <= NP <= 512 on the 16-wave one) the launch takes the RAW candidates (scaled on their way into LDS) and writes mu and sd
+    itself — prescale_kernel and posterior_finalize_kernel are gone from the pass, 3 launches -> 1.  Same arithmetic element for
+    element (prescale_elem's division, posterior_finalize_elem): bitwise the three launches (GPBO_POST_FUSE_ENDS=0, debug build),
+    ragged candidate counts, a candidate ON a training point (variance clipped at 0: the flag) and per-dimension length scales
+    included.  M = 9 with GPBO_POST_SMALL=0 keeps the MFMA kernel on a batch the latency path would take."""
+    import os
+
+    engine = debug_engine
+    X, y = _data(N, d, seed=71)
+    yn, ym, ys = O.normalize_targets(y)
+    engine.fit(X, yn, kernel, ls, 1e-10)
+    Xc = np.random.RandomState(72).uniform(size=(M, d))
+    Xc[min(7, M - 1)] = X[3]
+    os.environ["GPBO_POST_SMALL"] = "0"
+    try:
+        engine.take_negative_variance_flag()
+        mu, sd = engine.predict(Xc, y_mean=ym, y_std=ys)
+        flag = engine.take_negative_variance_flag()
+        os.environ["GPBO_POST_FUSE_ENDS"] = "0"
+        mu3, sd3 = engine.predict(Xc, y_mean=ym, y_std=ys)
+        flag3 = engine.take_negative_variance_flag()
+    finally:
+        os.environ.pop("GPBO_POST_SMALL")
+        os.environ.pop("GPBO_POST_FUSE_ENDS", None)
+    assert np.array_equal(mu, mu3) and np.array_equal(sd, sd3) and flag == flag3
+    gp = O.fit_fixed_theta(kernel, X, y, ls, 1e-10)
+    mu_o, sd_o = O.predict(gp, Xc)
+    assert np.max(np.abs(mu - mu_o)) <= 1e-6 * np.max(np.abs(mu_o))
 
 
 @pytest.mark.parametrize("N,d,kernel,ls", [(400, 6, O.MATERN25, 0.9), (512, 8, O.MATERN25, 1.0), (700, 3, O.RBF, 0.25),
