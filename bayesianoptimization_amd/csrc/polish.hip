@@ -9,10 +9,11 @@
 // (launch_posterior_grad per model: mu, sd and their input gradients from one k*) and a few hundred
 // flops of optimiser arithmetic per seed on the host.
 //
-// Round 5: for one model of NP <= 256 the whole stage is ONE LAUNCH instead (polish_fused.hip: a workgroup per run, evaluations and
-// optimiser inside it, the same bits as the rounds here for UCB): 20-37 us per evaluation against 41-51 us per round, and no
-// lockstep — a default suggest() spends 0.73 instead of 1.13 ms in its local searches at N <= 143.  The rounds below serve
-// everything else (larger models, constraint slots).
+// Rounds 5-6: for one model of NP <= 384 the whole stage is ONE LAUNCH instead (polish_fused.hip: a workgroup per run with a
+// thread per training point, evaluations and optimiser inside it; results agree with the rounds here to rounding, not to the
+// bit): 3.4-31 us per evaluation against 42-61 us per round, and no lockstep — a default suggest() spends 0.38 instead of 1.13 ms
+// in its local searches at N <= 143.  The rounds below serve everything else (larger models, constraint slots) and are the one
+// launch's checker in the tests.
 //
 // The optimiser (polish_opt.h) is a projected L-BFGS (two-loop recursion over the free variables, backtracking on the projected path
 // with an Armijo test on the actual displacement), NOT a transcription of L-BFGS-B: no generalised Cauchy point, no

@@ -1,9 +1,10 @@
 // The optimiser of gpbo_polish_seeds: the host's walk of it (polish.hip: the runs advance in lockstep, a batched device
 // evaluation per round) and everything the device's walk shares with it — constants, min / max, the acquisition's value and
 // gradient coefficients.  polish_fused.hip (one workgroup per run, evaluations and optimiser in one launch) restates the same
-// arithmetic with lane i of a wave owning variable i (pf_new_direction / pf_advance there follow polish_new_direction /
-// polish_advance here statement by statement, every sum in the same order); tests/test_gpu_polish_fused.py holds the two to the
-// same bits: end point, value, status, iteration and evaluation counts of whole searches.
+// algorithm with lane i of a wave owning variable i (pr_advance there follows polish_new_direction / polish_advance here
+// decision by decision); since round 6 its sums over the variables are wave reductions, not this file's left-to-right chains, so
+// the two walks agree to rounding, not to the bit: tests/test_gpu_polish_fused.py holds whole searches to "the same optimum or a
+// better one" and single evaluations to their error bar.
 //
 // A projected L-BFGS (two-loop recursion over the free variables, backtracking on the projected path with an Armijo test on
 // the actual displacement), NOT a transcription of L-BFGS-B: no generalised Cauchy point, no subspace minimisation.  It keeps
@@ -13,9 +14,13 @@
 // scipy.optimize.minimize(method="L-BFGS-B")); parity is statistical.
 //
 // Every function is plain sequential arithmetic on arrays the caller owns, in one fixed order and with floating-point
-// contraction OFF, so that both sides produce the same iterates from the same function values (x86-64 has no fused multiply-add
-// in its baseline: the host never contracts; the device would).  (A first device version ran these very functions on one thread
-// over LDS: correct, and 27 us per evaluation of pure LDS latency — docs/LAB_NOTEBOOK.md §9.7.)
+// contraction OFF: a host run is reproducible to the bit whatever the compiler (x86-64 has no fused multiply-add in its
+// baseline).  (A first device version ran these very functions on one thread over LDS: correct, and 27 us per evaluation of pure
+// LDS latency; round 5's lane-parallel version kept this file's summation order with v_readlane chains, 6 us per step; round 6's
+// uses DPP row sums — docs/LAB_NOTEBOOK.md §9.7, §10.4.)
+// First step: as L-BFGS-B, 1 / |g| without curvature information, 1 otherwise.  Over the 660 runs of the sweep
+// (profiles/r06_polish_sweep.json) a run is 23.2 evaluations for 18.5 iterations: the line search costs 3.7 evaluations a run in
+// all, which bounds what any other first-step rule could save.
 #pragma once
 #include <cstddef>
 
