@@ -825,8 +825,17 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
   // Lanes are processed in groups: a group runs the launch sequence once for its lanes on its own stream.  Small
   // problems are dispatch-bound (every kernel is tiny): ONE group of all lanes.  From NP = 2048 on the big GEMMs fill
   // the chip by themselves and what is left to win is hiding one lane's latency-bound steps (the diagonal-block
-  // kernels) behind another lane's GEMMs: one lane per group, i.e. one stream per lane.
-  int per_group = (NP >= 2048) ? 1 : n_theta;
+  // kernels) behind another lane's GEMMs — which a SECOND stream does and a third does not: three lanes on three streams
+  // take what two take plus one alone (2.16 against 1.22 + 0.94 ms at N = 2048; it is not the hardware queues — four streams of
+  // one-workgroup kernels do run side by side, scripts/probes/stream_queues.hip — but what two evaluations in the same phase
+  // leave free of the chip).  So: two groups, and inside a group lane = a grid dimension, where the chain's launches are
+  // shared (the diagonal blocks of all its lanes factor side by side in one step launch).  Until round 6: one lane per group
+  // from NP = 2048 on.  profiles/r06_lanes_grouping.json, ms for 3 / 4 / 6 lanes:
+  //   N = 2048: one lane per group 2.16 / 2.36 / 2.72, two groups 1.48 / 1.72 / 2.25;  N = 3072: 4.01 / 4.63 / 5.78 -> 3.17 / 3.82 / 5.31
+  //   N = 4096: 5.59 / 8.33 / 11.14 -> (three lanes on three streams stay) / 7.19 / 10.01 with two lanes per group;  N = 6144: 21.5 -> 18.9 at 4
+  int per_group = n_theta;
+  if (NP >= 4096) per_group = (n_theta <= 3) ? 1 : 2;
+  else if (NP >= 2048) per_group = (n_theta + 1) / 2;
   if (const char* e = dbg_env("GPBO_LML_PER_GROUP")) per_group = std::max(1, std::min(atoi(e), n_theta));   // A/B runs (debug build)
   const int n_groups = (n_theta + per_group - 1) / per_group;
   for (int g = 0; g < n_groups; ++g)
@@ -877,10 +886,23 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
     };
     // An evaluation is ~60 short launches: the second time the same problem shape comes by, the group's sequence is
     // captured into a hipGraph and from then on replayed with one launch.
-    LmlLane& key = ctx->lml_lane[g];
-    const bool same = key.seen && key.N == N && key.d == d && key.kernel == kernel && key.n_ls == n_ls &&
-                      key.eval_gradient == eval_gradient && key.noise == noise && key.lanes == gl &&
-                      key.X == ctx->lml_X && key.y == ctx->lml_y && key.K == gbase;
+    LmlLane* found = nullptr;
+    LmlLane* victim = &ctx->lml_lane[0];
+    for (auto& e : ctx->lml_lane) {
+      if (e.seen && e.N == N && e.d == d && e.kernel == kernel && e.n_ls == n_ls && e.eval_gradient == eval_gradient &&
+          e.noise == noise && e.lanes == gl && e.group == g && e.X == ctx->lml_X && e.y == ctx->lml_y && e.K == gbase) {
+        found = &e;
+        break;
+      }
+      if ((!e.seen && victim->seen) || (e.seen == victim->seen && e.used < victim->used)) victim = &e;
+    }
+    const bool same = found != nullptr;
+    LmlLane& key = same ? *found : *victim;
+    if (!same) {
+      if (key.exec) { (void)hipGraphExecDestroy(key.exec); key.exec = nullptr; }
+      key.seen = false;
+    }
+    key.used = ++ctx->lml_lane_clock;
     bool launched = false;
     if (same && key.exec && !no_graph) {
       hipError_t e = hipGraphLaunch(key.exec, ctx->stream);
@@ -939,7 +961,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
       rc = enqueue(&oh, &ih);
       key.seen = (rc == GPBO_OK);
       key.N = N; key.d = d; key.kernel = kernel; key.n_ls = n_ls; key.eval_gradient = eval_gradient; key.noise = noise;
-      key.lanes = gl; key.X = ctx->lml_X; key.y = ctx->lml_y; key.K = gbase;
+      key.lanes = gl; key.group = g; key.X = ctx->lml_X; key.y = ctx->lml_y; key.K = gbase;
     }
   }
   restore();

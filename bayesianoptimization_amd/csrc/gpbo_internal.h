@@ -54,15 +54,19 @@ struct Model {
   int64_t M_post = -1;     // number of candidates mu/sd are valid for (-1: none)
 };
 
-// gpbo_lml_batch, per lane count: the problem shape it last ran and, from the second run on, the captured launch sequence.
+// gpbo_lml_batch, per lane group it has run: the problem shape and, from the second run on, the captured launch sequence.  A pool
+// looked up by the whole key: the lanes of a call are dealt to groups by their number (gpbo_api.hip), and a theta search's rounds
+// come with 6, 6, 5, 3, 2, 1, 1 ... live runs — every grouping it passes through keeps its graphs.
 struct LmlLane {
   hipGraphExec_t exec = nullptr;
   bool seen = false;
   int64_t N = 0;
-  int d = 0, kernel = 0, n_ls = 0, eval_gradient = 0, lanes = 0;
+  int d = 0, kernel = 0, n_ls = 0, eval_gradient = 0, lanes = 0, group = 0;
   double noise = 0.0;
   const void* X = nullptr; const void* y = nullptr; const void* K = nullptr;
+  uint64_t used = 0;      // the pool's clock at its last use (the least recently used entry is the one replaced)
 };
+constexpr int LML_GRAPH_POOL = 24;
 
 struct EventPair {
   hipEvent_t a = nullptr, b = nullptr;
@@ -99,7 +103,8 @@ struct gpbo_ctx {
   int lanes = 1;
   int64_t lane_stride = 0;
   double* lml_slab = nullptr; int64_t cap_lml_slab = 0;
-  gpbo::LmlLane lml_lane[GPBO_LML_BATCH_MAX];
+  gpbo::LmlLane lml_lane[gpbo::LML_GRAPH_POOL];
+  uint64_t lml_lane_clock = 0;
   double* lml_X = nullptr; int64_t cap_lml_X = 0;   // the batch's raw inputs, uploaded once per call
   double* lml_y = nullptr; int64_t cap_lml_y = 0;
   int64_t lml_N = 0; int lml_d = 0;                 // shape of the resident inputs (0: none)

@@ -32,18 +32,26 @@ for N, d in ((512, 8), (1024, 16), (2048, 16), (4096, 16)):
     t0 = time.perf_counter(); [eng.lml(X, yn, MATERN25, s, 1e-6) for s in scales]; r["lml_x6_ms"] = (time.perf_counter() - t0) * 1e3
     res = {}
     rounds = []
-    orig_batch = eng.lml_batch_arrays        # (what a theta-search round calls: values and gradients as two arrays)
+    orig_frame = eng.lml_search_rounds        # (what a theta search calls: one frame per search, one call per round)
 
-    def timed_batch(*a, **k):
-        t0 = time.perf_counter()
-        out_ = orig_batch(*a, **k)
-        rounds.append((len(out_[0]), round((time.perf_counter() - t0) * 1e3, 3)))
-        return out_
+    def timed_frame(*a, **k):
+        one_round = orig_frame(*a, **k)
 
-    eng.lml_batch_arrays = timed_batch
-    for lockstep in (True, False):
+        def timed_round(scales_):
+            t1 = time.perf_counter()
+            out_ = one_round(scales_)
+            rounds.append((len(out_[0]), round((time.perf_counter() - t1) * 1e3, 3)))
+            return out_
+
+        return timed_round
+
+    eng.lml_search_rounds = timed_frame
+    lock_s = []
+    for lockstep in (True, True, True, False):          # the first search at a shape also captures its lane groups' graphs
         gp = HipGPR(kernel=Matern(nu=2.5), alpha=1e-6, normalize_y=True, n_restarts_optimizer=5,
                     random_state=np.random.RandomState(3), engine=eng, lml_on_device=True, theta_lockstep=lockstep)
+        if lockstep:
+            rounds.clear()
         t0 = time.perf_counter()
         n_eval = [0]
         if not lockstep:
@@ -56,10 +64,13 @@ for N, d in ((512, 8), (1024, 16), (2048, 16), (4096, 16)):
             gp.log_marginal_likelihood = counted
         gp.fit(X, y)
         res[lockstep] = (time.perf_counter() - t0, gp.kernel_.theta.copy())
+        if lockstep:
+            lock_s.append(res[True][0])
         if not lockstep:
             r["lml_evaluations"] = n_eval[0]
-    del eng.lml_batch_arrays
-    r["lockstep_rounds_lanes_ms"] = rounds
+    del eng.lml_search_rounds
+    r["fit_theta_search_lockstep_first_s"] = lock_s[0]
+    r["lockstep_rounds_lanes_ms"] = list(rounds)        # of the last lockstep search: (live runs, ms) per round
     r["fit_theta_search_lockstep_s"] = res[True][0]
     r["fit_theta_search_sequential_s"] = res[False][0]
     r["same_theta"] = bool(np.array_equal(res[True][1], res[False][1]))

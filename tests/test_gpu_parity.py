@@ -698,6 +698,32 @@ def test_lml_batch_lanes_are_bitwise_gpbo_lml(engine, N, d, kernel):
         engine.lml_batch(X, yn, kernel, np.ones((9, 1)), 1e-6)
 
 
+@pytest.mark.parametrize("N,d", [(2100, 5), (4096, 16)])
+def test_lml_lanes_dealt_to_two_groups_are_bitwise_gpbo_lml(engine, N, d):
+    """Round 6: from NP = 2048 on the lanes of a gpbo_lml_batch call are dealt to TWO groups (two streams is what the hardware
+    queues run side by side; inside a group lane = a grid dimension, so the diagonal blocks of its lanes factor in one launch) —
+    (n + 1) / 2 lanes per group below NP = 4096, two per group above for n >= 4.  Whatever the dealing, every lane returns the bits
+    gpbo_lml returns alone; the lane counts below are a theta search's (6, 6, 6, 5, 3, 2, 1, ...) and come round again, so every
+    grouping is run directly, captured and replayed from the graph pool."""
+    X, y = _data(N, d, seed=91)
+    yn, _, _ = O.normalize_targets(y)
+    rng = np.random.RandomState(92)
+    single = {}
+
+    def alone(ls):
+        key = float(ls)
+        if key not in single:
+            single[key] = engine.lml(X, yn, O.MATERN25, ls, 1e-6)
+        return single[key]
+
+    pool = rng.uniform(0.6, 2.5, size=8).round(3)
+    for n in (6, 6, 6, 5, 3, 2, 1, 1, 4, 6, 5, 3, 2, 4, 6):
+        sc = rng.choice(pool, size=(n, 1), replace=False)
+        for (val, grad), ls in zip(engine.lml_batch(X, yn, O.MATERN25, sc, 1e-6), sc):
+            v1, g1 = alone(ls[0])
+            assert np.isfinite(val) and val == v1 and np.array_equal(grad, g1)
+
+
 @pytest.mark.parametrize("N,d,kernel,ls,M", [(60, 3, O.MATERN25, 0.7, 1), (200, 5, O.RBF, 0.6, 7), (513, 8, O.MATERN25, 1.0, 10),
                                              (130, 4, O.MATERN25, [0.4, 0.7, 1.0, 1.3], 33), (1000, 16, O.MATERN25, 1.5, 64),
                                              (300, 40, O.RBF, 2.5, 256)])
