@@ -25,6 +25,8 @@ MAP = {
     "small_n_trace/t_kernel_stats.csv": "r06_trace_small_n_kernel_stats.csv", "n300_trace/t_kernel_stats.csv": "r06_trace_n300_kernel_stats.csv",
     "polish_sweep.json": "r06_polish_sweep.json", "conditioning.json": "r06_conditioning.json",
     "pytest.log": "r06_pytest_gpu.log", "smoke.log": "r06_smoke.log",
+    "suggest_host_profile_n16_64.txt": "r06_suggest_host_profile_n16_64.txt", "small_step_breakdown.txt": "r06_small_step_breakdown.txt",
+    "lanes_grouping.json": "r06_lanes_grouping.json", "gemm_bench.json": "r06_gemm_bench.json",
 }
 for src, dst in MAP.items():
     s = os.path.join(F, src)

@@ -3,7 +3,8 @@
 # bench command for C3 and C2 (their summaries are put under profiles/ ON THE BOX first, so that the bench line quotes PMC numbers of
 # the very library it runs), the default bench line, the 8-virtual-rank group line, the kernel trace + SQ counters of gpbo_lml alone
 # at N = 2048 / 4096, the theta-search timing, the small-fit timing of the three fit paths, the maximize() loop (seed 1 with the host
-# columns, seeds 2-4 without), the local-search A/B, the host profile and the kernel trace of the small-N loop.  Everything lands in
+# columns, seeds 2-4 without), the local-search A/B, the host profile and the kernel trace of the small-N loop, the per-call breakdown of a C1 / C2 step, the
+# lanes-per-group sweep and the fit-side GEMM benchmark.  Everything lands in
 # gpurun_out/r06f/ (scripts/r06_collect_final.py copies it to profiles/).
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -39,6 +40,10 @@ timeout 200 python scripts/r06_polish_fused_ab.py > $F/polish_fused_ab.json 2> $
 timeout 200 python scripts/r06_suggest_host_profile.py > $F/suggest_host_profile.txt 2>&1; head -2 $F/suggest_host_profile.txt
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $F/small_n_trace -o t -- python scripts/r06_suggest_host_profile.py > /dev/null 2>&1
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $F/n300_trace -o t -- python scripts/r06_suggest_host_profile.py 300 340 > /dev/null 2>&1
+timeout 200 python scripts/r06_suggest_host_profile.py 16 64 > $F/suggest_host_profile_n16_64.txt 2>&1; head -1 $F/suggest_host_profile_n16_64.txt
+timeout 200 python scripts/r06_small_step_breakdown.py > $F/small_step_breakdown.txt 2>&1; grep "whole step" $F/small_step_breakdown.txt
+timeout 300 python scripts/r06_lanes_grouping.py > $F/lanes_grouping.json 2> $F/lanes_grouping.err
+timeout 200 python scripts/r06_gemm_bench.py > $F/gemm_bench.json 2> $F/gemm_bench.err
 cp gpurun_out/r04_polish_sweep.json $F/polish_sweep.json 2>/dev/null; cp gpurun_out/r05_conditioning.json $F/conditioning.json 2>/dev/null
 cp gpurun_out/transcript_replay_*.json $F/ 2>/dev/null
 find $F -name '*.db' -delete; find $F -name '*_kernel_trace.csv' -size +3M -delete; find $F -name 'p_counter_collection.csv' -size +3M -delete
