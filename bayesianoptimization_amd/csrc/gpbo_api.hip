@@ -768,6 +768,63 @@ int lml_upload_inputs(gpbo_ctx* ctx, const double* X, const double* y_norm, int6
 }
 }  // namespace gpbo
 
+namespace gpbo {
+// One workgroup that spins for `ticks` of the 100 MHz wall clock: the probe of pick_lane_streams.
+__global__ void spin_ticks_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {}
+}
+
+// Do one-workgroup kernels on streams a and b run side by side?  (100 us each: ~120 us side by side, ~220 one behind the other.)
+static bool streams_overlap(hipStream_t a, hipStream_t b) {
+  double best = 1e30;
+  for (int r = 0; r < 3; ++r) {
+    (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+    const auto t0 = std::chrono::steady_clock::now();
+    spin_ticks_kernel<<<1, 64, 0, a>>>(10000);
+    spin_ticks_kernel<<<1, 64, 0, b>>>(10000);
+    (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+    best = std::min(best, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+  }
+  return best < 170.0;
+}
+
+// The streams of the lane groups of gpbo_lml_batch (n_groups > 1 from NP = 2048 on) must sit on DIFFERENT hardware queues, or the
+// groups run one behind the other: the runtime deals its (four) queues to streams by load at creation time, and streams created at
+// different moments of a process's life do collide — seen in round 6: the third group's stream, created when the first six-lane round
+// of a search at N = 4096 came by, shared a queue with the first: 12.1 ms for the round against 10.0 with the streams created back
+// to back (scripts/probes/stream_queues.hip: of eight streams created in a row the pairs (0,7), (1,6), (2,5), (3,4) serialise).
+// So the streams are PICKED: a candidate is kept when a 100 us one-workgroup kernel on it runs side by side with one on every
+// stream already chosen; rejected candidates are held until the picking is over (so that the next one lands elsewhere).  Once per
+// context and group count, ~1 ms; the first four groups only (there are four queues).
+static int pick_lane_streams(gpbo_ctx* ctx, int n_groups) {
+  if (!ctx->lml_stream[0]) GPBO_HIP(ctx, hipStreamCreateWithFlags(&ctx->lml_stream[0], hipStreamNonBlocking));
+  if (ctx->lane_streams_picked < 1) ctx->lane_streams_picked = 1;
+  if (n_groups <= ctx->lane_streams_picked) return GPBO_OK;
+  std::shared_lock<std::shared_mutex> not_while_capturing(g_capture_mu);
+  std::vector<hipStream_t> rejected;
+  for (int g = ctx->lane_streams_picked; g < n_groups; ++g) {
+    if (ctx->lml_stream[g]) continue;
+    hipStream_t cand = nullptr;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+      GPBO_HIP(ctx, hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+      if (g >= 4) break;
+      spin_ticks_kernel<<<1, 64, 0, cand>>>(100);          // (the first launch on a stream sets its queue up)
+      bool ok = true;
+      for (int c = 0; c < g && ok; ++c) ok = streams_overlap(ctx->lml_stream[c], cand);
+      if (ok || attempt == 7) break;
+      rejected.push_back(cand);
+      cand = nullptr;
+    }
+    ctx->lml_stream[g] = cand;
+  }
+  for (auto st : rejected) (void)hipStreamDestroy(st);
+  (void)hipGetLastError();
+  ctx->lane_streams_picked = n_groups;
+  return GPBO_OK;
+}
+}  // namespace gpbo
+
 extern "C" {
 
 int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_norm, int64_t N, int d, int kernel,
@@ -838,8 +895,7 @@ int gpbo_lml_batch(gpbo_ctx* ctx, int n_theta, const double* X, const double* y_
   else if (NP >= 2048) per_group = (n_theta + 1) / 2;
   if (const char* e = dbg_env("GPBO_LML_PER_GROUP")) per_group = std::max(1, std::min(atoi(e), n_theta));   // A/B runs (debug build)
   const int n_groups = (n_theta + per_group - 1) / per_group;
-  for (int g = 0; g < n_groups; ++g)
-    if (!ctx->lml_stream[g]) GPBO_HIP(ctx, hipStreamCreateWithFlags(&ctx->lml_stream[g], hipStreamNonBlocking));
+  if ((rc = pick_lane_streams(ctx, n_groups))) return rc;
   static const bool graphs_allowed = !(dbg_env("GPBO_LML_GRAPH") && dbg_env("GPBO_LML_GRAPH")[0] == '0');
   hipStream_t stream0 = ctx->stream;
   void* red0 = ctx->red; int64_t cap_red0 = ctx->cap_red;

@@ -90,6 +90,7 @@ struct gpbo_ctx {
   gpbo::Model models[GPBO_MAX_MODELS];
   // gpbo_lml_batch: its stream (lml_stream[0]); the lanes' buffers live in lml_slab
   hipStream_t lml_stream[GPBO_LML_BATCH_MAX] = {};
+  int lane_streams_picked = 0;   // how many of them were chosen to run side by side (pick_lane_streams, gpbo_api.hip)
   bool no_timing = false;   // batch lanes do not touch the timing events
   bool timing_off = false;  // gpbo_set_timing(ctx, 0): no event records at all (a record is a marker packet on the stream)
   bool no_lookahead = false;   // several lane streams in flight: the Cholesky look-ahead would only add streams to a full chip
