@@ -683,7 +683,7 @@ def main():
     mode = "ranks" if world > 1 else ("group" if args.gpus > 1 else "single")
     n_gpus = world if mode == "ranks" else args.gpus
 
-    w = W.ALL[args.config or ("C3" if n_gpus == 1 else "C4")]
+    w = resolved(W.ALL[args.config or ("C3" if n_gpus == 1 else "C4")])
     X, y, c = W.make_observations(w)
     y_mean, y_std = float(np.mean(y)), float(np.std(y))
     yn = (y - y_mean) / y_std
