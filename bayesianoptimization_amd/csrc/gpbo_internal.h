@@ -182,8 +182,10 @@ constexpr unsigned ATTR_GEMM128 = 4u, ATTR_CHOL128 = 16u, ATTR_FUSED = 32u, ATTR
 constexpr int FUSED_NP_DEFAULT = 64, FUSED_NP_CAP = 512;
 // mid_fit.hip: fused_max_np() < NP <= mid_max_np(): the strip algorithms, ~15 launches
 constexpr int MID_NP_DEFAULT = 768, MID_NP_CAP = 1024;
-// the local searches of gpbo_polish_seeds as one launch (polish_fused.hip): up to this padded size, one model
-constexpr int POLISH_FUSED_NP_DEFAULT = 384;
+// the local searches of gpbo_polish_seeds as one launch (polish_fused.hip): up to this padded size, one model — the kernel's own
+// limit: at N = 512 the launch still beats the lockstep rounds (profiles/r06_polish_fused_ab.json: 0.36-0.48 against 0.53-0.59 ms for
+// 8-10 evaluations, 2.09 against 2.13 for 48)
+constexpr int POLISH_FUSED_NP_DEFAULT = 512;
 // pinned staging of a small host-side fit's X (N, d) | y (N), read by the first kernel directly (one window per PIN window)
 constexpr int STAGE_NP_CAP = MID_NP_CAP;
 static_assert(STAGE_NP_CAP >= FUSED_NP_CAP, "the staging window serves both small paths");

@@ -5,12 +5,12 @@
 // six dependent launches and a stream synchronisation (41-75 us) for ~2 N^2 flops per run.  Here a run is a workgroup that owns
 // its search from the seed to the stopping rule, THREAD = TRAINING POINT (polish_rows_kernel, round 6):
 //   * thread i keeps k*_i, v_i = (W k*)_i and u_i = (W^T v)_i of its own point: it walks row i of W = L^-1 for v and column i for u;
-//   * NP <= 128: W sits in LDS as a padded square ([NP][NP + 1]: both walks conflict-free).  128 < NP <= 384: W stays in memory and
+//   * NP <= 128: W sits in LDS as a padded square ([NP][NP + 1]: both walks conflict-free).  128 < NP <= 512: W stays in memory and
 //     both walks are coalesced — the row walk over a transposed copy made once per fit, the column walk over W itself;
 //   * the sums over the points (mu, |v|^2, the 2 d gradient sums) are taken by lane groups of one dimension each and combined in a
 //     fixed order; the optimiser (polish_opt.h's steps) runs on wave 0 with a lane per variable, its sums over the variables as
 //     DPP row reductions, its two-loop recursion as ONE rolled loop;
-//   * four barriers per evaluation.  3.4-3.9 us per evaluation at N <= 64, 5.3-5.7 at 128, 17 / 23 / 34 at N = 143 / 256 / 384
+//   * four barriers per evaluation.  3.4-3.9 us per evaluation at N <= 64, 5.3-5.7 at 128, 16 / 21 / 31 / 41 at N = 143 / 256 / 384 / 512
 //     (one CU streams W at ~30 B per clock), against 14 / 19 / 24-46 for round 5's eight-wave kernel and 41-57 us per lockstep
 //     round (profiles/r06_polish_fused_ab.json).
 // Deterministic, and NOT the bits of the lockstep path (other summation orders): the evaluation agrees with gpbo_predict_grad to

@@ -1,5 +1,5 @@
 """GPU (-m gpu): the local searches of gpbo_polish_seeds as ONE launch (csrc/polish_fused.hip: polish_rows_kernel — a workgroup
-per run, thread = training point, the evaluations and the optimiser inside it; NP <= 384 in the product, <= 512 by switch) against
+per run, thread = training point, the evaluations and the optimiser inside it; NP <= 512) against
 the lockstep path it replaces there (csrc/polish.hip: six launches and a stream synchronisation per round, the optimiser on the
 host), which is its CHECKER, not its twin.
 
@@ -73,8 +73,8 @@ SHAPES = [(25, 2), (64, 4), (65, 3), (100, 5), (120, 40), (128, 16), (130, 8), (
 
 @pytest.fixture
 def any_size():
-    """The product serves NP <= 384 through the one launch (above it the six launches win on long runs); the kernel itself runs to
-    NP = 512: the tests pin the limit there (GPBO_POLISH_FUSED_MAX_NP, read per call by the debug build only)."""
+    """The one launch serves NP <= 512, the kernel's own limit (the product's since the end of round 6; 384 before): the tests pin the
+    limit there whatever the default (GPBO_POLISH_FUSED_MAX_NP, read per call by the debug build only)."""
     old = os.environ.get("GPBO_POLISH_FUSED_MAX_NP")
     os.environ["GPBO_POLISH_FUSED_MAX_NP"] = "512"
     yield
