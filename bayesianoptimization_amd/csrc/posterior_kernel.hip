@@ -107,6 +107,13 @@ int launch_posterior(gpbo_ctx* ctx, Model& m, int64_t M, double y_mean, double y
   const char* kv = dbg_env("GPBO_POST_KERNEL");
   const bool use_f32 = (m.precision == GPBO_F32);   // fp32 slab + f32 MFMA GEMM (posterior_kernel_f32.hip)
   int path = (nchunks <= 1 || (nchunks == 2 && Mp < 8192)) ? 2 : ((m.NP >= 384 && m.NP <= 512 && Mp >= 16384) ? 4 : 3);
+  // Two row chunks (256 < NP <= 512) and a batch around bayes_opt's DEFAULT n_random = 10 000 (round 6, scripts/r06_post_10k_ab.py,
+  // profiles/r06_post_10k_ab.json; ms at M = 10 000 / 20 000 for N = 300, 384, 450, 512; the slab pair was the rule's choice):
+  //   slab pair 0.125-0.147 / 0.16-0.19;  8-wave fused 0.092-0.113 / 0.12-0.17;  16-wave fused 0.080-0.100 / 0.14-0.18
+  // 144 ... 256 candidate tiles are one 16-wave workgroup per CU in ONE round (and that kernel takes the raw candidates and writes
+  // mu / sd itself); from there to 32 768 candidates the 8-wave kernel's two workgroups per CU fill the chip better than either.
+  if (nchunks == 2 && Mp >= 9216 && Mp <= 16384) path = 4;
+  else if (nchunks == 2 && Mp > 16384 && Mp < 32768) path = 2;
   if (kv && (kv[0] == '2' || kv[0] == '3' || (kv[0] == '4' && m.NP <= 1024))) path = kv[0] - '0';
   const bool use_v2 = path == 2, use_v4 = path == 4;
   const char* sm = dbg_env("GPBO_POST_SMALL");

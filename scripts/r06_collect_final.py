@@ -26,7 +26,7 @@ MAP = {
     "polish_sweep.json": "r06_polish_sweep.json", "conditioning.json": "r06_conditioning.json",
     "pytest.log": "r06_pytest_gpu.log", "smoke.log": "r06_smoke.log",
     "suggest_host_profile_n16_64.txt": "r06_suggest_host_profile_n16_64.txt", "small_step_breakdown.txt": "r06_small_step_breakdown.txt",
-    "lanes_grouping.json": "r06_lanes_grouping.json", "gemm_bench.json": "r06_gemm_bench.json",
+    "lanes_grouping.json": "r06_lanes_grouping.json", "gemm_bench.json": "r06_gemm_bench.json", "post_10k_ab.json": "r06_post_10k_ab.json",
 }
 for src, dst in MAP.items():
     s = os.path.join(F, src)

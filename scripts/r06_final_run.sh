@@ -44,6 +44,7 @@ timeout 200 python scripts/r06_suggest_host_profile.py 16 64 > $F/suggest_host_p
 timeout 200 python scripts/r06_small_step_breakdown.py > $F/small_step_breakdown.txt 2>&1; grep "whole step" $F/small_step_breakdown.txt
 timeout 300 python scripts/r06_lanes_grouping.py > $F/lanes_grouping.json 2> $F/lanes_grouping.err
 timeout 200 python scripts/r06_gemm_bench.py > $F/gemm_bench.json 2> $F/gemm_bench.err
+timeout 200 python scripts/r06_post_10k_ab.py > $F/post_10k_ab.json 2> $F/post_10k_ab.err
 cp gpurun_out/r04_polish_sweep.json $F/polish_sweep.json 2>/dev/null; cp gpurun_out/r05_conditioning.json $F/conditioning.json 2>/dev/null
 cp gpurun_out/transcript_replay_*.json $F/ 2>/dev/null
 find $F -name '*.db' -delete; find $F -name '*_kernel_trace.csv' -size +3M -delete; find $F -name 'p_counter_collection.csv' -size +3M -delete
