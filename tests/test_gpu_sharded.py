@@ -193,6 +193,13 @@ def test_device_group_equals_single_engine(engine, devices):
         assert o1[0] == o2[0] and o1[1] == o2[1]
         assert np.array_equal(o1[2], o2[2]) and np.array_equal(o1[3], o2[3]) and np.array_equal(o1[4], o2[4])
         assert np.array_equal(rows1, rows2) and np.array_equal(rows2[0], Xc[o2[0]])
+        # gpbo_set_timing through the group: every device stops recording its event pairs, nothing else changes
+        assert all(t["posterior_main"] > 0 for t in grp.per_device_timings())
+        grp.set_timing(False)
+        mu3, sd3, o3, _ = run(grp)
+        assert all(v == -1.0 for t in grp.per_device_timings() for v in t.values())
+        assert np.array_equal(mu1, mu3) and np.array_equal(sd1, sd3) and o1[0] == o3[0] and np.array_equal(o1[4], o3[4])
+        grp.set_timing(True)
         # NaN semantics across shards: the first NaN overall wins
         Xn = Xc.copy()
         Xn[[4000, 900]] = np.nan
