@@ -1,6 +1,7 @@
 """How much of each other do the lanes of one gpbo_lml_batch call hide at N = 4096 (one stream per lane there)?  Wall time of
 1 / 2 / 3 / 4 / 6 lanes (median of 7 after 3), value + gradient, d = 16 — and, with `trace` as the first argument, a workload for
-rocprofv3 --kernel-trace: 3 two-lane calls, then 3 six-lane calls (scripts/r06_lanes_overlap_report.py reads the trace).
+rocprofv3 --kernel-trace --stats: `trace1` = 24 single evaluations, `trace6` = 4 six-lane calls (the per-kernel totals of
+docs/LAB_NOTEBOOK.md §10.8), `trace` = 4 two-lane calls, then 4 six-lane calls.
 
     python scripts/r06_lanes_overlap.py > profiles/r06_lanes_overlap.json
 """
